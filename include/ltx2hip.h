@@ -1,0 +1,226 @@
+/*
+ * ltx2hip.h -- C ABI of libltx2hip.so: the MI355X (gfx950) implementation of the LTX-2
+ * denoise (DiT) + CausalVideoVAE decode hot path.
+ *
+ * This is the drop-in boundary.  The reference (Acelogic/LTX-2-MLX) is pure Python over
+ * Apple MLX; the entry points below are what its Python layer would bind (via ctypes, see
+ * INTEGRATION.md) in place of the MLX calls cited next to each function.  All paths are
+ * relative to /root/reference.
+ *
+ * Conventions
+ *   - every function returns int: 0 = LTX2_OK, negative = LTX2_E_* ; nothing throws across the
+ *     boundary; ltx2_last_error() returns a thread-local message for the last failure.
+ *   - all pointers are DEVICE pointers (HBM) unless named host_*; the library never allocates or
+ *     frees caller memory and never retains input/output pointers beyond the call, except
+ *     weights (owned by the caller for the lifetime of the context) and the bound workspace.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
+ *     enqueues work on that stream; no internal threads; one context per GPU / process.
+ *   - activations: bf16 = raw uint16 bfloat16; fp32 where stated.  Batch is 1 (the reference
+ *     hard-wires batch = 1: pipelines/distilled.py:314, scripts/generate.py:1768).
+ */
+#ifndef LTX2HIP_H
+#define LTX2HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTX2_OK 0
+#define LTX2_E_INVALID (-1) /* bad argument / unsupported shape  (Python side raises ValueError) */
+#define LTX2_E_HIP (-2)     /* HIP runtime error                   (RuntimeError) */
+#define LTX2_E_STATE (-3)   /* call order, missing weight, small workspace (RuntimeError) */
+
+#define LTX2_DTYPE_BF16 0
+#define LTX2_DTYPE_F32 1
+
+const char* ltx2_last_error(void);
+int ltx2_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel entry points (unit parity against the oracle)
+ * ------------------------------------------------------------------------------------------ */
+
+/* GEMM epilogues */
+#define LTX2_EPI_BF16 0            /* out_bf16 = acc + bias */
+#define LTX2_EPI_GELU_BF16 1       /* out_bf16 = gelu_tanh(acc + bias) */
+#define LTX2_EPI_SILU_BF16 2       /* out_bf16 = silu(acc + bias) */
+#define LTX2_EPI_F32 3             /* out_f32  = acc + bias */
+#define LTX2_EPI_RESID_GATE_F32 4  /* out_f32 += gate * (acc + bias) */
+#define LTX2_EPI_ADD_BF16 5        /* out_bf16 = acc + bias + res_bf16 */
+
+/* out[M,N] = epilogue(A[M,K] @ W[N,K]^T + bias).  Replaces mlx nn.Linear on the DiT path:
+ * model/transformer/attention.py:225-228,253 (to_q/k/v/out), feed_forward.py:23,49 (FFN),
+ * model.py:49-56 (caption projection), model.py:242 (patchify_proj), model.py:757 (proj_out),
+ * and the fused helpers transformer.py:35-46 (_compiled_residual_gate: epilogue 4) and
+ * feed_forward.py:26 (gelu_approx: epilogue 1).
+ * gate (epilogue 4): gate[m*gate_stride + n] (+ gate_table[n]); both NULL -> 1.            */
+int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M,
+                   int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table,
+                   const void* res, int64_t ldres, void* stream);
+
+/* Skinny fp32-activation path (M <= 16): out_f32 = act_out(act_in(a) @ W^T + bias); act: 0 none,
+ * 1 silu, 2 gelu_tanh.  Replaces TimestepEmbedding / AdaLayerNormSingle linears for a scalar
+ * sigma (model/transformer/timestep_embedding.py:112-124,187-202) and the VAE TimestepEmbedder
+ * (model/video_vae/simple_decoder.py:54-59).                                                 */
+int ltx2_gemv_f32(const float* a, int64_t lda, const void* W, const float* bias, float* out, int64_t ldo, int M,
+                  int N, int K, int act_in, int act_out, void* stream);
+
+/* 3x3x3 stride-1 conv3d on channels-last bf16 activations x[T][H][W][Cin], weights
+ * w[Cout][27][Cin] (tap = (kt*3+kh)*3+kw), reflect pad H/W, replicate pad T (causal: 2 front).
+ * Replaces Conv3dSimple.__call__ (model/video_vae/simple_decoder.py:90-180).
+ *   mode 0: out[T][H][W][Cout] = conv + bias
+ *   mode 1: out = conv + bias + res          (ResBlock3d skip, simple_decoder.py:240)
+ *   mode 2: depth-to-space upsample epilogue (DepthToSpaceUpsample3d, simple_decoder.py:287-313):
+ *           weight rows must be pre-permuted to n' = s*Cf + c (s = (a*fh+b)*fw+d, Cf = Cout/(ft*fh*fw));
+ *           out[T*ft - (ft>1)][H*fh][W*fw][Cf]; residual != 0 adds tile(d2s(x)).                */
+int ltx2_conv3d_fused(const void* x, const void* w, const float* bias, void* out, int T, int H, int W, int Cin,
+                      int Cout, int causal, int mode, const void* res, int ft, int fh, int fw, int residual,
+                      void* stream);
+
+/* out_bf16 = norm(x_f32) * (1 + scale) + shift ; scale = scale_tab[d] + scale_emb[row*emb_stride+d].
+ * layer_norm = 0: RMS  (transformer.py:16-31 _compiled_adaln_forward; attention.py:88-100 rms_norm)
+ * layer_norm = 1: LayerNorm without affine (model.py:553,744-758).  NULL pointers contribute 0.   */
+int ltx2_adaln_rmsnorm(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int D, float eps,
+                       int layer_norm, const float* scale_tab, const float* shift_tab, const float* scale_emb,
+                       const float* shift_emb, int64_t emb_stride, void* stream);
+
+/* In place on bf16 rows: RMSNorm(weight) over the full inner dim of q (and k), then SPLIT RoPE
+ * (cos/sin fp32 [rows][D/2], slot h*hd/2 + j) if cos != NULL.
+ * Replaces attention.py:231-237 + rope.py:92-144.  k_* may be NULL/absent (nseg = 1).        */
+int ltx2_qknorm_rope(void* buf, int64_t ld, int rows, int D, int head_dim, int q_off, const float* q_weight,
+                     int k_off, const float* k_weight, float eps, const float* cos, const float* sin, void* stream);
+
+/* V[Nkv][ld] (head h at columns h*128) -> VT[H][128][Npad], keys permuted inside each block of 32
+ * to match the MFMA accumulator layout of the attention kernel; padded keys are zero.        */
+int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, int H, void* stream);
+
+/* out[q][h*128..] = softmax(Q_h K_h^T * scale) V_h, non-causal, no mask, head_dim 128.
+ * Replaces _compiled_attention_core_no_mask (attention.py:12-34).                             */
+int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
+                    int64_t ldo, int Nq, int Nkv, int H, float scale, void* stream);
+
+/* [cos | sin] sinusoid, dim 256 (timestep_embedding.py:10-60 with flip_sin_to_cos, shift 0;
+ * simple_decoder.py:12-39).  Either output may be NULL.                                       */
+int ltx2_timestep_sinusoid(const float* t, int64_t t_stride, float mult, int T, int dim, float* out_f32,
+                           void* out_bf16, void* stream);
+
+int ltx2_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
+
+/* x0 = latent - ts * velocity  (X0Model.__call__, model.py:912-918); ts_ptr NULL -> ts_scalar. */
+int ltx2_x0_from_velocity(const float* latent, const float* velocity, const float* ts_ptr, int64_t ts_stride,
+                          float ts_scalar, float* x0, int rows, int C, void* stream);
+
+/* post_process_latent + EulerDiffusionStep.step fused (pipelines/common.py:169-190,
+ * components/diffusion_steps.py:36-67, scripts/generate.py:905-930).  sigma == 0 -> LTX2_E_INVALID
+ * with message "Sigma can't be 0.0" (core_utils.py:54-55).  mask/clean may both be NULL.      */
+int ltx2_euler_step(const float* x, const float* x0, const float* mask, const float* clean, float sigma,
+                    float sigma_next, float* out, int rows, int C, void* stream);
+
+/* VAE elementwise glue (simple_decoder.py:492-498, 228-238/339-342, ops.py:109-125, :792-798)  */
+int ltx2_vae_prepare_latent(const float* latent, const float* std, const float* mean, const float* noise,
+                            float noise_scale, void* out_bf16, int C, int64_t P, void* stream);
+int ltx2_pixnorm_mod_silu(const void* x, void* y, int64_t P, int C, float eps, const float* table, const float* te,
+                          int shift_row, int scale_row, void* stream);
+int ltx2_vae_unpatchify(const void* x, float* video, int T, int H, int W, void* stream);
+int ltx2_video_to_uint8(const float* video, uint8_t* frames, int T, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DiT engine: LTXModel (VideoOnly, V1) forward behind one call.
+ * Replaces X0Model(LTXModel(...)).__call__ (model/transformer/model.py:776-881,895-936) and
+ * BasicTransformerBlock.__call__ x num_layers (transformer.py:191-238).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ltx2_dit ltx2_dit;
+
+typedef struct ltx2_dit_config {
+    int num_layers;        /* 48 */
+    int num_heads;         /* 32 */
+    int head_dim;          /* 128 (only 128 is implemented) */
+    int in_channels;       /* 128 */
+    int out_channels;      /* 128 */
+    int caption_channels;  /* 3840; 0 = no caption_projection (context already inner_dim wide) */
+    float norm_eps;        /* 1e-6 */
+    float timestep_scale;  /* 1000 */
+} ltx2_dit_config;
+
+int ltx2_dit_create(const ltx2_dit_config* cfg, ltx2_dit** out);
+void ltx2_dit_destroy(ltx2_dit* ctx);
+
+/* Register a weight (caller keeps it alive).  Names are the checkpoint keys after stripping
+ * "model.diffusion_model." (loader/weight_converter.py:277-315), with these load-time fusions:
+ *   transformer_blocks.{i}.attn1.to_qkv.{weight,bias}  = cat(to_q, to_k, to_v)   [3D, D]
+ *   transformer_blocks.{i}.attn2.to_kv.{weight,bias}   = cat(to_k, to_v)         [2D, D]
+ * Linear weights: bf16 [out, in]; biases, norm weights, scale_shift_tables: fp32.           */
+int ltx2_dit_set_weight(ltx2_dit* ctx, const char* name, const void* ptr, int dtype, int64_t numel);
+
+/* Workspace (activations + per-prompt caches).  per_token != 0 sizes the per-token AdaLN path. */
+int64_t ltx2_dit_workspace_bytes(const ltx2_dit* ctx, int N, int S, int per_token);
+int ltx2_dit_bind_workspace(ltx2_dit* ctx, void* ptr, int64_t bytes, int N, int S, int per_token);
+
+/* Per-prompt, step-invariant work hoisted out of the loop (the reference recomputes it every
+ * step: model.py:262-271): caption projection (model.py:142-161), per-layer cross-attention
+ * K (k_norm applied) and V^T of the projected context (attention.py:227-232), and the RoPE
+ * tables cos/sin fp32 [N][D/2] computed by the caller from positions (rope.py:365-418).     */
+int ltx2_dit_prepare(ltx2_dit* ctx, const float* context, int S, const float* rope_cos, const float* rope_sin,
+                     void* stream);
+
+/* velocity[N][out_channels] (fp32) = LTXModel(latent[N][in_channels] fp32, timesteps).
+ * n_timesteps = 1: one sigma for all tokens (Modality.timesteps shape (B,), scripts/generate.py:1946);
+ * n_timesteps = N: per-token sigma (pipelines/common.py:193-232).                           */
+int ltx2_dit_forward(ltx2_dit* ctx, const float* latent, const float* timesteps, int n_timesteps, float* velocity,
+                     void* stream);
+
+/* One sampling step: forward -> x0 = latent - ts*v -> post_process -> Euler, latent updated in
+ * place (pipelines/distilled.py:214-253; scripts/generate.py:1942-1979).  x0_out may be NULL.  */
+int ltx2_dit_denoise_step(ltx2_dit* ctx, float* latent, const float* timesteps, int n_timesteps, const float* mask,
+                          const float* clean, float sigma, float sigma_next, float* x0_out, void* stream);
+
+/* hipGraph: capture n_steps of ltx2_dit_denoise_step over host_sigmas[n_steps+1] with a uniform
+ * sigma per step (timesteps = sigma for every token), then replay.  latent is updated in place. */
+int ltx2_dit_graph_capture(ltx2_dit* ctx, float* latent, const float* host_sigmas, int n_steps, void* stream);
+int ltx2_dit_graph_launch(ltx2_dit* ctx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VAE decoder engine: SimpleVideoDecoder.__call__ (model/video_vae/simple_decoder.py:446-563)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ltx2_vae ltx2_vae;
+
+#define LTX2_VAE_MAX_BLOCKS 16
+#define LTX2_VAE_RES 0
+#define LTX2_VAE_UPSAMPLE 1
+
+typedef struct ltx2_vae_config {
+    int n_blocks;                             /* up_blocks in execution order (reversed decoder_blocks) */
+    int kind[LTX2_VAE_MAX_BLOCKS];            /* LTX2_VAE_RES | LTX2_VAE_UPSAMPLE */
+    int num_layers[LTX2_VAE_MAX_BLOCKS];      /* res: number of ResBlock3d */
+    int stride[LTX2_VAE_MAX_BLOCKS][3];       /* upsample: (ft, fh, fw) */
+    int multiplier[LTX2_VAE_MAX_BLOCKS];      /* upsample: out_channels_reduction_factor */
+    int residual[LTX2_VAE_MAX_BLOCKS];
+    int base_channels;                        /* 128 -> first feature width 1024 */
+    int latent_channels;                      /* 128 */
+    int timestep_conditioning;
+    float decode_noise_scale;                 /* 0.025 */
+} ltx2_vae_config;
+
+int ltx2_vae_create(const ltx2_vae_config* cfg, ltx2_vae** out);
+void ltx2_vae_destroy(ltx2_vae* ctx);
+/* Names = checkpoint keys (simple_decoder.py:592-671).  conv weights: bf16 [Cout][27][Cin]
+ * (upsample convs row-permuted for the depth-to-space epilogue); linear weights bf16 [out,in];
+ * everything else fp32.                                                                       */
+int ltx2_vae_set_weight(ltx2_vae* ctx, const char* name, const void* ptr, int dtype, int64_t numel);
+/* value of the checkpoint scalar vae.decoder.timestep_scale_multiplier (default 1000) */
+int ltx2_vae_set_timestep_multiplier(ltx2_vae* ctx, float multiplier);
+int64_t ltx2_vae_workspace_bytes(const ltx2_vae* ctx, int T, int H, int W);
+int ltx2_vae_bind_workspace(ltx2_vae* ctx, void* ptr, int64_t bytes);
+/* latent fp32 [C][T][H][W] -> video fp32 [3][To][32H][32W] in [-1, 1].  timestep < 0 disables
+ * timestep conditioning for this call; noise (fp32, latent-shaped, N(0,1)) may be NULL (zeros). */
+int ltx2_vae_decode(ltx2_vae* ctx, const float* latent, int T, int H, int W, float timestep, const float* noise,
+                    int causal, float* video, void* stream);
+/* output frame count of one decode call for T latent frames */
+int ltx2_vae_out_frames(const ltx2_vae* ctx, int T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTX2HIP_H */

@@ -1,0 +1,131 @@
+"""ctypes binding of libltx2hip.so (C ABI declared in include/ltx2hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or a call is made
+without a GPU tensor, this module raises.  PyTorch is used only to own device memory and
+streams; every compute call goes through the C ABI with raw device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libltx2hip.so")
+
+OK, E_INVALID, E_HIP, E_STATE = 0, -1, -2, -3
+DTYPE_BF16, DTYPE_F32 = 0, 1
+EPI_BF16, EPI_GELU_BF16, EPI_SILU_BF16, EPI_F32, EPI_RESID_GATE_F32, EPI_ADD_BF16 = range(6)
+VAE_RES, VAE_UPSAMPLE = 0, 1
+VAE_MAX_BLOCKS = 16
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class DitConfig(C.Structure):
+    _fields_ = [("num_layers", i32), ("num_heads", i32), ("head_dim", i32), ("in_channels", i32),
+                ("out_channels", i32), ("caption_channels", i32), ("norm_eps", f32), ("timestep_scale", f32)]
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [("n_blocks", i32), ("kind", i32 * VAE_MAX_BLOCKS), ("num_layers", i32 * VAE_MAX_BLOCKS),
+                ("stride", (i32 * 3) * VAE_MAX_BLOCKS), ("multiplier", i32 * VAE_MAX_BLOCKS),
+                ("residual", i32 * VAE_MAX_BLOCKS), ("base_channels", i32), ("latent_channels", i32),
+                ("timestep_conditioning", i32), ("decode_noise_scale", f32)]
+
+
+# name -> (restype, argtypes); every symbol of include/ltx2hip.h
+SIGNATURES = {
+    "ltx2_last_error": (C.c_char_p, []),
+    "ltx2_abi_version": (i32, []),
+    "ltx2_gemm_bf16": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp, i64, vp]),
+    "ltx2_gemv_f32": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "ltx2_conv3d_fused": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
+    "ltx2_adaln_rmsnorm": (i32, [vp, i64, vp, i64, i32, i32, f32, i32, vp, vp, vp, vp, i64, vp]),
+    "ltx2_qknorm_rope": (i32, [vp, i64, i32, i32, i32, i32, vp, i32, vp, f32, vp, vp, vp]),
+    "ltx2_vt_transpose": (i32, [vp, i64, vp, i32, i32, i32, vp]),
+    "ltx2_flash_attn": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, f32, vp]),
+    "ltx2_timestep_sinusoid": (i32, [vp, i64, f32, i32, i32, vp, vp, vp]),
+    "ltx2_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
+    "ltx2_x0_from_velocity": (i32, [vp, vp, vp, i64, f32, vp, i32, i32, vp]),
+    "ltx2_euler_step": (i32, [vp, vp, vp, vp, f32, f32, vp, i32, i32, vp]),
+    "ltx2_vae_prepare_latent": (i32, [vp, vp, vp, vp, f32, vp, i32, i64, vp]),
+    "ltx2_pixnorm_mod_silu": (i32, [vp, vp, i64, i32, f32, vp, vp, i32, i32, vp]),
+    "ltx2_vae_unpatchify": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ltx2_video_to_uint8": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ltx2_dit_create": (i32, [C.POINTER(DitConfig), C.POINTER(vp)]),
+    "ltx2_dit_destroy": (None, [vp]),
+    "ltx2_dit_set_weight": (i32, [vp, C.c_char_p, vp, i32, i64]),
+    "ltx2_dit_workspace_bytes": (i64, [vp, i32, i32, i32]),
+    "ltx2_dit_bind_workspace": (i32, [vp, vp, i64, i32, i32, i32]),
+    "ltx2_dit_prepare": (i32, [vp, vp, i32, vp, vp, vp]),
+    "ltx2_dit_forward": (i32, [vp, vp, vp, i32, vp, vp]),
+    "ltx2_dit_denoise_step": (i32, [vp, vp, vp, i32, vp, vp, f32, f32, vp, vp]),
+    "ltx2_dit_graph_capture": (i32, [vp, vp, C.POINTER(f32), i32, vp]),
+    "ltx2_dit_graph_launch": (i32, [vp, vp]),
+    "ltx2_vae_create": (i32, [C.POINTER(VaeConfig), C.POINTER(vp)]),
+    "ltx2_vae_destroy": (None, [vp]),
+    "ltx2_vae_set_weight": (i32, [vp, C.c_char_p, vp, i32, i64]),
+    "ltx2_vae_set_timestep_multiplier": (i32, [vp, f32]),
+    "ltx2_vae_workspace_bytes": (i64, [vp, i32, i32, i32]),
+    "ltx2_vae_bind_workspace": (i32, [vp, vp, i64]),
+    "ltx2_vae_decode": (i32, [vp, vp, i32, i32, i32, f32, vp, i32, vp, vp]),
+    "ltx2_vae_out_frames": (i32, [vp, i32]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libltx2hip.so (once).  Fails loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C ltx-2-mlx_amd/csrc`). There is no CPU fallback for the hot path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)       # AttributeError if the ABI and the header drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def last_error() -> str:
+    return lib().ltx2_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map C-ABI status codes onto the exception types the reference raises (ValueError
+    for bad arguments such as sigma == 0; RuntimeError otherwise)."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(f"libltx2hip error {rc}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Raw device pointer of a contiguous CUDA(ROCm) tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libltx2hip operates on GPU tensors only (no CPU fallback)")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def exported_symbols() -> list:
+    return list(SIGNATURES.keys())

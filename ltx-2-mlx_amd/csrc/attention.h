@@ -1,0 +1,16 @@
+// Flash-attention forward (head_dim 128) + V^T re-layout: parameter block and host launchers.
+#pragma once
+#include "common.h"
+
+struct AttnParams {
+    const bf16* Q;   // [Nq][ldq], head h at columns h*128
+    const bf16* K;   // [Nkv][ldk], head h at columns h*128
+    const bf16* VT;  // [H][128][Npad], key-permuted (see vt_transpose_launch)
+    bf16* O;         // [Nq][ldo]
+    long ldq, ldk, ldo, vt_head_stride;
+    int Nq, Nkv, Npad, H;
+    float scale_log2e;  // (1/sqrt(d)) * log2(e)
+};
+
+int attn_launch(const AttnParams& p, hipStream_t stream);
+int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream);

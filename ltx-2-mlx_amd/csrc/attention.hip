@@ -1,0 +1,243 @@
+// Flash-attention forward (non-causal, no mask, head_dim 128) for gfx950 / CDNA4.
+//
+// Replaces mx.fast.scaled_dot_product_attention as called from the reference's
+// _compiled_attention_core_no_mask (LTX_2_MLX/model/transformer/attention.py:12-34):
+// out[q, h*128:(h+1)*128] = softmax(Q_h K_h^T / sqrt(128)) V_h, tokens-major (B=1, [T, H*d]).
+//
+// Design (v1):
+//  * block = 4 wave64 = 128 query rows of one head; KV tile = 64 keys; K tile [64][128] and
+//    V^T tile [128][64] double-buffered in LDS (64 KiB), staged with global_load_lds (16 B/lane)
+//    with the bank swizzle applied on the source address and again on the ds_read_b128.
+//  * "swapped" products so that every softmax statistic is lane-local:
+//      S^T[kv][q] = mfma(A = K frag, B = Q frag)   -> lane owns query column q = lane&31
+//      O^T[d][q]  = mfma(A = V^T frag, B = P frag) -> same owner; alpha/l need no broadcasts.
+//    The two lane halves (lane>>5) own complementary key subsets; row max is one xor-32 shuffle.
+//  * P never leaves registers: S^T's accumulator layout gives lane-half `hi`, k-step ks the keys
+//    {16ks+4hi+e, 16ks+8+4hi+e}; instead of permuting P across lanes, V^T is stored with exactly
+//    that key order inside every 32-key block (done once by vt_transpose_kernel), which makes the
+//    V^T fragment a single conflict-free 16-byte LDS read.
+//  * online softmax in the exp2 domain (scale * log2(e) folded into the scores), fp32 statistics.
+#include "attention.h"
+
+namespace {
+
+constexpr int QB = 128, KVB = 64, HD = 128;
+constexpr int K_TILE = KVB * HD * 2;           // 16 KiB, rows of 256 B
+constexpr int V_TILE = HD * KVB * 2;           // 16 KiB, rows of 128 B
+constexpr int STAGE = K_TILE + V_TILE;
+constexpr int LDS_BYTES = 2 * STAGE;
+
+__device__ __forceinline__ void glds16(const bf16* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void*)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int head = blockIdx.y;
+    const int q0 = blockIdx.x * QB + wv * 32;
+
+    // ---- Q fragments (B operand): Q[q0 + l31][16*ks + 8*hi .. +8], kept in registers ----
+    bf16x8 qf[8];
+    {
+        const int qrow = min(q0 + l31, p.Nq - 1);
+        const bf16* qp = p.Q + (long)qrow * p.ldq + head * HD + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+    }
+
+    // ---- staging addresses ----
+    const bf16* k_src[4];
+    const bf16* v_src[4];
+    int k_rowi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kr = (wv * 4 + j) * 4 + (lane >> 4);                 // 0..63
+        const int kchunk = (lane & 15) ^ (kr & 15);
+        k_rowi[j] = kr;
+        k_src[j] = p.K + head * HD + kchunk * 8;
+        const int vr = (wv * 4 + j) * 8 + (lane >> 3);                 // 0..127
+        const int vchunk = (lane & 7) ^ ((vr >> 1) & 7);
+        v_src[j] = p.VT + (long)head * p.vt_head_stride + (long)vr * p.Npad + vchunk * 8;
+    }
+    auto stage = [&](int t, int buf) {
+        char* sk = smem + buf * STAGE + wv * 4096;
+        char* sv = sk + K_TILE;
+        const int kv0 = t * KVB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kr = min(kv0 + k_rowi[j], p.Nkv - 1);
+            glds16(k_src[j] + (long)kr * p.ldk, sk + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(v_src[j] + kv0, sv + j * 1024);
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int k_xor = l31 & 15;
+    const int v_xor = (l31 >> 1) & 7;
+    const int nt = (p.Nkv + KVB - 1) / KVB;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        const char* ks_base = smem + (t & 1) * STAGE;
+        const char* vs_base = ks_base + K_TILE;
+
+        // ---- S^T = K . Q^T  (two 32-key blocks) ----
+        f32x16 s[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+            const char* krow = ks_base + (b * 32 + l31) * 256;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(krow + (((2 * ks + hi) ^ k_xor) << 4));
+                s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[b], 0, 0, 0);
+            }
+        }
+        // ---- scale, mask the ragged tail, running max ----
+        const int kv0 = t * KVB;
+        const bool tail = (kv0 + KVB > p.Nkv);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[b][r] * p.scale_log2e;
+                if (tail) {
+                    const int kv = kv0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (kv >= p.Nkv) v = -INFINITY;
+                }
+                s[b][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = exp2f(m_run - m_new);     // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(s[b][r] - m_new);
+                psum += pv;
+                pf[b][r >> 3][r & 7] = f2bf(pv);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const char* vrow = vs_base + (d * 32 + l31) * 128;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const bf16x8 vf = *(const bf16x8*)(vrow + (((4 * b + 2 * k2 + hi) ^ v_xor) << 4));
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][k2], o[d], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- finalize: lane owns query q0+l31, dims d*32 + (r&3) + 8*(r>>2) + 4*hi ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + l31;
+    if (qrow < p.Nq) {
+        bf16* op = p.O + (long)qrow * p.ldo + head * HD + 4 * hi;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = f2bf(o[d][g * 4 + e] * inv);
+                *(bf16x4*)(op + d * 32 + g * 8) = v;
+            }
+    }
+}
+
+// V [Nkv][ld] (head h at columns voff + h*128) -> VT[h][128][Npad] with the key permutation
+// pos(kv = 32b + 8g + 4hi + e) = 32b + 16(g>>1) + 8hi + 4(g&1) + e ; keys >= Nkv are zero-filled.
+__global__ __launch_bounds__(256) void vt_transpose_kernel(const bf16* __restrict__ V, long ld, bf16* __restrict__ VT,
+                                                           int Nkv, int Npad, long head_stride) {
+    __shared__ bf16 tile[64][HD + 2];
+    const int head = blockIdx.y, kv0 = blockIdx.x * 64, tid = threadIdx.x;
+    // load 64 keys x 128 dims: thread -> (row = tid/4 .. , 32 dims each) as 4 x 16-B
+    {
+        const int r = tid >> 2, c0 = (tid & 3) * 32;
+        const int kv = kv0 + r;
+        if (kv < Nkv) {
+            const bf16* src = V + (long)kv * ld + head * HD + c0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 v = *(const bf16x8*)(src + i * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tile[r][c0 + i * 8 + e] = v[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) tile[r][c0 + i] = f2bf(0.f);
+        }
+    }
+    __syncthreads();
+    // store: thread -> (d = tid/2, 32 permuted key slots) as 4 x 16-B
+    {
+        const int d = tid >> 1, p0 = (tid & 1) * 32;
+        bf16* dst = VT + (long)head * head_stride + (long)d * Npad + kv0 + p0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int pos = i * 8 + e;                       // position within the 32-block
+                const int ks = pos >> 4, hh = (pos >> 3) & 1, g0 = (pos >> 2) & 1, ee = pos & 3;
+                const int kvl = 8 * (2 * ks + g0) + 4 * hh + ee; // inverse of pos()
+                v[e] = tile[p0 + kvl][d];
+            }
+            *(bf16x8*)(dst + i * 8) = v;
+        }
+    }
+}
+
+}  // namespace
+
+int attn_launch(const AttnParams& p, hipStream_t stream) {
+    LTX2_CHECK_ARG(p.Nq > 0 && p.Nkv > 0 && p.H > 0, "attention: empty problem");
+    LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
+    LTX2_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid((p.Nq + QB - 1) / QB, p.H);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), LDS_BYTES, stream, p);
+    LTX2_CHECK_LAUNCH("attn_fwd_kernel");
+    return LTX2_OK;
+}
+
+int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream) {
+    LTX2_CHECK_ARG(Npad % 64 == 0 && Npad >= Nkv && ld % 8 == 0, "vt_transpose: bad strides");
+    dim3 grid(Npad / 64, H);
+    hipLaunchKernelGGL(vt_transpose_kernel, grid, dim3(256), 0, stream, V, ld, VT, Nkv, Npad, (long)HD * Npad);
+    LTX2_CHECK_LAUNCH("vt_transpose_kernel");
+    return LTX2_OK;
+}

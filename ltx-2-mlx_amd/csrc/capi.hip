@@ -1,0 +1,142 @@
+// C ABI (include/ltx2hip.h): error channel + thin extern "C" wrappers over the kernel launchers.
+// The DiT / VAE engine entry points live in dit_engine.hip / vae_engine.hip.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/ltx2hip.h"
+#include "attention.h"
+#include "gemm.h"
+#include "rowops.h"
+
+static thread_local char g_err[512] = "";
+
+void ltx2_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* ltx2_last_error(void) { return g_err; }
+int ltx2_abi_version(void) { return 1; }
+
+int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M,
+                   int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table,
+                   const void* res, int64_t ldres, void* stream) {
+    LTX2_CHECK_ARG(epilogue >= 0 && epilogue <= LTX2_EPI_ADD_BF16, "gemm: epilogue %d out of range", epilogue);
+    LTX2_CHECK_ARG(epilogue != LTX2_EPI_ADD_BF16 || res, "gemm: epilogue ADD_BF16 needs res");
+    GemmParams p{};
+    p.A = (const bf16*)A;
+    p.lda = lda;
+    p.W = (const bf16*)W;
+    p.bias = bias;
+    p.out = out;
+    p.ldo = ldo;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.gate = gate;
+    p.gate_stride = gate_stride;
+    p.gate_table = gate_table;
+    p.res = (const bf16*)res;
+    p.ldres = ldres;
+    return gemm_launch(p, epilogue, false, (hipStream_t)stream);
+}
+
+int ltx2_gemv_f32(const float* a, int64_t lda, const void* W, const float* bias, float* out, int64_t ldo, int M,
+                  int N, int K, int act_in, int act_out, void* stream) {
+    LTX2_CHECK_ARG(a && W && out, "gemv: null operand");
+    return gemv_launch(a, lda, (const bf16*)W, bias, out, ldo, M, N, K, act_in, act_out, (hipStream_t)stream);
+}
+
+int ltx2_adaln_rmsnorm(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int D, float eps,
+                       int layer_norm, const float* scale_tab, const float* shift_tab, const float* scale_emb,
+                       const float* shift_emb, int64_t emb_stride, void* stream) {
+    LTX2_CHECK_ARG(x && out, "adaln_rmsnorm: null operand");
+    return norm_mod_launch(x, ldx, (bf16*)out, ldo, rows, D, eps, layer_norm, scale_tab, shift_tab, scale_emb, shift_emb,
+                           emb_stride, (hipStream_t)stream);
+}
+
+int ltx2_qknorm_rope(void* buf, int64_t ld, int rows, int D, int head_dim, int q_off, const float* q_weight,
+                     int k_off, const float* k_weight, float eps, const float* cos, const float* sin, void* stream) {
+    LTX2_CHECK_ARG(buf && q_weight, "qknorm_rope: null operand");
+    const int offs[2] = {q_off, k_off};
+    const float* wts[2] = {q_weight, k_weight};
+    return qknorm_rope_launch((bf16*)buf, ld, rows, D, head_dim, k_weight ? 2 : 1, offs, wts, eps, cos, sin,
+                              (hipStream_t)stream);
+}
+
+int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, int H, void* stream) {
+    LTX2_CHECK_ARG(V && VT, "vt_transpose: null operand");
+    return vt_transpose_launch((const bf16*)V, ld, (bf16*)VT, Nkv, Npad, H, (hipStream_t)stream);
+}
+
+int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
+                    int64_t ldo, int Nq, int Nkv, int H, float scale, void* stream) {
+    LTX2_CHECK_ARG(Q && K && VT && out, "flash_attn: null operand");
+    AttnParams a{};
+    a.Q = (const bf16*)Q;
+    a.ldq = ldq;
+    a.K = (const bf16*)K;
+    a.ldk = ldk;
+    a.VT = (const bf16*)VT;
+    a.vt_head_stride = 128L * Npad;
+    a.O = (bf16*)out;
+    a.ldo = ldo;
+    a.Nq = Nq;
+    a.Nkv = Nkv;
+    a.Npad = Npad;
+    a.H = H;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    return attn_launch(a, (hipStream_t)stream);
+}
+
+int ltx2_timestep_sinusoid(const float* t, int64_t t_stride, float mult, int T, int dim, float* out_f32,
+                           void* out_bf16, void* stream) {
+    LTX2_CHECK_ARG(t && (out_f32 || out_bf16), "timestep_sinusoid: null operand");
+    return timestep_sinusoid_launch(t, t_stride, 0.f, mult, T, dim, out_f32, (bf16*)out_bf16, (hipStream_t)stream);
+}
+
+int ltx2_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
+    LTX2_CHECK_ARG(in && out, "cast: null operand");
+    return cast_f32_bf16_launch(in, (bf16*)out, n, (hipStream_t)stream);
+}
+
+int ltx2_x0_from_velocity(const float* latent, const float* velocity, const float* ts_ptr, int64_t ts_stride,
+                          float ts_scalar, float* x0, int rows, int C, void* stream) {
+    LTX2_CHECK_ARG(latent && velocity && x0, "x0_from_velocity: null operand");
+    return x0_from_velocity_launch(latent, velocity, ts_ptr, ts_stride, ts_scalar, x0, rows, C, (hipStream_t)stream);
+}
+
+int ltx2_euler_step(const float* x, const float* x0, const float* mask, const float* clean, float sigma,
+                    float sigma_next, float* out, int rows, int C, void* stream) {
+    LTX2_CHECK_ARG(x && x0 && out, "euler_step: null operand");
+    return euler_step_launch(x, x0, mask, clean, sigma, sigma_next, out, rows, C, (hipStream_t)stream);
+}
+
+int ltx2_vae_prepare_latent(const float* latent, const float* std, const float* mean, const float* noise,
+                            float noise_scale, void* out_bf16, int C, int64_t P, void* stream) {
+    LTX2_CHECK_ARG(latent && std && mean && out_bf16, "vae_prepare_latent: null operand");
+    return vae_prepare_latent_launch(latent, std, mean, noise, noise_scale, (bf16*)out_bf16, C, P, (hipStream_t)stream);
+}
+
+int ltx2_pixnorm_mod_silu(const void* x, void* y, int64_t P, int C, float eps, const float* table, const float* te,
+                          int shift_row, int scale_row, void* stream) {
+    LTX2_CHECK_ARG(x && y && table, "pixnorm_mod_silu: null operand");
+    return pixnorm_mod_silu_launch((const bf16*)x, (bf16*)y, P, C, eps, table, te, shift_row, scale_row,
+                                   (hipStream_t)stream);
+}
+
+int ltx2_vae_unpatchify(const void* x, float* video, int T, int H, int W, void* stream) {
+    LTX2_CHECK_ARG(x && video, "vae_unpatchify: null operand");
+    return vae_unpatchify_launch((const bf16*)x, video, T, H, W, (hipStream_t)stream);
+}
+
+int ltx2_video_to_uint8(const float* video, uint8_t* frames, int T, int H, int W, void* stream) {
+    LTX2_CHECK_ARG(video && frames, "video_to_uint8: null operand");
+    return video_to_uint8_launch(video, frames, T, H, W, (hipStream_t)stream);
+}
+
+}  // extern "C"

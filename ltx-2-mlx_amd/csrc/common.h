@@ -1,0 +1,64 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels of the LTX-2 hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define LTX2_OK 0
+#define LTX2_E_INVALID (-1)    // bad argument / unsupported shape
+#define LTX2_E_HIP (-2)        // HIP runtime error
+#define LTX2_E_STATE (-3)      // call order / missing weight / workspace too small
+
+// thread-local last-error string, readable through ltx2_last_error()
+void ltx2_set_error(const char* fmt, ...);
+
+#define LTX2_CHECK_ARG(cond, ...)            \
+    do {                                     \
+        if (!(cond)) {                       \
+            ltx2_set_error(__VA_ARGS__);     \
+            return LTX2_E_INVALID;           \
+        }                                    \
+    } while (0)
+
+#define LTX2_CHECK_LAUNCH(name)                                                   \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            ltx2_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return LTX2_E_HIP;                                                    \
+        }                                                                         \
+    } while (0)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2u)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: consecutive logical ids land on the same
+// XCD (observed placement: hardware block b -> XCD b % 8), so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

@@ -1,0 +1,37 @@
+// bf16 MFMA GEMM / implicit-GEMM conv3d for gfx950: parameter block + host launchers.
+#pragma once
+#include "common.h"
+
+enum GemmEpilogue {
+    EPI_BF16 = 0,            // out_bf16 = acc + bias
+    EPI_GELU_BF16 = 1,       // out_bf16 = gelu_tanh(acc + bias)
+    EPI_SILU_BF16 = 2,       // out_bf16 = silu(acc + bias)
+    EPI_F32 = 3,             // out_f32  = acc + bias
+    EPI_RESID_GATE_F32 = 4,  // out_f32[m][n] += (gate[m*gate_stride+n] + gate_table[n]) * (acc + bias)
+    EPI_ADD_BF16 = 5,        // out_bf16 = acc + bias + res_bf16[m*ldres + n]
+    EPI_D2S_BF16 = 6,        // conv only: depth-to-space scatter (+ tiled d2s(x) residual)
+    EPI_COUNT = 7
+};
+
+struct GemmParams {
+    const bf16* A;       // dense: [M][lda];  conv: activations [T][H][W][Cin] (channels-last)
+    const bf16* W;       // [N][K]  (K contiguous; conv: K = tap*Cin + c, tap = (kt*3+kh)*3+kw)
+    const float* bias;   // [N] or null
+    void* out;           // bf16 or f32, [M][ldo]  (D2S: [To][Ho][Wo][Cf])
+    const float* gate;   // EPI_RESID_GATE_F32: per-row part  gate[m*gate_stride + n]  (may be null)
+    const float* gate_table;  // EPI_RESID_GATE_F32: broadcast part gate_table[n]  (may be null; both null -> 1)
+    const bf16* res;     // EPI_ADD_BF16
+    long lda, ldo, gate_stride, ldres;
+    int M, N, K;
+    // conv geometry (implicit GEMM): M = T*H*Wd output positions, stride 1, 3x3x3
+    int T, H, Wd, Cin, cin_shift, pad_front;
+    // depth-to-space epilogue: column n = s*Cf + c, s = (a*fh + b)*fw + d
+    int ft, fh, fw, Cf, cf_shift, drop_first, d2s_residual, c_d2s;
+};
+
+int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream);
+
+// Skinny path (M <= 16 rows, fp32 activations, bf16 weights): out_f32 = act_out(in_act(a) @ W^T + b)
+// act codes: 0 none, 1 silu, 2 gelu_tanh
+int gemv_launch(const float* a, long lda, const bf16* W, const float* bias, float* out, long ldo,
+                int M, int N, int K, int in_act, int out_act, hipStream_t stream);

@@ -1,0 +1,45 @@
+// HBM-bound row / elementwise kernels of the DiT step and the VAE decoder: host launchers.
+#pragma once
+#include "common.h"
+
+// out_bf16[row][:] = norm(x_f32[row][:]) * (1 + scale) + shift
+//   norm  = RMS (layer_norm == 0) or mean-centred LayerNorm without affine (layer_norm == 1)
+//   scale = scale_tab[d] + scale_emb[row*emb_stride + d]   (either pointer may be null -> 0)
+//   shift = shift_tab[d] + shift_emb[row*emb_stride + d]
+// all four null -> plain normalisation.
+int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int D, float eps, int layer_norm,
+                    const float* scale_tab, const float* shift_tab, const float* scale_emb, const float* shift_emb,
+                    long emb_stride, hipStream_t stream);
+
+// In-place on bf16 rows: for each of nseg segments (q, k) at column offsets seg_off[i] of width D:
+//   y = x * rsqrt(mean(x^2) + eps) * weight_i ;  then (if cos != null) SPLIT RoPE per head:
+//   pairs (h*hd + j, h*hd + hd/2 + j) rotated with cos/sin[row][h*hd/2 + j].
+int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off,
+                       const float* const* weights, float eps, const float* cos, const float* sin, hipStream_t stream);
+
+// [cos | sin] sinusoid of reference get_timestep_embedding(flip_sin_to_cos=True, shift=0), dim 256.
+// t_scaled = (t ? t[i*t_stride] : t_scalar) * mult.  Writes fp32 (out_f32) and/or bf16 (out_bf16) [T][dim].
+int timestep_sinusoid_launch(const float* t, long t_stride, float t_scalar, float mult, int T, int dim, float* out_f32,
+                             bf16* out_bf16, hipStream_t stream);
+
+int cast_f32_bf16_launch(const float* in, bf16* out, long n, hipStream_t stream);
+
+// x0[row][c] = latent[row][c] - ts(row) * vel[row][c]   (ts = ts_ptr[row*ts_stride] if ts_ptr else ts_scalar)
+int x0_from_velocity_launch(const float* latent, const float* vel, const float* ts_ptr, long ts_stride, float ts_scalar,
+                            float* x0, int rows, int C, hipStream_t stream);
+
+// x0' = mask ? x0*mask(row) + clean*(1-mask(row)) : x0 ;  out = x + (x - x0')/sigma * (sigma_next - sigma)
+int euler_step_launch(const float* x, const float* x0, const float* mask, const float* clean, float sigma,
+                      float sigma_next, float* out, int rows, int C, hipStream_t stream);
+
+// ---- VAE decoder elementwise ops (channels-last bf16 activations [P][C]) ----
+// latent fp32 NCTHW [C][P] -> bf16 [P][C]: v = latent*std[c] + mean[c]; if noise_scale>0: v = noise*ns + (1-ns)*v
+int vae_prepare_latent_launch(const float* latent, const float* std, const float* mean, const float* noise,
+                              float noise_scale, bf16* out, int C, long P, hipStream_t stream);
+// y = silu( x * rsqrt(mean_c(x^2)+eps) * (1 + scale) + shift ), scale/shift = tab[row_idx*C + c] (+ te[row_idx*C + c])
+int pixnorm_mod_silu_launch(const bf16* x, bf16* y, long P, int C, float eps, const float* tab, const float* te,
+                            int shift_row, int scale_row, hipStream_t stream);
+// conv_out [T][H][W][48] bf16 -> video fp32 [3][T][4H][4W]  (reference ops.unpatchify packing (c, r_w, r_h))
+int vae_unpatchify_launch(const bf16* x, float* video, int T, int H, int W, hipStream_t stream);
+// video fp32 [3][T][H][W] -> frames uint8 [T][H][W][3] = trunc(clip((v+1)/2,0,1)*255)
+int video_to_uint8_launch(const float* video, unsigned char* frames, int T, int H, int W, hipStream_t stream);

@@ -1,0 +1,384 @@
+// HBM-bound row / elementwise kernels for gfx950: AdaLN-RMSNorm, QK-RMSNorm + SPLIT RoPE,
+// timestep sinusoid, x0/Euler update, and the VAE decoder's norm/activation/layout glue.
+// All loads are 8/16-byte vectors; reductions use wave64 shuffles.
+//
+// Reference semantics restated (paths under /root/reference/LTX_2_MLX):
+//   norm_mod          model/transformer/transformer.py:16-31 (_compiled_adaln_forward),
+//                     attention.py:88-100 (rms_norm), model.py:744-758 (LayerNorm + shift/scale)
+//   qknorm_rope       attention.py:231-237 (q_norm/k_norm over the FULL inner dim),
+//                     rope.py:92-144 (apply_split_rotary_emb)
+//   timestep_sinusoid timestep_embedding.py:10-60 with flip_sin_to_cos=True, shift 0;
+//                     video_vae/simple_decoder.py:12-39
+//   x0 / euler        model.py:912-918; components/diffusion_steps.py:36-67; pipelines/common.py:169-190
+//   vae_*             video_vae/simple_decoder.py:339-342,228-238,492-498,528-553; ops.py:109-125
+#include "rowops.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__ x, long ldx, bf16* __restrict__ out,
+                                                       long ldo, int D, float eps, int layer_norm,
+                                                       const float* __restrict__ scale_tab,
+                                                       const float* __restrict__ shift_tab,
+                                                       const float* __restrict__ scale_emb,
+                                                       const float* __restrict__ shift_emb, long emb_stride) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const float* xr = x + row * ldx;
+    float s1 = 0.f, s2 = 0.f;
+    for (int d = threadIdx.x * 4; d < D; d += 1024) {
+        const float4 v = *(const float4*)(xr + d);
+        s1 += v.x + v.y + v.z + v.w;
+        s2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    float mean = 0.f;
+    if (layer_norm) mean = block_sum_256(s1, red) / (float)D;
+    const float ms = block_sum_256(s2, red) / (float)D;
+    const float var = layer_norm ? fmaxf(ms - mean * mean, 0.f) : ms;
+    const float rstd = rsqrtf(var + eps);
+    const float* se = scale_emb ? scale_emb + row * emb_stride : nullptr;
+    const float* he = shift_emb ? shift_emb + row * emb_stride : nullptr;
+    bf16* orow = out + row * ldo;
+    for (int d = threadIdx.x * 4; d < D; d += 1024) {
+        const float4 v = *(const float4*)(xr + d);
+        float xs[4] = {v.x, v.y, v.z, v.w};
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sc = 0.f, sh = 0.f;
+            if (scale_tab) sc += scale_tab[d + e];
+            if (se) sc += se[d + e];
+            if (shift_tab) sh += shift_tab[d + e];
+            if (he) sh += he[d + e];
+            o[e] = f2bf((xs[e] - mean) * rstd * (1.f + sc) + sh);
+        }
+        *(bf16x4*)(orow + d) = o;
+    }
+}
+
+struct QKSegs {
+    int off[2];
+    const float* w[2];
+};
+
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16* __restrict__ buf, long ld, int D, int head_dim, int nseg,
+                                                          QKSegs segs, float eps, const float* __restrict__ cosp,
+                                                          const float* __restrict__ sinp) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const int half = head_dim >> 1;
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+        bf16* xr = buf + row * ld + segs.off[sgi];
+        const float* wt = segs.w[sgi];
+        float s2 = 0.f;
+        for (int d = threadIdx.x * 8; d < D; d += 2048) {
+            const bf16x8 v = *(const bf16x8*)(xr + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf2f(v[e]);
+                s2 += f * f;
+            }
+        }
+        const float rstd = rsqrtf(block_sum_256(s2, red) / (float)D + eps);
+        // pairs p in [0, D/2): a = (p/half)*head_dim + p%half, b = a + half ; 8 consecutive pairs per thread
+        for (int p0 = threadIdx.x * 8; p0 < D / 2; p0 += 2048) {
+            const int ia = (p0 / half) * head_dim + (p0 % half);
+            const int ib = ia + half;
+            const bf16x8 va = *(const bf16x8*)(xr + ia);
+            const bf16x8 vb = *(const bf16x8*)(xr + ib);
+            bf16x8 oa, ob;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = bf2f(va[e]) * rstd * wt[ia + e];
+                const float b = bf2f(vb[e]) * rstd * wt[ib + e];
+                if (cosp) {
+                    const float c = cosp[row * (D / 2) + p0 + e];
+                    const float s = sinp[row * (D / 2) + p0 + e];
+                    oa[e] = f2bf(a * c - b * s);
+                    ob[e] = f2bf(b * c + a * s);
+                } else {
+                    oa[e] = f2bf(a);
+                    ob[e] = f2bf(b);
+                }
+            }
+            *(bf16x8*)(xr + ia) = oa;
+            *(bf16x8*)(xr + ib) = ob;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void timestep_sinusoid_kernel(const float* __restrict__ t, long t_stride, float t_scalar, float mult, int T,
+                                         int dim, float* __restrict__ of, bf16* __restrict__ ob) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim >> 1;
+    if (idx >= T * half) return;
+    const int row = idx / half, i = idx - row * half;
+    const float freq = __expf(-9.210340371976184f * (float)i / (float)half);   // ln(10000)
+    const float arg = (t ? t[row * t_stride] : t_scalar) * mult * freq;
+    const float c = cosf(arg), s = sinf(arg);
+    if (of) {
+        of[(long)row * dim + i] = c;
+        of[(long)row * dim + half + i] = s;
+    }
+    if (ob) {
+        ob[(long)row * dim + i] = f2bf(c);
+        ob[(long)row * dim + half + i] = f2bf(s);
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *(const float4*)(in + i);
+            bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+            *(bf16x4*)(out + i) = o;
+        } else {
+            for (long j = i; j < n; ++j) out[j] = f2bf(in[j]);
+        }
+    }
+}
+
+__global__ void x0_from_velocity_kernel(const float* __restrict__ latent, const float* __restrict__ vel,
+                                        const float* __restrict__ ts_ptr, long ts_stride, float ts_scalar,
+                                        float* __restrict__ x0, int rows, int C) {
+    const long n = (long)rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / C;
+        const float ts = ts_ptr ? ts_ptr[row * ts_stride] : ts_scalar;
+        x0[i] = latent[i] - ts * vel[i];
+    }
+}
+
+__global__ void euler_step_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+                                  const float* __restrict__ mask, const float* __restrict__ clean, float inv_sigma,
+                                  float dt, float* __restrict__ out, int rows, int C) {
+    const long n = (long)rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float d = x0[i];
+        if (mask) {
+            const float m = mask[i / C];
+            d = d * m + clean[i] * (1.f - m);
+        }
+        const float xv = x[i];
+        out[i] = xv + (xv - d) * inv_sigma * dt;
+    }
+}
+
+// ---------------------------------- VAE glue ----------------------------------
+__global__ void vae_prepare_latent_kernel(const float* __restrict__ latent, const float* __restrict__ stdv,
+                                          const float* __restrict__ meanv, const float* __restrict__ noise,
+                                          float ns, bf16* __restrict__ out, int C, long P) {
+    // out[p][c] <- latent[c][p]; tile transpose through LDS (32 positions x 32 channels)
+    __shared__ float tile[32][33];
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k;
+        const long pp = p0 + tx;
+        float v = 0.f;
+        if (c < C && pp < P) {
+            v = latent[(long)c * P + pp] * stdv[c] + meanv[c];
+            if (ns > 0.f) v = (noise ? noise[(long)c * P + pp] : 0.f) * ns + (1.f - ns) * v;
+        }
+        tile[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const long pp = p0 + k;
+        const int c = c0 + tx;
+        if (c < C && pp < P) out[pp * C + c] = f2bf(tile[tx][k]);
+    }
+}
+
+// LP lanes per position, each lane owns C/LP contiguous channels (8 or 16).
+template <int E>
+__global__ __launch_bounds__(256) void pixnorm_mod_silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long P,
+                                                               int C, int lp_shift, float eps,
+                                                               const float* __restrict__ tab,
+                                                               const float* __restrict__ te, int shift_row,
+                                                               int scale_row) {
+    const int LP = 1 << lp_shift;
+    const long gthread = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long pos = gthread >> lp_shift;
+    const int sub = (int)(gthread & (LP - 1));
+    const bool active = pos < P;
+    const int c0 = sub * E;
+    float v[E];
+    float s2 = 0.f;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < E / 8; ++i) {
+            const bf16x8 t = *(const bf16x8*)(x + pos * C + c0 + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i * 8 + e] = bf2f(t[e]);
+                s2 += v[i * 8 + e] * v[i * 8 + e];
+            }
+        }
+    }
+    for (int o = LP >> 1; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    if (!active) return;
+    const float rstd = rsqrtf(s2 / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < E / 8; ++i) {
+        bf16x8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + i * 8 + e;
+            float sh = tab[shift_row * C + c], sc = tab[scale_row * C + c];
+            if (te) {
+                sh += te[shift_row * C + c];
+                sc += te[scale_row * C + c];
+            }
+            o8[e] = f2bf(silu_f(v[i * 8 + e] * rstd * (1.f + sc) + sh));
+        }
+        *(bf16x8*)(y + pos * C + c0 + i * 8) = o8;
+    }
+}
+
+__global__ void vae_unpatchify_kernel(const bf16* __restrict__ x, float* __restrict__ video, int T, int H, int W) {
+    // video[c][t][h*4+rh][w*4+rw] = x[t][h][w][c*16 + rw*4 + rh]
+    const int HO = H * 4, WO = W * 4;
+    const long n = (long)3 * T * HO * WO;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % WO);
+        long r = i / WO;
+        const int yo = (int)(r % HO);
+        r /= HO;
+        const int t = (int)(r % T);
+        const int c = (int)(r / T);
+        const int w = xo >> 2, rw = xo & 3, h = yo >> 2, rh = yo & 3;
+        video[i] = bf2f(x[(((long)t * H + h) * W + w) * 48 + c * 16 + rw * 4 + rh]);
+    }
+}
+
+__global__ void video_to_uint8_kernel(const float* __restrict__ video, unsigned char* __restrict__ frames, int T, int H,
+                                      int W) {
+    const long plane = (long)T * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = (video[c * plane + i] + 1.f) * 0.5f;
+            v = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
+            frames[i * 3 + c] = (unsigned char)v;
+        }
+    }
+}
+
+inline int grid_for(long n, int block, int cap = 4096) {
+    long g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int D, float eps, int layer_norm,
+                    const float* scale_tab, const float* shift_tab, const float* scale_emb, const float* shift_emb,
+                    long emb_stride, hipStream_t stream) {
+    LTX2_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "norm_mod: D, ldx, ldo must be multiples of 4");
+    hipLaunchKernelGGL(norm_mod_kernel, dim3(rows), dim3(256), 0, stream, x, ldx, out, ldo, D, eps, layer_norm,
+                       scale_tab, shift_tab, scale_emb, shift_emb, emb_stride);
+    LTX2_CHECK_LAUNCH("norm_mod_kernel");
+    return LTX2_OK;
+}
+
+int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off,
+                       const float* const* weights, float eps, const float* cos, const float* sin, hipStream_t stream) {
+    LTX2_CHECK_ARG(nseg >= 1 && nseg <= 2, "qknorm_rope: nseg must be 1 or 2");
+    LTX2_CHECK_ARG(head_dim % 16 == 0 && D % head_dim == 0 && ld % 8 == 0, "qknorm_rope: head_dim %% 16, D %% head_dim, ld %% 8");
+    LTX2_CHECK_ARG((cos == nullptr) == (sin == nullptr), "qknorm_rope: cos and sin must both be set or both null");
+    QKSegs s{};
+    for (int i = 0; i < nseg; ++i) {
+        LTX2_CHECK_ARG(seg_off[i] % 8 == 0 && weights[i], "qknorm_rope: bad segment");
+        s.off[i] = seg_off[i];
+        s.w[i] = weights[i];
+    }
+    hipLaunchKernelGGL(qknorm_rope_kernel, dim3(rows), dim3(256), 0, stream, buf, ld, D, head_dim, nseg, s, eps, cos, sin);
+    LTX2_CHECK_LAUNCH("qknorm_rope_kernel");
+    return LTX2_OK;
+}
+
+int timestep_sinusoid_launch(const float* t, long t_stride, float t_scalar, float mult, int T, int dim, float* out_f32,
+                             bf16* out_bf16, hipStream_t stream) {
+    LTX2_CHECK_ARG(T > 0 && dim % 2 == 0, "timestep_sinusoid: bad shape");
+    const int n = T * (dim / 2);
+    hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, t, t_stride, t_scalar, mult, T,
+                       dim, out_f32, out_bf16);
+    LTX2_CHECK_LAUNCH("timestep_sinusoid_kernel");
+    return LTX2_OK;
+}
+
+int cast_f32_bf16_launch(const float* in, bf16* out, long n, hipStream_t stream) {
+    LTX2_CHECK_ARG(n > 0, "cast: empty");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, stream, in, out, n);
+    LTX2_CHECK_LAUNCH("cast_f32_bf16_kernel");
+    return LTX2_OK;
+}
+
+int x0_from_velocity_launch(const float* latent, const float* vel, const float* ts_ptr, long ts_stride, float ts_scalar,
+                            float* x0, int rows, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(x0_from_velocity_kernel, dim3(grid_for((long)rows * C, 256)), dim3(256), 0, stream, latent, vel,
+                       ts_ptr, ts_stride, ts_scalar, x0, rows, C);
+    LTX2_CHECK_LAUNCH("x0_from_velocity_kernel");
+    return LTX2_OK;
+}
+
+int euler_step_launch(const float* x, const float* x0, const float* mask, const float* clean, float sigma,
+                      float sigma_next, float* out, int rows, int C, hipStream_t stream) {
+    LTX2_CHECK_ARG(sigma != 0.f, "Sigma can't be 0.0");   // reference core_utils.py:54-55
+    LTX2_CHECK_ARG((mask == nullptr) == (clean == nullptr), "euler_step: mask and clean go together");
+    hipLaunchKernelGGL(euler_step_kernel, dim3(grid_for((long)rows * C, 256)), dim3(256), 0, stream, x, x0, mask, clean,
+                       1.0f / sigma, sigma_next - sigma, out, rows, C);
+    LTX2_CHECK_LAUNCH("euler_step_kernel");
+    return LTX2_OK;
+}
+
+int vae_prepare_latent_launch(const float* latent, const float* std, const float* mean, const float* noise,
+                              float noise_scale, bf16* out, int C, long P, hipStream_t stream) {
+    dim3 grid((unsigned)((P + 31) / 32), (C + 31) / 32);
+    hipLaunchKernelGGL(vae_prepare_latent_kernel, grid, dim3(256), 0, stream, latent, std, mean, noise, noise_scale, out, C, P);
+    LTX2_CHECK_LAUNCH("vae_prepare_latent_kernel");
+    return LTX2_OK;
+}
+
+int pixnorm_mod_silu_launch(const bf16* x, bf16* y, long P, int C, float eps, const float* tab, const float* te,
+                            int shift_row, int scale_row, hipStream_t stream) {
+    LTX2_CHECK_ARG(C >= 64 && (C & (C - 1)) == 0 && C <= 1024, "pixnorm: C=%d must be a power of two in [64,1024]", C);
+    const int E = (C >= 1024) ? 16 : 8;
+    const int LP = C / E;
+    int lp_shift = 0;
+    while ((1 << lp_shift) < LP) ++lp_shift;
+    const long threads = P * LP;
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (E == 16)
+        hipLaunchKernelGGL((pixnorm_mod_silu_kernel<16>), dim3(grid), dim3(256), 0, stream, x, y, P, C, lp_shift, eps, tab, te, shift_row, scale_row);
+    else
+        hipLaunchKernelGGL((pixnorm_mod_silu_kernel<8>), dim3(grid), dim3(256), 0, stream, x, y, P, C, lp_shift, eps, tab, te, shift_row, scale_row);
+    LTX2_CHECK_LAUNCH("pixnorm_mod_silu_kernel");
+    return LTX2_OK;
+}
+
+int vae_unpatchify_launch(const bf16* x, float* video, int T, int H, int W, hipStream_t stream) {
+    const long n = (long)3 * T * H * 4 * W * 4;
+    hipLaunchKernelGGL(vae_unpatchify_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, video, T, H, W);
+    LTX2_CHECK_LAUNCH("vae_unpatchify_kernel");
+    return LTX2_OK;
+}
+
+int video_to_uint8_launch(const float* video, unsigned char* frames, int T, int H, int W, hipStream_t stream) {
+    const long n = (long)T * H * W;
+    hipLaunchKernelGGL(video_to_uint8_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, video, frames, T, H, W);
+    LTX2_CHECK_LAUNCH("video_to_uint8_kernel");
+    return LTX2_OK;
+}

@@ -1,0 +1,191 @@
+"""Tensor-level wrappers over the per-kernel C-ABI entry points (counterpart of the reference's
+LTX_2_MLX/kernels/ + the mx.fast.* / mx.conv2d leaf calls).  Used by the unit-parity tests and
+by host glue; the full DiT step and VAE pass go through the engine calls instead
+(ltx2_dit_* / ltx2_vae_*), which sequence the same kernels in C++.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as nv
+
+BF16 = torch.bfloat16
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = nv.EPI_BF16,
+         out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+         gate_table: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w bf16; bias/gate fp32."""
+    assert a.dtype == BF16 and w.dtype == BF16 and a.dim() == 2 and w.dim() == 2
+    a, w = _c(a), _c(w)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        odt = torch.float32 if epilogue in (nv.EPI_F32, nv.EPI_RESID_GATE_F32) else BF16
+        assert epilogue != nv.EPI_RESID_GATE_F32, "RESID_GATE accumulates into `out`; pass it"
+        out = torch.empty(M, N, device=a.device, dtype=odt)
+    gs = 0
+    if gate is not None:
+        gate = _c(gate)
+        gs = 0 if gate.shape[0] == 1 else gate.stride(0)
+    nv.check(nv.lib().ltx2_gemm_bf16(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
+                                     epilogue, nv.ptr(gate), gs, nv.ptr(gate_table), nv.ptr(res),
+                                     res.stride(0) if res is not None else 0, nv.stream()))
+    return out
+
+
+def gemv(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_in: int = 0, act_out: int = 0) -> torch.Tensor:
+    assert a.dtype == torch.float32 and w.dtype == BF16
+    a, w = _c(a), _c(w)
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    nv.check(nv.lib().ltx2_gemv_f32(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), N, M, N, K, act_in,
+                                    act_out, nv.stream()))
+    return out
+
+
+def conv_weight_to_engine(w: torch.Tensor, d2s_stride: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+    """PyTorch conv3d weight (Cout, Cin, 3, 3, 3) -> engine layout bf16 [Cout][27][Cin]
+    (tap = (kt*3+kh)*3+kw).  For depth-to-space convs the output rows are permuted from
+    ch = c*sp + s to n' = s*Cf + c so one contiguous channel run lands on one output voxel."""
+    cout, cin = w.shape[0], w.shape[1]
+    e = w.permute(0, 2, 3, 4, 1).reshape(cout, 27, cin)
+    if d2s_stride is not None:
+        sp = d2s_stride[0] * d2s_stride[1] * d2s_stride[2]
+        cf = cout // sp
+        e = e.reshape(cf, sp, 27, cin).permute(1, 0, 2, 3).reshape(cout, 27, cin)
+    return e.to(BF16).contiguous()
+
+
+def conv_bias_to_engine(b: torch.Tensor, d2s_stride: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+    if d2s_stride is not None:
+        sp = d2s_stride[0] * d2s_stride[1] * d2s_stride[2]
+        b = b.reshape(-1, sp).t().reshape(-1)
+    return b.float().contiguous()
+
+
+def conv3d(x: torch.Tensor, w_engine: torch.Tensor, bias: Optional[torch.Tensor], causal: bool = False, mode: int = 0,
+           res: Optional[torch.Tensor] = None, stride: Tuple[int, int, int] = (1, 1, 1), residual: bool = False) -> torch.Tensor:
+    """x bf16 [T,H,W,Cin] channels-last; w_engine from conv_weight_to_engine."""
+    assert x.dtype == BF16 and x.dim() == 4 and w_engine.dtype == BF16
+    x = _c(x)
+    T, H, W, Cin = x.shape
+    Cout = w_engine.shape[0]
+    ft, fh, fw = stride
+    if mode == 2:
+        sp = ft * fh * fw
+        out = torch.empty(T * ft - (1 if ft > 1 else 0), H * fh, W * fw, Cout // sp, device=x.device, dtype=BF16)
+    else:
+        out = torch.empty(T, H, W, Cout, device=x.device, dtype=BF16)
+    nv.check(nv.lib().ltx2_conv3d_fused(nv.ptr(x), nv.ptr(w_engine), nv.ptr(bias), nv.ptr(out), T, H, W, Cin, Cout,
+                                        int(causal), mode, nv.ptr(res), ft, fh, fw, int(residual), nv.stream()))
+    return out
+
+
+def adaln_rmsnorm(x: torch.Tensor, eps: float = 1e-6, layer_norm: bool = False,
+                  scale_tab: Optional[torch.Tensor] = None, shift_tab: Optional[torch.Tensor] = None,
+                  scale_emb: Optional[torch.Tensor] = None, shift_emb: Optional[torch.Tensor] = None,
+                  emb_stride: int = 0) -> torch.Tensor:
+    assert x.dtype == torch.float32 and x.dim() == 2
+    x = _c(x)
+    rows, D = x.shape
+    out = torch.empty(rows, D, device=x.device, dtype=BF16)
+    nv.check(nv.lib().ltx2_adaln_rmsnorm(nv.ptr(x), D, nv.ptr(out), D, rows, D, eps, int(layer_norm), nv.ptr(scale_tab),
+                                         nv.ptr(shift_tab), nv.ptr(scale_emb), nv.ptr(shift_emb), emb_stride, nv.stream()))
+    return out
+
+
+def qknorm_rope_(buf: torch.Tensor, D: int, head_dim: int, q_off: int, q_weight: torch.Tensor,
+                 k_off: int = 0, k_weight: Optional[torch.Tensor] = None, eps: float = 1e-6,
+                 cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert buf.dtype == BF16 and buf.dim() == 2 and buf.is_contiguous()
+    nv.check(nv.lib().ltx2_qknorm_rope(nv.ptr(buf), buf.stride(0), buf.shape[0], D, head_dim, q_off, nv.ptr(q_weight),
+                                       k_off, nv.ptr(k_weight), eps, nv.ptr(cos), nv.ptr(sin), nv.stream()))
+    return buf
+
+
+def vt_transpose(v: torch.Tensor, heads: int) -> torch.Tensor:
+    """v bf16 [Nkv, >= heads*128] (a strided column view is fine) -> VT [H,128,Npad]."""
+    assert v.dtype == BF16 and v.dim() == 2 and v.stride(1) == 1
+    nkv = v.shape[0]
+    npad = (nkv + 63) // 64 * 64
+    vt = torch.empty(heads, 128, npad, device=v.device, dtype=BF16)
+    nv.check(nv.lib().ltx2_vt_transpose(nv.ptr(v), v.stride(0), nv.ptr(vt), nkv, npad, heads, nv.stream()))
+    return vt
+
+
+def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int,
+               scale: Optional[float] = None) -> torch.Tensor:
+    """q [Nq, H*128], k [Nkv, H*128] bf16 (row-strided views allowed), vt from vt_transpose."""
+    assert q.dtype == BF16 and k.dtype == BF16 and vt.dtype == BF16 and q.stride(1) == 1 and k.stride(1) == 1
+    nq = q.shape[0]
+    out = torch.empty(nq, heads * 128, device=q.device, dtype=BF16)
+    if scale is None:
+        scale = 1.0 / math.sqrt(128.0)
+    nv.check(nv.lib().ltx2_flash_attn(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out),
+                                      out.stride(0), nq, nkv, heads, scale, nv.stream()))
+    return out
+
+
+def timestep_sinusoid(t: torch.Tensor, mult: float, dim: int = 256) -> torch.Tensor:
+    t = _c(t.float())
+    out = torch.empty(t.numel(), dim, device=t.device, dtype=torch.float32)
+    nv.check(nv.lib().ltx2_timestep_sinusoid(nv.ptr(t), 1, mult, t.numel(), dim, nv.ptr(out), None, nv.stream()))
+    return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    x = _c(x.float())
+    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    nv.check(nv.lib().ltx2_cast_f32_bf16(nv.ptr(x), nv.ptr(out), x.numel(), nv.stream()))
+    return out
+
+
+def x0_from_velocity(latent: torch.Tensor, velocity: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+    """latent/velocity fp32 [N,C]; timesteps fp32 with 1 or N elements."""
+    latent, velocity, timesteps = _c(latent), _c(velocity), _c(timesteps.float())
+    n, c = latent.shape
+    out = torch.empty_like(latent)
+    stride = 0 if timesteps.numel() == 1 else 1
+    nv.check(nv.lib().ltx2_x0_from_velocity(nv.ptr(latent), nv.ptr(velocity), nv.ptr(timesteps), stride, 0.0, nv.ptr(out),
+                                            n, c, nv.stream()))
+    return out
+
+
+def euler_step(x: torch.Tensor, x0: torch.Tensor, sigma: float, sigma_next: float,
+               mask: Optional[torch.Tensor] = None, clean: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x, x0 = _c(x), _c(x0)
+    n, c = x.shape
+    out = torch.empty_like(x)
+    nv.check(nv.lib().ltx2_euler_step(nv.ptr(x), nv.ptr(x0), nv.ptr(mask), nv.ptr(clean), float(sigma), float(sigma_next),
+                                      nv.ptr(out), n, c, nv.stream()))
+    return out
+
+
+def pixnorm_mod_silu(x: torch.Tensor, table: torch.Tensor, te: Optional[torch.Tensor], shift_row: int, scale_row: int,
+                     eps: float = 1e-6) -> torch.Tensor:
+    assert x.dtype == BF16
+    x = _c(x)
+    C_ = x.shape[-1]
+    P = x.numel() // C_
+    y = torch.empty_like(x)
+    nv.check(nv.lib().ltx2_pixnorm_mod_silu(nv.ptr(x), nv.ptr(y), P, C_, eps, nv.ptr(table), nv.ptr(te), shift_row,
+                                            scale_row, nv.stream()))
+    return y
+
+
+def video_to_uint8(video: torch.Tensor) -> torch.Tensor:
+    """video fp32 [3,T,H,W] -> uint8 [T,H,W,3] (reference simple_decoder.py:792-798)."""
+    video = _c(video.float())
+    _, T, H, W = video.shape
+    out = torch.empty(T, H, W, 3, device=video.device, dtype=torch.uint8)
+    nv.check(nv.lib().ltx2_video_to_uint8(nv.ptr(video), nv.ptr(out), T, H, W, nv.stream()))
+    return out

@@ -1,0 +1,270 @@
+"""Per-kernel parity: HIP kernel (through the C ABI) vs the CPU oracle / plain fp32 torch on the
+same seeded inputs.  Tolerances are for bf16 operands with fp32 accumulation."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def q(t):
+    """Round to bf16 and back, so the fp32 reference sees exactly the kernel's operands."""
+    return t.to(BF).float()
+
+
+@pytest.fixture(scope="module")
+def K(dev):
+    import ltx_2_mlx_amd.kernels as k
+    return k
+
+
+@pytest.mark.parametrize("M,N,Kd", [(128, 128, 64), (256, 384, 256), (288, 768, 1024), (3456, 4096, 128), (100, 128, 192), (37, 48, 128)])
+def test_gemm_bias(K, dev, M, N, Kd):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = q(torch.randn(M, Kd, generator=g))
+    w = q(torch.randn(N, Kd, generator=g) / math.sqrt(Kd))
+    b = torch.randn(N, generator=g)
+    ref = a @ w.t() + b
+    out = K.gemm(a.to(dev, BF), w.to(dev, BF), b.to(dev), epilogue=3)   # fp32 out
+    assert rel_l2(out.cpu(), ref) < 2e-3
+    # asymmetric-operand transpose check: distinct row/col patterns
+    out_bf = K.gemm(a.to(dev, BF), w.to(dev, BF), b.to(dev), epilogue=0)
+    assert rel_l2(out_bf.float().cpu(), ref) < 6e-3
+
+
+def test_gemm_epilogues(K, dev):
+    from ltx_2_mlx_amd import _native as nv
+    g = torch.Generator().manual_seed(5)
+    M, N, Kd = 200, 256, 320
+    a = q(torch.randn(M, Kd, generator=g))
+    w = q(torch.randn(N, Kd, generator=g) / math.sqrt(Kd))
+    b = torch.randn(N, generator=g)
+    lin = a @ w.t() + b
+    A, W, B = a.to(dev, BF), w.to(dev, BF), b.to(dev)
+    assert rel_l2(K.gemm(A, W, B, epilogue=nv.EPI_GELU_BF16).float().cpu(), F.gelu(lin, approximate="tanh")) < 8e-3
+    assert rel_l2(K.gemm(A, W, B, epilogue=nv.EPI_SILU_BF16).float().cpu(), F.silu(lin)) < 8e-3
+    # residual + gate accumulate: per-row gate + table, broadcast gate, no gate
+    x0 = torch.randn(M, N, generator=g)
+    gate = torch.randn(M, N, generator=g)
+    tab = torch.randn(N, generator=g)
+    x = x0.clone().to(dev)
+    K.gemm(A, W, B, epilogue=nv.EPI_RESID_GATE_F32, out=x, gate=gate.to(dev), gate_table=tab.to(dev))
+    assert rel_l2(x.cpu(), x0 + (gate + tab) * lin) < 3e-3
+    x = x0.clone().to(dev)
+    K.gemm(A, W, B, epilogue=nv.EPI_RESID_GATE_F32, out=x, gate=gate[:1].contiguous().to(dev), gate_table=tab.to(dev))
+    assert rel_l2(x.cpu(), x0 + (gate[:1] + tab) * lin) < 3e-3
+    x = x0.clone().to(dev)
+    K.gemm(A, W, B, epilogue=nv.EPI_RESID_GATE_F32, out=x)
+    assert rel_l2(x.cpu(), x0 + lin) < 3e-3
+    res = q(torch.randn(M, N, generator=g))
+    o = K.gemm(A, W, B, epilogue=nv.EPI_ADD_BF16, res=res.to(dev, BF))
+    assert rel_l2(o.float().cpu(), lin + res) < 8e-3
+
+
+def test_gemm_rejects_bad_k(K, dev):
+    a = torch.zeros(8, 72, device=dev, dtype=BF)
+    w = torch.zeros(128, 72, device=dev, dtype=BF)
+    with pytest.raises(ValueError):
+        K.gemm(a, w)
+
+
+@pytest.mark.parametrize("M", [1, 3, 9])
+def test_gemv(K, dev, M):
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, 512, generator=g)
+    w = q(torch.randn(300, 512, generator=g) / 20)
+    b = torch.randn(300, generator=g)
+    ref = F.silu(F.silu(a) @ w.t() + b)
+    out = K.gemv(a.to(dev), w.to(dev, BF), b.to(dev), act_in=1, act_out=1)
+    assert rel_l2(out.cpu(), ref) < 1e-4
+
+
+@pytest.mark.parametrize("rows,D", [(5, 256), (288, 4096)])
+def test_adaln_rmsnorm(K, dev, rows, D):
+    from oracle import dit
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, D, generator=g) * 3
+    tab = 0.1 * torch.randn(6, D, generator=g)
+    emb = 0.1 * torch.randn(rows, 6, D, generator=g)
+    # per-token modulation
+    ref = dit.adaln_forward(x, tab[1] + emb[:, 1], tab[0] + emb[:, 0], 1e-6)
+    e = emb.to(dev).contiguous()
+    t = tab.to(dev).contiguous()
+    out = K.adaln_rmsnorm(x.to(dev), scale_tab=t[1], shift_tab=t[0], scale_emb=e[:, 1], shift_emb=e[:, 0], emb_stride=6 * D)
+    assert rel_l2(out.float().cpu(), ref) < 4e-3
+    # broadcast modulation (stride 0) and plain rms
+    ref = dit.adaln_forward(x, tab[1] + emb[0, 1], tab[0] + emb[0, 0], 1e-6)
+    out = K.adaln_rmsnorm(x.to(dev), scale_tab=t[1], shift_tab=t[0], scale_emb=e[0, 1], shift_emb=e[0, 0], emb_stride=0)
+    assert rel_l2(out.float().cpu(), ref) < 4e-3
+    assert rel_l2(K.adaln_rmsnorm(x.to(dev)).float().cpu(), dit.rms_norm(x)) < 4e-3
+    # LayerNorm (output head)
+    ref = F.layer_norm(x, (D,), eps=1e-6) * (1 + tab[1]) + tab[0]
+    out = K.adaln_rmsnorm(x.to(dev), layer_norm=True, scale_tab=t[1], shift_tab=t[0])
+    assert rel_l2(out.float().cpu(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("heads,f,h,w", [(2, 3, 4, 4), (32, 2, 3, 5)])
+def test_qknorm_rope(K, dev, heads, f, h, w):
+    from oracle import dit, loop
+    D = heads * 128
+    N = f * h * w
+    g = torch.Generator().manual_seed(heads)
+    qkv = q(torch.randn(N, 3 * D, generator=g))
+    wq = 1 + 0.1 * torch.randn(D, generator=g)
+    wk = 1 + 0.1 * torch.randn(D, generator=g)
+    pos = loop.video_positions(1, f, h, w, 24.0)
+    cos, sin = dit.rope_split_tables(pos, D, heads, 10000.0, [20, 2048, 2048])
+    rq = dit.apply_split_rope(dit.rms_norm(qkv[None, :, :D], wq), cos, sin)[0]
+    rk = dit.apply_split_rope(dit.rms_norm(qkv[None, :, D:2 * D], wk), cos, sin)[0]
+    # token-major tables [N, D/2]: slot h*64 + j
+    cos_t = cos[0].permute(1, 0, 2).reshape(N, D // 2).contiguous().to(dev)
+    sin_t = sin[0].permute(1, 0, 2).reshape(N, D // 2).contiguous().to(dev)
+    buf = qkv.to(dev, BF).contiguous()
+    K.qknorm_rope_(buf, D, 128, 0, wq.to(dev), D, wk.to(dev), 1e-6, cos_t, sin_t)
+    assert rel_l2(buf[:, :D].float().cpu(), rq) < 6e-3
+    assert rel_l2(buf[:, D:2 * D].float().cpu(), rk) < 6e-3
+    assert torch.equal(buf[:, 2 * D:].cpu(), qkv[:, 2 * D:].to(BF))        # v untouched
+    # no-rope, single segment
+    buf = qkv[:, :D].to(dev, BF).contiguous()
+    K.qknorm_rope_(buf, D, 128, 0, wq.to(dev))
+    assert rel_l2(buf.float().cpu(), dit.rms_norm(qkv[:, :D], wq)) < 6e-3
+
+
+@pytest.mark.parametrize("heads,Nq,Nkv", [(2, 128, 64), (2, 288, 288), (3, 100, 37), (32, 288, 1024), (2, 130, 3456)])
+def test_flash_attn(K, dev, heads, Nq, Nkv):
+    from oracle import dit
+    D = heads * 128
+    g = torch.Generator().manual_seed(Nq + Nkv)
+    qq = q(torch.randn(Nq, D, generator=g))
+    kk = q(torch.randn(Nkv, D, generator=g))
+    vv = q(torch.randn(Nkv, D, generator=g))
+    ref = dit.sdpa(qq[None], kk[None], vv[None], heads)[0]
+    vt = K.vt_transpose(vv.to(dev, BF), heads)
+    out = K.flash_attn(qq.to(dev, BF), kk.to(dev, BF), vt, heads, Nkv)
+    assert rel_l2(out.float().cpu(), ref) < 1e-2
+
+
+def test_flash_attn_forced_rescale(K, dev):
+    """Spike one key against one query at a late tile so the running max jumps mid-stream."""
+    from oracle import dit
+    heads, Nq, Nkv = 1, 64, 512
+    g = torch.Generator().manual_seed(0)
+    qq = q(torch.randn(Nq, 128, generator=g))
+    kk = q(torch.randn(Nkv, 128, generator=g))
+    vv = q(torch.randn(Nkv, 128, generator=g))
+    kk[300] = qq[7] * 4.0
+    kk[301] = qq[33] * 6.0
+    kk = q(kk)
+    ref = dit.sdpa(qq[None], kk[None], vv[None], heads)[0]
+    vt = K.vt_transpose(vv.to(dev, BF), heads)
+    out = K.flash_attn(qq.to(dev, BF), kk.to(dev, BF), vt, heads, Nkv)
+    assert rel_l2(out.float().cpu(), ref) < 1e-2
+    assert (out.float().cpu() - ref).abs().max() < 5e-2
+
+
+def test_flash_attn_strided_views(K, dev):
+    """q/k/v as column slices of one fused qkv buffer (how the engine calls it)."""
+    from oracle import dit
+    heads, N = 2, 200
+    D = heads * 128
+    g = torch.Generator().manual_seed(3)
+    qkv = q(torch.randn(N, 3 * D, generator=g))
+    ref = dit.sdpa(qkv[None, :, :D], qkv[None, :, D:2 * D], qkv[None, :, 2 * D:], heads)[0]
+    buf = qkv.to(dev, BF)
+    vt = K.vt_transpose(buf[:, 2 * D:], heads)
+    out = K.flash_attn(buf[:, :D], buf[:, D:2 * D], vt, heads, N)
+    assert rel_l2(out.float().cpu(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("T,H,W,Cin,Cout", [(3, 4, 6, 64, 128), (2, 5, 3, 128, 64), (4, 8, 8, 64, 48), (1, 2, 2, 64, 256)])
+def test_conv3d(K, dev, causal, T, H, W, Cin, Cout):
+    from oracle import vae
+    g = torch.Generator().manual_seed(T * 100 + Cin)
+    x = q(torch.randn(1, Cin, T, H, W, generator=g))
+    w = q(torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin))
+    b = torch.randn(Cout, generator=g)
+    ref = vae.conv3d_simple(x, w, b, causal=causal)[0].permute(1, 2, 3, 0)      # T,H,W,C
+    xe = x[0].permute(1, 2, 3, 0).contiguous().to(dev, BF)
+    out = K.conv3d(xe, K.conv_weight_to_engine(w).to(dev), b.to(dev), causal=causal)
+    assert rel_l2(out.float().cpu(), ref) < 6e-3
+    res = q(torch.randn(T, H, W, Cout, generator=g))
+    out = K.conv3d(xe, K.conv_weight_to_engine(w).to(dev), b.to(dev), causal=causal, mode=1, res=res.to(dev, BF))
+    assert rel_l2(out.float().cpu(), ref + res) < 6e-3
+
+
+@pytest.mark.parametrize("stride,mult,residual", [((2, 2, 2), 2, True), ((2, 2, 2), 1, False), ((1, 2, 2), 2, True), ((2, 1, 1), 2, True)])
+def test_conv3d_depth_to_space(K, dev, stride, mult, residual):
+    from oracle import vae
+    Cin, T, H, W = 128, 3, 4, 5
+    sp = stride[0] * stride[1] * stride[2]
+    Cout = sp * Cin // mult
+    g = torch.Generator().manual_seed(sp + mult)
+    x = q(torch.randn(1, Cin, T, H, W, generator=g))
+    w = q(torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin))
+    b = torch.randn(Cout, generator=g)
+    wd = {"u.conv.conv.weight": w, "u.conv.conv.bias": b}
+    ref = vae.upsample_block(x, wd, "u", stride, mult, residual, causal=False)[0].permute(1, 2, 3, 0)
+    xe = x[0].permute(1, 2, 3, 0).contiguous().to(dev, BF)
+    out = K.conv3d(xe, K.conv_weight_to_engine(w, stride).to(dev), K.conv_bias_to_engine(b, stride).to(dev), mode=2,
+                   stride=stride, residual=residual)
+    assert out.shape == ref.shape
+    assert rel_l2(out.float().cpu(), ref) < 6e-3
+
+
+@pytest.mark.parametrize("C", [64, 128, 256, 512, 1024])
+def test_pixnorm_mod_silu(K, dev, C):
+    from oracle import vae
+    g = torch.Generator().manual_seed(C)
+    x = q(torch.randn(1, C, 2, 3, 5, generator=g) * 2)
+    tab = 0.2 * torch.randn(4, C, generator=g)
+    te = 0.2 * torch.randn(4, C, generator=g)
+    ss = tab + te
+    ref = F.silu(vae.pixel_norm(x) * (1 + ss[3])[None, :, None, None, None] + ss[2][None, :, None, None, None])
+    ref = ref[0].permute(1, 2, 3, 0)
+    xe = x[0].permute(1, 2, 3, 0).contiguous().to(dev, BF)
+    out = K.pixnorm_mod_silu(xe, tab.to(dev), te.to(dev).reshape(-1), 2, 3)
+    assert rel_l2(out.float().cpu(), ref) < 6e-3
+
+
+def test_euler_and_x0(K, dev):
+    from oracle import loop
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(50, 128, generator=g)
+    v = torch.randn(50, 128, generator=g)
+    ts = torch.rand(50, generator=g)
+    x0 = K.x0_from_velocity(x.to(dev), v.to(dev), ts.to(dev))
+    assert torch.allclose(x0.cpu(), x - ts[:, None] * v, atol=1e-6)
+    x0s = K.x0_from_velocity(x.to(dev), v.to(dev), torch.tensor([0.7], device=dev))
+    assert torch.allclose(x0s.cpu(), x - 0.7 * v, atol=1e-6)
+    mask = (torch.rand(50, generator=g) > 0.5).float()
+    clean = torch.randn(50, 128, generator=g)
+    ref = loop.euler_step(x, loop.post_process_latent(x0.cpu(), mask[:, None], clean), 0.9, 0.7)
+    out = K.euler_step(x.to(dev), x0, 0.9, 0.7, mask.to(dev), clean.to(dev))
+    assert torch.allclose(out.cpu(), ref, atol=1e-5)
+    with pytest.raises(ValueError, match="Sigma can't be 0.0"):
+        K.euler_step(x.to(dev), x0, 0.0, 0.0)
+
+
+def test_timestep_sinusoid(K, dev):
+    from oracle import dit
+    t = torch.tensor([0.0, 0.421875, 1.0])
+    ref = dit.sinusoidal_timestep_embedding(t * 1000.0)
+    out = K.timestep_sinusoid(t.to(dev), 1000.0)
+    assert torch.allclose(out.cpu(), ref, atol=2e-3)     # fp32 sin/cos of arguments up to 1000 rad
+
+
+def test_video_to_uint8(K, dev):
+    from oracle import vae
+    g = torch.Generator().manual_seed(2)
+    v = torch.randn(1, 3, 4, 6, 10, generator=g) * 0.8
+    ref = vae.to_uint8_frames(v)
+    out = K.video_to_uint8(v[0].to(dev))
+    d = (out.cpu().int() - ref.int()).abs()
+    assert d.max() <= 1 and (d > 0).float().mean() < 1e-3      # truncation at exact .0 boundaries only
