@@ -1,0 +1,101 @@
+"""Prompt-parallel multi-GPU execution: one process per GPU, independent (prompt, seed) units
+sharded across ranks, and exactly one collective -- an RCCL broadcast of the weight arenas from
+rank 0 over xGMI at start-up.  No per-step communication.
+
+The reference has no multi-device code at all (batch hard-wired to 1, no mx.distributed:
+SURVEY.md 2.3); every (prompt, seed) is a complete independent trajectory
+(pipelines/distilled.py:302), so the path shards as independent units ("weak" scaling).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  backend 'nccl' is RCCL on ROCm; 'gloo' for CPU tests."""
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def shard_units(n_units: int, rank: int, world: int) -> List[int]:
+    """Round-robin assignment of independent (prompt, seed) units: rank r takes r, r+G, r+2G, ..."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return list(range(rank, n_units, world))
+
+
+def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 256 << 20) -> int:
+    """Broadcast every tensor of `tensors` from rank `src`, in place, as large flat per-dtype
+    buckets (few, large collectives: xGMI is point-to-point, ~153 GB/s per link, so ring traffic
+    is per-link bound and small messages waste it).  All ranks must hold identically shaped
+    tensors under identical names.  Returns the number of collectives issued."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    names = sorted(tensors.keys())
+    by_dtype: Dict[torch.dtype, List[str]] = {}
+    for n in names:
+        by_dtype.setdefault(tensors[n].dtype, []).append(n)
+    n_coll = 0
+    for dtype, group in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
+        esz = tensors[group[0]].element_size()
+        cap = max(1, bucket_bytes // esz)
+        i = 0
+        while i < len(group):
+            # greedily pack whole tensors; a tensor larger than the bucket goes alone, unflattened
+            t0 = tensors[group[i]]
+            if t0.numel() >= cap:
+                dist.broadcast(t0, src=src)
+                n_coll += 1
+                i += 1
+                continue
+            j, total = i, 0
+            while j < len(group) and total + tensors[group[j]].numel() <= cap:
+                total += tensors[group[j]].numel()
+                j += 1
+            flat = torch.empty(total, dtype=dtype, device=t0.device)
+            off = 0
+            if dist.get_rank() == src:
+                for n in group[i:j]:
+                    k = tensors[n].numel()
+                    flat[off:off + k].copy_(tensors[n].reshape(-1))
+                    off += k
+            dist.broadcast(flat, src=src)
+            n_coll += 1
+            off = 0
+            if dist.get_rank() != src:
+                for n in group[i:j]:
+                    k = tensors[n].numel()
+                    tensors[n].reshape(-1).copy_(flat[off:off + k])
+                    off += k
+            i = j
+    return n_coll
+
+
+def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,371 @@
+"""LTX-2 DiT behind the reference's model API: Modality, LTXModel, X0Model.
+
+Mirrors (names, argument meaning, error behaviour) reference
+LTX_2_MLX/model/transformer/model.py:59-69 (Modality), :413-881 (LTXModel), :884-936 (X0Model)
+for the VideoOnly V1 model.  All arithmetic runs in libltx2hip.so (ltx2_dit_* engine calls);
+torch owns device memory and streams only.  Step-invariant per-prompt work (caption projection,
+cross-attention K/V, RoPE tables) is computed once per (context, positions) pair in
+``prepare`` -- the reference recomputes it every step (model.py:262-271) with identical results.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from enum import Enum
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from .. import _native as nv
+from .. import kernels as K
+
+BF16 = torch.bfloat16
+
+
+class LTXModelType(Enum):
+    AudioVideo = "ltx av model"
+    VideoOnly = "ltx video only model"
+    AudioOnly = "ltx audio only model"
+
+    def is_video_enabled(self) -> bool:
+        return self in (LTXModelType.AudioVideo, LTXModelType.VideoOnly)
+
+    def is_audio_enabled(self) -> bool:
+        return self in (LTXModelType.AudioVideo, LTXModelType.AudioOnly)
+
+
+class LTXRopeType(Enum):
+    INTERLEAVED = "interleaved"
+    SPLIT = "split"
+
+
+@dataclass
+class Modality:
+    """Input record (reference model.py:59-69)."""
+    latent: torch.Tensor                  # (B, T, C) patchified latents
+    context: torch.Tensor                 # (B, S, C_ctx) text context
+    context_mask: Optional[torch.Tensor]  # None on every live path (pipelines/common.py:223-232)
+    timesteps: torch.Tensor               # (B,) or (B, T) / (B, T, 1)
+    positions: torch.Tensor               # (B, 3, T, 2) [start, end) in (seconds, px, px)
+    enabled: bool = True
+    sigma: Optional[torch.Tensor] = None
+
+
+def rope_tables_token_major(positions: torch.Tensor, dim: int, heads: int, theta: float,
+                            max_pos: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """SPLIT RoPE cos/sin, fp32, token-major [N, dim/2] with slot h*(d/2)+j for head h.
+
+    Host-side per-prompt setup restating precompute_freqs_cis(SPLIT, use_middle_indices_grid=True)
+    (reference model/transformer/rope.py:181-211,242-328,365-418): freq grid
+    theta**linspace(0,1,dim//(2*n_dims)) * pi/2, fractional mid positions scaled to [-1,1], slot
+    order f*n_dims + d, identity padding at the FRONT.  Computed on the CPU in fp32 (the argument
+    reaches ~1.6e4 rad, so the table is evaluated once in one place) and uploaded by the caller."""
+    pos = positions.detach().float().cpu()
+    assert pos.shape[0] == 1, "batch is 1"
+    n_dims = pos.shape[1]
+    if n_dims != len(max_pos):
+        raise ValueError(f"Number of position dimensions ({n_dims}) must match max_pos length ({len(max_pos)})")
+    n_freq = dim // (2 * n_dims)
+    grid = (torch.tensor(float(theta)) ** torch.linspace(0.0, 1.0, n_freq, dtype=torch.float32) * (math.pi / 2)).float()
+    mid = (pos[0, :, :, 0] + pos[0, :, :, 1]) / 2.0                       # [n_dims, N]
+    frac = torch.stack([mid[i] / max_pos[i] for i in range(n_dims)], dim=-1)   # [N, n_dims]
+    freqs = grid[None, None, :] * (frac * 2 - 1)[:, :, None]                # [N, n_dims, n_freq]
+    freqs = freqs.transpose(1, 2).reshape(freqs.shape[0], -1)               # slot = f*n_dims + d
+    cos, sin = torch.cos(freqs), torch.sin(freqs)
+    pad = dim // 2 - freqs.shape[-1]
+    if pad:
+        cos = torch.cat([torch.ones(cos.shape[0], pad), cos], dim=-1)
+        sin = torch.cat([torch.zeros(sin.shape[0], pad), sin], dim=-1)
+    return cos.contiguous(), sin.contiguous()
+
+
+class LTXModel:
+    """Velocity model.  Constructor keywords follow reference model.py:436-461."""
+
+    def __init__(self, model_type: LTXModelType = LTXModelType.VideoOnly, num_attention_heads: int = 32,
+                 attention_head_dim: int = 128, in_channels: int = 128, out_channels: int = 128, num_layers: int = 48,
+                 cross_attention_dim: int = 4096, norm_eps: float = 1e-6, caption_channels: Optional[int] = 3840,
+                 positional_embedding_theta: float = 10000.0, positional_embedding_max_pos: Optional[List[int]] = None,
+                 timestep_scale_multiplier: int = 1000, av_ca_timestep_scale_multiplier: int = 1,
+                 use_middle_indices_grid: bool = True, rope_type: LTXRopeType = LTXRopeType.SPLIT,
+                 compute_dtype: torch.dtype = BF16, low_memory: bool = False, fast_mode: bool = False,
+                 cross_attention_adaln: bool = False, apply_gated_attention: bool = False,
+                 device: Union[str, torch.device] = "cuda"):
+        if model_type != LTXModelType.VideoOnly:
+            raise NotImplementedError("only the VideoOnly (LTX-2 19B V1) transformer is implemented on gfx950 so far; "
+                                      "AudioVideo / V2.3 is the next scope row (DESIGN.md)")
+        if cross_attention_adaln or apply_gated_attention:
+            raise NotImplementedError("V2.3 cross_attention_adaln / gated attention: next scope row (DESIGN.md)")
+        if rope_type != LTXRopeType.SPLIT or not use_middle_indices_grid:
+            raise NotImplementedError("the DiT uses SPLIT RoPE with middle-of-bounds positions (model.py:455,453)")
+        if compute_dtype not in (BF16,):
+            raise NotImplementedError("compute dtype is bf16 (fp32 accumulate / residual stream)")
+        self.model_type = model_type
+        self.num_attention_heads = num_attention_heads
+        self.attention_head_dim = attention_head_dim
+        self.inner_dim = self.video_inner_dim = num_attention_heads * attention_head_dim
+        self.in_channels, self.out_channels, self.num_layers = in_channels, out_channels, num_layers
+        self.caption_channels = caption_channels
+        self.norm_eps = norm_eps
+        self.positional_embedding_theta = positional_embedding_theta
+        self.positional_embedding_max_pos = positional_embedding_max_pos or [20, 2048, 2048]
+        self.timestep_scale_multiplier = timestep_scale_multiplier
+        self.compute_dtype = compute_dtype
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("LTXModel runs on the MI355X only (no CPU fallback); got device " + str(device))
+        cfg = nv.DitConfig(num_layers, num_attention_heads, attention_head_dim, in_channels, out_channels,
+                           caption_channels or 0, norm_eps, float(timestep_scale_multiplier))
+        h = C.c_void_p()
+        nv.check(nv.lib().ltx2_dit_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._w: Dict[str, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None
+        self._bound: Tuple[int, int, int] = (0, 0, 0)
+        self._prep_key = None
+        self._prep_refs = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                nv.lib().ltx2_dit_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def expected_weight_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """Checkpoint keys (after stripping 'model.diffusion_model.', reference
+        loader/weight_converter.py:277-315) and shapes this model consumes."""
+        d = self.inner_dim
+        s: Dict[str, Tuple[int, ...]] = {}
+
+        def lin(n, o, i):
+            s[n + ".weight"] = (o, i)
+            s[n + ".bias"] = (o,)
+
+        lin("patchify_proj", d, self.in_channels)
+        lin("adaln_single.emb.timestep_embedder.linear_1", d, 256)
+        lin("adaln_single.emb.timestep_embedder.linear_2", d, d)
+        lin("adaln_single.linear", 6 * d, d)
+        if self.caption_channels:
+            lin("caption_projection.linear_1", d, self.caption_channels)
+            lin("caption_projection.linear_2", d, d)
+        s["scale_shift_table"] = (2, d)
+        lin("proj_out", self.out_channels, d)
+        for i in range(self.num_layers):
+            p = f"transformer_blocks.{i}"
+            for a in ("attn1", "attn2"):
+                for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                    lin(f"{p}.{a}.{n}", d, d)
+                s[f"{p}.{a}.q_norm.weight"] = (d,)
+                s[f"{p}.{a}.k_norm.weight"] = (d,)
+            lin(f"{p}.ff.net.0.proj", 4 * d, d)
+            lin(f"{p}.ff.net.2", d, 4 * d)
+            s[f"{p}.scale_shift_table"] = (6, d)
+        return s
+
+    def _register(self, name: str, t: torch.Tensor) -> None:
+        t = t.contiguous()
+        self._w[name] = t
+        dt = nv.DTYPE_BF16 if t.dtype == BF16 else nv.DTYPE_F32
+        nv.check(nv.lib().ltx2_dit_set_weight(self._h, name.encode(), nv.ptr(t), dt, t.numel()))
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        """Consume checkpoint-keyed tensors (any float dtype, any device).  Linear weights stay
+        [out, in] (no transposes, weight_converter.py:303-307) and become bf16; biases, norm
+        weights and scale_shift_tables become fp32 (transformer.py:157-159).  q/k/v (attn1) and
+        k/v (attn2) are concatenated at load time for fused projection GEMMs."""
+        exp = self.expected_weight_shapes()
+        missing = [k for k in exp if k not in sd]
+        if missing and strict:
+            raise KeyError(f"missing {len(missing)} weights, e.g. {missing[:4]}")
+        for k, shp in exp.items():
+            if k in sd and tuple(sd[k].shape) != shp:
+                raise ValueError(f"weight {k}: shape {tuple(sd[k].shape)} != expected {shp}")
+        ff_key = "transformer_blocks.0.ff.net.0.proj.weight"
+        if ff_key in sd and sd[ff_key].shape[0] != 4 * self.inner_dim:
+            raise ValueError("FFN must be the ungated Linear(D->4D) (reference feed_forward.py:29-54)")
+        dev = self.device
+
+        def W(name):
+            return sd[name].to(dev, BF16)
+
+        def Fv(name):
+            return sd[name].to(dev, torch.float32)
+
+        fused = set()
+        for i in range(self.num_layers):
+            p = f"transformer_blocks.{i}"
+            self._register(f"{p}.attn1.to_qkv.weight", torch.cat([W(f"{p}.attn1.{n}.weight") for n in ("to_q", "to_k", "to_v")], 0))
+            self._register(f"{p}.attn1.to_qkv.bias", torch.cat([Fv(f"{p}.attn1.{n}.bias") for n in ("to_q", "to_k", "to_v")], 0))
+            self._register(f"{p}.attn2.to_kv.weight", torch.cat([W(f"{p}.attn2.{n}.weight") for n in ("to_k", "to_v")], 0))
+            self._register(f"{p}.attn2.to_kv.bias", torch.cat([Fv(f"{p}.attn2.{n}.bias") for n in ("to_k", "to_v")], 0))
+            for n in ("to_q", "to_k", "to_v"):
+                fused.add(f"{p}.attn1.{n}")
+            for n in ("to_k", "to_v"):
+                fused.add(f"{p}.attn2.{n}")
+        for k in exp:
+            if k not in sd or k.rsplit(".", 1)[0] in fused:
+                continue
+            is_linear_w = k.endswith(".weight") and len(exp[k]) == 2
+            self._register(k, W(k) if is_linear_w else Fv(k))
+        self._prep_key = None
+
+    def init_random_weights(self, seed: int = 0, std: float = 0.02) -> None:
+        """Synthetic N(0, std) weights generated directly in HBM (bench / smoke; no checkpoints exist
+        in this environment).  Uses the engine's fused layout directly."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        d = self.inner_dim
+
+        def rw(*shape):
+            return (torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32) * std).to(BF16)
+
+        def rf(*shape, scale=std, base=0.0):
+            return base + scale * torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32)
+
+        def lin(name, o, i):
+            self._register(name + ".weight", rw(o, i))
+            self._register(name + ".bias", rf(o))
+
+        lin("patchify_proj", d, self.in_channels)
+        lin("adaln_single.emb.timestep_embedder.linear_1", d, 256)
+        lin("adaln_single.emb.timestep_embedder.linear_2", d, d)
+        lin("adaln_single.linear", 6 * d, d)
+        if self.caption_channels:
+            lin("caption_projection.linear_1", d, self.caption_channels)
+            lin("caption_projection.linear_2", d, d)
+        self._register("scale_shift_table", rf(2, d))
+        lin("proj_out", self.out_channels, d)
+        for i in range(self.num_layers):
+            p = f"transformer_blocks.{i}"
+            lin(f"{p}.attn1.to_qkv", 3 * d, d)
+            lin(f"{p}.attn1.to_out.0", d, d)
+            lin(f"{p}.attn2.to_q", d, d)
+            lin(f"{p}.attn2.to_kv", 2 * d, d)
+            lin(f"{p}.attn2.to_out.0", d, d)
+            for a in ("attn1", "attn2"):
+                self._register(f"{p}.{a}.q_norm.weight", rf(d, scale=0.0, base=1.0))
+                self._register(f"{p}.{a}.k_norm.weight", rf(d, scale=0.0, base=1.0))
+            lin(f"{p}.ff.net.0.proj", 4 * d, d)
+            lin(f"{p}.ff.net.2", d, 4 * d)
+            self._register(f"{p}.scale_shift_table", rf(6, d))
+        self._prep_key = None
+
+    def weight_tensors(self) -> Dict[str, torch.Tensor]:
+        """Engine-layout device tensors (used by the RCCL weight broadcast)."""
+        return self._w
+
+    # ------------------------------------------------------------------ workspace / prepare
+    def _bind(self, n: int, s: int, per_token: bool) -> None:
+        want = (n, s, int(per_token))
+        if self._bound[:2] == want[:2] and self._bound[2] >= want[2] and self._ws is not None:
+            return
+        nbytes = nv.lib().ltx2_dit_workspace_bytes(self._h, n, s, int(per_token))
+        if nbytes <= 0:
+            raise ValueError(f"bad workspace request N={n} S={s}")
+        self._ws = None
+        self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = (self._ws.data_ptr() + 255) // 256 * 256
+        nv.check(nv.lib().ltx2_dit_bind_workspace(self._h, base, nbytes, n, s, int(per_token)))
+        self._bound = want
+        self._prep_key = None
+
+    def prepare(self, context: torch.Tensor, positions: torch.Tensor, per_token: bool = False) -> None:
+        """Per-prompt setup: bind workspace, upload RoPE tables, run caption projection and the
+        48 cross-attention K/V projections (ltx2_dit_prepare)."""
+        if context.shape[0] != 1 or positions.shape[0] != 1:
+            raise ValueError("batch must be 1 (the reference hard-wires batch=1: pipelines/distilled.py:314)")
+        n, s = positions.shape[2], context.shape[1]
+        self._bind(n, s, per_token)
+        cos, sin = rope_tables_token_major(positions, self.inner_dim, self.num_attention_heads,
+                                           self.positional_embedding_theta, self.positional_embedding_max_pos)
+        cos, sin = cos.to(self.device), sin.to(self.device)
+        ctx = context[0].to(self.device, torch.float32).contiguous()
+        nv.check(nv.lib().ltx2_dit_prepare(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.stream()))
+        self._prep_key = self._key(context, positions)
+        self._prep_refs = (context, positions, cos, sin, ctx)     # keep pointers alive / unaliased
+
+    @staticmethod
+    def _key(context: torch.Tensor, positions: torch.Tensor):
+        return (context.data_ptr(), context._version, tuple(context.shape), context.dtype,
+                positions.data_ptr(), positions._version, tuple(positions.shape))
+
+    def _ensure_prepared(self, video: Modality, per_token: bool) -> None:
+        if self._prep_key != self._key(video.context, video.positions) or (per_token and not self._bound[2]):
+            self.prepare(video.context, video.positions, per_token=per_token)
+
+    # ------------------------------------------------------------------ forward
+    def _timesteps(self, video: Modality) -> Tuple[torch.Tensor, int]:
+        """-> (fp32 device vector, n_timesteps in {1, N}).  Per-token timesteps that are all equal
+        take the broadcast path (identical arithmetic, N x fewer AdaLN MLP rows)."""
+        ts = video.timesteps.to(self.device, torch.float32).reshape(-1).contiguous()
+        n = video.latent.shape[1]
+        if ts.numel() == 1:
+            return ts, 1
+        if ts.numel() != n:
+            raise ValueError(f"timesteps has {ts.numel()} elements; expected 1 or N={n}")
+        lo, hi = torch.aminmax(ts)
+        if float(lo) == float(hi):
+            return ts[:1].contiguous(), 1
+        return ts, n
+
+    def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None, perturbations=None) -> torch.Tensor:
+        if video is None:
+            raise ValueError("Video modality required for video-enabled model")     # model.py:823-824
+        if audio is not None:
+            raise NotImplementedError("audio modality: AudioVideo model is the next scope row")
+        if perturbations is not None:
+            raise NotImplementedError("STG perturbations are outside the distilled hot path (cfg forced to 1)")
+        if video.context_mask is not None:
+            raise NotImplementedError("context_mask is None on every live reference path (pipelines/common.py:223-232)")
+        if video.latent.shape[0] != 1:
+            raise ValueError("batch must be 1")
+        ts, n_ts = self._timesteps(video)
+        self._ensure_prepared(video, per_token=(n_ts != 1))
+        lat = video.latent[0].to(self.device, torch.float32).contiguous()
+        out = torch.empty(lat.shape[0], self.out_channels, device=self.device, dtype=torch.float32)
+        nv.check(nv.lib().ltx2_dit_forward(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(out), nv.stream()))
+        return out[None]
+
+    # ------------------------------------------------------------------ fused sampling step / graph
+    def denoise_step_(self, latent: torch.Tensor, video: Modality, sigma: float, sigma_next: float,
+                      denoise_mask: Optional[torch.Tensor] = None, clean_latent: Optional[torch.Tensor] = None) -> None:
+        """In-place: latent (N, C) fp32 <- Euler(latent, post_process(x0)) -- forward + x0 + blend + step
+        enqueued by ONE C call (ltx2_dit_denoise_step)."""
+        ts, n_ts = self._timesteps(video)
+        self._ensure_prepared(video, per_token=(n_ts != 1))
+        assert latent.dtype == torch.float32 and latent.is_contiguous() and latent.dim() == 2
+        nv.check(nv.lib().ltx2_dit_denoise_step(self._h, nv.ptr(latent), nv.ptr(ts), n_ts, nv.ptr(denoise_mask),
+                                                nv.ptr(clean_latent), float(sigma), float(sigma_next), None, nv.stream()))
+
+    def capture_denoise_graph(self, latent: torch.Tensor, sigmas: Sequence[float]) -> None:
+        """hipGraph-capture len(sigmas)-1 steps over `latent` (N, C fp32, updated in place on replay)."""
+        assert self._prep_key is not None, "call prepare() first"
+        arr = (C.c_float * len(sigmas))(*[float(s) for s in sigmas])
+        st = torch.cuda.current_stream()
+        if st.cuda_stream == 0:
+            raise RuntimeError("graph capture needs a non-default stream: use `with torch.cuda.stream(torch.cuda.Stream()):`")
+        nv.check(nv.lib().ltx2_dit_graph_capture(self._h, nv.ptr(latent), arr, len(sigmas) - 1, st.cuda_stream))
+
+    def replay_denoise_graph(self) -> None:
+        nv.check(nv.lib().ltx2_dit_graph_launch(self._h, nv.stream()))
+
+
+class X0Model:
+    """x0 = latent - timesteps * velocity (reference model.py:884-936)."""
+
+    def __init__(self, velocity_model: LTXModel):
+        self.velocity_model = velocity_model
+
+    def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None, perturbations=None) -> torch.Tensor:
+        v = self.velocity_model(video, audio, perturbations=perturbations)
+        lat = video.latent[0].to(v.device, torch.float32).contiguous()
+        ts = video.timesteps.to(v.device, torch.float32).reshape(-1)
+        return K.x0_from_velocity(lat, v[0], ts)[None]
+
+
+# aliases kept by the reference for backward compatibility (model.py:939-941)
+LTXAVModel = LTXModel
+X0AVModel = X0Model

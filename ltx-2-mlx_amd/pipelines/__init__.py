@@ -1,0 +1,5 @@
+from .common import modality_from_state, post_process_latent, timesteps_from_mask
+from .distilled import DistilledConfig, DistilledPipeline, create_distilled_pipeline
+
+__all__ = ["modality_from_state", "post_process_latent", "timesteps_from_mask", "DistilledConfig", "DistilledPipeline",
+           "create_distilled_pipeline"]

@@ -1,0 +1,73 @@
+"""Shape / state types of the sampling loop (host-side; mirrors reference LTX_2_MLX/types.py:10-194
+for the video half).  Tensors are torch tensors on the GPU."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import NamedTuple, Tuple
+
+import torch
+
+
+class VideoPixelShape(NamedTuple):
+    batch: int
+    frames: int
+    height: int
+    width: int
+    fps: float = 25.0
+
+
+class SpatioTemporalScaleFactors(NamedTuple):
+    time: int
+    width: int
+    height: int
+
+    @classmethod
+    def default(cls) -> "SpatioTemporalScaleFactors":
+        return cls(time=8, width=32, height=32)
+
+
+VIDEO_SCALE_FACTORS = SpatioTemporalScaleFactors.default()
+
+
+class VideoLatentShape(NamedTuple):
+    batch: int
+    channels: int
+    frames: int
+    height: int
+    width: int
+
+    def to_tuple(self) -> Tuple[int, int, int, int, int]:
+        return (self.batch, self.channels, self.frames, self.height, self.width)
+
+    @staticmethod
+    def from_shape(shape) -> "VideoLatentShape":
+        return VideoLatentShape(*[int(s) for s in shape[:5]])
+
+    def mask_shape(self) -> "VideoLatentShape":
+        return self._replace(channels=1)
+
+    @staticmethod
+    def from_pixel_shape(shape: VideoPixelShape, latent_channels: int = 128,
+                         scale_factors: SpatioTemporalScaleFactors = VIDEO_SCALE_FACTORS) -> "VideoLatentShape":
+        # reference types.py:72-87
+        return VideoLatentShape(batch=shape.batch, channels=latent_channels,
+                                frames=(shape.frames - 1) // scale_factors.time + 1,
+                                height=shape.height // scale_factors.height,
+                                width=shape.width // scale_factors.width)
+
+    def upscale(self, scale_factors: SpatioTemporalScaleFactors = VIDEO_SCALE_FACTORS) -> "VideoLatentShape":
+        return self._replace(channels=3, frames=(self.frames - 1) * scale_factors.time + 1,
+                             height=self.height * scale_factors.height, width=self.width * scale_factors.width)
+
+
+@dataclass(frozen=True)
+class LatentState:
+    """latent / denoise_mask / positions / clean_latent (reference types.py:167-194)."""
+    latent: torch.Tensor
+    denoise_mask: torch.Tensor
+    positions: torch.Tensor
+    clean_latent: torch.Tensor
+
+    def replace(self, **kw) -> "LatentState":
+        return LatentState(latent=kw.get("latent", self.latent), denoise_mask=kw.get("denoise_mask", self.denoise_mask),
+                           positions=kw.get("positions", self.positions), clean_latent=kw.get("clean_latent", self.clean_latent))
