@@ -181,6 +181,12 @@ int ltx2_dit_denoise_step(ltx2_dit* ctx, float* latent, const float* timesteps, 
 int ltx2_dit_graph_capture(ltx2_dit* ctx, float* latent, const float* host_sigmas, int n_steps, void* stream);
 int ltx2_dit_graph_launch(ltx2_dit* ctx, void* stream);
 
+/* Measurement aid: bracket every launch of one GEMM kernel instantiation (epilogue id, or -1 for
+ * every GEMM) issued by this thread's ltx2_dit_* calls with HIP events on the launch stream;
+ * profile_end synchronises and returns the summed kernel time, launch count and 2*M*N*K flops. */
+int ltx2_dit_profile_begin(ltx2_dit* ctx, int epilogue);
+int ltx2_dit_profile_end(ltx2_dit* ctx, double* total_ms, int64_t* launches, double* flops);
+
 /* ------------------------------------------------------------------------------------------
  * VAE decoder engine: SimpleVideoDecoder.__call__ (model/video_vae/simple_decoder.py:446-563)
  * ------------------------------------------------------------------------------------------ */

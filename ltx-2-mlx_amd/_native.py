@@ -65,6 +65,8 @@ SIGNATURES = {
     "ltx2_dit_denoise_step": (i32, [vp, vp, vp, i32, vp, vp, f32, f32, vp, vp]),
     "ltx2_dit_graph_capture": (i32, [vp, vp, C.POINTER(f32), i32, vp]),
     "ltx2_dit_graph_launch": (i32, [vp, vp]),
+    "ltx2_dit_profile_begin": (i32, [vp, i32]),
+    "ltx2_dit_profile_end": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
     "ltx2_vae_create": (i32, [C.POINTER(VaeConfig), C.POINTER(vp)]),
     "ltx2_vae_destroy": (None, [vp]),
     "ltx2_vae_set_weight": (i32, [vp, C.c_char_p, vp, i32, i64]),

@@ -60,6 +60,11 @@ struct ltx2_dit {
     bool prepared = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // live HIP-event profiling of one GEMM kernel instantiation (bench.py roofline)
+    int prof_epi = -2;                 // -2 off, -1 every GEMM, >= 0 one epilogue
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
+    double prof_flops = 0;
 };
 
 namespace {
@@ -183,6 +188,8 @@ int resolve(ltx2_dit* c) {
     return LTX2_OK;
 }
 
+thread_local ltx2_dit* g_prof_ctx = nullptr;
+
 int dense(const bf16* A, long lda, const bf16* W, const float* bias, void* out, long ldo, int M, int N, int K, int epi,
           hipStream_t st, const float* gate = nullptr, long gate_stride = 0, const float* gate_table = nullptr) {
     GemmParams p{};
@@ -198,7 +205,23 @@ int dense(const bf16* A, long lda, const bf16* W, const float* bias, void* out, 
     p.gate = gate;
     p.gate_stride = gate_stride;
     p.gate_table = gate_table;
-    return gemm_launch(p, epi, false, st);
+    ltx2_dit* pc = g_prof_ctx;
+    const bool prof = pc && (pc->prof_epi == -1 || pc->prof_epi == epi);
+    if (prof) {
+        while (pc->prof_ev.size() < pc->prof_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return LTX2_E_HIP;
+            pc->prof_ev.push_back(e);
+        }
+        (void)hipEventRecord(pc->prof_ev[pc->prof_used], st);
+    }
+    const int rc = gemm_launch(p, epi, false, st);
+    if (prof) {
+        (void)hipEventRecord(pc->prof_ev[pc->prof_used + 1], st);
+        pc->prof_used += 2;
+        pc->prof_flops += 2.0 * M * N * K;
+    }
+    return rc;
 }
 
 __global__ void silu_cast_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
@@ -336,6 +359,7 @@ void ltx2_dit_destroy(ltx2_dit* c) {
     if (!c) return;
     if (c->exec) (void)hipGraphExecDestroy(c->exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -476,6 +500,35 @@ int ltx2_dit_graph_capture(ltx2_dit* c, float* latent, const float* host_sigmas,
         ltx2_set_error("dit_graph_capture: hipGraphInstantiate failed");
         return LTX2_E_HIP;
     }
+    return LTX2_OK;
+}
+
+int ltx2_dit_profile_begin(ltx2_dit* c, int epilogue) {
+    LTX2_CHECK_ARG(c && epilogue >= -1 && epilogue < EPI_COUNT, "dit_profile_begin: bad argument");
+    c->prof_epi = epilogue;
+    c->prof_used = 0;
+    c->prof_flops = 0;
+    g_prof_ctx = c;
+    return LTX2_OK;
+}
+
+int ltx2_dit_profile_end(ltx2_dit* c, double* total_ms, int64_t* launches, double* flops) {
+    LTX2_CHECK_ARG(c && total_ms && launches && flops, "dit_profile_end: null argument");
+    g_prof_ctx = nullptr;
+    c->prof_epi = -2;
+    double tot = 0;
+    for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+        if (hipEventSynchronize(c->prof_ev[i + 1]) != hipSuccess) {
+            ltx2_set_error("dit_profile_end: event synchronize failed");
+            return LTX2_E_HIP;
+        }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]);
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int64_t)(c->prof_used / 2);
+    *flops = c->prof_flops;
     return LTX2_OK;
 }
 

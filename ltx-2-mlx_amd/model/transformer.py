@@ -352,6 +352,17 @@ class LTXModel:
     def replay_denoise_graph(self) -> None:
         nv.check(nv.lib().ltx2_dit_graph_launch(self._h, nv.stream()))
 
+    # ------------------------------------------------------------------ measurement
+    def profile_begin(self, epilogue: int = -1) -> None:
+        """HIP-event bracket every launch of one GEMM kernel instantiation (or all, -1)."""
+        nv.check(nv.lib().ltx2_dit_profile_begin(self._h, epilogue))
+
+    def profile_end(self) -> Tuple[float, int, float]:
+        """-> (summed kernel ms, launches, 2*M*N*K flops) since profile_begin."""
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        nv.check(nv.lib().ltx2_dit_profile_end(self._h, C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
 
 class X0Model:
     """x0 = latent - timesteps * velocity (reference model.py:884-936)."""
