@@ -27,6 +27,9 @@ struct GemmParams {
     int T, H, Wd, Cin, cin_shift, pad_front;
     // depth-to-space epilogue: column n = s*Cf + c, s = (a*fh + b)*fw + d
     int ft, fh, fw, Cf, cf_shift, drop_first, d2s_residual, c_d2s;
+    int pp_ablate;       // ping-pong kernel: timing-ablation bitmask (debug only; results are wrong when set)
+    int pp_stagger;
+    void* dbg;           // ping-pong kernel: optional device buffer for interval timestamps (debug)      // ping-pong kernel: which wave bit selects the staggered group (tuning knob)
 };
 
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream);

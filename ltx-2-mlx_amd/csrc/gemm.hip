@@ -6,40 +6,59 @@
 // model.py:49-56,242,757) and the 3 x mx.conv2d temporal-tap loop of Conv3dSimple
 // (LTX_2_MLX/model/video_vae/simple_decoder.py:146-175).
 //
-// Structure (v1): 128x128x64 block tile, 4 wave64 as 2x2, each wave 64x64 = 2x2 tiles of
-// v_mfma_f32_32x32x16_bf16.  Both operands are K-contiguous, so A and B fragments are single
-// 16-byte LDS reads.  Tiles are staged HBM->LDS with global_load_lds (16 B per lane, no VGPR
-// round trip) into a double-buffered 2 x 32 KiB ring; the LDS image is lane-linear, so the bank
-// swizzle (16-B chunk index ^= (row>>1)&7 on 128-B rows: conflict-free for ds_read_b128's
-// 16-lane groups) is applied to the per-lane SOURCE address and again on the read.
-// Block ids are remapped so that an XCD (private L2) owns a contiguous run of tiles, walked in
-// groups of 8 row-tiles so concurrently resident tiles share A/W panels.
+// Structure: BM x BN x 64 block tile, WAVES_M x WAVES_N wave64 grid, each wave a grid of
+// v_mfma_f32_32x32x16_bf16 tiles.  Two configurations are instantiated:
+//   * 256x256, 8 waves (2x4, wave tile 128x64), 1 block/CU: large problems (128 FLOP per staged
+//     byte, keeps the L2->LDS stream well under the per-XCD L2 bandwidth);
+//   * 128x128, 4 waves (2x2, wave tile 64x64), 2 blocks/CU: small M / narrow N.
+// Both operands are K-contiguous, so A and B fragments are single 16-byte LDS reads.  Tiles are
+// staged HBM->LDS with global_load_lds (16 B per lane, no VGPR round trip) into a double-buffered
+// ring; the LDS image is lane-linear, so the bank swizzle (16-B chunk index ^= (row>>1)&7 on
+// 128-B rows: conflict-free for ds_read_b128's 16-lane groups) is applied to the per-lane SOURCE
+// address and again on the read.  Block ids are remapped so that an XCD (private L2) owns a
+// contiguous run of tiles, walked in groups of row-tiles so co-resident tiles share A/W panels.
 //
 // Conv mode gathers the A operand on the fly from the channels-last activation volume
 // [T][H][W][Cin]: row m = output position, K = tap*Cin + c; reflect padding in H/W and
 // replicate padding in T are index arithmetic on the per-lane source address.
-#include "gemm.h"
+#include <stdlib.h>
+#include <string.h>
+
+#include "gemm_epilogue.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;       // 16 KiB
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;    // double buffer = 64 KiB
+constexpr int BK = 64;
 
 __device__ __forceinline__ void glds16(const bf16* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const void*)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI, bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct TileCfg {
+    static constexpr int NW = WAVES_M * WAVES_N;
+    static constexpr int NT = NW * 64;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;     // wave tile
+    static constexpr int TM = WM / 32, TN = WN / 32;               // MFMA tiles per wave
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int A_LOADS = BM / 8 / NW, B_LOADS = BN / 8 / NW;   // 1-KiB glds per wave per tile
+    static constexpr int OCC = (NT == 512) ? 2 : 2;                // min waves/SIMD for launch bounds
+};
+
+template <class CFG, int EPI, bool CONV>
+__global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
+    constexpr int TBM = CFG::A_BYTES / (BK * 2), TBN = CFG::B_BYTES / (BK * 2);
+    constexpr int WAVES_N = TBN / CFG::WN;
+    constexpr int TM = CFG::TM, TN = CFG::TN, AL = CFG::A_LOADS, BL = CFG::B_LOADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- block -> tile (XCD-contiguous, grouped row-tiles) ----
-    const int Mt = (p.M + BM - 1) / BM, Nt = (p.N + BN - 1) / BN;
+    const int Mt = (p.M + TBM - 1) / TBM, Nt = (p.N + TBN - 1) / TBN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     constexpr int GROUP = 8;
     const int per_group = GROUP * Nt;
@@ -47,20 +66,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const int first_m = g * GROUP;
     const int gsz = min(Mt - first_m, GROUP);
     const int rem = id - g * per_group;
-    const int m0 = (first_m + rem % gsz) * BM;
-    const int n0 = (rem / gsz) * BN;
+    const int m0 = (first_m + rem % gsz) * TBM;
+    const int n0 = (rem / gsz) * TBN;
 
-    // ---- per-lane staging addresses: 4 row-slots each for A and W ----
-    const bf16* a_ptr[4];
-    const bf16* w_ptr[4];
-    int ct[4], chh[4], cww[4];
+    // ---- per-lane staging addresses ----
+    const bf16* a_ptr[AL];
+    const bf16* w_ptr[BL];
+    int ct[AL], chh[AL], cww[AL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rt = (wv * 4 + j) * 8 + (lane >> 3);
+    for (int j = 0; j < AL; ++j) {
+        const int rt = (wv * AL + j) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((rt >> 1) & 7);
         const int m = min(m0 + rt, p.M - 1);
-        const int n = min(n0 + rt, p.N - 1);
-        w_ptr[j] = p.W + (long)n * p.K + chunk * 8;
         if (CONV) {
             const int hw = p.H * p.Wd;
             ct[j] = m / hw;
@@ -72,10 +89,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             a_ptr[j] = p.A + (long)m * p.lda + chunk * 8;
         }
     }
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
+        const int rt = (wv * BL + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((rt >> 1) & 7);
+        const int n = min(n0 + rt, p.N - 1);
+        w_ptr[j] = p.W + (long)n * p.K + chunk * 8;
+    }
 
     auto stage = [&](int kt, int buf) {
-        char* sa = smem + buf * STAGE_BYTES + wv * 4096;
-        char* sb = sa + TILE_BYTES;
+        char* sa = smem + buf * CFG::STAGE_BYTES + wv * (AL * 1024);
+        char* sb = smem + buf * CFG::STAGE_BYTES + CFG::A_BYTES + wv * (BL * 1024);
         const int k0 = kt * BK;
         if (CONV) {
             const int tap = k0 >> p.cin_shift;
@@ -84,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             const int kh_ = (tap - kt_ * 9) / 3;
             const int kw_ = tap - kt_ * 9 - kh_ * 3;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < AL; ++j) {
                 int tt = ct[j] + kt_ - p.pad_front;
                 tt = max(0, min(tt, p.T - 1));
                 int hh = chh[j] + kh_ - 1;
@@ -96,24 +120,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(a_ptr[j] + k0, sa + j * 1024);
+            for (int j = 0; j < AL; ++j) glds16(a_ptr[j] + k0, sa + j * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(w_ptr[j] + k0, sb + j * 1024);
+        for (int j = 0; j < BL; ++j) glds16(w_ptr[j] + k0, sb + j * 1024);
     };
 
     // ---- MFMA fragment read offsets ----
-    const int wr = wv >> 1, wc = wv & 1;
+    const int wr = wv / WAVES_N, wc = wv % WAVES_N;
     const int l31 = lane & 31, hi = lane >> 5;
     const int xbase = hi ^ ((l31 >> 1) & 7);          // chunk(ks) = (2*ks) ^ xbase
-    const int a_row_off = (wr * 64 + l31) * 128;
-    const int b_row_off = TILE_BYTES + (wc * 64 + l31) * 128;
+    const int a_row_off = (wr * CFG::WM + l31) * 128;
+    const int b_row_off = CFG::A_BYTES + (wc * CFG::WN + l31) * 128;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -123,93 +147,98 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char* base = smem + (kt & 1) * STAGE_BYTES;
+        const char* base = smem + (kt & 1) * CFG::STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int coff = ((2 * ks) ^ xbase) << 4;
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *(const bf16x8*)(base + a_row_off + i * 32 * 128 + coff);
-                bfr[i] = *(const bf16x8*)(base + b_row_off + i * 32 * 128 + coff);
-            }
+            for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(base + a_row_off + i * 32 * 128 + coff);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TN; ++j) bfr[j] = *(const bf16x8*)(base + b_row_off + j * 32 * 128 + coff);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T orientation
         }
     }
 
-    // ---- epilogue: C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // ---- epilogue: lane owns rows (l31 per row slot) x 4-column groups (gemm_epilogue.h) ----
+    f32x4 bias4[TN][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wc * 64 + j * 32 + l31;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
-        int s_idx = 0, c_idx = 0, da = 0, db = 0, dd = 0;
-        if (EPI == EPI_D2S_BF16) {
-            s_idx = col >> p.cf_shift;
-            c_idx = col & (p.Cf - 1);
-            da = s_idx / (p.fh * p.fw);
-            db = (s_idx / p.fw) % p.fh;
-            dd = s_idx % p.fw;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int col = n0 + wc * CFG::WN + j * 32 + 8 * gq + 4 * hi;
+            bias4[j][gq] = (p.bias && col < p.N) ? *(const f32x4*)(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (EPI == EPI_BF16) {
-                    ((bf16*)p.out)[(long)row * p.ldo + col] = f2bf(v);
-                } else if (EPI == EPI_GELU_BF16) {
-                    ((bf16*)p.out)[(long)row * p.ldo + col] = f2bf(gelu_tanh(v));
-                } else if (EPI == EPI_SILU_BF16) {
-                    ((bf16*)p.out)[(long)row * p.ldo + col] = f2bf(silu_f(v));
-                } else if (EPI == EPI_F32) {
-                    ((float*)p.out)[(long)row * p.ldo + col] = v;
-                } else if (EPI == EPI_RESID_GATE_F32) {
-                    float gt = 1.f;
-                    if (p.gate || p.gate_table)
-                        gt = (p.gate ? p.gate[(long)row * p.gate_stride + col] : 0.f) + (p.gate_table ? p.gate_table[col] : 0.f);
-                    float* o = (float*)p.out + (long)row * p.ldo + col;
-                    *o = *o + gt * v;
-                } else if (EPI == EPI_ADD_BF16) {
-                    v += bf2f(p.res[(long)row * p.ldres + col]);
-                    ((bf16*)p.out)[(long)row * p.ldo + col] = f2bf(v);
-                } else if (EPI == EPI_D2S_BF16) {
-                    const int hw = p.H * p.Wd;
-                    const int t = row / hw;
-                    const int r2 = row - t * hw;
-                    const int h = r2 / p.Wd;
-                    const int w = r2 - h * p.Wd;
-                    const int to = t * p.ft + da - p.drop_first;
-                    if (to < 0) continue;
-                    if (p.d2s_residual) {
-                        const int cin_idx = (c_idx % p.c_d2s) * (p.ft * p.fh * p.fw) + s_idx;
-                        v += bf2f(p.A[(long)row * p.Cin + cin_idx]);
-                    }
-                    const long opos = ((long)to * (p.H * p.fh) + (h * p.fh + db)) * (p.Wd * p.fw) + (w * p.fw + dd);
-                    ((bf16*)p.out)[opos * p.Cf + c_idx] = f2bf(v);
-                }
+        for (int gq = 0; gq < 4; ++gq) asm volatile("" : "+v"(bias4[j][gq]));      // retire the loads once, here
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wr * CFG::WM + i * 32 + l31;
+        if (row >= p.M) continue;
+        const EpiRow er = epi_row_setup<EPI>(p, row);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int col = n0 + wc * CFG::WN + j * 32 + 8 * gq + 4 * hi;
+                if (col >= p.N) continue;
+                const f32x4 v = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+                epi_store4<EPI>(p, er, row, col, v, bias4[j][gq]);
             }
-        }
     }
+}
+
+using CfgBig = TileCfg<256, 256, 2, 4>;
+using CfgSmall = TileCfg<128, 128, 2, 2>;
+
+template <class CFG, int EPI, bool CONV>
+int launch_cfg(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<CFG, EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  CFG::LDS_BYTES);
+        attr_set = true;
+    }
+    constexpr int TBM = CFG::A_BYTES / (BK * 2), TBN = CFG::B_BYTES / (BK * 2);
+    const int Mt = (p.M + TBM - 1) / TBM, Nt = (p.N + TBN - 1) / TBN;
+    hipLaunchKernelGGL((gemm_kernel<CFG, EPI, CONV>), dim3(Mt * Nt), dim3(CFG::NT), CFG::LDS_BYTES, stream, p);
+    LTX2_CHECK_LAUNCH("gemm_kernel");
+    return LTX2_OK;
+}
+
+// Tile selection: the 256x256 tile needs enough tiles to fill the 256 CUs reasonably and wide N.
+inline bool use_big_tile(const GemmParams& p) {
+    if (p.N < 256 || p.M < 1024) return false;
+    const long tiles_big = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    return tiles_big >= 160;
+}
+
+// 0 = heuristic, 1 = force 128x128, 2 = force plain 256x256, 3 = force ping-pong 256x256 (A/B testing)
+inline int tile_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LTX2_GEMM_TILE");
+        v = 0;
+        if (e && !strcmp(e, "small")) v = 1;
+        if (e && !strcmp(e, "big")) v = 2;
+        if (e && !strcmp(e, "pp")) v = 3;
+    }
+    return v;
 }
 
 template <int EPI, bool CONV>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
-    const int Mt = (p.M + BM - 1) / BM, Nt = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kernel<EPI, CONV>), dim3(Mt * Nt), dim3(256), LDS_BYTES, stream, p);
-    LTX2_CHECK_LAUNCH("gemm_kernel");
-    return LTX2_OK;
+    const int ov = tile_override();
+    if (ov == 2) return launch_cfg<CfgBig, EPI, CONV>(p, stream);
+    if (ov == 1) return launch_cfg<CfgSmall, EPI, CONV>(p, stream);
+    if (ov == 3 || use_big_tile(p)) return gemm_pp_launch(p, EPI, CONV, stream);
+    return launch_cfg<CfgSmall, EPI, CONV>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -266,6 +295,8 @@ int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream
     LTX2_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     LTX2_CHECK_ARG(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
     LTX2_CHECK_ARG(p.A && p.W && p.out, "gemm: null operand");
+    LTX2_CHECK_ARG(p.N % 4 == 0 && p.ldo % 4 == 0 && p.ldres % 4 == 0 && p.gate_stride % 4 == 0,
+                   "gemm: N, ldo, ldres and gate_stride must be multiples of 4 (vector epilogue)");
     if (conv) {
         LTX2_CHECK_ARG(p.Cin >= 64 && (p.Cin & (p.Cin - 1)) == 0, "conv3d: Cin=%d must be a power of two >= 64", p.Cin);
         LTX2_CHECK_ARG(p.K == 27 * p.Cin, "conv3d: K=%d != 27*Cin", p.K);

@@ -1,0 +1,91 @@
+// Fused GEMM / conv3d epilogues shared by the tile kernels (see gemm.h for the epilogue list).
+//
+// The tile kernels issue mfma(A_op = W fragment, B_op = A fragment), so a 32x32 accumulator holds
+// C^T: lane l owns output ROW (l & 31) and, per register group g = r>>2, the 4 CONSECUTIVE columns
+// 8g + 4(l>>5) + (r&3).  The epilogue therefore works on float4 column groups: 8-byte bf16x4 or
+// 16-byte fp32x4 accesses, one row-bound check per row slot, no per-element branches.
+#pragma once
+#include "gemm.h"
+
+struct EpiRow {          // per output row (per lane, per row slot)
+    int t, h, w;         // conv position (D2S only)
+};
+
+template <int EPI>
+__device__ __forceinline__ EpiRow epi_row_setup(const GemmParams& p, int row) {
+    EpiRow r{};
+    if (EPI == EPI_D2S_BF16) {
+        const int hw = p.H * p.Wd;
+        r.t = row / hw;
+        const int r2 = row - r.t * hw;
+        r.h = r2 / p.Wd;
+        r.w = r2 - r.h * p.Wd;
+    }
+    return r;
+}
+
+__device__ __forceinline__ bf16x4 pack_bf16x4(float a, float b, float c, float d) {
+    bf16x4 o = {f2bf(a), f2bf(b), f2bf(c), f2bf(d)};
+    return o;
+}
+
+// v = 4 raw accumulators for columns col..col+3 of `row`; row < M and col+3 < N guaranteed.
+template <int EPI>
+__device__ __forceinline__ void epi_store4(const GemmParams& p, const EpiRow& er, int row, int col, f32x4 v,
+                                           f32x4 bias4) {
+    v += bias4;
+    if (EPI == EPI_BF16) {
+        *(bf16x4*)((bf16*)p.out + (long)row * p.ldo + col) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+    } else if (EPI == EPI_GELU_BF16) {
+        *(bf16x4*)((bf16*)p.out + (long)row * p.ldo + col) =
+            pack_bf16x4(gelu_tanh(v[0]), gelu_tanh(v[1]), gelu_tanh(v[2]), gelu_tanh(v[3]));
+    } else if (EPI == EPI_SILU_BF16) {
+        *(bf16x4*)((bf16*)p.out + (long)row * p.ldo + col) = pack_bf16x4(silu_f(v[0]), silu_f(v[1]), silu_f(v[2]), silu_f(v[3]));
+    } else if (EPI == EPI_F32) {
+        *(f32x4*)((float*)p.out + (long)row * p.ldo + col) = v;
+    } else if (EPI == EPI_RESID_GATE_F32) {
+        f32x4 gt = {1.f, 1.f, 1.f, 1.f};
+        if (p.gate || p.gate_table) {
+            gt = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.gate) gt += *(const f32x4*)(p.gate + (long)row * p.gate_stride + col);
+            if (p.gate_table) gt += *(const f32x4*)(p.gate_table + col);
+        }
+        f32x4* o = (f32x4*)((float*)p.out + (long)row * p.ldo + col);
+        *o = *o + gt * v;
+    } else if (EPI == EPI_ADD_BF16) {
+        const bf16x4 rs = *(const bf16x4*)(p.res + (long)row * p.ldres + col);
+        *(bf16x4*)((bf16*)p.out + (long)row * p.ldo + col) =
+            pack_bf16x4(v[0] + bf2f(rs[0]), v[1] + bf2f(rs[1]), v[2] + bf2f(rs[2]), v[3] + bf2f(rs[3]));
+    } else if (EPI == EPI_D2S_BF16) {
+        // column n' = s*Cf + c (Cf a power of two >= 4, so the 4 columns share s)
+        const int s_idx = col >> p.cf_shift;
+        const int c_idx = col & (p.Cf - 1);
+        const int da = s_idx / (p.fh * p.fw);
+        const int db = (s_idx / p.fw) % p.fh;
+        const int dd = s_idx % p.fw;
+        const int to = er.t * p.ft + da - p.drop_first;
+        if (to < 0) return;
+        if (p.d2s_residual) {
+            const int sp = p.ft * p.fh * p.fw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(p.A[(long)row * p.Cin + ((c_idx + e) % p.c_d2s) * sp + s_idx]);
+        }
+        const long opos = ((long)to * (p.H * p.fh) + (er.h * p.fh + db)) * (p.Wd * p.fw) + (er.w * p.fw + dd);
+        *(bf16x4*)((bf16*)p.out + opos * p.Cf + c_idx) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// Conv A-operand source position for output row (t,h,w) and tap (kt,kh,kw): replicate in T,
+// reflect in H/W (reference simple_decoder.py:105-134).
+__device__ __forceinline__ long conv_src_pos(const GemmParams& p, int t, int h, int w, int kt_, int kh_, int kw_) {
+    int tt = t + kt_ - p.pad_front;
+    tt = max(0, min(tt, p.T - 1));
+    int hh = h + kh_ - 1;
+    hh = hh < 0 ? -hh : (hh >= p.H ? 2 * p.H - 2 - hh : hh);
+    int ww = w + kw_ - 1;
+    ww = ww < 0 ? -ww : (ww >= p.Wd ? 2 * p.Wd - 2 - ww : ww);
+    return ((long)tt * p.H + hh) * p.Wd + ww;
+}
+
+// Launcher of the 256x256 ping-pong kernel (gemm_pp.hip)
+int gemm_pp_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream);
