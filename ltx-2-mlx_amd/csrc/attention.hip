@@ -22,6 +22,7 @@
 namespace {
 
 constexpr int QB = 128, KVB = 64, HD = 128;
+constexpr float RESCALE_THR = 6.0f;     // P <= 2^6: exact in bf16's 8-bit exponent, fp32 accumulation has ample headroom
 constexpr int K_TILE = KVB * HD * 2;           // 16 KiB, rows of 256 B
 constexpr int V_TILE = HD * KVB * 2;           // 16 KiB, rows of 128 B
 constexpr int STAGE = K_TILE + V_TILE;
@@ -106,41 +107,49 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[b], 0, 0, 0);
             }
         }
-        // ---- scale, mask the ragged tail, running max ----
+        // ---- mask the ragged tail, running max (raw score domain; the softmax scale * log2(e) is
+        //      folded into one fma in front of v_exp_f32: p = 2^(s*c - m*c)) ----
         const int kv0 = t * KVB;
-        const bool tail = (kv0 + KVB > p.Nkv);
-        float tmax = -INFINITY;
+        if (kv0 + KVB > p.Nkv) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[b][r] * p.scale_log2e;
-                if (tail) {
+                for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (kv >= p.Nkv) v = -INFINITY;
+                    if (kv >= p.Nkv) s[b][r] = -INFINITY;
                 }
-                s[b][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
+        }
+        float tmax = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);     // first tile: exp2(-inf) = 0
-        m_run = m_new;
+        // Deferred rescale: keep the old running max while the tile max exceeds it by at most
+        // RESCALE_THR (in exponent units), so P stays <= 2^THR and the O rescale pass is skipped.
+        // The decision is wave-uniform; when taken, O, l and the new P all move to the new max
+        // before anything is accumulated, so no term is ever at a stale scale.
+        const float c = p.scale_log2e;
+        if (!__all((tmax - m_run) * c <= RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);     // first tile: 2^-inf = 0
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        const float mc = m_run * c;
         float psum = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[b][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][r], c, -mc));
                 psum += pv;
                 pf[b][r >> 3][r & 7] = f2bf(pv);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T . P^T ----
 #pragma unroll

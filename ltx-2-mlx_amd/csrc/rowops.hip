@@ -24,42 +24,61 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// two simultaneous block sums over 256 threads
+__device__ __forceinline__ void block_sum2_256(float& a, float& b, float* red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) {
+        red[wv] = a;
+        red[4 + wv] = b;
+    }
+    __syncthreads();
+    a = red[0] + red[1] + red[2] + red[3];
+    b = red[4] + red[5] + red[6] + red[7];
+}
+
+// One block per row; the row (D <= 1024*NV fp32) is read ONCE and held in registers.
+template <int NV>
 __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__ x, long ldx, bf16* __restrict__ out,
                                                        long ldo, int D, float eps, int layer_norm,
                                                        const float* __restrict__ scale_tab,
                                                        const float* __restrict__ shift_tab,
                                                        const float* __restrict__ scale_emb,
                                                        const float* __restrict__ shift_emb, long emb_stride) {
-    __shared__ float red[4];
+    __shared__ float red[8];
     const long row = blockIdx.x;
     const float* xr = x + row * ldx;
+    f32x4 v[NV];
     float s1 = 0.f, s2 = 0.f;
-    for (int d = threadIdx.x * 4; d < D; d += 1024) {
-        const float4 v = *(const float4*)(xr + d);
-        s1 += v.x + v.y + v.z + v.w;
-        s2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int d = threadIdx.x * 4 + i * 1024;
+        v[i] = (d < D) ? *(const f32x4*)(xr + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s1 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        s2 += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
     }
-    float mean = 0.f;
-    if (layer_norm) mean = block_sum_256(s1, red) / (float)D;
-    const float ms = block_sum_256(s2, red) / (float)D;
+    block_sum2_256(s1, s2, red);
+    const float mean = layer_norm ? s1 / (float)D : 0.f;
+    const float ms = s2 / (float)D;
     const float var = layer_norm ? fmaxf(ms - mean * mean, 0.f) : ms;
     const float rstd = rsqrtf(var + eps);
     const float* se = scale_emb ? scale_emb + row * emb_stride : nullptr;
     const float* he = shift_emb ? shift_emb + row * emb_stride : nullptr;
     bf16* orow = out + row * ldo;
-    for (int d = threadIdx.x * 4; d < D; d += 1024) {
-        const float4 v = *(const float4*)(xr + d);
-        float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int d = threadIdx.x * 4 + i * 1024;
+        if (d >= D) continue;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (scale_tab) sc += *(const f32x4*)(scale_tab + d);
+        if (se) sc += *(const f32x4*)(se + d);
+        if (shift_tab) sh += *(const f32x4*)(shift_tab + d);
+        if (he) sh += *(const f32x4*)(he + d);
         bf16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float sc = 0.f, sh = 0.f;
-            if (scale_tab) sc += scale_tab[d + e];
-            if (se) sc += se[d + e];
-            if (shift_tab) sh += shift_tab[d + e];
-            if (he) sh += he[d + e];
-            o[e] = f2bf((xs[e] - mean) * rstd * (1.f + sc) + sh);
-        }
+        for (int e = 0; e < 4; ++e) o[e] = f2bf((v[i][e] - mean) * rstd * (1.f + sc[e]) + sh[e]);
         *(bf16x4*)(orow + d) = o;
     }
 }
@@ -69,50 +88,67 @@ struct QKSegs {
     const float* w[2];
 };
 
-__global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16* __restrict__ buf, long ld, int D, int head_dim, int nseg,
+// One block per row, D/2 <= 2048 rotation pairs: thread t owns pairs [8t, 8t+8) of EVERY segment
+// (q and k share the cos/sin row), everything register-resident, one read + one write per element.
+template <int NSEG>
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16* __restrict__ buf, long ld, int D, int head_dim,
                                                           QKSegs segs, float eps, const float* __restrict__ cosp,
                                                           const float* __restrict__ sinp) {
-    __shared__ float red[4];
+    __shared__ float red[8];
     const long row = blockIdx.x;
     const int half = head_dim >> 1;
-    for (int sgi = 0; sgi < nseg; ++sgi) {
-        bf16* xr = buf + row * ld + segs.off[sgi];
-        const float* wt = segs.w[sgi];
-        float s2 = 0.f;
-        for (int d = threadIdx.x * 8; d < D; d += 2048) {
-            const bf16x8 v = *(const bf16x8*)(xr + d);
+    const int p0 = threadIdx.x * 8;
+    const bool act = p0 < D / 2;
+    const int ia = act ? (p0 / half) * head_dim + (p0 % half) : 0;
+    const int ib = ia + half;
+    bf16x8 va[NSEG], vb[NSEG];
+    float ss[2] = {0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NSEG; ++g) {
+        bf16* xr = buf + row * ld + segs.off[g];
+        if (act) {
+            va[g] = *(const bf16x8*)(xr + ia);
+            vb[g] = *(const bf16x8*)(xr + ib);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = bf2f(v[e]);
-                s2 += f * f;
+                const float a = bf2f(va[g][e]), b = bf2f(vb[g][e]);
+                ss[g] += a * a + b * b;
             }
         }
-        const float rstd = rsqrtf(block_sum_256(s2, red) / (float)D + eps);
-        // pairs p in [0, D/2): a = (p/half)*head_dim + p%half, b = a + half ; 8 consecutive pairs per thread
-        for (int p0 = threadIdx.x * 8; p0 < D / 2; p0 += 2048) {
-            const int ia = (p0 / half) * head_dim + (p0 % half);
-            const int ib = ia + half;
-            const bf16x8 va = *(const bf16x8*)(xr + ia);
-            const bf16x8 vb = *(const bf16x8*)(xr + ib);
-            bf16x8 oa, ob;
+    }
+    block_sum2_256(ss[0], ss[1], red);
+    if (!act) return;
+    f32x4 c4[2], s4[2];
+    if (cosp) {
+        c4[0] = *(const f32x4*)(cosp + row * (D / 2) + p0);
+        c4[1] = *(const f32x4*)(cosp + row * (D / 2) + p0 + 4);
+        s4[0] = *(const f32x4*)(sinp + row * (D / 2) + p0);
+        s4[1] = *(const f32x4*)(sinp + row * (D / 2) + p0 + 4);
+    }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = bf2f(va[e]) * rstd * wt[ia + e];
-                const float b = bf2f(vb[e]) * rstd * wt[ib + e];
-                if (cosp) {
-                    const float c = cosp[row * (D / 2) + p0 + e];
-                    const float s = sinp[row * (D / 2) + p0 + e];
-                    oa[e] = f2bf(a * c - b * s);
-                    ob[e] = f2bf(b * c + a * s);
-                } else {
-                    oa[e] = f2bf(a);
-                    ob[e] = f2bf(b);
-                }
+    for (int g = 0; g < NSEG; ++g) {
+        bf16* xr = buf + row * ld + segs.off[g];
+        const float rstd = rsqrtf(ss[g] / (float)D + eps);
+        const float* wt = segs.w[g];
+        const f32x4 wa0 = *(const f32x4*)(wt + ia), wa1 = *(const f32x4*)(wt + ia + 4);
+        const f32x4 wb0 = *(const f32x4*)(wt + ib), wb1 = *(const f32x4*)(wt + ib + 4);
+        bf16x8 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = bf2f(va[g][e]) * rstd * (e < 4 ? wa0[e & 3] : wa1[e & 3]);
+            const float b = bf2f(vb[g][e]) * rstd * (e < 4 ? wb0[e & 3] : wb1[e & 3]);
+            if (cosp) {
+                const float c = e < 4 ? c4[0][e & 3] : c4[1][e & 3];
+                const float sn = e < 4 ? s4[0][e & 3] : s4[1][e & 3];
+                oa[e] = f2bf(a * c - b * sn);
+                ob[e] = f2bf(b * c + a * sn);
+            } else {
+                oa[e] = f2bf(a);
+                ob[e] = f2bf(b);
             }
-            *(bf16x8*)(xr + ia) = oa;
-            *(bf16x8*)(xr + ib) = ob;
         }
-        __syncthreads();
+        *(bf16x8*)(xr + ia) = oa;
+        *(bf16x8*)(xr + ib) = ob;
     }
 }
 
@@ -287,8 +323,13 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
                     const float* scale_tab, const float* shift_tab, const float* scale_emb, const float* shift_emb,
                     long emb_stride, hipStream_t stream) {
     LTX2_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "norm_mod: D, ldx, ldo must be multiples of 4");
-    hipLaunchKernelGGL(norm_mod_kernel, dim3(rows), dim3(256), 0, stream, x, ldx, out, ldo, D, eps, layer_norm,
-                       scale_tab, shift_tab, scale_emb, shift_emb, emb_stride);
+    LTX2_CHECK_ARG(D <= 8192 && emb_stride % 4 == 0, "norm_mod: D=%d exceeds 8192 or emb_stride not a multiple of 4", D);
+    if (D <= 4096)
+        hipLaunchKernelGGL((norm_mod_kernel<4>), dim3(rows), dim3(256), 0, stream, x, ldx, out, ldo, D, eps, layer_norm,
+                           scale_tab, shift_tab, scale_emb, shift_emb, emb_stride);
+    else
+        hipLaunchKernelGGL((norm_mod_kernel<8>), dim3(rows), dim3(256), 0, stream, x, ldx, out, ldo, D, eps, layer_norm,
+                           scale_tab, shift_tab, scale_emb, shift_emb, emb_stride);
     LTX2_CHECK_LAUNCH("norm_mod_kernel");
     return LTX2_OK;
 }
@@ -304,7 +345,11 @@ int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int ns
         s.off[i] = seg_off[i];
         s.w[i] = weights[i];
     }
-    hipLaunchKernelGGL(qknorm_rope_kernel, dim3(rows), dim3(256), 0, stream, buf, ld, D, head_dim, nseg, s, eps, cos, sin);
+    LTX2_CHECK_ARG(D <= 4096, "qknorm_rope: inner dim %d exceeds 4096", D);
+    if (nseg == 2)
+        hipLaunchKernelGGL((qknorm_rope_kernel<2>), dim3(rows), dim3(256), 0, stream, buf, ld, D, head_dim, s, eps, cos, sin);
+    else
+        hipLaunchKernelGGL((qknorm_rope_kernel<1>), dim3(rows), dim3(256), 0, stream, buf, ld, D, head_dim, s, eps, cos, sin);
     LTX2_CHECK_LAUNCH("qknorm_rope_kernel");
     return LTX2_OK;
 }

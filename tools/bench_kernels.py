@@ -57,6 +57,13 @@ def main():
     x = torch.randn(N, D, device=dev)
     t = timeit(lambda: K.adaln_rmsnorm(x))
     print(f"rmsnorm N={N} D={D}: {t*1e6:8.1f} us  {N*D*6/t/1e9:7.1f} GB/s")
+    tab = torch.randn(6, D, device=dev); emb = torch.randn(6, D, device=dev)
+    t = timeit(lambda: K.adaln_rmsnorm(x, scale_tab=tab[1], shift_tab=tab[0], scale_emb=emb[1], shift_emb=emb[0]))
+    print(f"adaln_rmsnorm N={N} D={D}: {t*1e6:8.1f} us  {N*D*6/t/1e9:7.1f} GB/s")
+    qkv = torch.randn(N, 3 * D, device=dev).to(BF)
+    wq = torch.ones(D, device=dev); cs = torch.randn(N, D // 2, device=dev)
+    t = timeit(lambda: K.qknorm_rope_(qkv, D, 128, 0, wq, D, wq, 1e-6, cs, cs))
+    print(f"qknorm_rope N={N} (q,k + rope): {t*1e6:8.1f} us  {(N*2*D*2*2 + N*D*4)/t/1e9:7.1f} GB/s")
     if quick:
         return
     for name, T, Hh, Ww, cin, cout in [("res1024", 7, 16, 24, 1024, 1024), ("res512", 13, 32, 48, 512, 512),
