@@ -17,6 +17,9 @@
 //    that key order inside every 32-key block (done once by vt_transpose_kernel), which makes the
 //    V^T fragment a single conflict-free 16-byte LDS read.
 //  * online softmax in the exp2 domain (scale * log2(e) folded into the scores), fp32 statistics.
+#include <stdlib.h>
+#include <string.h>
+
 #include "attention.h"
 
 namespace {
@@ -27,6 +30,13 @@ constexpr int K_TILE = KVB * HD * 2;           // 16 KiB, rows of 256 B
 constexpr int V_TILE = HD * KVB * 2;           // 16 KiB, rows of 128 B
 constexpr int STAGE = K_TILE + V_TILE;
 constexpr int LDS_BYTES = 2 * STAGE;
+
+#define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define SGB_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+#ifndef AT_DEPTH
+#define AT_DEPTH 3
+#endif
 
 __device__ __forceinline__ void glds16(const bf16* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const void*)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
@@ -107,6 +117,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[b], 0, 0, 0);
             }
         }
+        // keep 3 K-fragment reads in flight ahead of the MFMAs (hipcc otherwise serialises
+        // ds_read -> s_waitcnt lgkmcnt(0) -> mfma and exposes the LDS latency per fragment)
+        SGB_DSR(AT_DEPTH);
+#pragma unroll
+        for (int i_ = 0; i_ < 16 - AT_DEPTH; ++i_) {
+            SGB_MFMA(1);
+            SGB_DSR(1);
+        }
+        SGB_MFMA(AT_DEPTH);
         // ---- mask the ragged tail, running max (raw score domain; the softmax scale * log2(e) is
         //      folded into one fma in front of v_exp_f32: p = 2^(s*c - m*c)) ----
         const int kv0 = t * KVB;
@@ -163,8 +182,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][k2], o[d], 0, 0, 0);
                 }
         }
+        SGB_DSR(AT_DEPTH);
+#pragma unroll
+        for (int i_ = 0; i_ < 16 - AT_DEPTH; ++i_) {
+            SGB_MFMA(1);
+            SGB_DSR(1);
+        }
+        SGB_MFMA(AT_DEPTH);
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- finalize: lane owns query q0+l31, dims d*32 + (r&3) + 8*(r>>2) + 4*hi ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
@@ -232,6 +259,14 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.Nq > 0 && p.Nkv > 0 && p.H > 0, "attention: empty problem");
     LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
     LTX2_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
+    {   // large problems: 8-wave software-pipelined variant (LTX2_ATTN=v1|pp overrides the heuristic)
+        static int ov = -1;
+        if (ov < 0) {
+            const char* e = getenv("LTX2_ATTN");
+            ov = !e ? 0 : (!strcmp(e, "v1") ? 1 : (!strcmp(e, "pp") ? 2 : 0));
+        }
+        if (ov == 2) return attn_pp_launch(p, stream);   // experimental 8-wave variant: not faster yet
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
