@@ -183,6 +183,14 @@ def main():
     steps_per_s = world * K / dt
     ms_per_step = dt / K * 1e3
     alg = dit_algorithmic_flops(N, S, Dm, L)
+    # HBM/fabric traffic of the dominant kernel cannot be collected from inside the process; it comes
+    # from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), null if absent.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f).get("per_launch_avg_bytes")
+    except Exception:  # noqa: BLE001
+        pass
     kern_avg_ms = k_ms / max(k_n, 1)
     kern_tflops = (k_fl / max(k_n, 1)) / (kern_avg_ms * 1e-3) / 1e12
     out = {
@@ -200,7 +208,7 @@ def main():
         "prompt_setup_ms": round(prep_ms, 1), "weight_broadcast_s": round(bcast_s, 3), "weight_broadcast_collectives": n_coll,
         "roofline": {"kernel": "gemm_pp_kernel<4,false> (256x256x64 ping-pong bf16 MFMA GEMM, EPI_RESID_GATE_F32: attn1/attn2 to_out and ff.net.2 + bias + gate*residual)",
                      "bound": "mfma", "achieved": round(kern_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                      "launches": k_n, "avg_launch_us": round(kern_avg_ms * 1e3, 2),
                      "algorithmic_flops_per_launch": round(k_fl / max(k_n, 1))},
     }

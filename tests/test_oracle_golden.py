@@ -1,0 +1,159 @@
+"""The oracle against golden vectors recorded from the REFERENCE'S OWN source files
+(tools/pin_oracle_against_reference.py: reference modules from /root/reference executed over a
+throw-away mlx->torch leaf-op shim in the build container).  Inputs and weights are regenerated
+here from the same seeds; only reference outputs live in tests/golden/*.npz.  CPU-only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dit, loop, vae
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def g(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().float().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float32)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_loop_helpers_match_reference():
+    z = g("loop.npz")
+    assert loop.DISTILLED_SIGMA_VALUES == list(z["distilled"]) and loop.STAGE_2_DISTILLED_SIGMA_VALUES == list(z["stage2"])
+    for steps in (2, 8, 30):
+        close(loop.ltx2_scheduler(steps), z[f"ltx2_sched_{steps}"], rtol=1e-5, atol=1e-6)
+    close(loop.ltx2_scheduler(8, tokens=3456), z["ltx2_sched_8_tokens3456"], rtol=1e-5, atol=1e-6)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 24, 128, generator=gen)
+    x0 = torch.randn(1, 24, 128, generator=gen)
+    sig = loop.DISTILLED_SIGMA_VALUES
+    close(loop.euler_step(x, x0, sig[5], sig[6]), z["euler"], rtol=1e-5, atol=1e-6)
+    mask = (torch.rand(1, 24, 1, generator=gen) > 0.5).float()
+    close(loop.post_process_latent(x0, mask, x), z["post_process"], rtol=0, atol=0)
+    close(loop.timesteps_from_mask(mask, 0.725), z["timesteps_from_mask"], rtol=1e-6, atol=0)
+    close(loop.video_positions(1, 3, 4, 5, 24.0), z["positions_3x4x5_fps24"], rtol=1e-6, atol=1e-7)
+    lat5 = torch.randn(1, 128, 3, 4, 5, generator=gen)
+    close(loop.patchify(lat5), z["patchify"], rtol=0, atol=0)
+
+
+def test_product_host_logic_matches_reference():
+    """The product's own host-side mirrors (schedulers, positions, patchify) against the same vectors."""
+    from ltx_2_mlx_amd.components import LTX2Scheduler, VideoLatentPatchifier
+    from ltx_2_mlx_amd.conditioning import VideoLatentTools
+    from ltx_2_mlx_amd.pipelines import post_process_latent
+    from ltx_2_mlx_amd.types import VideoLatentShape
+    z = g("loop.npz")
+    for steps in (2, 8, 30):
+        close(LTX2Scheduler().execute(steps), z[f"ltx2_sched_{steps}"], rtol=1e-5, atol=1e-6)
+    close(LTX2Scheduler().execute(8, latent=torch.zeros(1, 128, 9, 16, 24)), z["ltx2_sched_8_tokens3456"], rtol=1e-5, atol=1e-6)
+    shp = VideoLatentShape(1, 128, 3, 4, 5)
+    st = VideoLatentTools(VideoLatentPatchifier(1), shp, fps=24.0).create_initial_state()
+    close(st.positions, z["positions_3x4x5_fps24"], rtol=1e-6, atol=1e-7)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 24, 128, generator=gen)
+    x0 = torch.randn(1, 24, 128, generator=gen)
+    mask = (torch.rand(1, 24, 1, generator=gen) > 0.5).float()
+    close(post_process_latent(x0, mask, x), z["post_process"], rtol=0, atol=0)
+    lat5 = torch.randn(1, 128, 3, 4, 5, generator=gen)
+    close(VideoLatentPatchifier(1).patchify(lat5), z["patchify"], rtol=0, atol=0)
+
+
+def test_dit_matches_reference():
+    z = g("dit_tiny.npz")
+    cfg = dit.DiTConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, caption_channels=64)
+    w = dit.make_dit_weights(cfg, seed=11)
+    f, h, wd, S = 3, 4, 4, 16
+    gen = torch.Generator().manual_seed(1234)
+    lat = torch.randn(1, f * h * wd, 128, generator=gen)
+    ctx = 0.1 * torch.randn(1, S, 64, generator=gen)
+    pos = loop.video_positions(1, f, h, wd, 24.0)
+    ts = torch.tensor([0.725])
+    emb, e = dit.prepare_timestep(ts.reshape(1, -1), w, cfg, 1)
+    close(emb, z["adaln_emb"], rtol=2e-4, atol=2e-5)
+    close(e, z["embedded_timestep"], rtol=2e-4, atol=2e-5)
+    close(dit.caption_projection(ctx, w), z["context_proj"], rtol=2e-4, atol=2e-5)
+    cos, sin = dit.rope_split_tables(pos, cfg.inner_dim, 2, 10000.0, [20, 2048, 2048])
+    close(cos, z["rope_cos"], rtol=0, atol=2e-5)
+    close(sin, z["rope_sin"], rtol=0, atol=2e-5)
+    close(dit.velocity_model(lat, ctx, ts, pos, w, cfg), z["velocity_scalar"], rtol=2e-3, atol=2e-4)
+    close(dit.x0_model(lat, ctx, ts, pos, w, cfg), z["x0_scalar"], rtol=2e-3, atol=2e-4)
+    tsp = (torch.rand(1, f * h * wd, 1, generator=gen) > 0.3).float() * 0.909375
+    close(dit.velocity_model(lat, ctx, tsp, pos, w, cfg), z["velocity_pertoken"], rtol=2e-3, atol=2e-4)
+    close(dit.x0_model(lat, ctx, tsp, pos, w, cfg), z["x0_pertoken"], rtol=2e-3, atol=2e-4)
+    # full-width RoPE (dim 4096, 32 heads) and the timestep sinusoid at the distilled sigmas
+    posf = loop.video_positions(1, 2, 3, 4, 24.0)
+    cf, sf = dit.rope_split_tables(posf, 4096, 32, 10000.0, [20, 2048, 2048])
+    close(cf[:, :, ::5], z["rope_full_cos"], rtol=0, atol=2e-3)      # arguments reach ~1.6e4 rad in fp32
+    close(sf[:, :, ::5], z["rope_full_sin"], rtol=0, atol=2e-3)
+    close(dit.sinusoidal_timestep_embedding(torch.tensor(loop.DISTILLED_SIGMA_VALUES) * 1000.0), z["sinusoid"], rtol=0, atol=2e-4)
+
+
+def test_product_rope_tables_match_reference():
+    from ltx_2_mlx_amd.model.transformer import rope_tables_token_major
+    z = g("dit_tiny.npz")
+    posf = loop.video_positions(1, 2, 3, 4, 24.0)
+    c, s = rope_tables_token_major(posf, 4096, 32, 10000.0, [20, 2048, 2048])
+    ref_c = torch.from_numpy(z["rope_full_cos"])[0].permute(1, 0, 2).reshape(-1, 2048)      # tokens 0,5,10,15,20
+    ref_s = torch.from_numpy(z["rope_full_sin"])[0].permute(1, 0, 2).reshape(-1, 2048)
+    close(c[::5], ref_c.numpy(), rtol=0, atol=2e-3)
+    close(s[::5], ref_s.numpy(), rtol=0, atol=2e-3)
+
+
+def _vae_ops():
+    z = g("vae_tiny.npz")
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 8, 3, 5, 6, generator=gen)
+    wc = torch.randn(16, 8, 3, 3, 3, generator=gen) / 15.0
+    bc = torch.randn(16, generator=gen)
+    close(vae.conv3d_simple(x, wc, bc, causal=False), z["conv_noncausal"], rtol=1e-4, atol=1e-5)
+    close(vae.conv3d_simple(x, wc, bc, causal=True), z["conv_causal"], rtol=1e-4, atol=1e-5)
+    for name, stride, mult, resid in (("all", (2, 2, 2), 2, True), ("space", (1, 2, 2), 2, True), ("time", (2, 1, 1), 1, False)):
+        cin = 16
+        sp = stride[0] * stride[1] * stride[2]
+        wu = torch.randn(sp * cin // mult, cin, 3, 3, 3, generator=gen) / 20.0
+        bu = torch.randn(sp * cin // mult, generator=gen)
+        xu = torch.randn(1, cin, 2, 3, 4, generator=gen)
+        out = vae.upsample_block(xu, {"u.conv.conv.weight": wu, "u.conv.conv.bias": bu}, "u", stride, mult, resid, causal=False)
+        close(out, z[f"up_{name}"], rtol=1e-4, atol=1e-5)
+    xp = torch.randn(1, 48, 2, 3, 4, generator=gen)
+    close(vae.unpatchify(xp, 4, 1), z["unpatchify"], rtol=0, atol=0)
+    return gen
+
+
+def test_vae_ops_match_reference():
+    _vae_ops()
+
+
+def test_vae_decoder_and_decode_paths_match_reference():
+    z = g("vae_tiny.npz")
+    gen = _vae_ops()          # advances the generator exactly like the recording script
+    blocks = [["res_x", {"num_layers": 2}], ["compress_all", {"multiplier": 2, "residual": True}],
+              ["res_x", {"num_layers": 1}], ["compress_all", {"multiplier": 2, "residual": True}],
+              ["res_x", {"num_layers": 1}], ["compress_all", {"multiplier": 2, "residual": True}],
+              ["res_x", {"num_layers": 1}]]
+    cfg = vae.VAEConfig(decoder_blocks=blocks, base_channels=8, timestep_conditioning=True)
+    w = vae.make_vae_weights(cfg, seed=31)
+    lat = torch.randn(1, 128, 2, 2, 3, generator=gen)
+    nz = torch.randn(1, 128, 2, 2, 3, generator=gen)
+    close(vae.decoder_forward(lat, w, cfg, timestep=0.05, noise=nz)[..., ::2, ::2], z["decoder_tcond"], rtol=2e-3, atol=2e-4)
+    close(vae.decoder_forward(lat, w, cfg, timestep=None)[..., ::2, ::2], z["decoder_no_t"], rtol=2e-3, atol=2e-4)
+    z9 = torch.randn(1, 128, 9, 2, 2, generator=gen)
+    n9 = torch.randn(1, 128, 9, 2, 2, generator=gen)
+    frames = vae.decode_latent(z9, w, cfg, timestep=0.05, noise=n9)
+    assert frames.shape == (65, 64, 64, 3)
+    d = np.abs(frames[::2, ::2, ::2].numpy().astype(np.int32) - z["decode_latent_u8"].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3           # truncation ties only
+    zt = torch.randn(1, 128, 4, 4, 6, generator=gen)
+    tiled = vae.decode_tiled(zt, lambda t: vae.decoder_forward(t, w, cfg, timestep=None), spatial=(96, 32), temporal=(16, 8))
+    close(tiled[:, :, :, ::4, ::4], z["decode_tiled"], rtol=2e-3, atol=2e-4)
+    specs = vae.tile_specs((1, 128, 9, 32, 48))
+    ref = z["tile_specs_9x32x48"]
+    got = np.array([[*s["in_t"], *s["in_h"], *s["in_w"], *s["out_t"], *s["out_h"], *s["out_w"], *s["ramp_t"], *s["ramp_h"], *s["ramp_w"]] for s in specs])
+    assert np.array_equal(got, ref)
+    close(vae.trapezoid_mask_1d(10, 3, 2, False), z["trapezoid_10_3_2"], rtol=1e-6, atol=1e-7)
+    close(vae.trapezoid_mask_1d(64, 0, 24, True), z["trapezoid_64_0_24_from0"], rtol=1e-6, atol=1e-7)

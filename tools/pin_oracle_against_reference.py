@@ -1,0 +1,236 @@
+"""Generate tests/golden/*.npz by executing the REFERENCE'S OWN source files (from /root/reference)
+through the throw-away mlx->torch shim (tools/mlx_shim.py), on the same seeded inputs and weights
+the oracle tests regenerate.  Run in the build container only:
+
+    python tools/pin_oracle_against_reference.py
+
+Only outputs (and the seeds/configs that regenerate the inputs) are stored; no reference source
+travels.  tests/test_oracle_golden.py checks the oracle against these vectors.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from tools import mlx_shim as shim  # noqa: E402
+
+mx, nn = shim.install()
+A = shim.Arr
+
+from oracle import dit as odit  # noqa: E402
+from oracle import loop as oloop  # noqa: E402
+from oracle import vae as ovae  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def set_param(root, dotted, tensor):
+    obj = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        obj = obj[int(p)] if p.isdigit() else getattr(obj, p)
+    assert hasattr(obj, parts[-1]) or parts[-1] in ("weight", "bias"), dotted
+    setattr(obj, parts[-1], A(tensor.clone().float()))
+
+
+def tn(x):
+    return np.asarray(x, dtype=np.float32) if not isinstance(x, torch.Tensor) else x.detach().float().numpy()
+
+
+# ------------------------------------------------------------------------------------------ DiT
+def pin_dit():
+    from LTX_2_MLX.loader.weight_converter import convert_pytorch_key_to_mlx
+    from LTX_2_MLX.model.transformer.model import LTXModel, LTXModelType, Modality
+    from LTX_2_MLX.model.transformer.rope import LTXRopeType, precompute_freqs_cis
+    from LTX_2_MLX.model.transformer.timestep_embedding import get_timestep_embedding
+
+    cfg = odit.DiTConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, caption_channels=64)
+    w = odit.make_dit_weights(cfg, seed=11)
+    model = LTXModel(model_type=LTXModelType.VideoOnly, num_attention_heads=2, attention_head_dim=128, num_layers=2,
+                     cross_attention_dim=256, caption_channels=64, compute_dtype=mx.float32)
+    for k, v in w.items():
+        mk = convert_pytorch_key_to_mlx(k)     # key as it is after stripping "model.diffusion_model."
+        assert mk is not None, k
+        set_param(model, mk, v)
+    f, h, wd, S = 3, 4, 4, 16
+    g = torch.Generator().manual_seed(1234)
+    lat = torch.randn(1, f * h * wd, 128, generator=g)
+    ctx = 0.1 * torch.randn(1, S, 64, generator=g)
+    pos = oloop.video_positions(1, f, h, wd, 24.0)
+    out = {}
+    for tag, ts in (("scalar", torch.tensor([0.725])), ("pertoken", (torch.rand(1, f * h * wd, 1, generator=g) > 0.3).float() * 0.909375)):
+        video = Modality(latent=A(lat), context=A(ctx), context_mask=None, timesteps=A(ts), positions=A(pos))
+        # LTXModel.__call__ (model.py:825) passes two arguments to the VideoOnly preprocessor's
+        # one-argument prepare(); call the same three stages it would run, directly.
+        args = model._video_args_preprocessor.prepare(video)
+        vargs, _ = model._process_transformer_blocks(args, None)
+        vel = model._process_video_output(vargs.x, vargs.embedded_timestep)
+        t = video.timesteps
+        t = t[:, None, None] if t.ndim == 1 else t
+        x0 = video.latent - t * vel
+        out[f"velocity_{tag}"] = tn(vel.t)
+        out[f"x0_{tag}"] = tn(x0.t)
+        if tag == "scalar":
+            out["adaln_emb"] = tn(args.timesteps.t)
+            out["embedded_timestep"] = tn(args.embedded_timestep.t)
+            out["context_proj"] = tn(args.context.t)
+            out["rope_cos"] = tn(args.positional_embeddings[0].t)
+            out["rope_sin"] = tn(args.positional_embeddings[1].t)
+    # full-width RoPE table slice + sinusoid
+    pos_full = oloop.video_positions(1, 2, 3, 4, 24.0)
+    c, s = precompute_freqs_cis(A(pos_full), dim=4096, out_dtype=mx.float32, theta=10000.0, max_pos=[20, 2048, 2048],
+                                use_middle_indices_grid=True, num_attention_heads=32, rope_type=LTXRopeType.SPLIT)
+    out["rope_full_cos"] = tn(c.t)[:, :, ::5, :]
+    out["rope_full_sin"] = tn(s.t)[:, :, ::5, :]
+    sig = torch.tensor(oloop.DISTILLED_SIGMA_VALUES) * 1000.0
+    out["sinusoid"] = tn(get_timestep_embedding(A(sig), 256, flip_sin_to_cos=True, downscale_freq_shift=0.0).t)
+    np.savez_compressed(os.path.join(GOLD, "dit_tiny.npz"), **out)
+    print("dit_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------------ loop helpers
+def pin_loop():
+    from LTX_2_MLX.components.diffusion_steps import EulerDiffusionStep
+    from LTX_2_MLX.components.patchifiers import VideoLatentPatchifier, get_pixel_coords
+    from LTX_2_MLX.components.schedulers import DISTILLED_SIGMA_VALUES, STAGE_2_DISTILLED_SIGMA_VALUES, LTX2Scheduler
+    from LTX_2_MLX.conditioning.tools import VideoLatentTools
+    from LTX_2_MLX.pipelines.common import post_process_latent, timesteps_from_mask
+    from LTX_2_MLX.types import VideoLatentShape
+
+    out = {"distilled": np.array(DISTILLED_SIGMA_VALUES), "stage2": np.array(STAGE_2_DISTILLED_SIGMA_VALUES)}
+    for steps in (2, 8, 30):
+        out[f"ltx2_sched_{steps}"] = tn(LTX2Scheduler().execute(steps).t)
+    out["ltx2_sched_8_tokens3456"] = tn(LTX2Scheduler().execute(8, latent=mx.zeros((1, 128, 9, 16, 24))).t)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 24, 128, generator=g)
+    x0 = torch.randn(1, 24, 128, generator=g)
+    out["euler"] = tn(EulerDiffusionStep().step(A(x), A(x0), A(torch.tensor(DISTILLED_SIGMA_VALUES)), 5).t)
+    mask = (torch.rand(1, 24, 1, generator=g) > 0.5).float()
+    out["post_process"] = tn(post_process_latent(A(x0), A(mask), A(x)).t)
+    out["timesteps_from_mask"] = tn(timesteps_from_mask(A(mask), 0.725).t)
+    shp = VideoLatentShape(batch=1, channels=128, frames=3, height=4, width=5)
+    st = VideoLatentTools(patchifier=VideoLatentPatchifier(patch_size=1), target_shape=shp, fps=24.0).create_initial_state()
+    out["positions_3x4x5_fps24"] = tn(st.positions.t)
+    lat5 = torch.randn(1, 128, 3, 4, 5, generator=g)
+    out["patchify"] = tn(VideoLatentPatchifier(patch_size=1).patchify(A(lat5)).t)
+    np.savez_compressed(os.path.join(GOLD, "loop.npz"), **out)
+    print("loop.npz", {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------------ VAE
+def load_ref_decoder(dec, w, cfg):
+    from LTX_2_MLX.model.video_vae.simple_decoder import TimestepEmbedder
+    dec.mean_of_means = A(w["vae.per_channel_statistics.mean-of-means"])
+    dec.std_of_means = A(w["vae.per_channel_statistics.std-of-means"])
+    for sfx in ("weight", "bias"):
+        setattr(dec.conv_in, sfx, A(w[f"vae.decoder.conv_in.conv.{sfx}"]))
+        setattr(dec.conv_out, sfx, A(w[f"vae.decoder.conv_out.conv.{sfx}"]))
+    for i, (block, btype) in enumerate(zip(dec.up_blocks, dec.block_types)):
+        pre = f"vae.decoder.up_blocks.{i}"
+        if btype == "res":
+            for j, rb in enumerate(block.res_blocks):
+                for cn in ("conv1", "conv2"):
+                    for sfx in ("weight", "bias"):
+                        setattr(getattr(rb, cn), sfx, A(w[f"{pre}.res_blocks.{j}.{cn}.conv.{sfx}"]))
+                rb.scale_shift_table = A(w[f"{pre}.res_blocks.{j}.scale_shift_table"])
+            k1 = f"{pre}.time_embedder.timestep_embedder.linear_1.weight"
+            if k1 in w:
+                te = TimestepEmbedder(hidden_dim=w[k1].shape[0], output_dim=4 * block.channels, input_dim=256)
+                for ln in ("linear_1", "linear_2"):
+                    for sfx in ("weight", "bias"):
+                        setattr(getattr(te, ln), sfx, A(w[f"{pre}.time_embedder.timestep_embedder.{ln}.{sfx}"]))
+                block.time_embedder = te
+        else:
+            for sfx in ("weight", "bias"):
+                setattr(block.conv, sfx, A(w[f"{pre}.conv.conv.{sfx}"]))
+    dec.last_scale_shift_table = A(w["vae.decoder.last_scale_shift_table"])
+    if cfg.timestep_conditioning:
+        dec.timestep_scale_multiplier = A(w["vae.decoder.timestep_scale_multiplier"])
+        lt = "vae.decoder.last_time_embedder.timestep_embedder"
+        te = TimestepEmbedder(hidden_dim=256, output_dim=2 * dec.final_channels, input_dim=256)
+        for ln in ("linear_1", "linear_2"):
+            for sfx in ("weight", "bias"):
+                setattr(getattr(te, ln), sfx, A(w[f"{lt}.{ln}.{sfx}"]))
+        dec.last_time_embedder = te
+
+
+def pin_vae():
+    from LTX_2_MLX.model.video_vae.ops import unpatchify
+    from LTX_2_MLX.model.video_vae.simple_decoder import (Conv3dSimple, DepthToSpaceUpsample3d, SimpleVideoDecoder,
+                                                          decode_latent)
+    from LTX_2_MLX.model.video_vae.tiling import (SpatialTilingConfig, TemporalTilingConfig, TilingConfig,
+                                                  compute_trapezoidal_mask_1d, decode_tiled, generate_tile_specs)
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    # single conv (causal / non-causal) and the three depth-to-space variants
+    x = torch.randn(1, 8, 3, 5, 6, generator=g)
+    wc = torch.randn(16, 8, 3, 3, 3, generator=g) / 15.0
+    bc = torch.randn(16, generator=g)
+    conv = Conv3dSimple(8, 16)
+    conv.weight, conv.bias = A(wc), A(bc)
+    out["conv_noncausal"] = tn(conv(A(x), causal=False).t)
+    out["conv_causal"] = tn(conv(A(x), causal=True).t)
+    for name, stride, mult, resid in (("all", (2, 2, 2), 2, True), ("space", (1, 2, 2), 2, True), ("time", (2, 1, 1), 1, False)):
+        cin = 16
+        sp = stride[0] * stride[1] * stride[2]
+        up = DepthToSpaceUpsample3d(cin, stride=stride, residual=resid, out_channels_reduction_factor=mult)
+        wu = torch.randn(sp * cin // mult, cin, 3, 3, 3, generator=g) / 20.0
+        bu = torch.randn(sp * cin // mult, generator=g)
+        up.conv.weight, up.conv.bias = A(wu), A(bu)
+        xu = torch.randn(1, cin, 2, 3, 4, generator=g)
+        out[f"up_{name}"] = tn(up(A(xu), causal=False).t)
+    xp = torch.randn(1, 48, 2, 3, 4, generator=g)
+    out["unpatchify"] = tn(unpatchify(A(xp), patch_size_hw=4, patch_size_t=1).t)
+
+    # tiny full decoder, default block structure, with timestep conditioning and a shared noise tensor
+    blocks = [["res_x", {"num_layers": 2}], ["compress_all", {"multiplier": 2, "residual": True}],
+              ["res_x", {"num_layers": 1}], ["compress_all", {"multiplier": 2, "residual": True}],
+              ["res_x", {"num_layers": 1}], ["compress_all", {"multiplier": 2, "residual": True}],
+              ["res_x", {"num_layers": 1}]]
+    cfg = ovae.VAEConfig(decoder_blocks=blocks, base_channels=8, timestep_conditioning=True)
+    w = ovae.make_vae_weights(cfg, seed=31)
+    dec = SimpleVideoDecoder(decoder_blocks=blocks, base_channels=8, timestep_conditioning=True, compute_dtype=mx.float32)
+    load_ref_decoder(dec, w, cfg)
+    z = torch.randn(1, 128, 2, 2, 3, generator=g)
+    nz = torch.randn(1, 128, 2, 2, 3, generator=g)
+    shim._Random.preset.append(nz)
+    out["decoder_tcond"] = tn(dec(A(z), timestep=0.05, show_progress=False).t)[..., ::2, ::2]
+    out["decoder_no_t"] = tn(dec(A(z), timestep=None, show_progress=False).t)[..., ::2, ::2]
+    # chunked decode_latent at T'=9 (noise per chunk shared with the oracle through `preset`)
+    z9 = torch.randn(1, 128, 9, 2, 2, generator=g)
+    n9 = torch.randn(1, 128, 9, 2, 2, generator=g)
+    for s, e in ovae.temporal_chunks(9):
+        shim._Random.preset.append(n9[:, :, s:e].contiguous())
+    import builtins
+    _print = builtins.print
+    frames = decode_latent(A(z9), dec, timestep=0.05)
+    out["decode_latent_u8"] = np.asarray(frames.t.numpy(), dtype=np.uint8)[::2, ::2, ::2]
+    # tiled decode (no timestep conditioning -> deterministic)
+    zt = torch.randn(1, 128, 4, 4, 6, generator=g)
+    tc = TilingConfig(SpatialTilingConfig(96, 32), TemporalTilingConfig(16, 8))
+    tiled = next(decode_tiled(A(zt), lambda lt, timestep=None: dec(lt, timestep=None, show_progress=False), tc, timestep=None,
+                              show_progress=False))
+    out["decode_tiled"] = tn(tiled.t)[:, :, :, ::4, ::4]
+    specs = generate_tile_specs((1, 128, 9, 32, 48), TilingConfig.default())
+    out["tile_specs_9x32x48"] = np.array([[s.in_t_start, s.in_t_end, s.in_h_start, s.in_h_end, s.in_w_start, s.in_w_end,
+                                           s.out_t_start, s.out_t_end, s.out_h_start, s.out_h_end, s.out_w_start, s.out_w_end,
+                                           s.ramp_t_left, s.ramp_t_right, s.ramp_h_left, s.ramp_h_right, s.ramp_w_left, s.ramp_w_right]
+                                          for s in specs])
+    out["trapezoid_10_3_2"] = tn(compute_trapezoidal_mask_1d(10, 3, 2, False).t)
+    out["trapezoid_64_0_24_from0"] = tn(compute_trapezoidal_mask_1d(64, 0, 24, True).t)
+    np.savez_compressed(os.path.join(GOLD, "vae_tiny.npz"), **out)
+    print("vae_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    with torch.no_grad():
+        pin_loop()
+        pin_dit()
+        pin_vae()
+    print("golden vectors written to", GOLD)
