@@ -270,14 +270,15 @@ __global__ __launch_bounds__(256) void pixnorm_mod_silu_kernel(const bf16* __res
     for (int i = 0; i < E / 8; ++i) {
         bf16x8 o8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = c0 + i * 8 + e;
-            float sh = tab[shift_row * C + c], sc = tab[scale_row * C + c];
+        for (int q4 = 0; q4 < 2; ++q4) {        // 16-byte table loads: 4 channels at a time
+            const int c = c0 + i * 8 + q4 * 4;
+            f32x4 sh = *(const f32x4*)(tab + shift_row * C + c), sc = *(const f32x4*)(tab + scale_row * C + c);
             if (te) {
-                sh += te[shift_row * C + c];
-                sc += te[scale_row * C + c];
+                sh += *(const f32x4*)(te + shift_row * C + c);
+                sc += *(const f32x4*)(te + scale_row * C + c);
             }
-            o8[e] = f2bf(silu_f(v[i * 8 + e] * rstd * (1.f + sc) + sh));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o8[q4 * 4 + e] = f2bf(silu_f(v[i * 8 + q4 * 4 + e] * rstd * (1.f + sc[e]) + sh[e]));
         }
         *(bf16x8*)(y + pos * C + c0 + i * 8) = o8;
     }

@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""LTX-2 generation CLI on MI355X for the distilled denoise + VAE-decode hot path.
+
+Keeps the flag names and `generate_video(...)` keyword names of the reference's
+scripts/generate.py (argparse block :2364-2641, `generate_video` :933-997) for this path:
+standard single-stage distilled loop (reference :1764-1984) followed by `decode_latent` (:2080-2091).
+Out of this path (and rejected with a clear message): Gemma text encoding, audio, CFG/STG guidance,
+image conditioning, LoRA, ffmpeg muxing.  Text embeddings come from `--embedding file.npz` (keys
+`embedding`, `attention_mask`, as the reference's `load_text_embedding` :730-750) or the reference's
+dummy encoder (`--no-gemma`, :642-661).  Frames are written as `<output>.npz` (uint8 T,H,W,3) and
+the final latent as `<output>_latent.npz` like the reference (:1994-1996).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES, VideoLatentPatchifier, get_pixel_coords, get_sigma_schedule  # noqa: E402
+from ltx_2_mlx_amd.model.transformer import LTXModel, Modality, X0Model  # noqa: E402
+from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder, TilingConfig, decode_latent, decode_tiled, load_vae_decoder_weights  # noqa: E402
+from ltx_2_mlx_amd.types import SpatioTemporalScaleFactors, VideoLatentShape  # noqa: E402
+
+
+def create_dummy_text_encoding(prompt: str, batch_size: int = 1, max_tokens: int = 256, embed_dim: int = 3840, device="cuda"):
+    """0.1 * N(0,1) embedding seeded by the prompt (reference :642-661; torch RNG instead of MLX's)."""
+    g = torch.Generator().manual_seed(hash(prompt) % (2 ** 31))
+    return (0.1 * torch.randn(batch_size, max_tokens, embed_dim, generator=g)).to(device), torch.ones(batch_size, max_tokens, device=device)
+
+
+def load_text_embedding(path: str, device="cuda"):
+    z = np.load(path)
+    emb = torch.from_numpy(z["embedding"]).float()
+    if emb.dim() == 2:
+        emb = emb[None]
+    mask = torch.from_numpy(z["attention_mask"]).float() if "attention_mask" in z else torch.ones(emb.shape[:2])
+    return emb.to(device), mask.to(device)
+
+
+def load_transformer(weights_path, num_layers=48, num_heads=32, caption_channels=3840, seed=0, device="cuda"):
+    """LTXModel(VideoOnly, 32x128, 48 layers, caption 3840) (reference load_transformer :788-835)."""
+    model = LTXModel(num_attention_heads=num_heads, attention_head_dim=128, num_layers=num_layers,
+                     caption_channels=caption_channels, device=device)
+    if weights_path:
+        from safetensors import safe_open
+        sd = {}
+        with safe_open(weights_path, framework="pt") as f:
+            for k in f.keys():
+                if k.startswith("model.diffusion_model."):
+                    sd[k[len("model.diffusion_model."):]] = f.get_tensor(k)
+        model.load_state_dict(sd, strict=True)
+    else:
+        model.init_random_weights(seed=seed)
+    return model
+
+
+def euler_step_x0(sample, denoised, sigma, sigma_next):
+    from ltx_2_mlx_amd import kernels as K
+    c = sample.shape[-1]
+    return K.euler_step(sample.reshape(-1, c).float(), denoised.reshape(-1, c).float(), sigma, sigma_next).reshape(sample.shape)
+
+
+def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames: int = 97, num_inference_steps: int = 8,
+                   seed: int = 42, output_path: str = "output.mp4", weights_path=None, embedding_path=None,
+                   use_gemma: bool = False, model_variant: str = "distilled", skip_vae: bool = False, use_placeholder: bool = False,
+                   tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, num_layers: int = 48,
+                   num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", **unsupported):
+    for k, v in unsupported.items():
+        if v:
+            raise NotImplementedError(f"--{k.replace('_', '-')} is outside the MI355X hot path (see DESIGN.md)")
+    if num_frames % 8 != 1:
+        raise ValueError(f"num_frames must be 8*k + 1, got {num_frames}")
+    if height % 32 != 0 or width % 32 != 0:
+        raise ValueError(f"Resolution ({height}x{width}) must be divisible by 32")
+    if use_gemma:
+        raise NotImplementedError("Gemma text encoding is outside the hot path: pass --embedding or --no-gemma")
+    if model_variant == "distilled" and cfg_scale != 1.0:
+        print("  distilled model: cfg forced to 1.0 (reference :1207-1216)")
+    torch.manual_seed(seed)
+    t_all = time.time()
+    print("[1/5] text encoding")
+    text_encoding, _ = load_text_embedding(embedding_path, device) if embedding_path else create_dummy_text_encoding(prompt, device=device)
+    print("[2/5] transformer")
+    model = X0Model(load_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device))
+    print("[3/5] VAE decoder")
+    vae_decoder = None
+    if not skip_vae:
+        vae_decoder = SimpleVideoDecoder(base_channels=vae_base_channels, device=device)
+        if weights_path:
+            load_vae_decoder_weights(vae_decoder, weights_path)
+        else:
+            vae_decoder.init_random_weights(seed=seed + 1)
+    print("[4/5] latent noise")
+    lf, lh, lw = (num_frames - 1) // 8 + 1, height // 32, width // 32
+    g = torch.Generator(device=device).manual_seed(seed)
+    latent = torch.randn(1, 128, lf, lh, lw, generator=g, device=device)
+    sigmas = DISTILLED_SIGMA_VALUES[:num_inference_steps + 1] if model_variant == "distilled" else \
+        [float(s) for s in get_sigma_schedule(num_inference_steps, distilled=False, latent=latent)]
+    patchifier = VideoLatentPatchifier(patch_size=1)
+    shape = VideoLatentShape(1, 128, lf, lh, lw)
+    coords = patchifier.get_patch_grid_bounds(shape, device=device)
+    positions = get_pixel_coords(coords, SpatioTemporalScaleFactors.default(), causal_fix=True).float()
+    positions = torch.cat([positions[:, 0:1] / 24.0, positions[:, 1:]], dim=1)          # fps = 24 on the CLI path (:1823)
+    print(f"[5/5] denoising ({len(sigmas) - 1} steps)")
+    t0 = time.time()
+    tok = patchifier.patchify(latent).contiguous()
+    if use_placeholder:
+        for i in range(len(sigmas) - 1):
+            tok = tok + 0.1 * torch.randn_like(tok) * (sigmas[i + 1] - sigmas[i])
+    elif use_hip_graph:
+        vm = model.velocity_model
+        vm.prepare(text_encoding, positions)
+        lat2d = tok[0].float().contiguous()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            vm.capture_denoise_graph(lat2d, sigmas)
+            vm.replay_denoise_graph()
+        torch.cuda.current_stream().wait_stream(side)
+        tok = lat2d[None]
+    else:
+        for i in range(len(sigmas) - 1):
+            m = Modality(latent=tok, context=text_encoding, context_mask=None,
+                         timesteps=torch.tensor([sigmas[i]], device=device), positions=positions, enabled=True)
+            tok = euler_step_x0(tok, model(m), sigmas[i], sigmas[i + 1])
+    torch.cuda.synchronize()
+    print(f"  denoise: {(time.time() - t0):.3f} s")
+    latent = patchifier.unpatchify(tok, shape)
+    base = os.path.splitext(output_path)[0]
+    np.savez(base + "_latent.npz", latent=latent.float().cpu().numpy())
+    frames = None
+    if vae_decoder is not None:
+        t0 = time.time()
+        if tiled_vae:
+            video = next(decode_tiled(latent, vae_decoder, TilingConfig.default()))
+            from ltx_2_mlx_amd import kernels as K
+            frames = K.video_to_uint8(video[0])
+        else:
+            frames = decode_latent(latent, vae_decoder)
+        torch.cuda.synchronize()
+        print(f"  decode: {(time.time() - t0):.3f} s -> {tuple(frames.shape)}")
+        np.savez_compressed(base + ".npz", frames=frames.cpu().numpy())
+    print(f"Done in {time.time() - t_all:.1f} s: {base}.npz")
+    return frames
+
+
+def main():
+    p = argparse.ArgumentParser(description="LTX-2 video generation (MI355X hot path)")
+    p.add_argument("prompt", type=str)
+    p.add_argument("--height", type=int, default=480)
+    p.add_argument("--width", type=int, default=704)
+    p.add_argument("--frames", type=int, default=97)
+    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--output", "-o", type=str, default="output.mp4")
+    p.add_argument("--weights", type=str, default=None)
+    p.add_argument("--embedding", type=str, default=None)
+    p.add_argument("--no-gemma", action="store_true", help="dummy text embeddings (reference default without Gemma weights)")
+    p.add_argument("--gemma-path", type=str, default=None)
+    p.add_argument("--model-variant", choices=["distilled", "dev"], default="distilled")
+    p.add_argument("--pipeline", type=str, default="text-to-video")
+    p.add_argument("--cfg", type=float, default=1.0)
+    p.add_argument("--fp16", action="store_true", help="accepted for compatibility; compute is bf16 / fp32-accumulate")
+    p.add_argument("--fp32", action="store_true")
+    p.add_argument("--fp8", action="store_true")
+    p.add_argument("--skip-vae", action="store_true")
+    p.add_argument("--placeholder", action="store_true")
+    p.add_argument("--tiled-vae", action="store_true")
+    p.add_argument("--low-memory", action="store_true")
+    p.add_argument("--fast-mode", action="store_true")
+    p.add_argument("--no-hip-graph", action="store_true", help="MI355X: run the step loop eagerly instead of replaying the captured hipGraph")
+    p.add_argument("--image", type=str, default=None)
+    p.add_argument("--lora", type=str, default=None)
+    p.add_argument("--generate-audio", action="store_true")
+    p.add_argument("--spatial-upscaler-weights", type=str, default=None)
+    p.add_argument("--layers", type=int, default=48, help="debug: number of DiT layers for random-weight runs")
+    p.add_argument("--heads", type=int, default=32, help="debug: attention heads (x128) for random-weight runs")
+    p.add_argument("--vae-base-channels", type=int, default=128)
+    a = p.parse_args()
+    if a.fp32 or a.fp8:
+        raise NotImplementedError("--fp32 / --fp8 weights: next scope row (DESIGN.md)")
+    if a.pipeline not in ("text-to-video", "distilled"):
+        raise NotImplementedError(f"--pipeline {a.pipeline} is outside the MI355X hot path")
+    generate_video(a.prompt, height=a.height, width=a.width, num_frames=a.frames, num_inference_steps=a.steps, seed=a.seed,
+                   output_path=a.output, weights_path=a.weights, embedding_path=a.embedding,
+                   use_gemma=bool(a.gemma_path) and not a.no_gemma, model_variant=a.model_variant, skip_vae=a.skip_vae,
+                   use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, cfg_scale=a.cfg, use_hip_graph=not a.no_hip_graph,
+                   num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,
+                   image=a.image, lora=a.lora, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights)
+
+
+if __name__ == "__main__":
+    main()
