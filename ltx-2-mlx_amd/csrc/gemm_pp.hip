@@ -32,6 +32,10 @@
 
 #include "gemm_epilogue.h"
 
+#ifndef PP_ORDER
+#define PP_ORDER 0
+#endif
+
 namespace {
 
 constexpr int BK = 64;
@@ -180,21 +184,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     issue_b(1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     PP_BARRIER();
-    const int grp = p.pp_stagger == 0 ? (wv >> 2) : (p.pp_stagger == 1 ? (wv & 1) : (p.pp_stagger == 3 ? ((wv >> 1) & 1) : 0));
-    if (grp == 1) PP_BARRIER();         // stagger the second group by one interval
+    const int grp = (p.pp_stagger == 0 || p.pp_stagger == 4) ? (wv >> 2) : (p.pp_stagger == 1 ? (wv & 1) : (p.pp_stagger == 3 ? ((wv >> 1) & 1) : 0));
+    const bool soft = p.pp_stagger == 4;
+    const bool bar_l = !soft || grp == 0, bar_m = !soft || grp == 1;
+    if (grp == 1 && !soft) PP_BARRIER();         // stagger the second group by one interval
 
+    // optional interval timestamps (tools/pp_timeline.py): waves 0 and 4 of block 0, K-tiles 8..11
+    unsigned long long* dbg = (p.dbg && blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 4)) ? (unsigned long long*)p.dbg + (wv >> 2) * 256 : nullptr;
+    int dbi = 0;
+#ifdef PP_TIMELINE      // compile-time only: the branches would split the scheduling regions
+#define PP_STAMP() do { if (dbg && t >= 8 && t < 12 && dbi < 256) dbg[dbi++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP_STAMP() do { (void)dbg; (void)dbi; } while (0)
+#endif
     for (int t = 0; t < nk; ++t) {
         const char* cb = smem + (t & 1) * BUF;
         // La: fragments of A0, B0, B1
+        PP_STAMP();
         read_a(cb, 0);
         read_b(cb, 0);
         read_b(cb, 1);
+        PP_STAMP();
         PP_LGKM0();
-        PP_BARRIER();
+        PP_STAMP();
+        if (bar_l) PP_BARRIER();
+        PP_STAMP();
         // Ma: 16 MFMAs on rows [0,64) of the wave slab + LDS-DMA of A1(t+1)
         PP_PIN_IN();
         __builtin_amdgcn_s_setprio(1);
         issue_a(1, t + 1);
+#if PP_ORDER
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                PP_MFMA(0, 0, qb, ks);
+                PP_MFMA(0, 1, qb, ks);
+            }
+#else
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -202,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 PP_MFMA(0, 0, qb, ks);
                 PP_MFMA(0, 1, qb, ks);
             }
+#endif
         SGB_MFMA(4);
         SGB_VMEM(1);
         SGB_MFMA(6);
@@ -209,18 +237,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         SGB_MFMA(6);
         __builtin_amdgcn_s_setprio(0);
         PP_PIN_OUT(0);
-        PP_BARRIER();
+        PP_STAMP();
+        if (bar_m) PP_BARRIER();
         // Lb: fragments of A1; this wave's share of A0,B0,B1(t+1) must have landed before the barrier
+        PP_STAMP();
         read_a(cb, 1);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        PP_STAMP();
         PP_LGKM0();
-        PP_BARRIER();
+        PP_STAMP();
+        if (bar_l) PP_BARRIER();
+        PP_STAMP();
         // Mb: 16 MFMAs on rows [64,128) + LDS-DMA of A0,B0,B1(t+2); A1(t+1) must have landed
         PP_PIN_IN();
         __builtin_amdgcn_s_setprio(1);
         issue_a(0, t + 2);
         issue_b(0, t + 2);
         issue_b(1, t + 2);
+#if PP_ORDER
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                PP_MFMA(1, 0, qb, ks);
+                PP_MFMA(1, 1, qb, ks);
+            }
+#else
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -228,6 +270,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 PP_MFMA(1, 0, qb, ks);
                 PP_MFMA(1, 1, qb, ks);
             }
+#endif
         SGB_MFMA(2);
         SGB_VMEM(1);
         SGB_MFMA(2);
@@ -243,10 +286,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         SGB_MFMA(4);
         __builtin_amdgcn_s_setprio(0);
         PP_PIN_OUT(1);
+        PP_STAMP();
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        PP_BARRIER();
+        PP_STAMP();
+        if (bar_m) PP_BARRIER();
     }
-    if (grp == 0 && p.pp_stagger != 2) PP_BARRIER();          // rebalance the barrier count
+    if (grp == 0 && p.pp_stagger != 2 && !soft) PP_BARRIER();          // rebalance the barrier count
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: lane owns rows (l31 per row slot) x 4-column groups (gemm_epilogue.h) ----

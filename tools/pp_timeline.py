@@ -12,11 +12,11 @@ for _ in range(3): K.gemm(a, w, None, out=out)
 torch.cuda.synchronize()
 d = dbg.cpu().reshape(2, 256)
 base = int(min(d[0, 0], d[1, 0]))
-names = ["La_start", "La_rd_iss", "La_dma_iss", "La_end", "Ma_start", "Ma_end", "Lb_start", "Lb_rd_iss", "Lb_dma_iss", "Lb_vmcnt", "Lb_end", "Mb_start", "Mb_end"]
+names = ["La_start", "La_rd_issued", "La_lgkm0", "Ma_start", "Ma_end", "Lb_start", "Lb_vmcnt2", "Lb_lgkm0", "Mb_start", "Mb_mfma_end", "Mb_vmcnt6"]
 for g in range(2):
     print(f"group {g} (wave {g*4}):")
     prev = None
-    for i in range(26):
+    for i in range(33):
         v = int(d[g, i]) - base
-        print(f"   t={8 + i // 13} {names[i % 13]:10s} {v:7d}" + (f"  (+{v - prev})" if prev is not None else ""))
+        print(f"   t={8 + i // 11} {names[i % 11]:12s} {v:7d}" + (f"  (+{v - prev})" if prev is not None else ""))
         prev = v
