@@ -157,3 +157,45 @@ def test_vae_decoder_and_decode_paths_match_reference():
     assert np.array_equal(got, ref)
     close(vae.trapezoid_mask_1d(10, 3, 2, False), z["trapezoid_10_3_2"], rtol=1e-6, atol=1e-7)
     close(vae.trapezoid_mask_1d(64, 0, 24, True), z["trapezoid_64_0_24_from0"], rtol=1e-6, atol=1e-7)
+
+
+def av_tiny_case(v23: bool):
+    """Inputs of tools/pin_oracle_against_reference.py:pin_dit_av, regenerated from the same seeds."""
+    from oracle import dit_av
+    cfg = dit_av.AVConfig(num_attention_heads=4, attention_head_dim=128, audio_heads=4, audio_head_dim=64, num_layers=2,
+                          caption_channels=None if v23 else 64, cross_attention_adaln=v23, apply_gated_attention=v23)
+    w = dit_av.make_av_weights(cfg, seed=17 + v23)
+    f, h, wd, S, Ta = 3, 4, 4, 16, 10
+    gen = torch.Generator().manual_seed(99)
+    vlat = torch.randn(1, f * h * wd, 128, generator=gen)
+    alat = torch.randn(1, Ta, 128, generator=gen)
+    vctx = 0.1 * torch.randn(1, S, 64 if not v23 else cfg.inner_dim, generator=gen)
+    actx = 0.1 * torch.randn(1, S, 64 if not v23 else cfg.audio_inner_dim, generator=gen)
+    vpos = loop.video_positions(1, f, h, wd, 24.0)
+    apos = dit_av.audio_positions(1, Ta)
+    sigma = 0.725
+    vmask = (torch.rand(1, f * h * wd, 1, generator=gen) > 0.2).float()
+    cases = {}
+    for tsk, vts, ats in (("scalar", torch.tensor([sigma]), torch.tensor([sigma])),
+                          ("pertoken", vmask * sigma, torch.ones(1, Ta, 1) * sigma)):
+        video = dict(latent=vlat, context=vctx, timesteps=vts, sigma=torch.tensor([sigma]), positions=vpos)
+        audio = dict(latent=alat, context=actx, timesteps=ats, sigma=torch.tensor([sigma]), positions=apos)
+        cases[tsk] = (video, audio)
+    return cfg, w, cases
+
+
+@pytest.mark.parametrize("v23", [False, True])
+def test_av_dit_matches_reference(v23):
+    """AudioVideo DiT (19B-style blocks and the V2.3 variant) against the reference's LTXModel / X0Model."""
+    from oracle import dit_av
+    z = g("dit_av_tiny.npz")
+    tag = "v23" if v23 else "v1"
+    cfg, w, cases = av_tiny_case(v23)
+    with torch.no_grad():
+        for tsk, (video, audio) in cases.items():
+            vv, av = dit_av.av_velocity_model(video, audio, w, cfg)
+            close(vv, z[f"{tag}_{tsk}_video_velocity"], rtol=2e-4, atol=2e-5)
+            close(av, z[f"{tag}_{tsk}_audio_velocity"], rtol=2e-4, atol=2e-5)
+            vx0, ax0 = dit_av.av_x0_model(video, audio, w, cfg)
+            close(vx0, z[f"{tag}_{tsk}_video_x0"], rtol=2e-4, atol=2e-5)
+            close(ax0, z[f"{tag}_{tsk}_audio_x0"], rtol=2e-4, atol=2e-5)

@@ -23,6 +23,7 @@ mx, nn = shim.install()
 A = shim.Arr
 
 from oracle import dit as odit  # noqa: E402
+from oracle import dit_av as oav  # noqa: E402
 from oracle import loop as oloop  # noqa: E402
 from oracle import vae as ovae  # noqa: E402
 
@@ -93,6 +94,56 @@ def pin_dit():
     np.savez_compressed(os.path.join(GOLD, "dit_tiny.npz"), **out)
     print("dit_tiny.npz", {k: v.shape for k, v in out.items()})
 
+
+
+# ------------------------------------------------------------------------------------------ AudioVideo DiT
+def pin_dit_av():
+    from LTX_2_MLX.components.patchifiers import AudioPatchifier
+    from LTX_2_MLX.loader.weight_converter import convert_pytorch_key_to_mlx
+    from LTX_2_MLX.model.transformer.model import LTXModel, LTXModelType, Modality, X0Model
+    from LTX_2_MLX.types import AudioLatentShape
+
+    class TinyAV(LTXModel):          # same code, 4 audio heads instead of 32 (class constants model.py:428-434)
+        AUDIO_ATTENTION_HEADS = 4
+
+    out = {}
+    f, h, wd, S, Ta = 3, 4, 4, 16, 10
+    for tag, v23 in (("v1", False), ("v23", True)):
+        cfg = oav.AVConfig(num_attention_heads=4, attention_head_dim=128, audio_heads=4, audio_head_dim=64, num_layers=2,
+                           caption_channels=None if v23 else 64, cross_attention_adaln=v23, apply_gated_attention=v23)
+        w = oav.make_av_weights(cfg, seed=17 + v23)
+        model = TinyAV(model_type=LTXModelType.AudioVideo, num_attention_heads=4, attention_head_dim=128, num_layers=2,
+                       cross_attention_dim=512, caption_channels=cfg.caption_channels, compute_dtype=mx.float32,
+                       cross_attention_adaln=v23, apply_gated_attention=v23)
+        for k, v in w.items():
+            mk = convert_pytorch_key_to_mlx(k, include_audio=True)
+            assert mk is not None, k
+            set_param(model, mk, v)
+        g = torch.Generator().manual_seed(99)
+        vlat = torch.randn(1, f * h * wd, 128, generator=g)
+        alat = torch.randn(1, Ta, 128, generator=g)
+        vctx = 0.1 * torch.randn(1, S, 64 if not v23 else cfg.inner_dim, generator=g)
+        actx = 0.1 * torch.randn(1, S, 64 if not v23 else cfg.audio_inner_dim, generator=g)
+        vpos = oloop.video_positions(1, f, h, wd, 24.0)
+        apos_ref = AudioPatchifier(patch_size=1).get_patch_grid_bounds(AudioLatentShape(1, 8, Ta, 16))
+        apos = oav.audio_positions(1, Ta)
+        assert np.allclose(tn(apos_ref.t), apos.numpy()), "audio positions differ"
+        sigma = 0.725
+        vmask = (torch.rand(1, f * h * wd, 1, generator=g) > 0.2).float()
+        for tsk, vts, ats in (("scalar", torch.tensor([sigma]), torch.tensor([sigma])),
+                              ("pertoken", vmask * sigma, torch.ones(1, Ta, 1) * sigma)):
+            video = Modality(latent=A(vlat), context=A(vctx), context_mask=None, timesteps=A(vts), positions=A(vpos),
+                             sigma=A(torch.tensor([sigma])))
+            audio = Modality(latent=A(alat), context=A(actx), context_mask=None, timesteps=A(ats), positions=A(apos),
+                             sigma=A(torch.tensor([sigma])))
+            vv, av = model(video, audio)
+            vx0, ax0 = X0Model(model)(video, audio)
+            out[f"{tag}_{tsk}_video_velocity"] = tn(vv.t)
+            out[f"{tag}_{tsk}_audio_velocity"] = tn(av.t)
+            out[f"{tag}_{tsk}_video_x0"] = tn(vx0.t)
+            out[f"{tag}_{tsk}_audio_x0"] = tn(ax0.t)
+    np.savez_compressed(os.path.join(GOLD, "dit_av_tiny.npz"), **out)
+    print("dit_av_tiny.npz", {k: v.shape for k, v in out.items()})
 
 # ------------------------------------------------------------------------------------------ loop helpers
 def pin_loop():
@@ -232,5 +283,6 @@ if __name__ == "__main__":
     with torch.no_grad():
         pin_loop()
         pin_dit()
+        pin_dit_av()
         pin_vae()
     print("golden vectors written to", GOLD)
