@@ -92,14 +92,15 @@ int ltx2_adaln_rmsnorm(const float* x, int64_t ldx, void* out, int64_t ldo, int 
 int ltx2_qknorm_rope(void* buf, int64_t ld, int rows, int D, int head_dim, int q_off, const float* q_weight,
                      int k_off, const float* k_weight, float eps, const float* cos, const float* sin, void* stream);
 
-/* V[Nkv][ld] (head h at columns h*128) -> VT[H][128][Npad], keys permuted inside each block of 32
- * to match the MFMA accumulator layout of the attention kernel; padded keys are zero.        */
-int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, int H, void* stream);
+/* V[Nkv][ld] (head h at columns h*hd) -> VT[H][hd][Npad], keys permuted inside each block of 32
+ * to match the MFMA accumulator layout of the attention kernel; padded keys are zero.
+ * head_dim hd = 128 (video streams) or 64 (audio streams, audio<->video attention).          */
+int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, int H, int head_dim, void* stream);
 
-/* out[q][h*128..] = softmax(Q_h K_h^T * scale) V_h, non-causal, no mask, head_dim 128.
+/* out[q][h*hd..] = softmax(Q_h K_h^T * scale) V_h, non-causal, no mask, head_dim 128 or 64.
  * Replaces _compiled_attention_core_no_mask (attention.py:12-34).                             */
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
-                    int64_t ldo, int Nq, int Nkv, int H, float scale, void* stream);
+                    int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream);
 
 /* [cos | sin] sinusoid, dim 256 (timestep_embedding.py:10-60 with flip_sin_to_cos, shift 0;
  * simple_decoder.py:12-39).  Either output may be NULL.                                       */
@@ -127,21 +128,35 @@ int ltx2_vae_unpatchify(const void* x, float* video, int T, int H, int W, void* 
 int ltx2_video_to_uint8(const float* video, uint8_t* frames, int T, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * DiT engine: LTXModel (VideoOnly, V1) forward behind one call.
- * Replaces X0Model(LTXModel(...)).__call__ (model/transformer/model.py:776-881,895-936) and
- * BasicTransformerBlock.__call__ x num_layers (transformer.py:191-238).
+ * DiT engine: LTXModel forward behind one call, VideoOnly or AudioVideo, 19B-style blocks or the
+ * 22B "V2.3" variant (cross_attention_adaln + apply_gated_attention).
+ * Replaces X0Model(LTXModel(...)).__call__ (model/transformer/model.py:776-881,895-936),
+ * BasicTransformerBlock.__call__ (transformer.py:191-238) and BasicAVTransformerBlock.__call__
+ * (transformer.py:457-648) x num_layers.
  * ------------------------------------------------------------------------------------------ */
+#define LTX2_MODEL_VIDEO_ONLY 0
+#define LTX2_MODEL_AUDIO_VIDEO 1
+
 typedef struct ltx2_dit ltx2_dit;
 
 typedef struct ltx2_dit_config {
     int num_layers;        /* 48 */
     int num_heads;         /* 32 */
-    int head_dim;          /* 128 (only 128 is implemented) */
+    int head_dim;          /* 128 */
     int in_channels;       /* 128 */
     int out_channels;      /* 128 */
     int caption_channels;  /* 3840; 0 = no caption_projection (context already inner_dim wide) */
     float norm_eps;        /* 1e-6 */
     float timestep_scale;  /* 1000 */
+    /* --- fields below default to 0 for the 19B VideoOnly model --- */
+    int model_type;             /* LTX2_MODEL_VIDEO_ONLY / LTX2_MODEL_AUDIO_VIDEO (model.py:436) */
+    int audio_heads;            /* 32  (LTXModel.AUDIO_ATTENTION_HEADS, model.py:429); must equal num_heads */
+    int audio_head_dim;         /* 64  (AUDIO_HEAD_DIM, model.py:430) */
+    int audio_in_channels;      /* 128 */
+    int audio_out_channels;     /* 128 */
+    int cross_attention_adaln;  /* V2.3: 9 AdaLN rows, prompt_adaln_single, prompt_scale_shift_table (transformer.py:427-455) */
+    int apply_gated_attention;  /* V2.3: to_gate_logits, out *= 2*sigmoid(.) per head (attention.py:241-249) */
+    float av_ca_timestep_scale; /* 1 (av_ca_timestep_scale_multiplier, model.py:452) */
 } ltx2_dit_config;
 
 int ltx2_dit_create(const ltx2_dit_config* cfg, ltx2_dit** out);
@@ -154,9 +169,12 @@ void ltx2_dit_destroy(ltx2_dit* ctx);
  * Linear weights: bf16 [out, in]; biases, norm weights, scale_shift_tables: fp32.           */
 int ltx2_dit_set_weight(ltx2_dit* ctx, const char* name, const void* ptr, int dtype, int64_t numel);
 
-/* Workspace (activations + per-prompt caches).  per_token != 0 sizes the per-token AdaLN path. */
+/* Workspace (activations + per-prompt caches).  per_token != 0 sizes the per-token AdaLN path.
+ * AudioVideo models use the *_av forms (Na audio tokens, Sa audio-text tokens).               */
 int64_t ltx2_dit_workspace_bytes(const ltx2_dit* ctx, int N, int S, int per_token);
 int ltx2_dit_bind_workspace(ltx2_dit* ctx, void* ptr, int64_t bytes, int N, int S, int per_token);
+int64_t ltx2_dit_workspace_bytes_av(const ltx2_dit* ctx, int N, int S, int Na, int Sa, int per_token);
+int ltx2_dit_bind_workspace_av(ltx2_dit* ctx, void* ptr, int64_t bytes, int N, int S, int Na, int Sa, int per_token);
 
 /* Per-prompt, step-invariant work hoisted out of the loop (the reference recomputes it every
  * step: model.py:262-271): caption projection (model.py:142-161), per-layer cross-attention
@@ -164,21 +182,42 @@ int ltx2_dit_bind_workspace(ltx2_dit* ctx, void* ptr, int64_t bytes, int N, int 
  * tables cos/sin fp32 [N][D/2] computed by the caller from positions (rope.py:365-418).     */
 int ltx2_dit_prepare(ltx2_dit* ctx, const float* context, int S, const float* rope_cos, const float* rope_sin,
                      void* stream);
+/* AudioVideo: per modality the text context, the self-attention RoPE tables [N][D/2] and the
+ * cross-modal tables [N][Da/2] (temporal axis only, audio inner dim; model.py:320-344).  With
+ * cross_attention_adaln the text K/V depend on sigma and are recomputed per step instead.    */
+int ltx2_dit_prepare_av(ltx2_dit* ctx, const float* v_context, int S, const float* v_cos, const float* v_sin,
+                        const float* v_cross_cos, const float* v_cross_sin, const float* a_context, int Sa,
+                        const float* a_cos, const float* a_sin, const float* a_cross_cos, const float* a_cross_sin,
+                        void* stream);
 
 /* velocity[N][out_channels] (fp32) = LTXModel(latent[N][in_channels] fp32, timesteps).
  * n_timesteps = 1: one sigma for all tokens (Modality.timesteps shape (B,), scripts/generate.py:1946);
  * n_timesteps = N: per-token sigma (pipelines/common.py:193-232).                           */
 int ltx2_dit_forward(ltx2_dit* ctx, const float* latent, const float* timesteps, int n_timesteps, float* velocity,
                      void* stream);
+/* AudioVideo forward (model.py:776-881).  *_sigma: one device float per modality = Modality.sigma
+ * (drives the prompt AdaLN of its own modality and the cross-modal AdaLN of the OTHER one,
+ * model.py:151-161,392-404).  The VideoOnly entry uses timesteps[0] for it.                  */
+int ltx2_dit_forward_av(ltx2_dit* ctx, const float* v_latent, const float* v_timesteps, int n_v_timesteps,
+                        const float* v_sigma, const float* a_latent, const float* a_timesteps, int n_a_timesteps,
+                        const float* a_sigma, float* v_velocity, float* a_velocity, void* stream);
 
 /* One sampling step: forward -> x0 = latent - ts*v -> post_process -> Euler, latent updated in
  * place (pipelines/distilled.py:214-253; scripts/generate.py:1942-1979).  x0_out may be NULL.  */
 int ltx2_dit_denoise_step(ltx2_dit* ctx, float* latent, const float* timesteps, int n_timesteps, const float* mask,
                           const float* clean, float sigma, float sigma_next, float* x0_out, void* stream);
+/* Joint audio+video step (pipelines/distilled.py:198-271): both latents updated in place;
+ * sigma_dev = device copy of sigma.                                                          */
+int ltx2_dit_denoise_step_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* v_timesteps,
+                             int n_v_timesteps, const float* a_timesteps, int n_a_timesteps, const float* sigma_dev,
+                             const float* v_mask, const float* v_clean, const float* a_mask, const float* a_clean,
+                             float sigma, float sigma_next, float* v_x0_out, float* a_x0_out, void* stream);
 
 /* hipGraph: capture n_steps of ltx2_dit_denoise_step over host_sigmas[n_steps+1] with a uniform
  * sigma per step (timesteps = sigma for every token), then replay.  latent is updated in place. */
 int ltx2_dit_graph_capture(ltx2_dit* ctx, float* latent, const float* host_sigmas, int n_steps, void* stream);
+int ltx2_dit_graph_capture_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps,
+                              void* stream);
 int ltx2_dit_graph_launch(ltx2_dit* ctx, void* stream);
 
 /* Measurement aid: bracket every launch of one GEMM kernel instantiation (epilogue id, or -1 for

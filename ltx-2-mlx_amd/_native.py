@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libltx2hip.so")
 
 OK, E_INVALID, E_HIP, E_STATE = 0, -1, -2, -3
 DTYPE_BF16, DTYPE_F32 = 0, 1
+MODEL_VIDEO_ONLY, MODEL_AUDIO_VIDEO = 0, 1
 EPI_BF16, EPI_GELU_BF16, EPI_SILU_BF16, EPI_F32, EPI_RESID_GATE_F32, EPI_ADD_BF16 = range(6)
 VAE_RES, VAE_UPSAMPLE = 0, 1
 VAE_MAX_BLOCKS = 16
@@ -26,7 +27,10 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 class DitConfig(C.Structure):
     _fields_ = [("num_layers", i32), ("num_heads", i32), ("head_dim", i32), ("in_channels", i32),
-                ("out_channels", i32), ("caption_channels", i32), ("norm_eps", f32), ("timestep_scale", f32)]
+                ("out_channels", i32), ("caption_channels", i32), ("norm_eps", f32), ("timestep_scale", f32),
+                ("model_type", i32), ("audio_heads", i32), ("audio_head_dim", i32), ("audio_in_channels", i32),
+                ("audio_out_channels", i32), ("cross_attention_adaln", i32), ("apply_gated_attention", i32),
+                ("av_ca_timestep_scale", f32)]
 
 
 class VaeConfig(C.Structure):
@@ -45,8 +49,8 @@ SIGNATURES = {
     "ltx2_conv3d_fused": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
     "ltx2_adaln_rmsnorm": (i32, [vp, i64, vp, i64, i32, i32, f32, i32, vp, vp, vp, vp, i64, vp]),
     "ltx2_qknorm_rope": (i32, [vp, i64, i32, i32, i32, i32, vp, i32, vp, f32, vp, vp, vp]),
-    "ltx2_vt_transpose": (i32, [vp, i64, vp, i32, i32, i32, vp]),
-    "ltx2_flash_attn": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, f32, vp]),
+    "ltx2_vt_transpose": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
+    "ltx2_flash_attn": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp]),
     "ltx2_timestep_sinusoid": (i32, [vp, i64, f32, i32, i32, vp, vp, vp]),
     "ltx2_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "ltx2_x0_from_velocity": (i32, [vp, vp, vp, i64, f32, vp, i32, i32, vp]),
@@ -60,7 +64,13 @@ SIGNATURES = {
     "ltx2_dit_set_weight": (i32, [vp, C.c_char_p, vp, i32, i64]),
     "ltx2_dit_workspace_bytes": (i64, [vp, i32, i32, i32]),
     "ltx2_dit_bind_workspace": (i32, [vp, vp, i64, i32, i32, i32]),
+    "ltx2_dit_workspace_bytes_av": (i64, [vp, i32, i32, i32, i32, i32]),
+    "ltx2_dit_bind_workspace_av": (i32, [vp, vp, i64, i32, i32, i32, i32, i32]),
     "ltx2_dit_prepare": (i32, [vp, vp, i32, vp, vp, vp]),
+    "ltx2_dit_prepare_av": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "ltx2_dit_forward_av": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "ltx2_dit_denoise_step_av": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp]),
+    "ltx2_dit_graph_capture_av": (i32, [vp, vp, vp, C.POINTER(f32), i32, vp]),
     "ltx2_dit_forward": (i32, [vp, vp, vp, i32, vp, vp]),
     "ltx2_dit_denoise_step": (i32, [vp, vp, vp, i32, vp, vp, f32, f32, vp, vp]),
     "ltx2_dit_graph_capture": (i32, [vp, vp, C.POINTER(f32), i32, vp]),

@@ -1,18 +1,19 @@
-// Flash-attention forward (head_dim 128) + V^T re-layout: parameter block and host launchers.
+// Flash-attention forward (head_dim 128 / 64) + V^T re-layout: parameter block and host launchers.
 #pragma once
 #include "common.h"
 
 struct AttnParams {
     const bf16* Q;   // [Nq][ldq], head h at columns h*128
     const bf16* K;   // [Nkv][ldk], head h at columns h*128
-    const bf16* VT;  // [H][128][Npad], key-permuted (see vt_transpose_launch)
+    const bf16* VT;  // [H][head_dim][Npad], key-permuted (see vt_transpose_launch)
     bf16* O;         // [Nq][ldo]
     long ldq, ldk, ldo, vt_head_stride;
     int Nq, Nkv, Npad, H;
+    int head_dim;       // 128 (default when 0) or 64
     float scale_log2e;  // (1/sqrt(d)) * log2(e)
     void* dbg;          // optional device buffer for interval timestamps (debug)
 };
 
 int attn_launch(const AttnParams& p, hipStream_t stream);
 int attn_pp_launch(const AttnParams& p, hipStream_t stream);   // 8-wave / 256-row variant (attention_pp.hip)
-int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream);
+int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream, int head_dim = 128);

@@ -1,4 +1,4 @@
-// Flash-attention forward (non-causal, no mask, head_dim 128) for gfx950 / CDNA4.
+// Flash-attention forward (non-causal, no mask, head_dim 128 or 64) for gfx950 / CDNA4.
 //
 // Replaces mx.fast.scaled_dot_product_attention as called from the reference's
 // _compiled_attention_core_no_mask (LTX_2_MLX/model/transformer/attention.py:12-34):
@@ -24,12 +24,20 @@
 
 namespace {
 
-constexpr int QB = 128, KVB = 64, HD = 128;
+constexpr int QB = 128, KVB = 64;
 constexpr float RESCALE_THR = 6.0f;     // P <= 2^6: exact in bf16's 8-bit exponent, fp32 accumulation has ample headroom
-constexpr int K_TILE = KVB * HD * 2;           // 16 KiB, rows of 256 B
-constexpr int V_TILE = HD * KVB * 2;           // 16 KiB, rows of 128 B
-constexpr int STAGE = K_TILE + V_TILE;
-constexpr int LDS_BYTES = 2 * STAGE;
+// HD = 128 (video streams) or 64 (audio streams and audio<->video cross-modal attention):
+// K tile [64][HD] has rows of 2*HD bytes, V^T tile [HD][64] rows of 128 bytes.
+template <int HD>
+struct Geo {
+    static constexpr int K_TILE = KVB * HD * 2;
+    static constexpr int V_TILE = HD * KVB * 2;
+    static constexpr int STAGE = K_TILE + V_TILE;
+    static constexpr int LDS_BYTES = 2 * STAGE;
+    static constexpr int NKS = HD / 16;         // k-steps of S^T = K Q^T
+    static constexpr int ND = HD / 32;          // 32-row blocks of O^T
+    static constexpr int NJ = HD / 32;          // LDS-DMA instructions per wave per tile (K and V^T each)
+};
 
 #define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
 #define SGB_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
@@ -42,7 +50,10 @@ __device__ __forceinline__ void glds16(const bf16* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const void*)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
 
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+    using G = Geo<HD>;
+    constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NKS = G::NKS, ND = G::ND, NJ = G::NJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,49 +62,50 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int q0 = blockIdx.x * QB + wv * 32;
 
     // ---- Q fragments (B operand): Q[q0 + l31][16*ks + 8*hi .. +8], kept in registers ----
-    bf16x8 qf[8];
+    bf16x8 qf[NKS];
     {
         const int qrow = min(q0 + l31, p.Nq - 1);
         const bf16* qp = p.Q + (long)qrow * p.ldq + head * HD + 8 * hi;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
     }
 
     // ---- staging addresses ----
-    const bf16* k_src[4];
-    const bf16* v_src[4];
-    int k_rowi[4];
+    const bf16* k_src[NJ];
+    const bf16* v_src[NJ];
+    int k_rowi[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int kr = (wv * 4 + j) * 4 + (lane >> 4);                 // 0..63
-        const int kchunk = (lane & 15) ^ (kr & 15);
+    for (int j = 0; j < NJ; ++j) {
+        // one LDS-DMA instruction covers 1 KiB: 4 K rows of 256 B (HD 128) or 8 rows of 128 B (HD 64)
+        const int kr = HD == 128 ? (wv * NJ + j) * 4 + (lane >> 4) : (wv * NJ + j) * 8 + (lane >> 3);   // 0..63
+        const int kchunk = HD == 128 ? ((lane & 15) ^ (kr & 15)) : ((lane & 7) ^ ((kr >> 1) & 7));
         k_rowi[j] = kr;
         k_src[j] = p.K + head * HD + kchunk * 8;
-        const int vr = (wv * 4 + j) * 8 + (lane >> 3);                 // 0..127
+        const int vr = (wv * NJ + j) * 8 + (lane >> 3);                // 0..HD-1
         const int vchunk = (lane & 7) ^ ((vr >> 1) & 7);
         v_src[j] = p.VT + (long)head * p.vt_head_stride + (long)vr * p.Npad + vchunk * 8;
     }
     auto stage = [&](int t, int buf) {
-        char* sk = smem + buf * STAGE + wv * 4096;
+        char* sk = smem + buf * STAGE + wv * (NJ * 1024);
         char* sv = sk + K_TILE;
         const int kv0 = t * KVB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int kr = min(kv0 + k_rowi[j], p.Nkv - 1);
             glds16(k_src[j] + (long)kr * p.ldk, sk + j * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(v_src[j] + kv0, sv + j * 1024);
+        for (int j = 0; j < NJ; ++j) glds16(v_src[j] + kv0, sv + j * 1024);
     };
 
-    f32x16 o[4];
+    f32x16 o[ND];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < ND; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int k_xor = l31 & 15;
+    const int k_xor = HD == 128 ? (l31 & 15) : ((l31 >> 1) & 7);
     const int v_xor = (l31 >> 1) & 7;
     const int nt = (p.Nkv + KVB - 1) / KVB;
     stage(0, 0);
@@ -110,9 +122,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         for (int b = 0; b < 2; ++b) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
-            const char* krow = ks_base + (b * 32 + l31) * 256;
+            const char* krow = ks_base + (b * 32 + l31) * (2 * HD);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(krow + (((2 * ks + hi) ^ k_xor) << 4));
                 s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[b], 0, 0, 0);
             }
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         // ds_read -> s_waitcnt lgkmcnt(0) -> mfma and exposes the LDS latency per fragment)
         SGB_DSR(AT_DEPTH);
 #pragma unroll
-        for (int i_ = 0; i_ < 16 - AT_DEPTH; ++i_) {
+        for (int i_ = 0; i_ < 2 * NKS - AT_DEPTH; ++i_) {
             SGB_MFMA(1);
             SGB_DSR(1);
         }
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             m_run = m_new;
             l_run *= alpha;
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+            for (int d = 0; d < ND; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
         // ---- O^T += V^T . P^T ----
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < ND; ++d) {
             const char* vrow = vs_base + (d * 32 + l31) * 128;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         }
         SGB_DSR(AT_DEPTH);
 #pragma unroll
-        for (int i_ = 0; i_ < 16 - AT_DEPTH; ++i_) {
+        for (int i_ = 0; i_ < 4 * ND - AT_DEPTH; ++i_) {
             SGB_MFMA(1);
             SGB_DSR(1);
         }
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     if (qrow < p.Nq) {
         bf16* op = p.O + (long)qrow * p.ldo + head * HD + 4 * hi;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 bf16x4 v;
@@ -210,32 +222,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
-// V [Nkv][ld] (head h at columns voff + h*128) -> VT[h][128][Npad] with the key permutation
+// V [Nkv][ld] (head h at columns h*HD) -> VT[h][HD][Npad] with the key permutation
 // pos(kv = 32b + 8g + 4hi + e) = 32b + 16(g>>1) + 8hi + 4(g&1) + e ; keys >= Nkv are zero-filled.
+template <int HD>
 __global__ __launch_bounds__(256) void vt_transpose_kernel(const bf16* __restrict__ V, long ld, bf16* __restrict__ VT,
                                                            int Nkv, int Npad, long head_stride) {
     __shared__ bf16 tile[64][HD + 2];
     const int head = blockIdx.y, kv0 = blockIdx.x * 64, tid = threadIdx.x;
-    // load 64 keys x 128 dims: thread -> (row = tid/4 .. , 32 dims each) as 4 x 16-B
+    // load 64 keys x HD dims: thread -> (row = tid/4, HD/4 dims) as 16-B pieces
     {
-        const int r = tid >> 2, c0 = (tid & 3) * 32;
+        constexpr int W = HD / 4;
+        const int r = tid >> 2, c0 = (tid & 3) * W;
         const int kv = kv0 + r;
         if (kv < Nkv) {
             const bf16* src = V + (long)kv * ld + head * HD + c0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < W / 8; ++i) {
                 const bf16x8 v = *(const bf16x8*)(src + i * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) tile[r][c0 + i * 8 + e] = v[e];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) tile[r][c0 + i] = f2bf(0.f);
+            for (int i = 0; i < W; ++i) tile[r][c0 + i] = f2bf(0.f);
         }
     }
     __syncthreads();
     // store: thread -> (d = tid/2, 32 permuted key slots) as 4 x 16-B
-    {
+    if (tid < 2 * HD) {
         const int d = tid >> 1, p0 = (tid & 1) * 32;
         bf16* dst = VT + (long)head * head_stride + (long)d * Npad + kv0 + p0;
 #pragma unroll
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(256) void vt_transpose_kernel(const bf16* __restric
 
 int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.Nq > 0 && p.Nkv > 0 && p.H > 0, "attention: empty problem");
+    LTX2_CHECK_ARG(p.head_dim == 0 || p.head_dim == 128 || p.head_dim == 64, "attention: head_dim=%d, only 128 and 64 are implemented", p.head_dim);
     LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
     LTX2_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
     {   // large problems: 8-wave software-pipelined variant (LTX2_ATTN=v1|pp overrides the heuristic)
@@ -265,23 +280,31 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
             const char* e = getenv("LTX2_ATTN");
             ov = !e ? 0 : (!strcmp(e, "v1") ? 1 : (!strcmp(e, "pp") ? 2 : 0));
         }
-        if (ov == 2) return attn_pp_launch(p, stream);   // experimental 8-wave variant: not faster yet
+        if (ov == 2 && p.head_dim != 64) return attn_pp_launch(p, stream);   // experimental 8-wave variant: not faster yet
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid((p.Nq + QB - 1) / QB, p.H);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), LDS_BYTES, stream, p);
+    if (p.head_dim == 64)
+        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), Geo<64>::LDS_BYTES, stream, p);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
     LTX2_CHECK_LAUNCH("attn_fwd_kernel");
     return LTX2_OK;
 }
 
-int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream) {
+int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream, int head_dim) {
     LTX2_CHECK_ARG(Npad % 64 == 0 && Npad >= Nkv && ld % 8 == 0, "vt_transpose: bad strides");
+    LTX2_CHECK_ARG(head_dim == 128 || head_dim == 64, "vt_transpose: head_dim=%d, only 128 and 64 are implemented", head_dim);
     dim3 grid(Npad / 64, H);
-    hipLaunchKernelGGL(vt_transpose_kernel, grid, dim3(256), 0, stream, V, ld, VT, Nkv, Npad, (long)HD * Npad);
+    if (head_dim == 64)
+        hipLaunchKernelGGL(vt_transpose_kernel<64>, grid, dim3(256), 0, stream, V, ld, VT, Nkv, Npad, 64L * Npad);
+    else
+        hipLaunchKernelGGL(vt_transpose_kernel<128>, grid, dim3(256), 0, stream, V, ld, VT, Nkv, Npad, 128L * Npad);
     LTX2_CHECK_LAUNCH("vt_transpose_kernel");
     return LTX2_OK;
 }

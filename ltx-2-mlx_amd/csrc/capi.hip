@@ -68,21 +68,23 @@ int ltx2_qknorm_rope(void* buf, int64_t ld, int rows, int D, int head_dim, int q
                               (hipStream_t)stream);
 }
 
-int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, int H, void* stream) {
+int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, int H, int head_dim, void* stream) {
     LTX2_CHECK_ARG(V && VT, "vt_transpose: null operand");
-    return vt_transpose_launch((const bf16*)V, ld, (bf16*)VT, Nkv, Npad, H, (hipStream_t)stream);
+    return vt_transpose_launch((const bf16*)V, ld, (bf16*)VT, Nkv, Npad, H, (hipStream_t)stream, head_dim);
 }
 
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
-                    int64_t ldo, int Nq, int Nkv, int H, float scale, void* stream) {
+                    int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream) {
     LTX2_CHECK_ARG(Q && K && VT && out, "flash_attn: null operand");
+    LTX2_CHECK_ARG(head_dim == 128 || head_dim == 64, "flash_attn: head_dim=%d, only 128 and 64 are implemented", head_dim);
     AttnParams a{};
     a.Q = (const bf16*)Q;
     a.ldq = ldq;
     a.K = (const bf16*)K;
     a.ldk = ldk;
     a.VT = (const bf16*)VT;
-    a.vt_head_stride = 128L * Npad;
+    a.vt_head_stride = (long)head_dim * Npad;
+    a.head_dim = head_dim;
     a.O = (bf16*)out;
     a.ldo = ldo;
     a.Nq = Nq;

@@ -1,9 +1,16 @@
 // DiT engine: sequences the gfx950 kernels of one LTX-2 denoise step on a caller stream and owns
-// the hipGraph of the distilled sampling loop.  Host-side only (no kernels here).
+// the hipGraph of the distilled sampling loop.  Host-side only (no heavy kernels here).
 //
-// Restates the control flow of the reference's LTXModel.__call__ / BasicTransformerBlock.__call__
-// (LTX_2_MLX/model/transformer/model.py:776-881, transformer.py:191-238) with the step-invariant
-// work (caption projection, cross-attention K/V, RoPE tables) hoisted into ltx2_dit_prepare.
+// Restates the control flow of the reference's LTXModel.__call__ (LTX_2_MLX/model/transformer/
+// model.py:776-881), BasicTransformerBlock.__call__ (transformer.py:191-238) and, for AudioVideo
+// models, BasicAVTransformerBlock.__call__ (transformer.py:457-648) with
+// MultiModalTransformerArgsPreprocessor (model.py:284-410).  Step-invariant work (caption
+// projection, RoPE tables, and - when the text K/V are not sigma-modulated - the per-layer text
+// cross-attention K/V) is hoisted into ltx2_dit_prepare*.
+//
+// A model is two "modalities" (video m[0], audio m[1]; audio absent for VideoOnly) that run the
+// same per-block program (self-attention, text cross-attention, feed-forward) on their own widths,
+// plus the audio<->video cross-modal attention between them.
 #include <math.h>
 #include <string.h>
 
@@ -16,9 +23,9 @@
 #include "gemm.h"
 #include "rowops.h"
 
-#define TRY(expr)                   \
-    do {                            \
-        int rc_ = (expr);           \
+#define TRY(expr)                       \
+    do {                                \
+        int rc_ = (expr);               \
         if (rc_ != LTX2_OK) return rc_; \
     } while (0)
 
@@ -29,10 +36,46 @@ struct Wt {
     long n;
 };
 
+struct AdaW {       // AdaLayerNormSingle (timestep_embedding.py:166-202)
+    const bf16 *t1_w = nullptr, *t2_w = nullptr, *lin_w = nullptr;
+    const float *t1_b = nullptr, *t2_b = nullptr, *lin_b = nullptr;
+    int rows = 0;
+};
+
+struct AttnW {      // Attention (attention.py:144-253); self: fused qkv, cross: q + fused kv
+    const bf16 *qkv_w = nullptr, *q_w = nullptr, *kv_w = nullptr, *o_w = nullptr, *g_w = nullptr;
+    const float *qkv_b = nullptr, *q_b = nullptr, *kv_b = nullptr, *o_b = nullptr, *g_b = nullptr, *qn = nullptr,
+                *kn = nullptr;
+};
+
+struct BlockW {     // one modality's share of a transformer block
+    AttnW self, text;
+    const bf16 *ff1_w = nullptr, *ff2_w = nullptr;
+    const float *ff1_b = nullptr, *ff2_b = nullptr, *sst = nullptr, *prompt_sst = nullptr;
+};
+
 struct LayerW {
-    const bf16 *qkv_w, *o_w, *q2_w, *kv2_w, *o2_w, *ff1_w, *ff2_w;
-    const float *qkv_b, *o_b, *q2_b, *kv2_b, *o2_b, *ff1_b, *ff2_b;
-    const float *qn1, *kn1, *qn2, *kn2, *sst;
+    BlockW m[2];
+    AttnW a2v, v2a;
+    const float* ca[2] = {nullptr, nullptr};     // scale_shift_table_a2v_ca_{video,audio}  [5][D]
+};
+
+struct ModW {       // per-modality model-level weights
+    const bf16 *patch_w = nullptr, *cap1_w = nullptr, *cap2_w = nullptr, *proj_w = nullptr;
+    const float *patch_b = nullptr, *cap1_b = nullptr, *cap2_b = nullptr, *proj_b = nullptr, *sst_out = nullptr;
+    AdaW ada, prompt, cross_ss, cross_gate;
+};
+
+struct Mod {        // per-modality geometry + workspace
+    int D = 0, H = 0, hd = 0, Cin = 0, Cout = 0;
+    int N = 0, Npad = 0, S = 0, Spad = 0;
+    float *x = nullptr, *sin_f = nullptr, *e1_f = nullptr, *e_f = nullptr, *emb = nullptr, *vel = nullptr, *x0 = nullptr,
+          *cosb = nullptr, *sinb = nullptr, *ccos = nullptr, *csin = nullptr, *aux_e = nullptr, *prompt_emb = nullptr,
+          *cross_ss = nullptr, *cross_gate = nullptr, *glog = nullptr;
+    bf16 *lat = nullptr, *h = nullptr, *h2 = nullptr, *qkv = nullptr, *vt = nullptr, *att = nullptr, *ff = nullptr,
+         *sin_b = nullptr, *e1_b = nullptr, *es_b = nullptr, *ctx_in = nullptr, *c1 = nullptr, *ctxp = nullptr,
+         *ctxm = nullptr, *kv2 = nullptr, *vt2 = nullptr;
+    const bf16* ctx = nullptr;      // projected text context (ctxp or ctx_in)
 };
 
 inline long align_up(long v, long a = 256) { return (v + a - 1) / a * a; }
@@ -40,23 +83,16 @@ inline long align_up(long v, long a = 256) { return (v + a - 1) / a * a; }
 
 struct ltx2_dit {
     ltx2_dit_config cfg{};
-    int D = 0;
+    bool av = false, v2 = false, gated = false;
     std::unordered_map<std::string, Wt> weights;
     std::vector<LayerW> layers;
+    ModW mw[2];
+    Mod m[2];
     bool resolved = false;
-    const bf16 *patch_w = nullptr, *t1_w = nullptr, *t2_w = nullptr, *ada_w = nullptr, *cap1_w = nullptr,
-               *cap2_w = nullptr, *proj_w = nullptr;
-    const float *patch_b = nullptr, *t1_b = nullptr, *t2_b = nullptr, *ada_b = nullptr, *cap1_b = nullptr,
-                *cap2_b = nullptr, *proj_b = nullptr, *sst_out = nullptr;
-    // workspace
     char* ws = nullptr;
     long ws_bytes = 0;
-    int N = 0, S = 0, Npad = 0, Spad = 0, per_token = 0;
-    float *x = nullptr, *sin_f = nullptr, *e1_f = nullptr, *e_f = nullptr, *emb = nullptr, *vel = nullptr,
-          *x0 = nullptr, *cosb = nullptr, *sinb = nullptr, *sigmas_dev = nullptr;
-    bf16 *lat = nullptr, *h = nullptr, *qkv = nullptr, *vt = nullptr, *att = nullptr, *ff = nullptr, *sin_b = nullptr,
-         *e1_b = nullptr, *es_b = nullptr, *ctx_in = nullptr, *c1 = nullptr, *ctxp = nullptr, *kv2 = nullptr,
-         *vt2 = nullptr;
+    int per_token = 0;
+    float* sigmas_dev = nullptr;
     bool prepared = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -70,48 +106,63 @@ struct ltx2_dit {
 namespace {
 
 // Carve the workspace; base == nullptr only computes the size.
-long carve(ltx2_dit* c, char* base, int N, int S, int per_token) {
-    const long D = c->D, L = c->cfg.num_layers, H = c->cfg.num_heads;
-    const long Npad = align_up(N, 64), Spad = align_up(S, 64);
-    const long Cctx = c->cfg.caption_channels > 0 ? c->cfg.caption_channels : D;
-    const long T = per_token ? N : 1;
+long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token) {
+    const long L = c->cfg.num_layers;
     long off = 0;
     auto take = [&](long bytes) {
         char* p = base ? base + off : nullptr;
         off += align_up(bytes);
         return p;
     };
-    c->x = (float*)take(4L * N * D);
-    c->lat = (bf16*)take(2L * N * c->cfg.in_channels);
-    c->h = (bf16*)take(2L * N * D);
-    c->qkv = (bf16*)take(2L * N * 3 * D);
-    c->vt = (bf16*)take(2L * H * 128 * Npad);
-    c->att = (bf16*)take(2L * N * D);
-    c->ff = (bf16*)take(2L * N * 4 * D);
-    c->sin_f = (float*)take(4L * 256);
-    c->e1_f = (float*)take(4L * D);
-    c->e_f = (float*)take(4L * T * D);
-    c->emb = (float*)take(4L * T * 6 * D);
-    c->sin_b = (bf16*)take(per_token ? 2L * N * 256 : 0);
-    c->e1_b = (bf16*)take(per_token ? 2L * N * D : 0);
-    c->es_b = (bf16*)take(per_token ? 2L * N * D : 0);
-    c->vel = (float*)take(4L * N * c->cfg.out_channels);
-    c->x0 = (float*)take(4L * N * c->cfg.out_channels);
-    c->cosb = (float*)take(4L * N * (D / 2));
-    c->sinb = (float*)take(4L * N * (D / 2));
     c->sigmas_dev = (float*)take(4L * 64);
-    c->ctx_in = (bf16*)take(2L * S * Cctx);
-    c->c1 = (bf16*)take(2L * S * D);
-    c->ctxp = (bf16*)take(2L * S * D);
-    c->kv2 = (bf16*)take(2L * L * S * 2 * D);
-    c->vt2 = (bf16*)take(2L * L * H * 128 * Spad);
+    for (int k = 0; k < (c->av ? 2 : 1); ++k) {
+        Mod& m = c->m[k];
+        const long n = k ? Na : N, s = k ? Sa : S;
+        const long D = m.D, npad = align_up(n, 64), spad = align_up(s, 64);
+        const long Cctx = c->cfg.caption_channels > 0 ? c->cfg.caption_channels : D;
+        const long T = per_token ? n : 1, rows = c->v2 ? 9 : 6;
+        m.x = (float*)take(4L * n * D);
+        m.lat = (bf16*)take(2L * n * m.Cin);
+        m.h = (bf16*)take(2L * n * D);
+        m.h2 = (bf16*)take(c->av ? 2L * n * D : 0);
+        m.qkv = (bf16*)take(2L * n * 3 * D);      // also the cross-modal Q / K,V projected from this modality's tokens
+        m.vt = (bf16*)take(2L * D * npad);
+        m.att = (bf16*)take(2L * n * D);
+        m.ff = (bf16*)take(2L * n * 4 * D);
+        m.glog = (float*)take(c->gated ? 4L * n * m.H : 0);
+        m.sin_f = (float*)take(4L * 256);
+        m.e1_f = (float*)take(4L * D);
+        m.aux_e = (float*)take(4L * D);
+        m.e_f = (float*)take(4L * T * D);
+        m.emb = (float*)take(4L * T * rows * D);
+        m.prompt_emb = (float*)take(c->v2 ? 4L * 2 * D : 0);
+        m.cross_ss = (float*)take(c->av ? 4L * 4 * D : 0);
+        m.cross_gate = (float*)take(c->av ? 4L * D : 0);
+        m.sin_b = (bf16*)take(per_token ? 2L * n * 256 : 0);
+        m.e1_b = (bf16*)take(per_token ? 2L * n * D : 0);
+        m.es_b = (bf16*)take(per_token ? 2L * n * D : 0);
+        m.vel = (float*)take(4L * n * m.Cout);
+        m.x0 = (float*)take(4L * n * m.Cout);
+        m.cosb = (float*)take(4L * n * (D / 2));
+        m.sinb = (float*)take(4L * n * (D / 2));
+        const long Dc = c->m[c->av ? 1 : 0].D;         // cross-modal RoPE lives in the audio inner dim
+        m.ccos = (float*)take(c->av ? 4L * n * (Dc / 2) : 0);
+        m.csin = (float*)take(c->av ? 4L * n * (Dc / 2) : 0);
+        m.ctx_in = (bf16*)take(2L * s * Cctx);
+        m.c1 = (bf16*)take(c->cfg.caption_channels > 0 ? 2L * s * D : 0);
+        m.ctxp = (bf16*)take(c->cfg.caption_channels > 0 ? 2L * s * D : 0);
+        m.ctxm = (bf16*)take(c->v2 ? 2L * s * D : 0);
+        const long kv_layers = c->v2 ? 1 : L;          // sigma-modulated text K/V cannot be cached per prompt
+        m.kv2 = (bf16*)take(2L * kv_layers * s * 2 * D);
+        m.vt2 = (bf16*)take(2L * kv_layers * D * spad);
+    }
     return off;
 }
 
-const void* find(ltx2_dit* c, const std::string& name, int dtype, long numel, bool required = true) {
+const void* find(ltx2_dit* c, const std::string& name, int dtype, long numel) {
     auto it = c->weights.find(name);
     if (it == c->weights.end()) {
-        if (required) ltx2_set_error("dit: missing weight '%s'", name.c_str());
+        ltx2_set_error("dit: missing weight '%s'", name.c_str());
         return nullptr;
     }
     if (it->second.dtype != dtype || it->second.n != numel) {
@@ -122,71 +173,114 @@ const void* find(ltx2_dit* c, const std::string& name, int dtype, long numel, bo
     return it->second.p;
 }
 
+#define GETW(dst, name, rows, cols)                                                                          \
+    do {                                                                                                     \
+        dst = (const bf16*)find(c, std::string(name) + ".weight", LTX2_DTYPE_BF16, (long)(rows) * (cols));   \
+        if (!dst) return LTX2_E_STATE;                                                                       \
+    } while (0)
+#define GETB(dst, name, n)                                                                    \
+    do {                                                                                      \
+        dst = (const float*)find(c, std::string(name) + ".bias", LTX2_DTYPE_F32, (long)(n));  \
+        if (!dst) return LTX2_E_STATE;                                                        \
+    } while (0)
+#define GETF(dst, name, n)                                                          \
+    do {                                                                            \
+        dst = (const float*)find(c, std::string(name), LTX2_DTYPE_F32, (long)(n));  \
+        if (!dst) return LTX2_E_STATE;                                              \
+    } while (0)
+
+int resolve_ada(ltx2_dit* c, AdaW& a, const std::string& name, long D, int rows) {
+    GETW(a.t1_w, name + ".emb.timestep_embedder.linear_1", D, 256);
+    GETB(a.t1_b, name + ".emb.timestep_embedder.linear_1", D);
+    GETW(a.t2_w, name + ".emb.timestep_embedder.linear_2", D, D);
+    GETB(a.t2_b, name + ".emb.timestep_embedder.linear_2", D);
+    GETW(a.lin_w, name + ".linear", rows * D, D);
+    GETB(a.lin_b, name + ".linear", rows * D);
+    a.rows = rows;
+    return LTX2_OK;
+}
+
+// query width Dq, key/value source width Dc, attention inner width Di, `heads` gate logits
+int resolve_attn(ltx2_dit* c, AttnW& a, const std::string& name, long Dq, long Dc, long Di, int heads, bool self) {
+    if (self) {
+        GETW(a.qkv_w, name + ".to_qkv", 3 * Di, Dq);
+        GETB(a.qkv_b, name + ".to_qkv", 3 * Di);
+    } else {
+        GETW(a.q_w, name + ".to_q", Di, Dq);
+        GETB(a.q_b, name + ".to_q", Di);
+        GETW(a.kv_w, name + ".to_kv", 2 * Di, Dc);
+        GETB(a.kv_b, name + ".to_kv", 2 * Di);
+    }
+    GETW(a.o_w, name + ".to_out.0", Dq, Di);
+    GETB(a.o_b, name + ".to_out.0", Dq);
+    GETF(a.qn, name + ".q_norm.weight", Di);
+    GETF(a.kn, name + ".k_norm.weight", Di);
+    if (c->gated) {
+        GETW(a.g_w, name + ".to_gate_logits", heads, Dq);
+        GETB(a.g_b, name + ".to_gate_logits", heads);
+    }
+    return LTX2_OK;
+}
+
 int resolve(ltx2_dit* c) {
     if (c->resolved) return LTX2_OK;
-    const long D = c->D;
-#define GETW(dst, name, rows, cols)                                                         \
-    do {                                                                                    \
-        dst = (const bf16*)find(c, std::string(name) + ".weight", LTX2_DTYPE_BF16, (long)(rows) * (cols)); \
-        if (!dst) return LTX2_E_STATE;                                                      \
-    } while (0)
-#define GETB(dst, name, n)                                                                  \
-    do {                                                                                    \
-        dst = (const float*)find(c, std::string(name) + ".bias", LTX2_DTYPE_F32, (long)(n)); \
-        if (!dst) return LTX2_E_STATE;                                                      \
-    } while (0)
-#define GETF(dst, name, n)                                                                  \
-    do {                                                                                    \
-        dst = (const float*)find(c, std::string(name), LTX2_DTYPE_F32, (long)(n));          \
-        if (!dst) return LTX2_E_STATE;                                                      \
-    } while (0)
-    GETW(c->patch_w, "patchify_proj", D, c->cfg.in_channels);
-    GETB(c->patch_b, "patchify_proj", D);
-    GETW(c->t1_w, "adaln_single.emb.timestep_embedder.linear_1", D, 256);
-    GETB(c->t1_b, "adaln_single.emb.timestep_embedder.linear_1", D);
-    GETW(c->t2_w, "adaln_single.emb.timestep_embedder.linear_2", D, D);
-    GETB(c->t2_b, "adaln_single.emb.timestep_embedder.linear_2", D);
-    GETW(c->ada_w, "adaln_single.linear", 6 * D, D);
-    GETB(c->ada_b, "adaln_single.linear", 6 * D);
-    if (c->cfg.caption_channels > 0) {
-        GETW(c->cap1_w, "caption_projection.linear_1", D, c->cfg.caption_channels);
-        GETB(c->cap1_b, "caption_projection.linear_1", D);
-        GETW(c->cap2_w, "caption_projection.linear_2", D, D);
-        GETB(c->cap2_b, "caption_projection.linear_2", D);
+    const int nm = c->av ? 2 : 1;
+    const int rows = c->v2 ? 9 : 6;
+    for (int k = 0; k < nm; ++k) {
+        const std::string pre = k ? "audio_" : "";
+        const long D = c->m[k].D;
+        ModW& w = c->mw[k];
+        GETW(w.patch_w, pre + "patchify_proj", D, c->m[k].Cin);
+        GETB(w.patch_b, pre + "patchify_proj", D);
+        TRY(resolve_ada(c, w.ada, pre + "adaln_single", D, rows));
+        if (c->v2) TRY(resolve_ada(c, w.prompt, pre + "prompt_adaln_single", D, 2));
+        if (c->cfg.caption_channels > 0) {
+            GETW(w.cap1_w, pre + "caption_projection.linear_1", D, c->cfg.caption_channels);
+            GETB(w.cap1_b, pre + "caption_projection.linear_1", D);
+            GETW(w.cap2_w, pre + "caption_projection.linear_2", D, D);
+            GETB(w.cap2_b, pre + "caption_projection.linear_2", D);
+        }
+        GETF(w.sst_out, pre + "scale_shift_table", 2 * D);
+        GETW(w.proj_w, pre + "proj_out", c->m[k].Cout, D);
+        GETB(w.proj_b, pre + "proj_out", c->m[k].Cout);
     }
-    GETF(c->sst_out, "scale_shift_table", 2 * D);
-    GETW(c->proj_w, "proj_out", c->cfg.out_channels, D);
-    GETB(c->proj_b, "proj_out", c->cfg.out_channels);
-    c->layers.resize(c->cfg.num_layers);
+    if (c->av) {
+        TRY(resolve_ada(c, c->mw[0].cross_ss, "av_ca_video_scale_shift_adaln_single", c->m[0].D, 4));
+        TRY(resolve_ada(c, c->mw[0].cross_gate, "av_ca_a2v_gate_adaln_single", c->m[0].D, 1));
+        TRY(resolve_ada(c, c->mw[1].cross_ss, "av_ca_audio_scale_shift_adaln_single", c->m[1].D, 4));
+        TRY(resolve_ada(c, c->mw[1].cross_gate, "av_ca_v2a_gate_adaln_single", c->m[1].D, 1));
+    }
+    c->layers.assign(c->cfg.num_layers, LayerW());
     for (int i = 0; i < c->cfg.num_layers; ++i) {
         LayerW& w = c->layers[i];
-        const std::string p = "transformer_blocks." + std::to_string(i);
-        GETW(w.qkv_w, p + ".attn1.to_qkv", 3 * D, D);
-        GETB(w.qkv_b, p + ".attn1.to_qkv", 3 * D);
-        GETW(w.o_w, p + ".attn1.to_out.0", D, D);
-        GETB(w.o_b, p + ".attn1.to_out.0", D);
-        GETF(w.qn1, p + ".attn1.q_norm.weight", D);
-        GETF(w.kn1, p + ".attn1.k_norm.weight", D);
-        GETW(w.q2_w, p + ".attn2.to_q", D, D);
-        GETB(w.q2_b, p + ".attn2.to_q", D);
-        GETW(w.kv2_w, p + ".attn2.to_kv", 2 * D, D);
-        GETB(w.kv2_b, p + ".attn2.to_kv", 2 * D);
-        GETW(w.o2_w, p + ".attn2.to_out.0", D, D);
-        GETB(w.o2_b, p + ".attn2.to_out.0", D);
-        GETF(w.qn2, p + ".attn2.q_norm.weight", D);
-        GETF(w.kn2, p + ".attn2.k_norm.weight", D);
-        GETW(w.ff1_w, p + ".ff.net.0.proj", 4 * D, D);
-        GETB(w.ff1_b, p + ".ff.net.0.proj", 4 * D);
-        GETW(w.ff2_w, p + ".ff.net.2", D, 4 * D);
-        GETB(w.ff2_b, p + ".ff.net.2", D);
-        GETF(w.sst, p + ".scale_shift_table", 6 * D);
+        const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+        for (int k = 0; k < nm; ++k) {
+            const std::string pre = k ? "audio_" : "";
+            const long D = c->m[k].D;
+            BlockW& b = w.m[k];
+            TRY(resolve_attn(c, b.self, p + pre + "attn1", D, D, D, c->m[k].H, true));
+            TRY(resolve_attn(c, b.text, p + pre + "attn2", D, D, D, c->m[k].H, false));
+            GETW(b.ff1_w, p + pre + "ff.net.0.proj", 4 * D, D);
+            GETB(b.ff1_b, p + pre + "ff.net.0.proj", 4 * D);
+            GETW(b.ff2_w, p + pre + "ff.net.2", D, 4 * D);
+            GETB(b.ff2_b, p + pre + "ff.net.2", D);
+            GETF(b.sst, p + pre + "scale_shift_table", rows * D);
+            if (c->v2) GETF(b.prompt_sst, p + pre + "prompt_scale_shift_table", 2 * D);
+        }
+        if (c->av) {
+            const long Dv = c->m[0].D, Da = c->m[1].D;
+            TRY(resolve_attn(c, w.a2v, p + "audio_to_video_attn", Dv, Da, Da, c->m[1].H, false));
+            TRY(resolve_attn(c, w.v2a, p + "video_to_audio_attn", Da, Dv, Da, c->m[1].H, false));
+            GETF(w.ca[0], p + "scale_shift_table_a2v_ca_video", 5 * Dv);
+            GETF(w.ca[1], p + "scale_shift_table_a2v_ca_audio", 5 * Da);
+        }
     }
-#undef GETW
-#undef GETB
-#undef GETF
     c->resolved = true;
     return LTX2_OK;
 }
+#undef GETW
+#undef GETB
+#undef GETF
 
 thread_local ltx2_dit* g_prof_ctx = nullptr;
 
@@ -229,112 +323,341 @@ __global__ void silu_cast_kernel(const float* __restrict__ in, bf16* __restrict_
         out[i] = f2bf(silu_f(in[i]));
 }
 
-int forward(ltx2_dit* c, const float* latent, const float* timesteps, int n_ts, float* velocity, hipStream_t st) {
-    const int N = c->N, D = c->D, H = c->cfg.num_heads, Cin = c->cfg.in_channels;
-    const float eps = c->cfg.norm_eps;
-    LTX2_CHECK_ARG(n_ts == 1 || n_ts == N, "dit_forward: n_timesteps=%d must be 1 or N=%d", n_ts, N);
-    LTX2_CHECK_ARG(n_ts == 1 || c->per_token, "dit_forward: workspace was not sized for per-token timesteps");
-    const float attn_scale = 1.0f / sqrtf((float)c->cfg.head_dim);
-
-    // patchify_proj (model.py:242) -> fp32 residual stream
-    TRY(cast_f32_bf16_launch(latent, c->lat, (long)N * Cin, st));
-    TRY(dense(c->lat, Cin, c->patch_w, c->patch_b, c->x, D, N, D, Cin, EPI_F32, st));
-
-    // AdaLN-single (model.py:113-140; timestep_embedding.py:187-202)
-    long es = 0, ee = 0;   // row strides of emb / e
-    if (n_ts == 1) {
-        TRY(timestep_sinusoid_launch(timesteps, 0, 0.f, c->cfg.timestep_scale, 1, 256, c->sin_f, nullptr, st));
-        TRY(gemv_launch(c->sin_f, 256, c->t1_w, c->t1_b, c->e1_f, D, 1, D, 256, 0, 1, st));
-        TRY(gemv_launch(c->e1_f, D, c->t2_w, c->t2_b, c->e_f, D, 1, D, D, 0, 0, st));
-        TRY(gemv_launch(c->e_f, D, c->ada_w, c->ada_b, c->emb, 6 * D, 1, 6 * D, D, 1, 0, st));
+// AdaLayerNormSingle over T rows of timesteps (ts[i*t_stride] * mult): emb [T][rows*D] (fp32) and,
+// when e_out != null, the embedded timestep e [T][D] (model.py:113-140).
+int adaln_chain(Mod& m, const AdaW& a, const float* ts, long t_stride, int T, float mult, float* emb, float* e_out,
+                hipStream_t st) {
+    const int D = m.D;
+    if (T == 1) {
+        float* e = e_out ? e_out : m.aux_e;
+        TRY(timestep_sinusoid_launch(ts, 0, 0.f, mult, 1, 256, m.sin_f, nullptr, st));
+        TRY(gemv_launch(m.sin_f, 256, a.t1_w, a.t1_b, m.e1_f, D, 1, D, 256, 0, 1, st));
+        TRY(gemv_launch(m.e1_f, D, a.t2_w, a.t2_b, e, D, 1, D, D, 0, 0, st));
+        TRY(gemv_launch(e, D, a.lin_w, a.lin_b, emb, (long)a.rows * D, 1, a.rows * D, D, 1, 0, st));
     } else {
-        TRY(timestep_sinusoid_launch(timesteps, 1, 0.f, c->cfg.timestep_scale, N, 256, nullptr, c->sin_b, st));
-        TRY(dense(c->sin_b, 256, c->t1_w, c->t1_b, c->e1_b, D, N, D, 256, EPI_SILU_BF16, st));
-        TRY(dense(c->e1_b, D, c->t2_w, c->t2_b, c->e_f, D, N, D, D, EPI_F32, st));
-        hipLaunchKernelGGL(silu_cast_kernel, dim3(2048), dim3(256), 0, st, c->e_f, c->es_b, (long)N * D);
+        TRY(timestep_sinusoid_launch(ts, t_stride, 0.f, mult, T, 256, nullptr, m.sin_b, st));
+        TRY(dense(m.sin_b, 256, a.t1_w, a.t1_b, m.e1_b, D, T, D, 256, EPI_SILU_BF16, st));
+        TRY(dense(m.e1_b, D, a.t2_w, a.t2_b, e_out, D, T, D, D, EPI_F32, st));
+        hipLaunchKernelGGL(silu_cast_kernel, dim3(2048), dim3(256), 0, st, e_out, m.es_b, (long)T * D);
         LTX2_CHECK_LAUNCH("silu_cast_kernel");
-        TRY(dense(c->es_b, D, c->ada_w, c->ada_b, c->emb, 6 * D, N, 6 * D, D, EPI_F32, st));
-        es = 6L * D;
-        ee = D;
+        TRY(dense(m.es_b, D, a.lin_w, a.lin_b, emb, (long)a.rows * D, T, a.rows * D, D, EPI_F32, st));
     }
-    const float* emb = c->emb;
-
-    for (int l = 0; l < c->cfg.num_layers; ++l) {
-        const LayerW& w = c->layers[l];
-        // self-attention: AdaLN rows (shift, scale, gate) = sst[0:3] + emb[0:3]  (transformer.py:207-214)
-        TRY(norm_mod_launch(c->x, D, c->h, D, N, D, eps, 0, w.sst + D, w.sst, emb + D, emb, es, st));
-        TRY(dense(c->h, D, w.qkv_w, w.qkv_b, c->qkv, 3 * D, N, 3 * D, D, EPI_BF16, st));
-        {
-            const int offs[2] = {0, D};
-            const float* wts[2] = {w.qn1, w.kn1};
-            TRY(qknorm_rope_launch(c->qkv, 3 * D, N, D, c->cfg.head_dim, 2, offs, wts, eps, c->cosb, c->sinb, st));
-        }
-        TRY(vt_transpose_launch(c->qkv + 2 * D, 3 * D, c->vt, N, c->Npad, H, st));
-        {
-            AttnParams a{};
-            a.Q = c->qkv;
-            a.ldq = 3 * D;
-            a.K = c->qkv + D;
-            a.ldk = 3 * D;
-            a.VT = c->vt;
-            a.vt_head_stride = 128L * c->Npad;
-            a.O = c->att;
-            a.ldo = D;
-            a.Nq = N;
-            a.Nkv = N;
-            a.Npad = c->Npad;
-            a.H = H;
-            a.scale_log2e = attn_scale * 1.4426950408889634f;
-            TRY(attn_launch(a, st));
-        }
-        TRY(dense(c->att, D, w.o_w, w.o_b, c->x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 2 * D, es, w.sst + 2 * D));
-
-        // text cross-attention: plain RMSNorm on x, no RoPE, no mask, no gate (transformer.py:217-226)
-        TRY(norm_mod_launch(c->x, D, c->h, D, N, D, eps, 0, nullptr, nullptr, nullptr, nullptr, 0, st));
-        TRY(dense(c->h, D, w.q2_w, w.q2_b, c->qkv, D, N, D, D, EPI_BF16, st));
-        {
-            const int offs[1] = {0};
-            const float* wts[1] = {w.qn2};
-            TRY(qknorm_rope_launch(c->qkv, D, N, D, c->cfg.head_dim, 1, offs, wts, eps, nullptr, nullptr, st));
-        }
-        {
-            AttnParams a{};
-            a.Q = c->qkv;
-            a.ldq = D;
-            a.K = c->kv2 + (long)l * c->S * 2 * D;
-            a.ldk = 2 * D;
-            a.VT = c->vt2 + (long)l * H * 128 * c->Spad;
-            a.vt_head_stride = 128L * c->Spad;
-            a.O = c->att;
-            a.ldo = D;
-            a.Nq = N;
-            a.Nkv = c->S;
-            a.Npad = c->Spad;
-            a.H = H;
-            a.scale_log2e = attn_scale * 1.4426950408889634f;
-            TRY(attn_launch(a, st));
-        }
-        TRY(dense(c->att, D, w.o2_w, w.o2_b, c->x, D, N, D, D, EPI_RESID_GATE_F32, st));
-
-        // feed-forward: AdaLN rows 3..5 (transformer.py:229-236); Linear -> GELU(tanh) -> Linear, ungated
-        TRY(norm_mod_launch(c->x, D, c->h, D, N, D, eps, 0, w.sst + 4 * D, w.sst + 3 * D, emb + 4 * D, emb + 3 * D, es, st));
-        TRY(dense(c->h, D, w.ff1_w, w.ff1_b, c->ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st));
-        TRY(dense(c->ff, 4 * D, w.ff2_w, w.ff2_b, c->x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, emb + 5 * D, es, w.sst + 5 * D));
-    }
-
-    // output head (model.py:744-758): LayerNorm(no affine) * (1 + scale) + shift, rows (shift, scale)
-    TRY(norm_mod_launch(c->x, D, c->h, D, N, D, eps, 1, c->sst_out + D, c->sst_out, c->e_f, c->e_f, ee, st));
-    TRY(dense(c->h, D, c->proj_w, c->proj_b, velocity, c->cfg.out_channels, N, c->cfg.out_channels, D, EPI_F32, st));
     return LTX2_OK;
 }
 
-int denoise_step(ltx2_dit* c, float* latent, const float* timesteps, int n_ts, const float* mask, const float* clean,
-                 float sigma, float sigma_next, float* x0_out, hipStream_t st) {
-    TRY(forward(c, latent, timesteps, n_ts, c->vel, st));
-    float* x0 = x0_out ? x0_out : c->x0;
-    const int C = c->cfg.out_channels;
-    TRY(x0_from_velocity_launch(latent, c->vel, timesteps, n_ts == 1 ? 0 : 1, 0.f, x0, c->N, C, st));
-    TRY(euler_step_launch(latent, x0, mask, clean, sigma, sigma_next, latent, c->N, C, st));
+int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int npad, bf16* out, long ldo, int nq,
+           int nkv, int H, int hd, hipStream_t st) {
+    AttnParams a{};
+    a.Q = q;
+    a.ldq = ldq;
+    a.K = k;
+    a.ldk = ldk;
+    a.VT = vt;
+    a.vt_head_stride = (long)hd * npad;
+    a.O = out;
+    a.ldo = ldo;
+    a.Nq = nq;
+    a.Nkv = nkv;
+    a.Npad = npad;
+    a.H = H;
+    a.head_dim = hd;
+    a.scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
+    return attn_launch(a, st);
+}
+
+// Per-head gates (attention.py:241-249): att[:, h*hd:(h+1)*hd] *= 2*sigmoid(x @ Wg^T + bg)[:, h]
+int gate_heads(ltx2_dit* c, Mod& m, const AttnW& w, const bf16* xin, int Dq, bf16* att, int rows, int H, int hd,
+               hipStream_t st) {
+    if (!c->gated) return LTX2_OK;
+    TRY(dense(xin, Dq, w.g_w, w.g_b, m.glog, H, rows, H, Dq, EPI_F32, st));
+    return head_gate_launch(att, (long)H * hd, m.glog, H, rows, H, hd, st);
+}
+
+// K (k_norm applied, optional RoPE) and V^T of a text / cross-modal context
+int project_kv(const bf16* ctx, int rows, int Dc, const AttnW& w, int Di, int H, int hd, float eps, const float* cosb,
+               const float* sinb, bf16* kv, bf16* vt, int npad, hipStream_t st) {
+    TRY(dense(ctx, Dc, w.kv_w, w.kv_b, kv, 2 * Di, rows, 2 * Di, Dc, EPI_BF16, st));
+    const int offs[1] = {0};
+    const float* wts[1] = {w.kn};
+    TRY(qknorm_rope_launch(kv, 2 * Di, rows, Di, hd, 1, offs, wts, eps, cosb, sinb, st));
+    return vt_transpose_launch(kv + Di, 2 * Di, vt, rows, npad, H, st, hd);
+}
+
+// Self-attention, text cross-attention of one modality (transformer.py:503-554 / 191-226)
+int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
+    Mod& m = c->m[k];
+    const BlockW& w = c->layers[l].m[k];
+    const int N = m.N, D = m.D, H = m.H, hd = m.hd;
+    const float eps = c->cfg.norm_eps;
+    const float* emb = m.emb;
+    // self-attention: AdaLN rows (shift, scale, gate) = sst[0:3] + emb[0:3]
+    TRY(norm_mod_launch(m.x, D, m.h, D, N, D, eps, 0, w.sst + D, w.sst, emb + D, emb, es, st));
+    TRY(dense(m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st));
+    {
+        const int offs[2] = {0, D};
+        const float* wts[2] = {w.self.qn, w.self.kn};
+        TRY(qknorm_rope_launch(m.qkv, 3 * D, N, D, hd, 2, offs, wts, eps, m.cosb, m.sinb, st));
+    }
+    TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
+    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st));
+    TRY(gate_heads(c, m, w.self, m.h, D, m.att, N, H, hd, st));
+    TRY(dense(m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 2 * D, es, w.sst + 2 * D));
+
+    // text cross-attention: no RoPE, no mask.  V1: plain RMSNorm on x, K/V cached per prompt.
+    // V2.3 (transformer.py:427-455): q side modulated by rows (6,7) and gated by row 8; the context
+    // is modulated by the prompt AdaLN (rows shift, scale), so K/V are recomputed every step.
+    const bf16* kk;
+    const bf16* vt;
+    if (c->v2) {
+        TRY(norm_mod_launch(m.x, D, m.h, D, N, D, eps, 0, w.sst + 7 * D, w.sst + 6 * D, emb + 7 * D, emb + 6 * D, es, st));
+        TRY(ctx_mod_launch(m.ctx, m.ctxm, m.S, D, w.prompt_sst + D, w.prompt_sst, m.prompt_emb + D, m.prompt_emb, st));
+        TRY(project_kv(m.ctxm, m.S, D, w.text, D, H, hd, eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st));
+        kk = m.kv2;
+        vt = m.vt2;
+    } else {
+        TRY(norm_mod_launch(m.x, D, m.h, D, N, D, eps, 0, nullptr, nullptr, nullptr, nullptr, 0, st));
+        kk = m.kv2 + (long)l * m.S * 2 * D;
+        vt = m.vt2 + (long)l * D * m.Spad;
+    }
+    TRY(dense(m.h, D, w.text.q_w, w.text.q_b, m.qkv, D, N, D, D, EPI_BF16, st));
+    {
+        const int offs[1] = {0};
+        const float* wts[1] = {w.text.qn};
+        TRY(qknorm_rope_launch(m.qkv, D, N, D, hd, 1, offs, wts, eps, nullptr, nullptr, st));
+    }
+    TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st));
+    TRY(gate_heads(c, m, w.text, m.h, D, m.att, N, H, hd, st));
+    if (c->v2)
+        TRY(dense(m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 8 * D, es, w.sst + 8 * D));
+    else
+        TRY(dense(m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st));
+    return LTX2_OK;
+}
+
+// Feed-forward: AdaLN rows 3..5 (transformer.py:229-236,622-642); Linear -> GELU(tanh) -> Linear
+int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
+    Mod& m = c->m[k];
+    const BlockW& w = c->layers[l].m[k];
+    const int N = m.N, D = m.D;
+    const float* emb = m.emb;
+    TRY(norm_mod_launch(m.x, D, m.h, D, N, D, c->cfg.norm_eps, 0, w.sst + 4 * D, w.sst + 3 * D, emb + 4 * D, emb + 3 * D, es, st));
+    TRY(dense(m.h, D, w.ff1_w, w.ff1_b, m.ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st));
+    TRY(dense(m.ff, 4 * D, w.ff2_w, w.ff2_b, m.x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, emb + 5 * D, es, w.sst + 5 * D));
+    return LTX2_OK;
+}
+
+// Audio <-> video cross-modal attention (transformer.py:556-620).  Table rows
+// (scale_a2v, shift_a2v, scale_v2a, shift_v2a, gate); both directions read the SAME pre-update
+// RMS-normalised streams, so all four modulated inputs are formed before x is touched.
+int block_cross_modal(ltx2_dit* c, int l, hipStream_t st) {
+    Mod &v = c->m[0], &a = c->m[1];
+    const LayerW& w = c->layers[l];
+    const int Dv = v.D, Da = a.D, H = a.H, hd = a.hd;
+    const float eps = c->cfg.norm_eps;
+    const float *tv = w.ca[0], *ta = w.ca[1];
+    TRY(norm_mod_launch(v.x, Dv, v.h, Dv, v.N, Dv, eps, 0, tv, tv + Dv, v.cross_ss, v.cross_ss + Dv, 0, st));                      // a2v query side
+    TRY(norm_mod_launch(v.x, Dv, v.h2, Dv, v.N, Dv, eps, 0, tv + 2 * Dv, tv + 3 * Dv, v.cross_ss + 2 * Dv, v.cross_ss + 3 * Dv, 0, st));  // v2a context side
+    TRY(norm_mod_launch(a.x, Da, a.h, Da, a.N, Da, eps, 0, ta, ta + Da, a.cross_ss, a.cross_ss + Da, 0, st));                      // a2v context side
+    TRY(norm_mod_launch(a.x, Da, a.h2, Da, a.N, Da, eps, 0, ta + 2 * Da, ta + 3 * Da, a.cross_ss + 2 * Da, a.cross_ss + 3 * Da, 0, st));  // v2a query side
+    const int offs[1] = {0};
+    // audio -> video: Q from video (Dv -> Da), K/V from audio
+    TRY(dense(v.h, Dv, w.a2v.q_w, w.a2v.q_b, v.qkv, Da, v.N, Da, Dv, EPI_BF16, st));
+    {
+        const float* wts[1] = {w.a2v.qn};
+        TRY(qknorm_rope_launch(v.qkv, Da, v.N, Da, hd, 1, offs, wts, eps, v.ccos, v.csin, st));
+    }
+    TRY(project_kv(a.h, a.N, Da, w.a2v, Da, H, hd, eps, a.ccos, a.csin, a.qkv, a.vt, a.Npad, st));
+    TRY(attend(v.qkv, Da, a.qkv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st));
+    TRY(gate_heads(c, v, w.a2v, v.h, Dv, v.att, v.N, H, hd, st));
+    TRY(dense(v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, v.cross_gate, 0, tv + 4 * Dv));
+    // video -> audio: Q from audio, K/V from video (Dv -> Da)
+    TRY(dense(a.h2, Da, w.v2a.q_w, w.v2a.q_b, a.qkv, Da, a.N, Da, Da, EPI_BF16, st));
+    {
+        const float* wts[1] = {w.v2a.qn};
+        TRY(qknorm_rope_launch(a.qkv, Da, a.N, Da, hd, 1, offs, wts, eps, a.ccos, a.csin, st));
+    }
+    TRY(project_kv(v.h2, v.N, Dv, w.v2a, Da, H, hd, eps, v.ccos, v.csin, v.qkv, v.vt, v.Npad, st));
+    TRY(attend(a.qkv, Da, v.qkv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, st));
+    TRY(gate_heads(c, a, w.v2a, a.h2, Da, a.att, a.N, H, hd, st));
+    TRY(dense(a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, st, a.cross_gate, 0, ta + 4 * Da));
+    return LTX2_OK;
+}
+
+struct ModIn {
+    const float* latent;
+    const float* ts;       // n_ts timesteps (device)
+    int n_ts;
+    const float* sigma;    // 1 float (device): this modality's scalar sigma (prompt / cross AdaLN)
+    float* velocity;
+};
+
+int forward(ltx2_dit* c, const ModIn* in, hipStream_t st) {
+    const int nm = c->av ? 2 : 1;
+    long es[2] = {0, 0}, ee[2] = {0, 0};
+    for (int k = 0; k < nm; ++k) {
+        Mod& m = c->m[k];
+        const ModW& w = c->mw[k];
+        LTX2_CHECK_ARG(in[k].n_ts == 1 || in[k].n_ts == m.N, "dit_forward: n_timesteps=%d must be 1 or N=%d", in[k].n_ts, m.N);
+        LTX2_CHECK_ARG(in[k].n_ts == 1 || c->per_token, "dit_forward: workspace was not sized for per-token timesteps");
+        // patchify_proj (model.py:242) -> fp32 residual stream
+        TRY(cast_f32_bf16_launch(in[k].latent, m.lat, (long)m.N * m.Cin, st));
+        TRY(dense(m.lat, m.Cin, w.patch_w, w.patch_b, m.x, m.D, m.N, m.D, m.Cin, EPI_F32, st));
+        // AdaLN-single (model.py:113-140)
+        TRY(adaln_chain(m, w.ada, in[k].ts, 1, in[k].n_ts, c->cfg.timestep_scale, m.emb, m.e_f, st));
+        if (in[k].n_ts > 1) {
+            es[k] = (long)w.ada.rows * m.D;
+            ee[k] = m.D;
+        }
+        if (c->v2)           // prompt AdaLN from this modality's sigma (model.py:151-161)
+            TRY(adaln_chain(m, w.prompt, in[k].sigma, 0, 1, c->cfg.timestep_scale, m.prompt_emb, nullptr, st));
+        if (c->av) {         // cross-modal AdaLN from the OTHER modality's sigma (model.py:346-364,392-404)
+            const float* cs = in[1 - k].sigma;
+            TRY(adaln_chain(m, w.cross_ss, cs, 0, 1, c->cfg.timestep_scale, m.cross_ss, nullptr, st));
+            TRY(adaln_chain(m, w.cross_gate, cs, 0, 1, c->cfg.av_ca_timestep_scale, m.cross_gate, nullptr, st));
+        }
+    }
+    for (int l = 0; l < c->cfg.num_layers; ++l) {
+        for (int k = 0; k < nm; ++k) TRY(block_attention(c, k, l, es[k], st));
+        if (c->av) TRY(block_cross_modal(c, l, st));
+        for (int k = 0; k < nm; ++k) TRY(block_ffn(c, k, l, es[k], st));
+    }
+    // output heads (model.py:744-774): LayerNorm(no affine) * (1 + scale) + shift, rows (shift, scale)
+    for (int k = 0; k < nm; ++k) {
+        Mod& m = c->m[k];
+        const ModW& w = c->mw[k];
+        TRY(norm_mod_launch(m.x, m.D, m.h, m.D, m.N, m.D, c->cfg.norm_eps, 1, w.sst_out + m.D, w.sst_out, m.e_f, m.e_f, ee[k], st));
+        TRY(dense(m.h, m.D, w.proj_w, w.proj_b, in[k].velocity, m.Cout, m.N, m.Cout, m.D, EPI_F32, st));
+    }
+    return LTX2_OK;
+}
+
+struct StepIo {
+    float* latent;
+    const float* mask;
+    const float* clean;
+    float* x0_out;
+};
+
+int denoise_step(ltx2_dit* c, ModIn* in, const StepIo* io, float sigma, float sigma_next, hipStream_t st) {
+    const int nm = c->av ? 2 : 1;
+    for (int k = 0; k < nm; ++k) {
+        in[k].latent = io[k].latent;
+        in[k].velocity = c->m[k].vel;
+    }
+    TRY(forward(c, in, st));
+    for (int k = 0; k < nm; ++k) {
+        Mod& m = c->m[k];
+        float* x0 = io[k].x0_out ? io[k].x0_out : m.x0;
+        TRY(x0_from_velocity_launch(io[k].latent, m.vel, in[k].ts, in[k].n_ts == 1 ? 0 : 1, 0.f, x0, m.N, m.Cout, st));
+        TRY(euler_step_launch(io[k].latent, x0, io[k].mask, io[k].clean, sigma, sigma_next, io[k].latent, m.N, m.Cout, st));
+    }
+    return LTX2_OK;
+}
+
+int prepare_modality(ltx2_dit* c, int k, const float* context, int S, const float* cosb, const float* sinb,
+                     const float* ccos, const float* csin, hipStream_t st) {
+    Mod& m = c->m[k];
+    const ModW& w = c->mw[k];
+    LTX2_CHECK_ARG(context && cosb && sinb, "dit_prepare: null argument");
+    LTX2_CHECK_ARG(S == m.S, "dit_prepare: S=%d differs from the bound workspace S=%d", S, m.S);
+    const int D = m.D;
+    const int Cctx = c->cfg.caption_channels > 0 ? c->cfg.caption_channels : D;
+    bool ok = hipMemcpyAsync(m.cosb, cosb, 4L * m.N * (D / 2), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(m.sinb, sinb, 4L * m.N * (D / 2), hipMemcpyDeviceToDevice, st) == hipSuccess;
+    if (c->av) {
+        LTX2_CHECK_ARG(ccos && csin, "dit_prepare: cross-modal RoPE tables are required for AudioVideo models");
+        const long Dc = c->m[1].D;
+        ok = ok && hipMemcpyAsync(m.ccos, ccos, 4L * m.N * (Dc / 2), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+             hipMemcpyAsync(m.csin, csin, 4L * m.N * (Dc / 2), hipMemcpyDeviceToDevice, st) == hipSuccess;
+    }
+    if (!ok) {
+        ltx2_set_error("dit_prepare: RoPE table copy failed");
+        return LTX2_E_HIP;
+    }
+    TRY(cast_f32_bf16_launch(context, m.ctx_in, (long)S * Cctx, st));
+    m.ctx = m.ctx_in;
+    if (c->cfg.caption_channels > 0) {   // PixArtAlphaTextProjection (model.py:52-56)
+        TRY(dense(m.ctx_in, Cctx, w.cap1_w, w.cap1_b, m.c1, D, S, D, Cctx, EPI_GELU_BF16, st));
+        TRY(dense(m.c1, D, w.cap2_w, w.cap2_b, m.ctxp, D, S, D, D, EPI_BF16, st));
+        m.ctx = m.ctxp;
+    }
+    if (!c->v2)
+        for (int l = 0; l < c->cfg.num_layers; ++l)
+            TRY(project_kv(m.ctx, S, D, c->layers[l].m[k].text, D, m.H, m.hd, c->cfg.norm_eps, nullptr, nullptr,
+                           m.kv2 + (long)l * S * 2 * D, m.vt2 + (long)l * D * m.Spad, m.Spad, st));
+    return LTX2_OK;
+}
+
+int begin_capture(ltx2_dit* c, const float* host_sigmas, int n_steps, hipStream_t st) {
+    LTX2_CHECK_ARG(st != nullptr, "dit_graph_capture: needs a non-default stream");
+    for (int i = 0; i < n_steps; ++i) LTX2_CHECK_ARG(host_sigmas[i] != 0.f, "Sigma can't be 0.0");
+    if (hipMemcpyAsync(c->sigmas_dev, host_sigmas, 4L * (n_steps + 1), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        ltx2_set_error("dit_graph_capture: sigma upload failed");
+        return LTX2_E_HIP;
+    }
+    if (c->exec) {
+        (void)hipGraphExecDestroy(c->exec);
+        c->exec = nullptr;
+    }
+    if (c->graph) {
+        (void)hipGraphDestroy(c->graph);
+        c->graph = nullptr;
+    }
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        ltx2_set_error("dit_graph_capture: hipStreamBeginCapture failed");
+        return LTX2_E_HIP;
+    }
+    return LTX2_OK;
+}
+
+int end_capture(ltx2_dit* c, int rc, hipStream_t st) {
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != LTX2_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess || !g) {
+        ltx2_set_error("dit_graph_capture: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return LTX2_E_HIP;
+    }
+    c->graph = g;
+    if (hipGraphInstantiate(&c->exec, g, nullptr, nullptr, 0) != hipSuccess) {
+        ltx2_set_error("dit_graph_capture: hipGraphInstantiate failed");
+        return LTX2_E_HIP;
+    }
+    return LTX2_OK;
+}
+
+int check_ready(ltx2_dit* c, const char* who, bool want_av) {
+    LTX2_CHECK_ARG(c, "%s: null context", who);
+    LTX2_CHECK_ARG(c->av == want_av, "%s: model is %s", who, c->av ? "AudioVideo (use the *_av entry points)" : "VideoOnly");
+    if (!c->prepared) {
+        ltx2_set_error("%s: ltx2_dit_prepare has not been called", who);
+        return LTX2_E_STATE;
+    }
+    return LTX2_OK;
+}
+
+int bind(ltx2_dit* c, void* ptr, int64_t bytes, int N, int S, int Na, int Sa, int per_token) {
+    LTX2_CHECK_ARG(((uintptr_t)ptr & 255) == 0, "dit_bind_workspace: pointer must be 256-byte aligned");
+    const long need = carve(c, (char*)ptr, N, S, Na, Sa, per_token);
+    if (bytes < need) {
+        ltx2_set_error("dit_bind_workspace: %ld bytes given, %ld needed", (long)bytes, need);
+        return LTX2_E_STATE;
+    }
+    c->ws = (char*)ptr;
+    c->ws_bytes = bytes;
+    const int n[2] = {N, Na}, s[2] = {S, Sa};
+    for (int k = 0; k < 2; ++k) {
+        c->m[k].N = n[k];
+        c->m[k].S = s[k];
+        c->m[k].Npad = (int)align_up(n[k], 64);
+        c->m[k].Spad = (int)align_up(s[k], 64);
+    }
+    c->per_token = per_token;
+    c->prepared = false;
     return LTX2_OK;
 }
 
@@ -344,13 +667,35 @@ extern "C" {
 
 int ltx2_dit_create(const ltx2_dit_config* cfg, ltx2_dit** out) {
     LTX2_CHECK_ARG(cfg && out, "dit_create: null argument");
-    LTX2_CHECK_ARG(cfg->head_dim == 128, "dit_create: head_dim=%d, only 128 is implemented", cfg->head_dim);
+    LTX2_CHECK_ARG(cfg->head_dim == 128 || cfg->head_dim == 64, "dit_create: head_dim=%d, only 128 and 64 are implemented", cfg->head_dim);
     LTX2_CHECK_ARG(cfg->num_layers > 0 && cfg->num_heads > 0, "dit_create: bad layer/head count");
     LTX2_CHECK_ARG(cfg->in_channels % 64 == 0, "dit_create: in_channels must be a multiple of 64");
     LTX2_CHECK_ARG(cfg->caption_channels % 64 == 0, "dit_create: caption_channels must be a multiple of 64");
+    LTX2_CHECK_ARG(cfg->model_type == LTX2_MODEL_VIDEO_ONLY || cfg->model_type == LTX2_MODEL_AUDIO_VIDEO, "dit_create: bad model_type %d", cfg->model_type);
     ltx2_dit* c = new ltx2_dit();
     c->cfg = *cfg;
-    c->D = cfg->num_heads * cfg->head_dim;
+    c->av = cfg->model_type == LTX2_MODEL_AUDIO_VIDEO;
+    c->v2 = cfg->cross_attention_adaln != 0;
+    c->gated = cfg->apply_gated_attention != 0;
+    Mod& v = c->m[0];
+    v.H = cfg->num_heads;
+    v.hd = cfg->head_dim;
+    v.D = v.H * v.hd;
+    v.Cin = cfg->in_channels;
+    v.Cout = cfg->out_channels;
+    if (c->av) {
+        if (!(cfg->audio_head_dim == 64 && cfg->audio_heads == cfg->num_heads && cfg->audio_in_channels % 64 == 0)) {
+            delete c;
+            ltx2_set_error("dit_create: AudioVideo needs audio_head_dim = 64, audio_heads = num_heads (shared cross-modal RoPE heads) and audio_in_channels %% 64 == 0");
+            return LTX2_E_INVALID;
+        }
+        Mod& a = c->m[1];
+        a.H = cfg->audio_heads;
+        a.hd = cfg->audio_head_dim;
+        a.D = a.H * a.hd;
+        a.Cin = cfg->audio_in_channels;
+        a.Cout = cfg->audio_out_channels;
+    }
     *out = c;
     return LTX2_OK;
 }
@@ -371,136 +716,134 @@ int ltx2_dit_set_weight(ltx2_dit* c, const char* name, const void* ptr, int dtyp
     return LTX2_OK;
 }
 
-int64_t ltx2_dit_workspace_bytes(const ltx2_dit* c, int N, int S, int per_token) {
-    if (!c || N <= 0 || S <= 0) return -1;
+int64_t ltx2_dit_workspace_bytes_av(const ltx2_dit* c, int N, int S, int Na, int Sa, int per_token) {
+    if (!c || N <= 0 || S <= 0 || (c->av && (Na <= 0 || Sa <= 0))) return -1;
     ltx2_dit tmp;            // carve() writes pointers; use a scratch context
     tmp.cfg = c->cfg;
-    tmp.D = c->D;
-    return carve(&tmp, nullptr, N, S, per_token);
+    tmp.av = c->av;
+    tmp.v2 = c->v2;
+    tmp.gated = c->gated;
+    tmp.m[0] = c->m[0];
+    tmp.m[1] = c->m[1];
+    return carve(&tmp, nullptr, N, S, Na, Sa, per_token);
+}
+
+int64_t ltx2_dit_workspace_bytes(const ltx2_dit* c, int N, int S, int per_token) {
+    if (!c || c->av) return -1;
+    return ltx2_dit_workspace_bytes_av(c, N, S, 0, 0, per_token);
 }
 
 int ltx2_dit_bind_workspace(ltx2_dit* c, void* ptr, int64_t bytes, int N, int S, int per_token) {
     LTX2_CHECK_ARG(c && ptr && N > 0 && S > 0, "dit_bind_workspace: bad argument");
-    LTX2_CHECK_ARG(((uintptr_t)ptr & 255) == 0, "dit_bind_workspace: pointer must be 256-byte aligned");
-    const long need = carve(c, (char*)ptr, N, S, per_token);
-    if (bytes < need) {
-        ltx2_set_error("dit_bind_workspace: %ld bytes given, %ld needed", (long)bytes, need);
-        return LTX2_E_STATE;
-    }
-    c->ws = (char*)ptr;
-    c->ws_bytes = bytes;
-    c->N = N;
-    c->S = S;
-    c->Npad = (int)align_up(N, 64);
-    c->Spad = (int)align_up(S, 64);
-    c->per_token = per_token;
-    c->prepared = false;
-    return LTX2_OK;
+    LTX2_CHECK_ARG(!c->av, "dit_bind_workspace: AudioVideo model, use ltx2_dit_bind_workspace_av");
+    return bind(c, ptr, bytes, N, S, 0, 0, per_token);
+}
+
+int ltx2_dit_bind_workspace_av(ltx2_dit* c, void* ptr, int64_t bytes, int N, int S, int Na, int Sa, int per_token) {
+    LTX2_CHECK_ARG(c && ptr && N > 0 && S > 0 && Na > 0 && Sa > 0, "dit_bind_workspace_av: bad argument");
+    LTX2_CHECK_ARG(c->av, "dit_bind_workspace_av: VideoOnly model, use ltx2_dit_bind_workspace");
+    return bind(c, ptr, bytes, N, S, Na, Sa, per_token);
 }
 
 int ltx2_dit_prepare(ltx2_dit* c, const float* context, int S, const float* rope_cos, const float* rope_sin,
                      void* stream) {
-    LTX2_CHECK_ARG(c && context && rope_cos && rope_sin, "dit_prepare: null argument");
+    LTX2_CHECK_ARG(c, "dit_prepare: null context");
+    LTX2_CHECK_ARG(!c->av, "dit_prepare: AudioVideo model, use ltx2_dit_prepare_av");
     if (!c->ws) {
         ltx2_set_error("dit_prepare: no workspace bound");
         return LTX2_E_STATE;
     }
-    LTX2_CHECK_ARG(S == c->S, "dit_prepare: S=%d differs from the bound workspace S=%d", S, c->S);
     TRY(resolve(c));
-    hipStream_t st = (hipStream_t)stream;
-    const int D = c->D, H = c->cfg.num_heads;
-    const int Cctx = c->cfg.caption_channels > 0 ? c->cfg.caption_channels : D;
-    const float eps = c->cfg.norm_eps;
-    if (hipMemcpyAsync(c->cosb, rope_cos, 4L * c->N * (D / 2), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(c->sinb, rope_sin, 4L * c->N * (D / 2), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-        ltx2_set_error("dit_prepare: RoPE table copy failed");
-        return LTX2_E_HIP;
+    TRY(prepare_modality(c, 0, context, S, rope_cos, rope_sin, nullptr, nullptr, (hipStream_t)stream));
+    c->prepared = true;
+    return LTX2_OK;
+}
+
+int ltx2_dit_prepare_av(ltx2_dit* c, const float* v_context, int S, const float* v_cos, const float* v_sin,
+                        const float* v_cross_cos, const float* v_cross_sin, const float* a_context, int Sa,
+                        const float* a_cos, const float* a_sin, const float* a_cross_cos, const float* a_cross_sin,
+                        void* stream) {
+    LTX2_CHECK_ARG(c, "dit_prepare_av: null context");
+    LTX2_CHECK_ARG(c->av, "dit_prepare_av: VideoOnly model, use ltx2_dit_prepare");
+    if (!c->ws) {
+        ltx2_set_error("dit_prepare_av: no workspace bound");
+        return LTX2_E_STATE;
     }
-    TRY(cast_f32_bf16_launch(context, c->ctx_in, (long)S * Cctx, st));
-    const bf16* ctx = c->ctx_in;
-    if (c->cfg.caption_channels > 0) {   // PixArtAlphaTextProjection (model.py:52-56)
-        TRY(dense(c->ctx_in, Cctx, c->cap1_w, c->cap1_b, c->c1, D, S, D, Cctx, EPI_GELU_BF16, st));
-        TRY(dense(c->c1, D, c->cap2_w, c->cap2_b, c->ctxp, D, S, D, D, EPI_BF16, st));
-        ctx = c->ctxp;
-    }
-    for (int l = 0; l < c->cfg.num_layers; ++l) {
-        const LayerW& w = c->layers[l];
-        bf16* kv = c->kv2 + (long)l * S * 2 * D;
-        TRY(dense(ctx, D, w.kv2_w, w.kv2_b, kv, 2 * D, S, 2 * D, D, EPI_BF16, st));
-        const int offs[1] = {0};
-        const float* wts[1] = {w.kn2};
-        TRY(qknorm_rope_launch(kv, 2 * D, S, D, c->cfg.head_dim, 1, offs, wts, eps, nullptr, nullptr, st));
-        TRY(vt_transpose_launch(kv + D, 2 * D, c->vt2 + (long)l * H * 128 * c->Spad, S, c->Spad, H, st));
-    }
+    TRY(resolve(c));
+    TRY(prepare_modality(c, 0, v_context, S, v_cos, v_sin, v_cross_cos, v_cross_sin, (hipStream_t)stream));
+    TRY(prepare_modality(c, 1, a_context, Sa, a_cos, a_sin, a_cross_cos, a_cross_sin, (hipStream_t)stream));
     c->prepared = true;
     return LTX2_OK;
 }
 
 int ltx2_dit_forward(ltx2_dit* c, const float* latent, const float* timesteps, int n_timesteps, float* velocity,
                      void* stream) {
-    LTX2_CHECK_ARG(c && latent && timesteps && velocity, "dit_forward: null argument");
-    if (!c->prepared) {
-        ltx2_set_error("dit_forward: ltx2_dit_prepare has not been called");
-        return LTX2_E_STATE;
-    }
-    return forward(c, latent, timesteps, n_timesteps, velocity, (hipStream_t)stream);
+    LTX2_CHECK_ARG(latent && timesteps && velocity, "dit_forward: null argument");
+    TRY(check_ready(c, "dit_forward", false));
+    ModIn in[1] = {{latent, timesteps, n_timesteps, timesteps, velocity}};
+    return forward(c, in, (hipStream_t)stream);
+}
+
+int ltx2_dit_forward_av(ltx2_dit* c, const float* v_latent, const float* v_timesteps, int n_v_timesteps,
+                        const float* v_sigma, const float* a_latent, const float* a_timesteps, int n_a_timesteps,
+                        const float* a_sigma, float* v_velocity, float* a_velocity, void* stream) {
+    LTX2_CHECK_ARG(v_latent && v_timesteps && v_sigma && a_latent && a_timesteps && a_sigma && v_velocity && a_velocity,
+                   "dit_forward_av: null argument");
+    TRY(check_ready(c, "dit_forward_av", true));
+    ModIn in[2] = {{v_latent, v_timesteps, n_v_timesteps, v_sigma, v_velocity},
+                   {a_latent, a_timesteps, n_a_timesteps, a_sigma, a_velocity}};
+    return forward(c, in, (hipStream_t)stream);
 }
 
 int ltx2_dit_denoise_step(ltx2_dit* c, float* latent, const float* timesteps, int n_timesteps, const float* mask,
                           const float* clean, float sigma, float sigma_next, float* x0_out, void* stream) {
-    LTX2_CHECK_ARG(c && latent && timesteps, "dit_denoise_step: null argument");
-    if (!c->prepared) {
-        ltx2_set_error("dit_denoise_step: ltx2_dit_prepare has not been called");
-        return LTX2_E_STATE;
-    }
-    return denoise_step(c, latent, timesteps, n_timesteps, mask, clean, sigma, sigma_next, x0_out, (hipStream_t)stream);
+    LTX2_CHECK_ARG(latent && timesteps, "dit_denoise_step: null argument");
+    TRY(check_ready(c, "dit_denoise_step", false));
+    ModIn in[1] = {{latent, timesteps, n_timesteps, timesteps, nullptr}};
+    const StepIo io[1] = {{latent, mask, clean, x0_out}};
+    return denoise_step(c, in, io, sigma, sigma_next, (hipStream_t)stream);
+}
+
+int ltx2_dit_denoise_step_av(ltx2_dit* c, float* v_latent, float* a_latent, const float* v_timesteps, int n_v_timesteps,
+                             const float* a_timesteps, int n_a_timesteps, const float* sigma_dev, const float* v_mask,
+                             const float* v_clean, const float* a_mask, const float* a_clean, float sigma,
+                             float sigma_next, float* v_x0_out, float* a_x0_out, void* stream) {
+    LTX2_CHECK_ARG(v_latent && a_latent && v_timesteps && a_timesteps && sigma_dev, "dit_denoise_step_av: null argument");
+    TRY(check_ready(c, "dit_denoise_step_av", true));
+    ModIn in[2] = {{v_latent, v_timesteps, n_v_timesteps, sigma_dev, nullptr},
+                   {a_latent, a_timesteps, n_a_timesteps, sigma_dev, nullptr}};
+    const StepIo io[2] = {{v_latent, v_mask, v_clean, v_x0_out}, {a_latent, a_mask, a_clean, a_x0_out}};
+    return denoise_step(c, in, io, sigma, sigma_next, (hipStream_t)stream);
 }
 
 int ltx2_dit_graph_capture(ltx2_dit* c, float* latent, const float* host_sigmas, int n_steps, void* stream) {
-    LTX2_CHECK_ARG(c && latent && host_sigmas && n_steps > 0 && n_steps < 64, "dit_graph_capture: bad argument");
-    if (!c->prepared) {
-        ltx2_set_error("dit_graph_capture: ltx2_dit_prepare has not been called");
-        return LTX2_E_STATE;
-    }
+    LTX2_CHECK_ARG(latent && host_sigmas && n_steps > 0 && n_steps < 64, "dit_graph_capture: bad argument");
+    TRY(check_ready(c, "dit_graph_capture", false));
     hipStream_t st = (hipStream_t)stream;
-    LTX2_CHECK_ARG(st != nullptr, "dit_graph_capture: needs a non-default stream");
-    for (int i = 0; i < n_steps; ++i) LTX2_CHECK_ARG(host_sigmas[i] != 0.f, "Sigma can't be 0.0");
-    if (hipMemcpyAsync(c->sigmas_dev, host_sigmas, 4L * (n_steps + 1), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) {
-        ltx2_set_error("dit_graph_capture: sigma upload failed");
-        return LTX2_E_HIP;
-    }
-    if (c->exec) {
-        (void)hipGraphExecDestroy(c->exec);
-        c->exec = nullptr;
-    }
-    if (c->graph) {
-        (void)hipGraphDestroy(c->graph);
-        c->graph = nullptr;
-    }
-    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-        ltx2_set_error("dit_graph_capture: hipStreamBeginCapture failed");
-        return LTX2_E_HIP;
-    }
+    TRY(begin_capture(c, host_sigmas, n_steps, st));
     int rc = LTX2_OK;
-    for (int i = 0; i < n_steps && rc == LTX2_OK; ++i)
-        rc = denoise_step(c, latent, c->sigmas_dev + i, 1, nullptr, nullptr, host_sigmas[i], host_sigmas[i + 1], nullptr, st);
-    hipGraph_t g = nullptr;
-    const hipError_t e = hipStreamEndCapture(st, &g);
-    if (rc != LTX2_OK) {
-        if (g) (void)hipGraphDestroy(g);
-        return rc;
+    for (int i = 0; i < n_steps && rc == LTX2_OK; ++i) {
+        ModIn in[1] = {{latent, c->sigmas_dev + i, 1, c->sigmas_dev + i, nullptr}};
+        const StepIo io[1] = {{latent, nullptr, nullptr, nullptr}};
+        rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st);
     }
-    if (e != hipSuccess || !g) {
-        ltx2_set_error("dit_graph_capture: hipStreamEndCapture failed: %s", hipGetErrorString(e));
-        return LTX2_E_HIP;
+    return end_capture(c, rc, st);
+}
+
+int ltx2_dit_graph_capture_av(ltx2_dit* c, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps,
+                              void* stream) {
+    LTX2_CHECK_ARG(v_latent && a_latent && host_sigmas && n_steps > 0 && n_steps < 64, "dit_graph_capture_av: bad argument");
+    TRY(check_ready(c, "dit_graph_capture_av", true));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(begin_capture(c, host_sigmas, n_steps, st));
+    int rc = LTX2_OK;
+    for (int i = 0; i < n_steps && rc == LTX2_OK; ++i) {
+        const float* s = c->sigmas_dev + i;
+        ModIn in[2] = {{v_latent, s, 1, s, nullptr}, {a_latent, s, 1, s, nullptr}};
+        const StepIo io[2] = {{v_latent, nullptr, nullptr, nullptr}, {a_latent, nullptr, nullptr, nullptr}};
+        rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st);
     }
-    c->graph = g;
-    if (hipGraphInstantiate(&c->exec, g, nullptr, nullptr, 0) != hipSuccess) {
-        ltx2_set_error("dit_graph_capture: hipGraphInstantiate failed");
-        return LTX2_E_HIP;
-    }
-    return LTX2_OK;
+    return end_capture(c, rc, st);
 }
 
 int ltx2_dit_profile_begin(ltx2_dit* c, int epilogue) {

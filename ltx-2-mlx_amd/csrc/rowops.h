@@ -17,6 +17,14 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
 int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off,
                        const float* const* weights, float eps, const float* cos, const float* sin, hipStream_t stream);
 
+// out_bf16[row][d] = ctx_bf16[row][d] * (1 + scale_tab[d] + scale_emb[d]) + shift_tab[d] + shift_emb[d]
+// (V2.3 prompt modulation of the text context, transformer.py:441-451)
+int ctx_mod_launch(const bf16* ctx, bf16* out, int rows, int D, const float* scale_tab, const float* shift_tab,
+                   const float* scale_emb, const float* shift_emb, hipStream_t stream);
+
+// att[row][h*hd + j] *= 2 * sigmoid(logits[row*ldl + h])   (per-head attention gates, attention.py:241-249)
+int head_gate_launch(bf16* att, long ld, const float* logits, long ldl, int rows, int H, int hd, hipStream_t stream);
+
 // [cos | sin] sinusoid of reference get_timestep_embedding(flip_sin_to_cos=True, shift=0), dim 256.
 // t_scaled = (t ? t[i*t_stride] : t_scalar) * mult.  Writes fp32 (out_f32) and/or bf16 (out_bf16) [T][dim].
 int timestep_sinusoid_launch(const float* t, long t_stride, float t_scalar, float mult, int T, int dim, float* out_f32,

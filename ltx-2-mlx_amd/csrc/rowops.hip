@@ -152,6 +152,35 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16* __restrict__ buf
     }
 }
 
+__global__ void ctx_mod_kernel(const bf16* __restrict__ ctx, bf16* __restrict__ out, long n4, int D,
+                               const float* __restrict__ scale_tab, const float* __restrict__ shift_tab,
+                               const float* __restrict__ scale_emb, const float* __restrict__ shift_emb) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)((i * 4) % D);
+        const bf16x4 v = *(const bf16x4*)(ctx + i * 4);
+        const f32x4 sc = *(const f32x4*)(scale_tab + d) + *(const f32x4*)(scale_emb + d);
+        const f32x4 sh = *(const f32x4*)(shift_tab + d) + *(const f32x4*)(shift_emb + d);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(v[e]) * (1.f + sc[e]) + sh[e]);
+        *(bf16x4*)(out + i * 4) = o;
+    }
+}
+
+__global__ void head_gate_kernel(bf16* __restrict__ att, long ld, const float* __restrict__ logits, long ldl, long n8,
+                                 int per_row8, int hd) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / per_row8;
+        const int col = (int)(i - row * per_row8) * 8;
+        const float g = 2.f / (1.f + __expf(-logits[row * ldl + col / hd]));
+        bf16x8* p = (bf16x8*)(att + row * ld + col);
+        bf16x8 v = *p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * g);
+        *p = v;
+    }
+}
+
 __global__ void timestep_sinusoid_kernel(const float* __restrict__ t, long t_stride, float t_scalar, float mult, int T,
                                          int dim, float* __restrict__ of, bf16* __restrict__ ob) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,6 +381,27 @@ int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int ns
     else
         hipLaunchKernelGGL((qknorm_rope_kernel<1>), dim3(rows), dim3(256), 0, stream, buf, ld, D, head_dim, s, eps, cos, sin);
     LTX2_CHECK_LAUNCH("qknorm_rope_kernel");
+    return LTX2_OK;
+}
+
+int ctx_mod_launch(const bf16* ctx, bf16* out, int rows, int D, const float* scale_tab, const float* shift_tab,
+                   const float* scale_emb, const float* shift_emb, hipStream_t stream) {
+    LTX2_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0, "ctx_mod: D must be a multiple of 4");
+    LTX2_CHECK_ARG(scale_tab && shift_tab && scale_emb && shift_emb, "ctx_mod: null table");
+    const long n4 = (long)rows * D / 4;
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(ctx_mod_kernel, dim3(grid), dim3(256), 0, stream, ctx, out, n4, D, scale_tab, shift_tab, scale_emb, shift_emb);
+    LTX2_CHECK_LAUNCH("ctx_mod_kernel");
+    return LTX2_OK;
+}
+
+int head_gate_launch(bf16* att, long ld, const float* logits, long ldl, int rows, int H, int hd, hipStream_t stream) {
+    LTX2_CHECK_ARG(rows > 0 && H > 0 && hd % 8 == 0 && ld % 8 == 0, "head_gate: head_dim and ld must be multiples of 8");
+    const int per_row8 = H * hd / 8;
+    const long n8 = (long)rows * per_row8;
+    const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(head_gate_kernel, dim3(grid), dim3(256), 0, stream, att, ld, logits, ldl, n8, per_row8, hd);
+    LTX2_CHECK_LAUNCH("head_gate_kernel");
     return LTX2_OK;
 }
 

@@ -112,26 +112,26 @@ def qknorm_rope_(buf: torch.Tensor, D: int, head_dim: int, q_off: int, q_weight:
     return buf
 
 
-def vt_transpose(v: torch.Tensor, heads: int) -> torch.Tensor:
-    """v bf16 [Nkv, >= heads*128] (a strided column view is fine) -> VT [H,128,Npad]."""
+def vt_transpose(v: torch.Tensor, heads: int, head_dim: int = 128) -> torch.Tensor:
+    """v bf16 [Nkv, >= heads*head_dim] (a strided column view is fine) -> VT [H,head_dim,Npad]."""
     assert v.dtype == BF16 and v.dim() == 2 and v.stride(1) == 1
     nkv = v.shape[0]
     npad = (nkv + 63) // 64 * 64
-    vt = torch.empty(heads, 128, npad, device=v.device, dtype=BF16)
-    nv.check(nv.lib().ltx2_vt_transpose(nv.ptr(v), v.stride(0), nv.ptr(vt), nkv, npad, heads, nv.stream()))
+    vt = torch.empty(heads, head_dim, npad, device=v.device, dtype=BF16)
+    nv.check(nv.lib().ltx2_vt_transpose(nv.ptr(v), v.stride(0), nv.ptr(vt), nkv, npad, heads, head_dim, nv.stream()))
     return vt
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int,
                scale: Optional[float] = None) -> torch.Tensor:
-    """q [Nq, H*128], k [Nkv, H*128] bf16 (row-strided views allowed), vt from vt_transpose."""
+    """q [Nq, H*hd], k [Nkv, H*hd] bf16 (row-strided views allowed), vt [H,hd,Npad] from vt_transpose (hd 128 or 64)."""
     assert q.dtype == BF16 and k.dtype == BF16 and vt.dtype == BF16 and q.stride(1) == 1 and k.stride(1) == 1
-    nq = q.shape[0]
-    out = torch.empty(nq, heads * 128, device=q.device, dtype=BF16)
+    nq, hd = q.shape[0], vt.shape[1]
+    out = torch.empty(nq, heads * hd, device=q.device, dtype=BF16)
     if scale is None:
-        scale = 1.0 / math.sqrt(128.0)
+        scale = 1.0 / math.sqrt(float(hd))
     nv.check(nv.lib().ltx2_flash_attn(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out),
-                                      out.stride(0), nq, nkv, heads, scale, nv.stream()))
+                                      out.stride(0), nq, nkv, heads, hd, scale, nv.stream()))
     return out
 
 

@@ -2,7 +2,7 @@
 
 Mirrors (names, argument meaning, error behaviour) reference
 LTX_2_MLX/model/transformer/model.py:59-69 (Modality), :413-881 (LTXModel), :884-936 (X0Model)
-for the VideoOnly V1 model.  All arithmetic runs in libltx2hip.so (ltx2_dit_* engine calls);
+for the VideoOnly and AudioVideo models (19B blocks and the V2.3 variant).  All arithmetic runs in libltx2hip.so (ltx2_dit_* engine calls);
 torch owns device memory and streams only.  Step-invariant per-prompt work (caption projection,
 cross-attention K/V, RoPE tables) is computed once per (context, positions) pair in
 ``prepare`` -- the reference recomputes it every step (model.py:262-271) with identical results.
@@ -81,7 +81,14 @@ def rope_tables_token_major(positions: torch.Tensor, dim: int, heads: int, theta
 
 
 class LTXModel:
-    """Velocity model.  Constructor keywords follow reference model.py:436-461."""
+    """Velocity model.  Constructor keywords follow reference model.py:436-461; VideoOnly and
+    AudioVideo model types, 19B-style blocks or V2.3 (cross_attention_adaln / apply_gated_attention)."""
+
+    AUDIO_ATTENTION_HEADS = 32          # reference model.py:428-434
+    AUDIO_HEAD_DIM = 64
+    AUDIO_IN_CHANNELS = 128
+    AUDIO_OUT_CHANNELS = 128
+    AUDIO_CROSS_PE_MAX_POS = 20
 
     def __init__(self, model_type: LTXModelType = LTXModelType.VideoOnly, num_attention_heads: int = 32,
                  attention_head_dim: int = 128, in_channels: int = 128, out_channels: int = 128, num_layers: int = 48,
@@ -91,38 +98,46 @@ class LTXModel:
                  use_middle_indices_grid: bool = True, rope_type: LTXRopeType = LTXRopeType.SPLIT,
                  compute_dtype: torch.dtype = BF16, low_memory: bool = False, fast_mode: bool = False,
                  cross_attention_adaln: bool = False, apply_gated_attention: bool = False,
-                 device: Union[str, torch.device] = "cuda"):
-        if model_type != LTXModelType.VideoOnly:
-            raise NotImplementedError("only the VideoOnly (LTX-2 19B V1) transformer is implemented on gfx950 so far; "
-                                      "AudioVideo / V2.3 is the next scope row (DESIGN.md)")
-        if cross_attention_adaln or apply_gated_attention:
-            raise NotImplementedError("V2.3 cross_attention_adaln / gated attention: next scope row (DESIGN.md)")
+                 device: Union[str, torch.device] = "cuda", audio_attention_heads: Optional[int] = None):
+        if model_type == LTXModelType.AudioOnly:
+            raise NotImplementedError("AudioOnly transformer is outside the denoise hot path (DESIGN.md)")
         if rope_type != LTXRopeType.SPLIT or not use_middle_indices_grid:
             raise NotImplementedError("the DiT uses SPLIT RoPE with middle-of-bounds positions (model.py:455,453)")
         if compute_dtype not in (BF16,):
             raise NotImplementedError("compute dtype is bf16 (fp32 accumulate / residual stream)")
         self.model_type = model_type
+        self.is_av = model_type == LTXModelType.AudioVideo
         self.num_attention_heads = num_attention_heads
         self.attention_head_dim = attention_head_dim
         self.inner_dim = self.video_inner_dim = num_attention_heads * attention_head_dim
+        self.audio_heads = audio_attention_heads or self.AUDIO_ATTENTION_HEADS
+        self.audio_inner_dim = self.audio_heads * self.AUDIO_HEAD_DIM
         self.in_channels, self.out_channels, self.num_layers = in_channels, out_channels, num_layers
         self.caption_channels = caption_channels
         self.norm_eps = norm_eps
         self.positional_embedding_theta = positional_embedding_theta
         self.positional_embedding_max_pos = positional_embedding_max_pos or [20, 2048, 2048]
         self.timestep_scale_multiplier = timestep_scale_multiplier
+        self.av_ca_timestep_scale_multiplier = av_ca_timestep_scale_multiplier
+        self.cross_attention_adaln = cross_attention_adaln
+        self.apply_gated_attention = apply_gated_attention
         self.compute_dtype = compute_dtype
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("LTXModel runs on the MI355X only (no CPU fallback); got device " + str(device))
+        if self.is_av and self.audio_heads != num_attention_heads:
+            raise ValueError("AudioVideo: audio heads must equal video heads (shared cross-modal RoPE head split, model.py:336-343)")
         cfg = nv.DitConfig(num_layers, num_attention_heads, attention_head_dim, in_channels, out_channels,
-                           caption_channels or 0, norm_eps, float(timestep_scale_multiplier))
+                           caption_channels or 0, norm_eps, float(timestep_scale_multiplier),
+                           nv.MODEL_AUDIO_VIDEO if self.is_av else nv.MODEL_VIDEO_ONLY, self.audio_heads, self.AUDIO_HEAD_DIM,
+                           self.AUDIO_IN_CHANNELS, self.AUDIO_OUT_CHANNELS, int(cross_attention_adaln),
+                           int(apply_gated_attention), float(av_ca_timestep_scale_multiplier))
         h = C.c_void_p()
         nv.check(nv.lib().ltx2_dit_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self._w: Dict[str, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
-        self._bound: Tuple[int, int, int] = (0, 0, 0)
+        self._bound: Tuple[int, ...] = (0, 0, 0, 0, 0)
         self._prep_key = None
         self._prep_refs = None
 
@@ -135,35 +150,70 @@ class LTXModel:
             pass
 
     # ------------------------------------------------------------------ weights
+    def _attn_specs(self) -> List[Tuple[str, int, int, int, int, bool]]:
+        """(block-relative name, query dim, context dim, inner dim, heads, is_self) per attention module
+        (transformer.py:283-365)."""
+        dv, da, hv, ha = self.inner_dim, self.audio_inner_dim, self.num_attention_heads, self.audio_heads
+        a = [("attn1", dv, dv, dv, hv, True), ("attn2", dv, dv, dv, hv, False)]
+        if self.is_av:
+            a += [("audio_attn1", da, da, da, ha, True), ("audio_attn2", da, da, da, ha, False),
+                  ("audio_to_video_attn", dv, da, da, ha, False), ("video_to_audio_attn", da, dv, da, ha, False)]
+        return a
+
     def expected_weight_shapes(self) -> Dict[str, Tuple[int, ...]]:
         """Checkpoint keys (after stripping 'model.diffusion_model.', reference
         loader/weight_converter.py:277-315) and shapes this model consumes."""
-        d = self.inner_dim
+        dv, da = self.inner_dim, self.audio_inner_dim
+        rows = 9 if self.cross_attention_adaln else 6
         s: Dict[str, Tuple[int, ...]] = {}
 
         def lin(n, o, i):
             s[n + ".weight"] = (o, i)
             s[n + ".bias"] = (o,)
 
-        lin("patchify_proj", d, self.in_channels)
-        lin("adaln_single.emb.timestep_embedder.linear_1", d, 256)
-        lin("adaln_single.emb.timestep_embedder.linear_2", d, d)
-        lin("adaln_single.linear", 6 * d, d)
-        if self.caption_channels:
-            lin("caption_projection.linear_1", d, self.caption_channels)
-            lin("caption_projection.linear_2", d, d)
-        s["scale_shift_table"] = (2, d)
-        lin("proj_out", self.out_channels, d)
+        def adaln(n, d, r):
+            lin(n + ".emb.timestep_embedder.linear_1", d, 256)
+            lin(n + ".emb.timestep_embedder.linear_2", d, d)
+            lin(n + ".linear", r * d, d)
+
+        mods = [("", dv, self.in_channels, self.out_channels)]
+        if self.is_av:
+            mods.append(("audio_", da, self.AUDIO_IN_CHANNELS, self.AUDIO_OUT_CHANNELS))
+        for pre, d, cin, cout in mods:
+            lin(pre + "patchify_proj", d, cin)
+            adaln(pre + "adaln_single", d, rows)
+            if self.cross_attention_adaln:
+                adaln(pre + "prompt_adaln_single", d, 2)
+            if self.caption_channels:
+                lin(pre + "caption_projection.linear_1", d, self.caption_channels)
+                lin(pre + "caption_projection.linear_2", d, d)
+            s[pre + "scale_shift_table"] = (2, d)
+            lin(pre + "proj_out", cout, d)
+        if self.is_av:
+            adaln("av_ca_video_scale_shift_adaln_single", dv, 4)
+            adaln("av_ca_a2v_gate_adaln_single", dv, 1)
+            adaln("av_ca_audio_scale_shift_adaln_single", da, 4)
+            adaln("av_ca_v2a_gate_adaln_single", da, 1)
         for i in range(self.num_layers):
             p = f"transformer_blocks.{i}"
-            for a in ("attn1", "attn2"):
-                for n in ("to_q", "to_k", "to_v", "to_out.0"):
-                    lin(f"{p}.{a}.{n}", d, d)
-                s[f"{p}.{a}.q_norm.weight"] = (d,)
-                s[f"{p}.{a}.k_norm.weight"] = (d,)
-            lin(f"{p}.ff.net.0.proj", 4 * d, d)
-            lin(f"{p}.ff.net.2", d, 4 * d)
-            s[f"{p}.scale_shift_table"] = (6, d)
+            for name, dq, dc, di, heads, _ in self._attn_specs():
+                lin(f"{p}.{name}.to_q", di, dq)
+                lin(f"{p}.{name}.to_k", di, dc)
+                lin(f"{p}.{name}.to_v", di, dc)
+                lin(f"{p}.{name}.to_out.0", dq, di)
+                s[f"{p}.{name}.q_norm.weight"] = (di,)
+                s[f"{p}.{name}.k_norm.weight"] = (di,)
+                if self.apply_gated_attention:
+                    lin(f"{p}.{name}.to_gate_logits", heads, dq)
+            for pre, d, _, _ in mods:
+                lin(f"{p}.{pre}ff.net.0.proj", 4 * d, d)
+                lin(f"{p}.{pre}ff.net.2", d, 4 * d)
+                s[f"{p}.{pre}scale_shift_table"] = (rows, d)
+                if self.cross_attention_adaln:
+                    s[f"{p}.{pre}prompt_scale_shift_table"] = (2, d)
+            if self.is_av:
+                s[f"{p}.scale_shift_table_a2v_ca_audio"] = (5, da)
+                s[f"{p}.scale_shift_table_a2v_ca_video"] = (5, dv)
         return s
 
     def _register(self, name: str, t: torch.Tensor) -> None:
@@ -175,8 +225,9 @@ class LTXModel:
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
         """Consume checkpoint-keyed tensors (any float dtype, any device).  Linear weights stay
         [out, in] (no transposes, weight_converter.py:303-307) and become bf16; biases, norm
-        weights and scale_shift_tables become fp32 (transformer.py:157-159).  q/k/v (attn1) and
-        k/v (attn2) are concatenated at load time for fused projection GEMMs."""
+        weights and scale_shift_tables become fp32 (transformer.py:157-159).  q/k/v of the
+        self-attentions and k/v of the cross-attentions are concatenated at load time for fused
+        projection GEMMs."""
         exp = self.expected_weight_shapes()
         missing = [k for k in exp if k not in sd]
         if missing and strict:
@@ -198,14 +249,14 @@ class LTXModel:
         fused = set()
         for i in range(self.num_layers):
             p = f"transformer_blocks.{i}"
-            self._register(f"{p}.attn1.to_qkv.weight", torch.cat([W(f"{p}.attn1.{n}.weight") for n in ("to_q", "to_k", "to_v")], 0))
-            self._register(f"{p}.attn1.to_qkv.bias", torch.cat([Fv(f"{p}.attn1.{n}.bias") for n in ("to_q", "to_k", "to_v")], 0))
-            self._register(f"{p}.attn2.to_kv.weight", torch.cat([W(f"{p}.attn2.{n}.weight") for n in ("to_k", "to_v")], 0))
-            self._register(f"{p}.attn2.to_kv.bias", torch.cat([Fv(f"{p}.attn2.{n}.bias") for n in ("to_k", "to_v")], 0))
-            for n in ("to_q", "to_k", "to_v"):
-                fused.add(f"{p}.attn1.{n}")
-            for n in ("to_k", "to_v"):
-                fused.add(f"{p}.attn2.{n}")
+            for name, _, _, _, _, is_self in self._attn_specs():
+                parts = ("to_q", "to_k", "to_v") if is_self else ("to_k", "to_v")
+                dst = "to_qkv" if is_self else "to_kv"
+                if any(f"{p}.{name}.{n}.weight" not in sd for n in parts):
+                    continue
+                self._register(f"{p}.{name}.{dst}.weight", torch.cat([W(f"{p}.{name}.{n}.weight") for n in parts], 0))
+                self._register(f"{p}.{name}.{dst}.bias", torch.cat([Fv(f"{p}.{name}.{n}.bias") for n in parts], 0))
+                fused.update(f"{p}.{name}.{n}" for n in parts)
         for k in exp:
             if k not in sd or k.rsplit(".", 1)[0] in fused:
                 continue
@@ -214,10 +265,9 @@ class LTXModel:
         self._prep_key = None
 
     def init_random_weights(self, seed: int = 0, std: float = 0.02) -> None:
-        """Synthetic N(0, std) weights generated directly in HBM (bench / smoke; no checkpoints exist
-        in this environment).  Uses the engine's fused layout directly."""
+        """Synthetic N(0, std) weights generated directly in HBM in the engine's fused layout (bench /
+        smoke; no checkpoints exist in this environment)."""
         g = torch.Generator(device=self.device).manual_seed(seed)
-        d = self.inner_dim
 
         def rw(*shape):
             return (torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32) * std).to(BF16)
@@ -225,32 +275,28 @@ class LTXModel:
         def rf(*shape, scale=std, base=0.0):
             return base + scale * torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32)
 
-        def lin(name, o, i):
-            self._register(name + ".weight", rw(o, i))
-            self._register(name + ".bias", rf(o))
-
-        lin("patchify_proj", d, self.in_channels)
-        lin("adaln_single.emb.timestep_embedder.linear_1", d, 256)
-        lin("adaln_single.emb.timestep_embedder.linear_2", d, d)
-        lin("adaln_single.linear", 6 * d, d)
-        if self.caption_channels:
-            lin("caption_projection.linear_1", d, self.caption_channels)
-            lin("caption_projection.linear_2", d, d)
-        self._register("scale_shift_table", rf(2, d))
-        lin("proj_out", self.out_channels, d)
-        for i in range(self.num_layers):
-            p = f"transformer_blocks.{i}"
-            lin(f"{p}.attn1.to_qkv", 3 * d, d)
-            lin(f"{p}.attn1.to_out.0", d, d)
-            lin(f"{p}.attn2.to_q", d, d)
-            lin(f"{p}.attn2.to_kv", 2 * d, d)
-            lin(f"{p}.attn2.to_out.0", d, d)
-            for a in ("attn1", "attn2"):
-                self._register(f"{p}.{a}.q_norm.weight", rf(d, scale=0.0, base=1.0))
-                self._register(f"{p}.{a}.k_norm.weight", rf(d, scale=0.0, base=1.0))
-            lin(f"{p}.ff.net.0.proj", 4 * d, d)
-            lin(f"{p}.ff.net.2", d, 4 * d)
-            self._register(f"{p}.scale_shift_table", rf(6, d))
+        fuse = {}
+        for name, _, _, _, _, is_self in self._attn_specs():
+            fuse[name] = ("to_q", "to_k", "to_v") if is_self else ("to_k", "to_v")
+        done = set()
+        exp = self.expected_weight_shapes()
+        for k, shp in exp.items():
+            mod, leaf = k.rsplit(".", 1) if "." in k else ("", k)
+            parent, last = mod.rsplit(".", 1) if "." in mod else ("", mod)
+            attn = parent.rsplit(".", 1)[-1]
+            if attn in fuse and last in fuse[attn]:
+                dst = f"{parent}.{'to_qkv' if len(fuse[attn]) == 3 else 'to_kv'}.{leaf}"
+                if dst in done:
+                    continue
+                done.add(dst)
+                rows = sum(exp[f"{parent}.{n}.{leaf}"][0] for n in fuse[attn])
+                self._register(dst, rw(rows, shp[1]) if leaf == "weight" else rf(rows))
+            elif k.endswith("_norm.weight"):
+                self._register(k, rf(*shp, scale=0.0, base=1.0))
+            elif leaf == "weight" and len(shp) == 2:
+                self._register(k, rw(*shp))
+            else:
+                self._register(k, rf(*shp))
         self._prep_key = None
 
     def weight_tensors(self) -> Dict[str, torch.Tensor]:
@@ -258,50 +304,77 @@ class LTXModel:
         return self._w
 
     # ------------------------------------------------------------------ workspace / prepare
-    def _bind(self, n: int, s: int, per_token: bool) -> None:
-        want = (n, s, int(per_token))
-        if self._bound[:2] == want[:2] and self._bound[2] >= want[2] and self._ws is not None:
+    def _bind(self, n: int, s: int, per_token: bool, na: int = 0, sa: int = 0) -> None:
+        want = (n, s, na, sa, int(per_token))
+        if self._bound[:4] == want[:4] and self._bound[4] >= want[4] and self._ws is not None:
             return
-        nbytes = nv.lib().ltx2_dit_workspace_bytes(self._h, n, s, int(per_token))
+        L = nv.lib()
+        nbytes = (L.ltx2_dit_workspace_bytes_av(self._h, n, s, na, sa, int(per_token)) if self.is_av else
+                  L.ltx2_dit_workspace_bytes(self._h, n, s, int(per_token)))
         if nbytes <= 0:
-            raise ValueError(f"bad workspace request N={n} S={s}")
+            raise ValueError(f"bad workspace request N={n} S={s} Na={na} Sa={sa}")
         self._ws = None
         self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         base = (self._ws.data_ptr() + 255) // 256 * 256
-        nv.check(nv.lib().ltx2_dit_bind_workspace(self._h, base, nbytes, n, s, int(per_token)))
+        if self.is_av:
+            nv.check(L.ltx2_dit_bind_workspace_av(self._h, base, nbytes, n, s, na, sa, int(per_token)))
+        else:
+            nv.check(L.ltx2_dit_bind_workspace(self._h, base, nbytes, n, s, int(per_token)))
         self._bound = want
         self._prep_key = None
 
-    def prepare(self, context: torch.Tensor, positions: torch.Tensor, per_token: bool = False) -> None:
-        """Per-prompt setup: bind workspace, upload RoPE tables, run caption projection and the
-        48 cross-attention K/V projections (ltx2_dit_prepare)."""
+    def prepare(self, context: torch.Tensor, positions: torch.Tensor, per_token: bool = False,
+                audio_context: Optional[torch.Tensor] = None, audio_positions: Optional[torch.Tensor] = None) -> None:
+        """Per-prompt setup: bind workspace, upload RoPE tables (self-attention and, for AudioVideo,
+        the temporal cross-modal tables of model.py:320-344), run caption projection and the per-layer
+        text cross-attention K/V projections (ltx2_dit_prepare / ltx2_dit_prepare_av)."""
         if context.shape[0] != 1 or positions.shape[0] != 1:
             raise ValueError("batch must be 1 (the reference hard-wires batch=1: pipelines/distilled.py:314)")
         n, s = positions.shape[2], context.shape[1]
-        self._bind(n, s, per_token)
-        cos, sin = rope_tables_token_major(positions, self.inner_dim, self.num_attention_heads,
-                                           self.positional_embedding_theta, self.positional_embedding_max_pos)
-        cos, sin = cos.to(self.device), sin.to(self.device)
-        ctx = context[0].to(self.device, torch.float32).contiguous()
-        nv.check(nv.lib().ltx2_dit_prepare(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.stream()))
-        self._prep_key = self._key(context, positions)
-        self._prep_refs = (context, positions, cos, sin, ctx)     # keep pointers alive / unaliased
+        dev = self.device
+        theta = self.positional_embedding_theta
+        cos, sin = (t.to(dev) for t in rope_tables_token_major(positions, self.inner_dim, self.num_attention_heads, theta,
+                                                               self.positional_embedding_max_pos))
+        ctx = context[0].to(dev, torch.float32).contiguous()
+        if not self.is_av:
+            self._bind(n, s, per_token)
+            nv.check(nv.lib().ltx2_dit_prepare(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.stream()))
+            self._prep_refs = (context, positions, cos, sin, ctx)     # keep pointers alive / unaliased
+        else:
+            if audio_context is None or audio_positions is None:
+                raise ValueError("AudioVideo model: audio context and positions are required")
+            na, sa = audio_positions.shape[2], audio_context.shape[1]
+            self._bind(n, s, per_token, na, sa)
+            mp = [self.AUDIO_CROSS_PE_MAX_POS]
+            da, ha = self.audio_inner_dim, self.audio_heads
+            acos, asin = (t.to(dev) for t in rope_tables_token_major(audio_positions, da, ha, theta, mp))
+            vcc, vcs = (t.to(dev) for t in rope_tables_token_major(positions[:, 0:1], da, self.num_attention_heads, theta, mp))
+            acc, acs = (t.to(dev) for t in rope_tables_token_major(audio_positions[:, 0:1], da, ha, theta, mp))
+            actx = audio_context[0].to(dev, torch.float32).contiguous()
+            nv.check(nv.lib().ltx2_dit_prepare_av(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.ptr(vcc), nv.ptr(vcs),
+                                                  nv.ptr(actx), sa, nv.ptr(acos), nv.ptr(asin), nv.ptr(acc), nv.ptr(acs),
+                                                  nv.stream()))
+            self._prep_refs = (context, positions, audio_context, audio_positions, cos, sin, ctx, acos, asin, vcc, vcs, acc, acs, actx)
+        self._prep_key = self._key(context, positions, audio_context, audio_positions)
 
     @staticmethod
-    def _key(context: torch.Tensor, positions: torch.Tensor):
-        return (context.data_ptr(), context._version, tuple(context.shape), context.dtype,
-                positions.data_ptr(), positions._version, tuple(positions.shape))
+    def _key(context, positions, audio_context=None, audio_positions=None):
+        def one(t):
+            return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+        return (one(context), one(positions), one(audio_context), one(audio_positions))
 
-    def _ensure_prepared(self, video: Modality, per_token: bool) -> None:
-        if self._prep_key != self._key(video.context, video.positions) or (per_token and not self._bound[2]):
-            self.prepare(video.context, video.positions, per_token=per_token)
+    def _ensure_prepared(self, video: Modality, per_token: bool, audio: Optional[Modality] = None) -> None:
+        key = self._key(video.context, video.positions, audio.context if audio else None, audio.positions if audio else None)
+        if self._prep_key != key or (per_token and not self._bound[4]):
+            self.prepare(video.context, video.positions, per_token=per_token,
+                         audio_context=audio.context if audio else None, audio_positions=audio.positions if audio else None)
 
     # ------------------------------------------------------------------ forward
-    def _timesteps(self, video: Modality) -> Tuple[torch.Tensor, int]:
+    def _timesteps(self, m: Modality) -> Tuple[torch.Tensor, int]:
         """-> (fp32 device vector, n_timesteps in {1, N}).  Per-token timesteps that are all equal
         take the broadcast path (identical arithmetic, N x fewer AdaLN MLP rows)."""
-        ts = video.timesteps.to(self.device, torch.float32).reshape(-1).contiguous()
-        n = video.latent.shape[1]
+        ts = m.timesteps.to(self.device, torch.float32).reshape(-1).contiguous()
+        n = m.latent.shape[1]
         if ts.numel() == 1:
             return ts, 1
         if ts.numel() != n:
@@ -311,43 +384,79 @@ class LTXModel:
             return ts[:1].contiguous(), 1
         return ts, n
 
-    def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None, perturbations=None) -> torch.Tensor:
+    def _sigma(self, m: Modality) -> torch.Tensor:
+        """Modality.sigma, or the first timestep when absent (model.py:154-156,393-395)."""
+        s = m.sigma if m.sigma is not None else m.timesteps
+        return s.to(self.device, torch.float32).reshape(-1)[:1].contiguous()
+
+    def _check_inputs(self, video, audio, perturbations):
         if video is None:
             raise ValueError("Video modality required for video-enabled model")     # model.py:823-824
-        if audio is not None:
-            raise NotImplementedError("audio modality: AudioVideo model is the next scope row")
         if perturbations is not None:
             raise NotImplementedError("STG perturbations are outside the distilled hot path (cfg forced to 1)")
-        if video.context_mask is not None:
-            raise NotImplementedError("context_mask is None on every live reference path (pipelines/common.py:223-232)")
-        if video.latent.shape[0] != 1:
-            raise ValueError("batch must be 1")
+        for m in (video, audio):
+            if m is not None and m.context_mask is not None:
+                raise NotImplementedError("context_mask is None on every live reference path (pipelines/common.py:223-232)")
+            if m is not None and m.latent.shape[0] != 1:
+                raise ValueError("batch must be 1")
+        if self.is_av and audio is None:
+            raise NotImplementedError("video-only inference on an AudioVideo model: build a VideoOnly LTXModel from the same weights")
+        if not self.is_av and audio is not None:
+            raise ValueError("audio modality passed to a VideoOnly model")
+
+    def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None, perturbations=None):
+        self._check_inputs(video, audio, perturbations)
         ts, n_ts = self._timesteps(video)
-        self._ensure_prepared(video, per_token=(n_ts != 1))
         lat = video.latent[0].to(self.device, torch.float32).contiguous()
         out = torch.empty(lat.shape[0], self.out_channels, device=self.device, dtype=torch.float32)
-        nv.check(nv.lib().ltx2_dit_forward(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(out), nv.stream()))
-        return out[None]
+        if not self.is_av:
+            self._ensure_prepared(video, per_token=(n_ts != 1))
+            nv.check(nv.lib().ltx2_dit_forward(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(out), nv.stream()))
+            return out[None]
+        ats, n_ats = self._timesteps(audio)
+        self._ensure_prepared(video, per_token=(n_ts != 1 or n_ats != 1), audio=audio)
+        alat = audio.latent[0].to(self.device, torch.float32).contiguous()
+        aout = torch.empty(alat.shape[0], self.AUDIO_OUT_CHANNELS, device=self.device, dtype=torch.float32)
+        vs, as_ = self._sigma(video), self._sigma(audio)
+        nv.check(nv.lib().ltx2_dit_forward_av(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(vs), nv.ptr(alat), nv.ptr(ats), n_ats,
+                                              nv.ptr(as_), nv.ptr(out), nv.ptr(aout), nv.stream()))
+        return out[None], aout[None]
 
     # ------------------------------------------------------------------ fused sampling step / graph
     def denoise_step_(self, latent: torch.Tensor, video: Modality, sigma: float, sigma_next: float,
-                      denoise_mask: Optional[torch.Tensor] = None, clean_latent: Optional[torch.Tensor] = None) -> None:
+                      denoise_mask: Optional[torch.Tensor] = None, clean_latent: Optional[torch.Tensor] = None,
+                      audio_latent: Optional[torch.Tensor] = None, audio: Optional[Modality] = None,
+                      audio_denoise_mask: Optional[torch.Tensor] = None, audio_clean_latent: Optional[torch.Tensor] = None) -> None:
         """In-place: latent (N, C) fp32 <- Euler(latent, post_process(x0)) -- forward + x0 + blend + step
-        enqueued by ONE C call (ltx2_dit_denoise_step)."""
+        enqueued by ONE C call (ltx2_dit_denoise_step / _av; the AudioVideo form updates both latents)."""
         ts, n_ts = self._timesteps(video)
-        self._ensure_prepared(video, per_token=(n_ts != 1))
         assert latent.dtype == torch.float32 and latent.is_contiguous() and latent.dim() == 2
-        nv.check(nv.lib().ltx2_dit_denoise_step(self._h, nv.ptr(latent), nv.ptr(ts), n_ts, nv.ptr(denoise_mask),
-                                                nv.ptr(clean_latent), float(sigma), float(sigma_next), None, nv.stream()))
+        if not self.is_av:
+            self._ensure_prepared(video, per_token=(n_ts != 1))
+            nv.check(nv.lib().ltx2_dit_denoise_step(self._h, nv.ptr(latent), nv.ptr(ts), n_ts, nv.ptr(denoise_mask),
+                                                    nv.ptr(clean_latent), float(sigma), float(sigma_next), None, nv.stream()))
+            return
+        assert audio is not None and audio_latent is not None and audio_latent.dtype == torch.float32 and audio_latent.is_contiguous()
+        ats, n_ats = self._timesteps(audio)
+        self._ensure_prepared(video, per_token=(n_ts != 1 or n_ats != 1), audio=audio)
+        sg = torch.tensor([float(sigma)], device=self.device, dtype=torch.float32)
+        nv.check(nv.lib().ltx2_dit_denoise_step_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), nv.ptr(ts), n_ts, nv.ptr(ats), n_ats,
+                                                   nv.ptr(sg), nv.ptr(denoise_mask), nv.ptr(clean_latent), nv.ptr(audio_denoise_mask),
+                                                   nv.ptr(audio_clean_latent), float(sigma), float(sigma_next), None, None, nv.stream()))
 
-    def capture_denoise_graph(self, latent: torch.Tensor, sigmas: Sequence[float]) -> None:
-        """hipGraph-capture len(sigmas)-1 steps over `latent` (N, C fp32, updated in place on replay)."""
+    def capture_denoise_graph(self, latent: torch.Tensor, sigmas: Sequence[float], audio_latent: Optional[torch.Tensor] = None) -> None:
+        """hipGraph-capture len(sigmas)-1 steps over `latent` (N, C fp32; plus the audio latent for
+        AudioVideo models), updated in place on replay."""
         assert self._prep_key is not None, "call prepare() first"
         arr = (C.c_float * len(sigmas))(*[float(s) for s in sigmas])
         st = torch.cuda.current_stream()
         if st.cuda_stream == 0:
             raise RuntimeError("graph capture needs a non-default stream: use `with torch.cuda.stream(torch.cuda.Stream()):`")
-        nv.check(nv.lib().ltx2_dit_graph_capture(self._h, nv.ptr(latent), arr, len(sigmas) - 1, st.cuda_stream))
+        if self.is_av:
+            assert audio_latent is not None
+            nv.check(nv.lib().ltx2_dit_graph_capture_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), arr, len(sigmas) - 1, st.cuda_stream))
+        else:
+            nv.check(nv.lib().ltx2_dit_graph_capture(self._h, nv.ptr(latent), arr, len(sigmas) - 1, st.cuda_stream))
 
     def replay_denoise_graph(self) -> None:
         nv.check(nv.lib().ltx2_dit_graph_launch(self._h, nv.stream()))
@@ -365,16 +474,22 @@ class LTXModel:
 
 
 class X0Model:
-    """x0 = latent - timesteps * velocity (reference model.py:884-936)."""
+    """x0 = latent - timesteps * velocity per modality (reference model.py:884-936)."""
 
     def __init__(self, velocity_model: LTXModel):
         self.velocity_model = velocity_model
 
-    def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None, perturbations=None) -> torch.Tensor:
-        v = self.velocity_model(video, audio, perturbations=perturbations)
-        lat = video.latent[0].to(v.device, torch.float32).contiguous()
-        ts = video.timesteps.to(v.device, torch.float32).reshape(-1)
+    @staticmethod
+    def _denoise(m: Modality, v: torch.Tensor) -> torch.Tensor:
+        lat = m.latent[0].to(v.device, torch.float32).contiguous()
+        ts = m.timesteps.to(v.device, torch.float32).reshape(-1)
         return K.x0_from_velocity(lat, v[0], ts)[None]
+
+    def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None, perturbations=None):
+        out = self.velocity_model(video, audio, perturbations=perturbations)
+        if isinstance(out, tuple):
+            return self._denoise(video, out[0]), self._denoise(audio, out[1])
+        return self._denoise(video, out)
 
 
 # aliases kept by the reference for backward compatibility (model.py:939-941)

@@ -150,6 +150,23 @@ def test_flash_attn(K, dev, heads, Nq, Nkv):
     assert rel_l2(out.float().cpu(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("heads,Nq,Nkv", [(2, 130, 37), (4, 37, 700), (32, 68, 68), (1, 256, 64)])
+def test_flash_attn_head_dim_64(K, dev, heads, Nq, Nkv):
+    """Audio-stream / audio<->video attention geometry: head_dim 64, ragged and tiny token counts."""
+    from oracle import dit
+    D = heads * 64
+    g = torch.Generator().manual_seed(Nq * 7 + Nkv)
+    qq = q(torch.randn(Nq, D, generator=g))
+    kk = q(torch.randn(Nkv, D, generator=g))
+    vv = q(torch.randn(Nkv, D, generator=g))
+    ref = dit.sdpa(qq[None], kk[None], vv[None], heads)[0]
+    vt = K.vt_transpose(vv.to(dev, BF), heads, head_dim=64)
+    assert vt.shape == (heads, 64, (Nkv + 63) // 64 * 64)
+    out = K.flash_attn(qq.to(dev, BF), kk.to(dev, BF), vt, heads, Nkv)
+    assert out.shape == (Nq, D)
+    assert rel_l2(out.float().cpu(), ref) < 1e-2
+
+
 def test_flash_attn_forced_rescale(K, dev):
     """Spike one key against one query at a late tile so the running max jumps mid-stream."""
     from oracle import dit

@@ -217,3 +217,96 @@ def test_distilled_pipeline_api(dev):
     d.generator = torch.Generator(device=dev).manual_seed(0)
     frames = pipe2(ctx.to(dev), None, conf, initial_noise=noise.to(dev))
     assert frames.shape == (17, 128, 192, 3) and frames.dtype == torch.uint8
+
+
+# ------------------------------------------------------------------------------------------ AudioVideo DiT
+def make_av(dev, v23, layers=2, heads=4, seed=17):
+    from oracle import dit_av
+    from ltx_2_mlx_amd.model.transformer import LTXModel, LTXModelType
+    cfg = dit_av.AVConfig(num_attention_heads=heads, attention_head_dim=128, audio_heads=heads, audio_head_dim=64,
+                          num_layers=layers, caption_channels=None if v23 else 64, cross_attention_adaln=v23,
+                          apply_gated_attention=v23)
+    w = dit_av.make_av_weights(cfg, seed=seed)
+    wq = {k: (v.to(torch.bfloat16).float() if (k.endswith(".weight") and v.dim() == 2) else v) for k, v in w.items()}
+    m = LTXModel(model_type=LTXModelType.AudioVideo, num_attention_heads=heads, attention_head_dim=128, num_layers=layers,
+                 caption_channels=cfg.caption_channels, cross_attention_adaln=v23, apply_gated_attention=v23,
+                 audio_attention_heads=heads, device=dev)
+    m.load_state_dict(w)
+    return cfg, w, wq, m
+
+
+def to_modality(d, dev):
+    from ltx_2_mlx_amd.model.transformer import Modality
+    return Modality(latent=d["latent"].to(dev), context=d["context"].to(dev), context_mask=None,
+                    timesteps=d["timesteps"].to(dev), positions=d["positions"].to(dev), sigma=d["sigma"].to(dev))
+
+
+@pytest.mark.parametrize("v23", [False, True])
+def test_av_dit_against_oracle_and_reference_vectors(dev, v23):
+    """AudioVideo X0Model (tiny 2-layer, 4+4 heads) on the GPU vs the fp32 oracle AND vs the vectors
+    recorded from the reference's own LTXModel (tests/golden/dit_av_tiny.npz), scalar and per-token."""
+    import numpy as np
+    import os
+    from oracle import dit_av
+    from test_oracle_golden import av_tiny_case
+    from ltx_2_mlx_amd.model.transformer import X0Model
+    cfg, w, cases = av_tiny_case(v23)
+    _, _, wq, m = make_av(dev, v23, seed=17 + v23)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_av_tiny.npz"))
+    tag = "v23" if v23 else "v1"
+    for tsk, (video, audio) in cases.items():
+        vx0, ax0 = X0Model(m)(to_modality(video, dev), to_modality(audio, dev))
+        rv, ra = dit_av.av_x0_model(video, audio, wq, cfg)
+        assert rel_l2(vx0.cpu(), rv) < 2e-2 and pearson(vx0.cpu(), rv) > 0.999, tsk
+        assert rel_l2(ax0.cpu(), ra) < 2e-2 and pearson(ax0.cpu(), ra) > 0.999, tsk
+        assert rel_l2(vx0.cpu(), torch.from_numpy(z[f"{tag}_{tsk}_video_x0"])) < 3e-2
+        assert rel_l2(ax0.cpu(), torch.from_numpy(z[f"{tag}_{tsk}_audio_x0"])) < 3e-2
+        vv, av = m(to_modality(video, dev), to_modality(audio, dev))
+        ov, oa = dit_av.av_velocity_model(video, audio, wq, cfg)
+        assert rel_l2(vv.cpu(), ov) < 3e-2 and rel_l2(av.cpu(), oa) < 3e-2
+
+
+@pytest.mark.parametrize("v23", [False, True])
+def test_av_denoise_loop_and_graph(dev, v23):
+    """Joint audio+video distilled loop (pipelines/distilled.py:198-271): fused steps, hipGraph replay and
+    the oracle loop agree; ragged token counts (N=70, Na=37, S=50)."""
+    from oracle import dit_av, loop
+    from ltx_2_mlx_amd.model.transformer import Modality
+    cfg, w, wq, m = make_av(dev, v23, seed=5)
+    g = torch.Generator().manual_seed(3)
+    f, h, wd, Ta, S = 2, 5, 7, 37, 50
+    vlat = torch.randn(1, f * h * wd, 128, generator=g)
+    alat = torch.randn(1, Ta, 128, generator=g)
+    cdim_v = cfg.caption_channels or cfg.inner_dim
+    cdim_a = cfg.caption_channels or cfg.audio_inner_dim
+    vctx = 0.1 * torch.randn(1, S, cdim_v, generator=g)
+    actx = 0.1 * torch.randn(1, S, cdim_a, generator=g)
+    vpos, apos = loop.video_positions(1, f, h, wd, 24.0), dit_av.audio_positions(1, Ta)
+    sigmas = loop.DISTILLED_SIGMA_VALUES[4:]
+    # oracle loop
+    rv, ra = vlat.clone(), alat.clone()
+    for i in range(len(sigmas) - 1):
+        s = torch.tensor([sigmas[i]])
+        vx0, ax0 = dit_av.av_x0_model(dict(latent=rv, context=vctx, timesteps=s, sigma=s, positions=vpos),
+                                      dict(latent=ra, context=actx, timesteps=s, sigma=s, positions=apos), wq, cfg)
+        rv, ra = loop.euler_step(rv, vx0, sigmas[i], sigmas[i + 1]), loop.euler_step(ra, ax0, sigmas[i], sigmas[i + 1])
+    # fused eager steps
+    lv, la = vlat[0].to(dev).contiguous(), alat[0].to(dev).contiguous()
+    vc, ac, vp, ap = vctx.to(dev), actx.to(dev), vpos.to(dev), apos.to(dev)
+    for i in range(len(sigmas) - 1):
+        s = torch.tensor([sigmas[i]], device=dev)
+        mv = Modality(latent=lv[None], context=vc, context_mask=None, timesteps=s, positions=vp, sigma=s)
+        ma = Modality(latent=la[None], context=ac, context_mask=None, timesteps=s, positions=ap, sigma=s)
+        m.denoise_step_(lv, mv, sigmas[i], sigmas[i + 1], audio_latent=la, audio=ma)
+    assert rel_l2(lv.cpu(), rv[0]) < 3e-2 and rel_l2(la.cpu(), ra[0]) < 3e-2
+    # hipGraph replay
+    gv, ga = vlat[0].to(dev).contiguous(), alat[0].to(dev).contiguous()
+    m.prepare(vc, vp, audio_context=ac, audio_positions=ap)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.capture_denoise_graph(gv, sigmas, audio_latent=ga)
+        m.replay_denoise_graph()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert rel_l2(gv, lv) < 1e-5 and rel_l2(ga, la) < 1e-5
