@@ -102,6 +102,11 @@ int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, in
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
                     int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream);
 
+/* Per-head attention gates (V2.3, attention.py:241-249): logits[rows][H] (fp32 scratch, also returned)
+ * = x[rows][Dq] @ gate_w[H][Dq]^T + gate_b ; att[:, h*hd:(h+1)*hd] *= 2*sigmoid(logits[:, h]).  H <= 32. */
+int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const void* gate_w, const float* gate_b,
+                        float* logits, int rows, int Dq, int H, int head_dim, void* stream);
+
 /* [cos | sin] sinusoid, dim 256 (timestep_embedding.py:10-60 with flip_sin_to_cos, shift 0;
  * simple_decoder.py:12-39).  Either output may be NULL.                                       */
 int ltx2_timestep_sinusoid(const float* t, int64_t t_stride, float mult, int T, int dim, float* out_f32,

@@ -73,6 +73,14 @@ int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, in
     return vt_transpose_launch((const bf16*)V, ld, (bf16*)VT, Nkv, Npad, H, (hipStream_t)stream, head_dim);
 }
 
+int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const void* gate_w, const float* gate_b,
+                        float* logits, int rows, int Dq, int H, int head_dim, void* stream) {
+    LTX2_CHECK_ARG(att && x && gate_w && gate_b && logits, "attn_head_gate: null operand");
+    int rc = gate_logits_launch((const bf16*)x, ldx, (const bf16*)gate_w, gate_b, logits, H, rows, Dq, H, (hipStream_t)stream);
+    if (rc != LTX2_OK) return rc;
+    return head_gate_launch((bf16*)att, ld, logits, H, rows, H, head_dim, (hipStream_t)stream);
+}
+
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
                     int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream) {
     LTX2_CHECK_ARG(Q && K && VT && out, "flash_attn: null operand");

@@ -96,6 +96,11 @@ struct ltx2_dit {
     bool prepared = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // AudioVideo: the audio modality's (small, latency-bound) kernels run on a side stream beside the video
+    // GEMMs, whose 224-tile grids leave CUs idle; fork/join by events (captured as parallel graph branches).
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> sync_ev;
+    size_t sync_next = 0;
     // live HIP-event profiling of one GEMM kernel instantiation (bench.py roofline)
     int prof_epi = -2;                 // -2 off, -1 every GEMM, >= 0 one epilogue
     std::vector<hipEvent_t> prof_ev;
@@ -365,11 +370,36 @@ int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int
     return attn_launch(a, st);
 }
 
+// One event per fork/join edge of a forward (or of a whole captured loop): the pool grows on demand and
+// is rewound at the start of every eager call / capture, so no event is re-recorded inside a capture.
+hipEvent_t next_event(ltx2_dit* c) {
+    if (c->sync_next == c->sync_ev.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        c->sync_ev.push_back(e);
+    }
+    return c->sync_ev[c->sync_next++];
+}
+
+// `to` continues after everything enqueued on `from` so far
+int stream_after(ltx2_dit* c, hipStream_t from, hipStream_t to) {
+    if (from == to) return LTX2_OK;
+    hipEvent_t e = next_event(c);
+    if (!e || hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
+        ltx2_set_error("dit: stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
+        return LTX2_E_HIP;
+    }
+    return LTX2_OK;
+}
+
 // Per-head gates (attention.py:241-249): att[:, h*hd:(h+1)*hd] *= 2*sigmoid(x @ Wg^T + bg)[:, h]
-int gate_heads(ltx2_dit* c, Mod& m, const AttnW& w, const bf16* xin, int Dq, bf16* att, int rows, int H, int hd,
-               hipStream_t st) {
+int gate_logits(ltx2_dit* c, Mod& m, const AttnW& w, const bf16* xin, int Dq, int rows, int H, hipStream_t st) {
     if (!c->gated) return LTX2_OK;
-    TRY(dense(xin, Dq, w.g_w, w.g_b, m.glog, H, rows, H, Dq, EPI_F32, st));
+    return gate_logits_launch(xin, Dq, w.g_w, w.g_b, m.glog, H, rows, Dq, H, st);
+}
+
+int gate_apply(ltx2_dit* c, Mod& m, bf16* att, int rows, int H, int hd, hipStream_t st) {
+    if (!c->gated) return LTX2_OK;
     return head_gate_launch(att, (long)H * hd, m.glog, H, rows, H, hd, st);
 }
 
@@ -392,6 +422,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     const float* emb = m.emb;
     // self-attention: AdaLN rows (shift, scale, gate) = sst[0:3] + emb[0:3]
     TRY(norm_mod_launch(m.x, D, m.h, D, N, D, eps, 0, w.sst + D, w.sst, emb + D, emb, es, st));
+    TRY(gate_logits(c, m, w.self, m.h, D, N, H, st));
     TRY(dense(m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st));
     {
         const int offs[2] = {0, D};
@@ -400,7 +431,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     }
     TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
     TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st));
-    TRY(gate_heads(c, m, w.self, m.h, D, m.att, N, H, hd, st));
+    TRY(gate_apply(c, m, m.att, N, H, hd, st));
     TRY(dense(m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 2 * D, es, w.sst + 2 * D));
 
     // text cross-attention: no RoPE, no mask.  V1: plain RMSNorm on x, K/V cached per prompt.
@@ -419,6 +450,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
         kk = m.kv2 + (long)l * m.S * 2 * D;
         vt = m.vt2 + (long)l * D * m.Spad;
     }
+    TRY(gate_logits(c, m, w.text, m.h, D, N, H, st));
     TRY(dense(m.h, D, w.text.q_w, w.text.q_b, m.qkv, D, N, D, D, EPI_BF16, st));
     {
         const int offs[1] = {0};
@@ -426,7 +458,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
         TRY(qknorm_rope_launch(m.qkv, D, N, D, hd, 1, offs, wts, eps, nullptr, nullptr, st));
     }
     TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st));
-    TRY(gate_heads(c, m, w.text, m.h, D, m.att, N, H, hd, st));
+    TRY(gate_apply(c, m, m.att, N, H, hd, st));
     if (c->v2)
         TRY(dense(m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 8 * D, es, w.sst + 8 * D));
     else
@@ -461,6 +493,7 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st) {
     TRY(norm_mod_launch(a.x, Da, a.h2, Da, a.N, Da, eps, 0, ta + 2 * Da, ta + 3 * Da, a.cross_ss + 2 * Da, a.cross_ss + 3 * Da, 0, st));  // v2a query side
     const int offs[1] = {0};
     // audio -> video: Q from video (Dv -> Da), K/V from audio
+    TRY(gate_logits(c, v, w.a2v, v.h, Dv, v.N, H, st));
     TRY(dense(v.h, Dv, w.a2v.q_w, w.a2v.q_b, v.qkv, Da, v.N, Da, Dv, EPI_BF16, st));
     {
         const float* wts[1] = {w.a2v.qn};
@@ -468,9 +501,10 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st) {
     }
     TRY(project_kv(a.h, a.N, Da, w.a2v, Da, H, hd, eps, a.ccos, a.csin, a.qkv, a.vt, a.Npad, st));
     TRY(attend(v.qkv, Da, a.qkv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st));
-    TRY(gate_heads(c, v, w.a2v, v.h, Dv, v.att, v.N, H, hd, st));
+    TRY(gate_apply(c, v, v.att, v.N, H, hd, st));
     TRY(dense(v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, v.cross_gate, 0, tv + 4 * Dv));
     // video -> audio: Q from audio, K/V from video (Dv -> Da)
+    TRY(gate_logits(c, a, w.v2a, a.h2, Da, a.N, H, st));
     TRY(dense(a.h2, Da, w.v2a.q_w, w.v2a.q_b, a.qkv, Da, a.N, Da, Da, EPI_BF16, st));
     {
         const float* wts[1] = {w.v2a.qn};
@@ -478,7 +512,7 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st) {
     }
     TRY(project_kv(v.h2, v.N, Dv, w.v2a, Da, H, hd, eps, v.ccos, v.csin, v.qkv, v.vt, v.Npad, st));
     TRY(attend(a.qkv, Da, v.qkv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, st));
-    TRY(gate_heads(c, a, w.v2a, a.h2, Da, a.att, a.N, H, hd, st));
+    TRY(gate_apply(c, a, a.att, a.N, H, hd, st));
     TRY(dense(a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, st, a.cross_gate, 0, ta + 4 * Da));
     return LTX2_OK;
 }
@@ -491,8 +525,9 @@ struct ModIn {
     float* velocity;
 };
 
-int forward(ltx2_dit* c, const ModIn* in, hipStream_t st) {
+int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = true) {
     const int nm = c->av ? 2 : 1;
+    if (rewind_events) c->sync_next = 0;
     long es[2] = {0, 0}, ee[2] = {0, 0};
     for (int k = 0; k < nm; ++k) {
         Mod& m = c->m[k];
@@ -516,10 +551,22 @@ int forward(ltx2_dit* c, const ModIn* in, hipStream_t st) {
             TRY(adaln_chain(m, w.cross_gate, cs, 0, 1, c->cfg.av_ca_timestep_scale, m.cross_gate, nullptr, st));
         }
     }
+    // the audio modality's block program runs on the side stream, joined around the cross-modal attention
+    hipStream_t sa = (c->av && c->side) ? c->side : st;
     for (int l = 0; l < c->cfg.num_layers; ++l) {
-        for (int k = 0; k < nm; ++k) TRY(block_attention(c, k, l, es[k], st));
-        if (c->av) TRY(block_cross_modal(c, l, st));
-        for (int k = 0; k < nm; ++k) TRY(block_ffn(c, k, l, es[k], st));
+        if (c->av) {
+            TRY(stream_after(c, st, sa));
+            TRY(block_attention(c, 1, l, es[1], sa));
+        }
+        TRY(block_attention(c, 0, l, es[0], st));
+        if (c->av) {
+            TRY(stream_after(c, sa, st));
+            TRY(block_cross_modal(c, l, st));
+            TRY(stream_after(c, st, sa));
+            TRY(block_ffn(c, 1, l, es[1], sa));
+        }
+        TRY(block_ffn(c, 0, l, es[0], st));
+        if (c->av) TRY(stream_after(c, sa, st));
     }
     // output heads (model.py:744-774): LayerNorm(no affine) * (1 + scale) + shift, rows (shift, scale)
     for (int k = 0; k < nm; ++k) {
@@ -538,13 +585,14 @@ struct StepIo {
     float* x0_out;
 };
 
-int denoise_step(ltx2_dit* c, ModIn* in, const StepIo* io, float sigma, float sigma_next, hipStream_t st) {
+int denoise_step(ltx2_dit* c, ModIn* in, const StepIo* io, float sigma, float sigma_next, hipStream_t st,
+                 bool rewind_events = true) {
     const int nm = c->av ? 2 : 1;
     for (int k = 0; k < nm; ++k) {
         in[k].latent = io[k].latent;
         in[k].velocity = c->m[k].vel;
     }
-    TRY(forward(c, in, st));
+    TRY(forward(c, in, st, rewind_events));
     for (int k = 0; k < nm; ++k) {
         Mod& m = c->m[k];
         float* x0 = io[k].x0_out ? io[k].x0_out : m.x0;
@@ -696,12 +744,21 @@ int ltx2_dit_create(const ltx2_dit_config* cfg, ltx2_dit** out) {
         a.Cin = cfg->audio_in_channels;
         a.Cout = cfg->audio_out_channels;
     }
+    if (c->av) {
+        const bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+        if (!ok) {
+            ltx2_set_error("dit_create: side stream / event creation failed");
+            return LTX2_E_HIP;
+        }
+    }
     *out = c;
     return LTX2_OK;
 }
 
 void ltx2_dit_destroy(ltx2_dit* c) {
     if (!c) return;
+    for (hipEvent_t e : c->sync_ev) (void)hipEventDestroy(e);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->exec) (void)hipGraphExecDestroy(c->exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -825,7 +882,7 @@ int ltx2_dit_graph_capture(ltx2_dit* c, float* latent, const float* host_sigmas,
     for (int i = 0; i < n_steps && rc == LTX2_OK; ++i) {
         ModIn in[1] = {{latent, c->sigmas_dev + i, 1, c->sigmas_dev + i, nullptr}};
         const StepIo io[1] = {{latent, nullptr, nullptr, nullptr}};
-        rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st);
+        rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st, i == 0);
     }
     return end_capture(c, rc, st);
 }
@@ -841,7 +898,7 @@ int ltx2_dit_graph_capture_av(ltx2_dit* c, float* v_latent, float* a_latent, con
         const float* s = c->sigmas_dev + i;
         ModIn in[2] = {{v_latent, s, 1, s, nullptr}, {a_latent, s, 1, s, nullptr}};
         const StepIo io[2] = {{v_latent, nullptr, nullptr, nullptr}, {a_latent, nullptr, nullptr, nullptr}};
-        rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st);
+        rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st, i == 0);
     }
     return end_capture(c, rc, st);
 }

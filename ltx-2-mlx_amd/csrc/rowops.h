@@ -22,6 +22,10 @@ int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int ns
 int ctx_mod_launch(const bf16* ctx, bf16* out, int rows, int D, const float* scale_tab, const float* shift_tab,
                    const float* scale_emb, const float* shift_emb, hipStream_t stream);
 
+// logits_f32[M][H] = X_bf16[M][K] @ Wg_bf16[H][K]^T + bg   (to_gate_logits, H <= 32 heads)
+int gate_logits_launch(const bf16* X, long ldx, const bf16* Wg, const float* bg, float* out, long ldo, int M, int K, int H,
+                       hipStream_t stream);
+
 // att[row][h*hd + j] *= 2 * sigmoid(logits[row*ldl + h])   (per-head attention gates, attention.py:241-249)
 int head_gate_launch(bf16* att, long ld, const float* logits, long ldl, int rows, int H, int hd, hipStream_t stream);
 

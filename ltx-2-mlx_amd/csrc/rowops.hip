@@ -167,6 +167,42 @@ __global__ void ctx_mod_kernel(const bf16* __restrict__ ctx, bf16* __restrict__ 
     }
 }
 
+// Tall-skinny gate-logit GEMM (attention.py:241-243): logits[M][H] = X[M][K] @ Wg[H][K]^T + bg, H <= 32.
+// One block per 16 rows; the 4 waves split K and reduce through LDS.  v_mfma_f32_16x16x32_bf16:
+// A/B lane l holds row/col l&15, k = 8*(l>>4)..+7; D lane l holds rows 4*(l>>4)+r, col l&15.
+__global__ __launch_bounds__(256) void gate_logits_kernel(const bf16* __restrict__ X, long ldx, const bf16* __restrict__ Wg,
+                                                          const float* __restrict__ bg, float* __restrict__ out, long ldo,
+                                                          int M, int K, int H) {
+    __shared__ float part[4][16][33];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int row = min((int)blockIdx.x * 16 + r16, M - 1);
+    const int kw = K / 4;                                   // this wave's K range
+    const bf16* xp = X + (long)row * ldx + wv * kw + kq * 8;
+    const bf16* w0 = Wg + (long)min(r16, H - 1) * K + wv * kw + kq * 8;
+    const bf16* w1 = Wg + (long)min(16 + r16, H - 1) * K + wv * kw + kq * 8;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < kw; k += 32) {
+        const bf16x8 a = *(const bf16x8*)(xp + k);
+        const bf16x8 b0 = *(const bf16x8*)(w0 + k);
+        const bf16x8 b1 = *(const bf16x8*)(w1 + k);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[wv][4 * kq + r][r16] = acc0[r];
+        part[wv][4 * kq + r][16 + r16] = acc1[r];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 32; i += 256) {
+        const int rr = i >> 5, cc = i & 31;
+        const int grow = blockIdx.x * 16 + rr;
+        if (grow < M && cc < H) out[(long)grow * ldo + cc] = part[0][rr][cc] + part[1][rr][cc] + part[2][rr][cc] + part[3][rr][cc] + bg[cc];
+    }
+}
+
 __global__ void head_gate_kernel(bf16* __restrict__ att, long ld, const float* __restrict__ logits, long ldl, long n8,
                                  int per_row8, int hd) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -392,6 +428,14 @@ int ctx_mod_launch(const bf16* ctx, bf16* out, int rows, int D, const float* sca
     const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(ctx_mod_kernel, dim3(grid), dim3(256), 0, stream, ctx, out, n4, D, scale_tab, shift_tab, scale_emb, shift_emb);
     LTX2_CHECK_LAUNCH("ctx_mod_kernel");
+    return LTX2_OK;
+}
+
+int gate_logits_launch(const bf16* X, long ldx, const bf16* Wg, const float* bg, float* out, long ldo, int M, int K, int H,
+                       hipStream_t stream) {
+    LTX2_CHECK_ARG(M > 0 && H > 0 && H <= 32 && K % 128 == 0 && ldx % 8 == 0, "gate_logits: need H <= 32, K %% 128 == 0, ldx %% 8 == 0");
+    hipLaunchKernelGGL(gate_logits_kernel, dim3((M + 15) / 16), dim3(256), 0, stream, X, ldx, Wg, bg, out, ldo, M, K, H);
+    LTX2_CHECK_LAUNCH("gate_logits_kernel");
     return LTX2_OK;
 }
 

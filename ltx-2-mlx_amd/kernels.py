@@ -135,6 +135,16 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n
     return out
 
 
+def attn_head_gate_(att: torch.Tensor, x: torch.Tensor, gate_w: torch.Tensor, gate_b: torch.Tensor, heads: int) -> torch.Tensor:
+    """In place: att [rows, H*hd] bf16 *= 2*sigmoid(x @ gate_w^T + gate_b) per head; returns the fp32 logits."""
+    assert att.dtype == BF16 and x.dtype == BF16 and gate_w.dtype == BF16 and att.is_contiguous() and x.stride(1) == 1
+    rows, hd = att.shape[0], att.shape[1] // heads
+    logits = torch.empty(rows, heads, device=att.device, dtype=torch.float32)
+    nv.check(nv.lib().ltx2_attn_head_gate(nv.ptr(att), att.stride(0), nv.ptr(x), x.stride(0), nv.ptr(_c(gate_w)), nv.ptr(_c(gate_b.float())),
+                                          nv.ptr(logits), rows, x.shape[1], heads, hd, nv.stream()))
+    return logits
+
+
 def timestep_sinusoid(t: torch.Tensor, mult: float, dim: int = 256) -> torch.Tensor:
     t = _c(t.float())
     out = torch.empty(t.numel(), dim, device=t.device, dtype=torch.float32)

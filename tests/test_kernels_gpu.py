@@ -167,6 +167,22 @@ def test_flash_attn_head_dim_64(K, dev, heads, Nq, Nkv):
     assert rel_l2(out.float().cpu(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("rows,Dq,heads,hd", [(3456 // 8, 4096, 32, 128), (68, 2048, 32, 64), (37, 512, 4, 64), (50, 4096, 32, 64)])
+def test_attn_head_gate(K, dev, rows, Dq, heads, hd):
+    """to_gate_logits + 2*sigmoid gating (reference attention.py:241-249)."""
+    g = torch.Generator().manual_seed(rows + Dq)
+    x = q(torch.randn(rows, Dq, generator=g))
+    wg = q(torch.randn(heads, Dq, generator=g) / math.sqrt(Dq))
+    bg = torch.randn(heads, generator=g)
+    att = q(torch.randn(rows, heads * hd, generator=g))
+    logits_ref = x @ wg.t() + bg
+    ref = (att.reshape(rows, heads, hd) * (2 * torch.sigmoid(logits_ref))[..., None]).reshape(rows, -1)
+    a = att.to(dev, BF).contiguous()
+    logits = K.attn_head_gate_(a, x.to(dev, BF), wg.to(dev, BF), bg.to(dev), heads)
+    assert (logits.cpu() - logits_ref).abs().max() < 2e-3
+    assert rel_l2(a.float().cpu(), ref) < 6e-3
+
+
 def test_flash_attn_forced_rescale(K, dev):
     """Spike one key against one query at a late tile so the running max jumps mid-stream."""
     from oracle import dit
