@@ -125,7 +125,7 @@ def main():
     torch.cuda.synchronize()
 
     # ---------------- timed region: exactly K steps, dominant GEMM bracketed by HIP events ----------------
-    DOM_EPI = nv.EPI_RESID_GATE_F32     # gemm_pp_kernel<4,false>: attn1.to_out, attn2.to_out, ff.net.2 (+ gated residual)
+    DOM_EPI = nv.EPI_RESID_GATE_F32     # gemm_pp_kernel<4,false,224>: attn1.to_out, attn2.to_out, ff.net.2 (+ gated residual)
     D.barrier()
     torch.cuda.synchronize()
     model.profile_begin(DOM_EPI)
@@ -206,7 +206,7 @@ def main():
         "step_mfma_roofline_frac": round(alg / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "hipgraph_ms_per_step": graph_ms if not isinstance(graph_ms, float) else round(graph_ms, 3),
         "prompt_setup_ms": round(prep_ms, 1), "weight_broadcast_s": round(bcast_s, 3), "weight_broadcast_collectives": n_coll,
-        "roofline": {"kernel": "gemm_pp_kernel<4,false> (256x256x64 ping-pong bf16 MFMA GEMM, EPI_RESID_GATE_F32: attn1/attn2 to_out and ff.net.2 + bias + gate*residual)",
+        "roofline": {"kernel": "gemm_pp_kernel<4,false,224> (224x256x64 ping-pong bf16 MFMA GEMM, EPI_RESID_GATE_F32: attn1/attn2 to_out and ff.net.2 + bias + gate*residual)",
                      "bound": "mfma", "achieved": round(kern_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                      "launches": k_n, "avg_launch_us": round(kern_avg_ms * 1e3, 2),

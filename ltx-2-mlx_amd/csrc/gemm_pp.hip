@@ -1,4 +1,4 @@
-// 256x256x64 "ping-pong" bf16 MFMA GEMM / implicit-GEMM conv3d for gfx950 (large problems).
+// 256x256x64 (and 224x256x64) "ping-pong" bf16 MFMA GEMM / implicit-GEMM conv3d for gfx950.
 //
 // 8 wave64 (2 row groups x 4 column waves), wave tile 128x64, one workgroup per CU, 128 KiB of
 // LDS (2 K-tile buffers).  The two row groups run the same program staggered by ONE barrier, so
@@ -27,19 +27,24 @@
 // Each L interval ends with lgkmcnt(0) BEFORE its barrier and every slot is refilled at least
 // two intervals after its last read by either group (WAR).  Out-of-range K-tiles in the tail are
 // clamped to the last tile (same slots, dead data), so the wait counts are uniform.
+//
+// BM = 224 variant (tile-quantisation fix): the DiT's M = 3456 tokens are 13.5 tiles of 256 rows,
+// so with N = 4096 a 256-row grid is 224 tiles on 256 CUs (and 3.5 waves for N = 16384); 224-row
+// tiles give 16 x 16 = 256 tiles of 0.875 the work each.  Row group 1 then owns 96 rows (three
+// 32-row blocks b0,b1 in A0 and b2 in A1) and runs 12 + 12 MFMAs per K-tile:
+//        La : as group 0 (A0 = b0,b1 ; B0,B1)      Ma': b0 x ks0..3 (8) + b1 x ks0,1 (4)
+//        Lb': read b2 (4 x ds_read_b128)            Mb': b1 x ks2,3 (4) + b2 x ks0..3 (8)
+// with the same barriers, DMA issue slots and wait counts as group 0 (the staged A1 half-tile
+// keeps 128 rows; its last 32 are never read).
 // LDS swizzle / XCD-aware tile order as in gemm.hip.
 #include <stdlib.h>
 
 #include "gemm_epilogue.h"
 
-#ifndef PP_ORDER
-#define PP_ORDER 0
-#endif
-
 namespace {
 
 constexpr int BK = 64;
-constexpr int TB = 256;                 // BM = BN
+constexpr int TBN = 256;                // BN
 constexpr int HALF = 16384;             // one half-tile
 constexpr int BUF = 4 * HALF;           // A0 A1 B0 B1
 constexpr int LDS_BYTES = 2 * BUF;      // 128 KiB
@@ -56,8 +61,10 @@ __device__ __forceinline__ void glds16(const bf16* g, char* lds_wave_base) {
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
 
-template <int EPI, bool CONV>
+template <int EPI, bool CONV, int BM>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    static_assert(BM == 256 || BM == 224, "row tile is 256 or 224");
+    constexpr bool ASYM = BM == 224;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const int wr = wv >> 2, wc = wv & 3;
 
     // ---- block -> tile (XCD-contiguous, grouped row-tiles) ----
-    const int Mt = (p.M + TB - 1) / TB, Nt = (p.N + TB - 1) / TB;
+    const int Mt = (p.M + BM - 1) / BM, Nt = (p.N + TBN - 1) / TBN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     constexpr int GROUP = 8;
     const int per_group = GROUP * Nt;
@@ -73,8 +80,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const int first_m = g * GROUP;
     const int gsz = min(Mt - first_m, GROUP);
     const int rem = id - g * per_group;
-    const int m0 = (first_m + rem % gsz) * TB;
-    const int n0 = (rem / gsz) * TB;
+    const int m0 = (first_m + rem % gsz) * BM;
+    const int n0 = (rem / gsz) * TBN;
 
     // ---- staging addresses: per half-tile kind, 2 LDS-DMA instructions per wave ----
     // LDS row r' = (wv*2 + j)*8 + lane/8 of the 128-row half-tile; chunk swizzle on the source.
@@ -155,6 +162,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             for (int ks = 0; ks < 4; ++ks)
                 af[i][ks] = *(const bf16x8*)(buf + h * HALF + a_off + i * 4096 + (((2 * ks) ^ xbase) << 4));
     };
+    auto read_a2 = [&](const char* buf) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) af[0][ks] = *(const bf16x8*)(buf + HALF + a_off + (((2 * ks) ^ xbase) << 4));   // b0's fragments are dead by now
+    };
     auto read_b = [&](const char* buf, int h) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -168,8 +179,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 // matrix-pipe occupancy of the neighbouring MFMAs instead of stretching an L interval.
 #define PP_MFMA(QA, I, QB, KS) \
     acc[QA][I][QB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[QB][KS], af[I][KS], acc[QA][I][QB], 0, 0, 0)
+#define PP_MFMA2(QB, KS) \
+    acc[1][0][QB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[QB][KS], af[0][KS], acc[1][0][QB], 0, 0, 0)
 #define PP_PIN_IN() asm volatile("" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]), "+v"(bfr[0][3]))
 #define PP_PIN_OUT(QA) asm volatile("" : "+v"(acc[QA][0][0]), "+v"(acc[QA][1][0]), "+v"(acc[QA][0][1]), "+v"(acc[QA][1][1]))
+#define PP_PIN_OUT_B() asm volatile("" : "+v"(acc[0][1][0]), "+v"(acc[0][1][1]), "+v"(acc[1][0][0]), "+v"(acc[1][0][1]))
 #define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
 #define SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
@@ -184,10 +198,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     issue_b(1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     PP_BARRIER();
-    const int grp = (p.pp_stagger == 0 || p.pp_stagger == 4) ? (wv >> 2) : (p.pp_stagger == 1 ? (wv & 1) : (p.pp_stagger == 3 ? ((wv >> 1) & 1) : 0));
-    const bool soft = p.pp_stagger == 4;
-    const bool bar_l = !soft || grp == 0, bar_m = !soft || grp == 1;
-    if (grp == 1 && !soft) PP_BARRIER();         // stagger the second group by one interval
+    if (wr == 1) PP_BARRIER();          // stagger the second group by one interval
 
     // optional interval timestamps (tools/pp_timeline.py): waves 0 and 4 of block 0, K-tiles 8..11
     unsigned long long* dbg = (p.dbg && blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 4)) ? (unsigned long long*)p.dbg + (wv >> 2) * 256 : nullptr;
@@ -197,101 +208,172 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #else
 #define PP_STAMP() do { (void)dbg; (void)dbi; } while (0)
 #endif
-    for (int t = 0; t < nk; ++t) {
-        const char* cb = smem + (t & 1) * BUF;
-        // La: fragments of A0, B0, B1
-        PP_STAMP();
-        read_a(cb, 0);
-        read_b(cb, 0);
-        read_b(cb, 1);
-        PP_STAMP();
-        PP_LGKM0();
-        PP_STAMP();
-        if (bar_l) PP_BARRIER();
-        PP_STAMP();
-        // Ma: 16 MFMAs on rows [0,64) of the wave slab + LDS-DMA of A1(t+1)
-        PP_PIN_IN();
-        __builtin_amdgcn_s_setprio(1);
-        issue_a(1, t + 1);
-#if PP_ORDER
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                PP_MFMA(0, 0, qb, ks);
-                PP_MFMA(0, 1, qb, ks);
+    // Two copies of the K loop (one per row-group program) rather than a branch inside one loop:
+    // with the branch inside, hipcc keeps a second copy of the 128 accumulator registers across the
+    // merge point and spills ~130 VGPRs.
+    if (!ASYM || wr == 0) {
+        for (int t = 0; t < nk; ++t) {
+            const char* cb = smem + (t & 1) * BUF;
+            // La: fragments of A0, B0, B1 (both groups)
+            PP_STAMP();
+            read_a(cb, 0);
+            read_b(cb, 0);
+            read_b(cb, 1);
+            PP_STAMP();
+            PP_LGKM0();
+            PP_STAMP();
+            PP_BARRIER();
+            PP_STAMP();
+            // Ma: 16 MFMAs on rows [0,64) of the wave slab + LDS-DMA of A1(t+1)
+            PP_PIN_IN();
+            __builtin_amdgcn_s_setprio(1);
+            issue_a(1, t + 1);
+    #pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    PP_MFMA(0, 0, qb, ks);
+                    PP_MFMA(0, 1, qb, ks);
+                }
+            SGB_MFMA(4);
+            SGB_VMEM(1);
+            SGB_MFMA(6);
+            SGB_VMEM(1);
+            SGB_MFMA(6);
+            __builtin_amdgcn_s_setprio(0);
+            PP_PIN_OUT(0);
+            PP_STAMP();
+            PP_BARRIER();
+            // Lb: fragments of A1; this wave's share of A0,B0,B1(t+1) must have landed before the barrier
+            PP_STAMP();
+            read_a(cb, 1);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            PP_STAMP();
+            PP_LGKM0();
+            PP_STAMP();
+            PP_BARRIER();
+            PP_STAMP();
+            // Mb: 16 MFMAs on rows [64,128) + LDS-DMA of A0,B0,B1(t+2); A1(t+1) must have landed
+            PP_PIN_IN();
+            __builtin_amdgcn_s_setprio(1);
+            issue_a(0, t + 2);
+            issue_b(0, t + 2);
+            issue_b(1, t + 2);
+    #pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    PP_MFMA(1, 0, qb, ks);
+                    PP_MFMA(1, 1, qb, ks);
+                }
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(4);
+            __builtin_amdgcn_s_setprio(0);
+            PP_PIN_OUT(1);
+            PP_STAMP();
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            PP_STAMP();
+            PP_BARRIER();
+        }
+    } else {
+        for (int t = 0; t < nk; ++t) {
+            const char* cb = smem + (t & 1) * BUF;
+            // La: fragments of A0, B0, B1 (both groups)
+            PP_STAMP();
+            read_a(cb, 0);
+            read_b(cb, 0);
+            read_b(cb, 1);
+            PP_STAMP();
+            PP_LGKM0();
+            PP_STAMP();
+            PP_BARRIER();
+            PP_STAMP();
+            // Ma': block b0 (K=64) + first half of b1's K + LDS-DMA of A1(t+1)
+            PP_PIN_IN();
+            __builtin_amdgcn_s_setprio(1);
+            issue_a(1, t + 1);
+            // issue order keeps every accumulator at least two MFMAs away from its previous use
+    #pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                PP_MFMA(0, 0, 0, ks);
+                PP_MFMA(0, 0, 1, ks);
+                PP_MFMA(0, 1, 0, ks);
+                PP_MFMA(0, 1, 1, ks);
             }
-#else
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                PP_MFMA(0, 0, qb, ks);
-                PP_MFMA(0, 1, qb, ks);
+    #pragma unroll
+            for (int ks = 2; ks < 4; ++ks) {
+                PP_MFMA(0, 0, 0, ks);
+                PP_MFMA(0, 0, 1, ks);
             }
-#endif
-        SGB_MFMA(4);
-        SGB_VMEM(1);
-        SGB_MFMA(6);
-        SGB_VMEM(1);
-        SGB_MFMA(6);
-        __builtin_amdgcn_s_setprio(0);
-        PP_PIN_OUT(0);
-        PP_STAMP();
-        if (bar_m) PP_BARRIER();
-        // Lb: fragments of A1; this wave's share of A0,B0,B1(t+1) must have landed before the barrier
-        PP_STAMP();
-        read_a(cb, 1);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        PP_STAMP();
-        PP_LGKM0();
-        PP_STAMP();
-        if (bar_l) PP_BARRIER();
-        PP_STAMP();
-        // Mb: 16 MFMAs on rows [64,128) + LDS-DMA of A0,B0,B1(t+2); A1(t+1) must have landed
-        PP_PIN_IN();
-        __builtin_amdgcn_s_setprio(1);
-        issue_a(0, t + 2);
-        issue_b(0, t + 2);
-        issue_b(1, t + 2);
-#if PP_ORDER
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                PP_MFMA(1, 0, qb, ks);
-                PP_MFMA(1, 1, qb, ks);
+            SGB_MFMA(4);
+            SGB_VMEM(1);
+            SGB_MFMA(4);
+            SGB_VMEM(1);
+            SGB_MFMA(4);
+            __builtin_amdgcn_s_setprio(0);
+            PP_PIN_OUT(0);
+            PP_STAMP();
+            PP_BARRIER();
+            // Lb': fragments of b2 (first 32 rows of this group's A1)
+            PP_STAMP();
+            read_a2(cb);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            PP_STAMP();
+            PP_LGKM0();
+            PP_STAMP();
+            PP_BARRIER();
+            PP_STAMP();
+            // Mb': second half of b1's K + block b2 + LDS-DMA of A0,B0,B1(t+2)
+            PP_PIN_IN();
+            __builtin_amdgcn_s_setprio(1);
+            issue_a(0, t + 2);
+            issue_b(0, t + 2);
+            issue_b(1, t + 2);
+    #pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                PP_MFMA(0, 1, 0, 2 + ks);
+                PP_MFMA2(0, ks);
+                PP_MFMA(0, 1, 1, 2 + ks);
+                PP_MFMA2(1, ks);
             }
-#else
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                PP_MFMA(1, 0, qb, ks);
-                PP_MFMA(1, 1, qb, ks);
+    #pragma unroll
+            for (int ks = 2; ks < 4; ++ks) {
+                PP_MFMA2(0, ks);
+                PP_MFMA2(1, ks);
             }
-#endif
-        SGB_MFMA(2);
-        SGB_VMEM(1);
-        SGB_MFMA(2);
-        SGB_VMEM(1);
-        SGB_MFMA(2);
-        SGB_VMEM(1);
-        SGB_MFMA(2);
-        SGB_VMEM(1);
-        SGB_MFMA(2);
-        SGB_VMEM(1);
-        SGB_MFMA(2);
-        SGB_VMEM(1);
-        SGB_MFMA(4);
-        __builtin_amdgcn_s_setprio(0);
-        PP_PIN_OUT(1);
-        PP_STAMP();
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        PP_STAMP();
-        if (bar_m) PP_BARRIER();
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(2);
+            SGB_VMEM(1);
+            SGB_MFMA(1);
+            SGB_VMEM(1);
+            SGB_MFMA(1);
+            SGB_VMEM(1);
+            SGB_MFMA(2);
+            __builtin_amdgcn_s_setprio(0);
+            PP_PIN_OUT_B();
+            PP_STAMP();
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            PP_STAMP();
+            PP_BARRIER();
+        }
     }
-    if (grp == 0 && p.pp_stagger != 2 && !soft) PP_BARRIER();          // rebalance the barrier count
+    if (wr == 0) PP_BARRIER();          // rebalance the barrier count
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: lane owns rows (l31 per row slot) x 4-column groups (gemm_epilogue.h) ----
@@ -311,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (ASYM && wr == 1 && qa == 1 && i == 1) continue;      // rows [224,256) belong to the next tile
             const int row = m0 + wr * 128 + qa * 64 + i * 32 + l31;
             if (row >= p.M) continue;
             const EpiRow er = epi_row_setup<EPI>(p, row);
@@ -327,17 +410,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         }
 }
 
-template <int EPI, bool CONV>
+template <int EPI, bool CONV, int BM>
 int launch_pp(const GemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, CONV, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    const int Mt = (p.M + TB - 1) / TB, Nt = (p.N + TB - 1) / TB;
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV>), dim3(Mt * Nt), dim3(512), LDS_BYTES, stream, p);
+    const int Mt = (p.M + BM - 1) / BM, Nt = (p.N + TBN - 1) / TBN;
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, BM>), dim3(Mt * Nt), dim3(512), LDS_BYTES, stream, p);
     LTX2_CHECK_LAUNCH("gemm_pp_kernel");
     return LTX2_OK;
+}
+
+// 224-row tiles when they need fewer CU-rounds of work than 256-row tiles (dense GEMMs only).
+bool prefer_224(const GemmParams& p) {
+    static int ov = -1;     // LTX2_PP_BM=256|224 forces one variant (tuning / tests)
+    if (ov < 0) {
+        const char* e = getenv("LTX2_PP_BM");
+        ov = e ? atoi(e) : 0;
+    }
+    if (ov == 224) return true;
+    if (ov == 256) return false;
+    const long nt = (p.N + TBN - 1) / TBN, cus = 256;
+    const long t256 = ((long)(p.M + 255) / 256) * nt, t224 = ((long)(p.M + 223) / 224) * nt;
+    const long cost256 = (t256 + cus - 1) / cus * 256, cost224 = (t224 + cus - 1) / cus * 224;
+    return cost224 < cost256;
 }
 
 }  // namespace
@@ -345,27 +443,24 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
 int gemm_pp_launch(const GemmParams& p_in, int epilogue, bool conv, hipStream_t stream) {
     GemmParams p = p_in;
     {
-        static int st = -1;
-        if (st < 0) { const char* e = getenv("LTX2_PP_STAGGER"); st = e ? atoi(e) : 0; }
-        p.pp_stagger = st;
-        static int ab = -1;
-        if (ab < 0) { const char* e = getenv("LTX2_PP_ABLATE"); ab = e ? atoi(e) : 0; }
-        p.pp_ablate = ab;
         const char* d = getenv("LTX2_PP_DBG");
         p.dbg = d ? (void*)strtoull(d, nullptr, 0) : nullptr;
     }
-#define CASE(E)                                                       \
-    case E:                                                           \
-        return conv ? launch_pp<E, true>(p, stream) : launch_pp<E, false>(p, stream);
+    const bool b224 = !conv && prefer_224(p);
+#define CASE(E)                                                                            \
+    case E:                                                                                \
+        return conv ? launch_pp<E, true, 256>(p, stream)                                   \
+                    : (b224 ? launch_pp<E, false, 224>(p, stream) : launch_pp<E, false, 256>(p, stream));
     switch (epilogue) {
         CASE(EPI_BF16)
         CASE(EPI_GELU_BF16)
         CASE(EPI_SILU_BF16)
         CASE(EPI_F32)
         CASE(EPI_RESID_GATE_F32)
-        CASE(EPI_ADD_BF16)
+        case EPI_ADD_BF16:
+            return conv ? launch_pp<EPI_ADD_BF16, true, 256>(p, stream) : launch_pp<EPI_ADD_BF16, false, 256>(p, stream);
         case EPI_D2S_BF16:
-            return launch_pp<EPI_D2S_BF16, true>(p, stream);
+            return launch_pp<EPI_D2S_BF16, true, 256>(p, stream);
         default:
             ltx2_set_error("gemm: unknown epilogue %d", epilogue);
             return LTX2_E_INVALID;
