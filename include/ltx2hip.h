@@ -112,6 +112,9 @@ int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const
 int ltx2_timestep_sinusoid(const float* t, int64_t t_stride, float mult, int T, int dim, float* out_f32,
                            void* out_bf16, void* stream);
 
+/* Load-time dequantisation of fp8 checkpoints: out_bf16[i] = bf16(f32(e4m3fn in[i]) * weight_scale)
+ * (loader/weight_converter.py:391-395, loader/fp8_loader.py:14-51).                            */
+int ltx2_dequant_fp8_e4m3fn(const void* in, float scale, void* out_bf16, int64_t n, void* stream);
 int ltx2_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
 
 /* x0 = latent - ts * velocity  (X0Model.__call__, model.py:912-918); ts_ptr NULL -> ts_scalar. */

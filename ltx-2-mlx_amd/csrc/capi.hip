@@ -109,6 +109,10 @@ int ltx2_timestep_sinusoid(const float* t, int64_t t_stride, float mult, int T, 
     return timestep_sinusoid_launch(t, t_stride, 0.f, mult, T, dim, out_f32, (bf16*)out_bf16, (hipStream_t)stream);
 }
 
+int ltx2_dequant_fp8_e4m3fn(const void* in, float scale, void* out_bf16, int64_t n, void* stream) {
+    return dequant_fp8_launch((const unsigned char*)in, scale, (bf16*)out_bf16, n, (hipStream_t)stream);
+}
+
 int ltx2_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
     LTX2_CHECK_ARG(in && out, "cast: null operand");
     return cast_f32_bf16_launch(in, (bf16*)out, n, (hipStream_t)stream);

@@ -35,6 +35,8 @@ int timestep_sinusoid_launch(const float* t, long t_stride, float t_scalar, floa
                              bf16* out_bf16, hipStream_t stream);
 
 int cast_f32_bf16_launch(const float* in, bf16* out, long n, hipStream_t stream);
+// out_bf16 = bf16(f32(fp8_e4m3fn) * scale): checkpoint weights quantised with a per-tensor weight_scale
+int dequant_fp8_launch(const unsigned char* in, float scale, bf16* out, long n, hipStream_t stream);
 
 // x0[row][c] = latent[row][c] - ts(row) * vel[row][c]   (ts = ts_ptr[row*ts_stride] if ts_ptr else ts_scalar)
 int x0_from_velocity_launch(const float* latent, const float* vel, const float* ts_ptr, long ts_stride, float ts_scalar,

@@ -236,6 +236,30 @@ __global__ void timestep_sinusoid_kernel(const float* __restrict__ t, long t_str
     }
 }
 
+// fp8 e4m3fn (OCP: bias 7, no inf, 0x7f/0xff = NaN) -> fp32, exact (loader/fp8_loader.py:14-51)
+__device__ __forceinline__ float e4m3fn_to_f32(unsigned int b) {
+    const unsigned int sign = (b & 0x80u) << 24, exp = (b >> 3) & 0xfu, man = b & 7u;
+    if ((b & 0x7fu) == 0x7fu) return __uint_as_float(0x7fc00000u | sign);
+    if (exp == 0) return __uint_as_float(__float_as_uint((float)man * 0.001953125f) | sign);     // man * 2^-9
+    return __uint_as_float(sign | ((exp + 120u) << 23) | (man << 20));
+}
+
+// out_bf16[i] = bf16( f32(fp8[i]) * scale )   (weight_converter.py:391-395: fp8 -> f32 * weight_scale -> target dtype)
+__global__ void dequant_fp8_kernel(const unsigned char* __restrict__ in, float scale, bf16* __restrict__ out, long n) {
+    const long stride = (long)gridDim.x * blockDim.x * 8;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 7 < n) {
+            const u32x2 w = *(const u32x2*)(in + i);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(e4m3fn_to_f32((w[e >> 2] >> (8 * (e & 3))) & 0xffu) * scale);
+            *(bf16x8*)(out + i) = o;
+        } else {
+            for (long j = i; j < n; ++j) out[j] = f2bf(e4m3fn_to_f32(in[j]) * scale);
+        }
+    }
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -456,6 +480,15 @@ int timestep_sinusoid_launch(const float* t, long t_stride, float t_scalar, floa
     hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, t, t_stride, t_scalar, mult, T,
                        dim, out_f32, out_bf16);
     LTX2_CHECK_LAUNCH("timestep_sinusoid_kernel");
+    return LTX2_OK;
+}
+
+int dequant_fp8_launch(const unsigned char* in, float scale, bf16* out, long n, hipStream_t stream) {
+    LTX2_CHECK_ARG(in && out && n > 0, "dequant_fp8: bad argument");
+    LTX2_CHECK_ARG((((uintptr_t)in) & 7) == 0 && (((uintptr_t)out) & 15) == 0, "dequant_fp8: pointers must be 8/16-byte aligned");
+    const long blocks = (n / 8 + 255) / 256;
+    hipLaunchKernelGGL(dequant_fp8_kernel, dim3((int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks))), dim3(256), 0, stream, in, scale, out, n);
+    LTX2_CHECK_LAUNCH("dequant_fp8_kernel");
     return LTX2_OK;
 }
 

@@ -152,6 +152,15 @@ def timestep_sinusoid(t: torch.Tensor, mult: float, dim: int = 256) -> torch.Ten
     return out
 
 
+def dequant_fp8(w: torch.Tensor, scale: float) -> torch.Tensor:
+    """fp8 e4m3fn weight (device tensor, torch.float8_e4m3fn or its uint8 view) * scale -> bf16."""
+    raw = w.view(torch.uint8) if w.dtype != torch.uint8 else w
+    raw = _c(raw)
+    out = torch.empty(raw.shape, device=raw.device, dtype=BF16)
+    nv.check(nv.lib().ltx2_dequant_fp8_e4m3fn(nv.ptr(raw), float(scale), nv.ptr(out), raw.numel(), nv.stream()))
+    return out
+
+
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     x = _c(x.float())
     out = torch.empty(x.shape, device=x.device, dtype=BF16)

@@ -42,18 +42,13 @@ def load_text_embedding(path: str, device="cuda"):
     return emb.to(device), mask.to(device)
 
 
-def load_transformer(weights_path, num_layers=48, num_heads=32, caption_channels=3840, seed=0, device="cuda"):
+def load_transformer(weights_path, num_layers=48, num_heads=32, caption_channels=3840, seed=0, device="cuda", use_fp8=False):
     """LTXModel(VideoOnly, 32x128, 48 layers, caption 3840) (reference load_transformer :788-835)."""
     model = LTXModel(num_attention_heads=num_heads, attention_head_dim=128, num_layers=num_layers,
                      caption_channels=caption_channels, device=device)
     if weights_path:
-        from safetensors import safe_open
-        sd = {}
-        with safe_open(weights_path, framework="pt") as f:
-            for k in f.keys():
-                if k.startswith("model.diffusion_model."):
-                    sd[k[len("model.diffusion_model."):]] = f.get_tensor(k)
-        model.load_state_dict(sd, strict=True)
+        from ltx_2_mlx_amd.loader import is_fp8_checkpoint, load_transformer_weights
+        load_transformer_weights(model, weights_path, strict=True, use_fp8=use_fp8 or is_fp8_checkpoint(weights_path))
     else:
         model.init_random_weights(seed=seed)
     return model
@@ -68,7 +63,7 @@ def euler_step_x0(sample, denoised, sigma, sigma_next):
 def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames: int = 97, num_inference_steps: int = 8,
                    seed: int = 42, output_path: str = "output.mp4", weights_path=None, embedding_path=None,
                    use_gemma: bool = False, model_variant: str = "distilled", skip_vae: bool = False, use_placeholder: bool = False,
-                   tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, num_layers: int = 48,
+                   tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, use_fp8: bool = False, num_layers: int = 48,
                    num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", **unsupported):
     for k, v in unsupported.items():
         if v:
@@ -86,7 +81,7 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
     print("[1/5] text encoding")
     text_encoding, _ = load_text_embedding(embedding_path, device) if embedding_path else create_dummy_text_encoding(prompt, device=device)
     print("[2/5] transformer")
-    model = X0Model(load_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device))
+    model = X0Model(load_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device, use_fp8=use_fp8))
     print("[3/5] VAE decoder")
     vae_decoder = None
     if not skip_vae:
@@ -182,14 +177,14 @@ def main():
     p.add_argument("--heads", type=int, default=32, help="debug: attention heads (x128) for random-weight runs")
     p.add_argument("--vae-base-channels", type=int, default=128)
     a = p.parse_args()
-    if a.fp32 or a.fp8:
-        raise NotImplementedError("--fp32 / --fp8 weights: next scope row (DESIGN.md)")
+    if a.fp32:
+        raise NotImplementedError("--fp32: the MI355X path computes in bf16 with fp32 accumulation / residual stream")
     if a.pipeline not in ("text-to-video", "distilled"):
         raise NotImplementedError(f"--pipeline {a.pipeline} is outside the MI355X hot path")
     generate_video(a.prompt, height=a.height, width=a.width, num_frames=a.frames, num_inference_steps=a.steps, seed=a.seed,
                    output_path=a.output, weights_path=a.weights, embedding_path=a.embedding,
                    use_gemma=bool(a.gemma_path) and not a.no_gemma, model_variant=a.model_variant, skip_vae=a.skip_vae,
-                   use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, cfg_scale=a.cfg, use_hip_graph=not a.no_hip_graph,
+                   use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, cfg_scale=a.cfg, use_hip_graph=not a.no_hip_graph, use_fp8=a.fp8,
                    num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,
                    image=a.image, lora=a.lora, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights)
 

@@ -301,3 +301,16 @@ def test_video_to_uint8(K, dev):
     out = K.video_to_uint8(v[0].to(dev))
     d = (out.cpu().int() - ref.int()).abs()
     assert d.max() <= 1 and (d > 0).float().mean() < 1e-3      # truncation at exact .0 boundaries only
+
+
+def test_dequant_fp8_all_codes(K, dev):
+    """Every e4m3fn code x scale against torch's own float8_e4m3fn -> f32 conversion (bit-exact before the
+    bf16 rounding; reference loader/fp8_loader.py:14-51)."""
+    codes = torch.arange(256, dtype=torch.uint8).repeat(5)[:1275]          # ragged tail (not a multiple of 8)
+    ref32 = codes.view(torch.float8_e4m3fn).float()
+    for scale in (1.0, 0.0123, 3.5):
+        out = K.dequant_fp8(codes.to(dev), scale).float().cpu()
+        ref = (ref32 * scale).to(BF).float()
+        nan = torch.isnan(ref)
+        assert torch.equal(torch.isnan(out), nan)
+        assert torch.equal(out[~nan], ref[~nan])

@@ -310,3 +310,41 @@ def test_av_denoise_loop_and_graph(dev, v23):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert rel_l2(gv, lv) < 1e-5 and rel_l2(ga, la) < 1e-5
+
+
+def test_fp8_checkpoint_loader(dev, tmp_path):
+    """BASELINE config 3 plumbing: an fp8 (e4m3fn + weight_scale) safetensors checkpoint with the reference's
+    key scheme goes through load_transformer_weights(use_fp8=True) (GPU dequantisation) and the model matches
+    the oracle run on the dequantised weights; non-DiT and audio keys are skipped as the reference does."""
+    from safetensors.torch import save_file
+    from oracle import dit
+    from ltx_2_mlx_amd.loader import is_fp8_checkpoint, load_transformer_weights
+    from ltx_2_mlx_amd.model.transformer import LTXModel, Modality, X0Model
+    cfg = dit.DiTConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, caption_channels=128)
+    w = dit.make_dit_weights(cfg, seed=4)
+    ck, wq = {}, {}
+    for k, v in w.items():
+        full = "model.diffusion_model." + k
+        if k.endswith(".weight") and v.dim() == 2 and "transformer_blocks" in k:
+            scale = float(v.abs().max() / 448.0)
+            q8 = (v / scale).to(torch.float8_e4m3fn)
+            ck[full] = q8
+            ck[full + "_scale"] = torch.tensor(scale)
+            ck[full.replace(".weight", ".input_scale")] = torch.tensor(1.0)          # ignored (fp8_loader.py:87-97)
+            wq[k] = (q8.float() * scale).to(torch.bfloat16).float()
+        else:
+            ck[full] = v.to(torch.bfloat16) if (k.endswith(".weight") and v.dim() == 2) else v
+            wq[k] = ck[full].float()
+    ck["vae.decoder.conv_in.conv.weight"] = torch.zeros(4)
+    ck["model.diffusion_model.audio_patchify_proj.weight"] = torch.zeros(4, 4)
+    ck["model.diffusion_model.video_embeddings_connector.x.weight"] = torch.zeros(4)
+    path = str(tmp_path / "tiny_fp8.safetensors")
+    save_file(ck, path)
+    assert is_fp8_checkpoint(path)
+    m = LTXModel(num_attention_heads=2, attention_head_dim=128, num_layers=2, caption_channels=128, device=dev)
+    load_transformer_weights(m, path, strict=True, use_fp8=True)
+    lat, ctx, pos = inputs(3, 4, 4, 64, 128)
+    sigma = torch.tensor([0.725])
+    ref = dit.x0_model(lat, ctx, sigma, pos, wq, cfg)
+    x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
+    assert rel_l2(x0.cpu(), ref) < 2e-2 and pearson(x0.cpu(), ref) > 0.999
