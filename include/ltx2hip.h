@@ -77,7 +77,21 @@ int ltx2_gemv_f32(const float* a, int64_t lda, const void* W, const float* bias,
  *           out[T*ft - (ft>1)][H*fh][W*fw][Cf]; residual != 0 adds tile(d2s(x)).                */
 int ltx2_conv3d_fused(const void* x, const void* w, const float* bias, void* out, int T, int H, int W, int Cin,
                       int Cout, int causal, int mode, const void* res, int ft, int fh, int fw, int residual,
-                      void* stream);
+                      int pad_zero, int kt, void* stream);
+/* pad_zero = 1: zero padding in T/H/W instead of reflect/replicate (spatial upscaler, upscaler/spatial.py:20-87);
+ * kt = 1: per-frame 3x3 conv2d (weight [Cout][9*Cin]); with mode 2, ft=1, fh=fw=2 the epilogue is
+ * PixelShuffle(2) (SpatialRationalResampler, upscaler/spatial.py:267-323).                               */
+
+/* GroupNorm over (C/groups, T, H, W) on channels-last bf16 x[P][C] (upscaler/spatial.py:89-128), fused with the
+ * affine, an optional residual add and SiLU:  y = silu(gn(x) * gamma + beta + res).  sums: 2*groups floats of
+ * scratch (zeroed inside).  act = 0 skips the SiLU.                                                      */
+int ltx2_groupnorm_silu(const void* x, const void* res, void* y, int64_t P, int C, int groups, float eps,
+                        const float* gamma, const float* beta, float* sums, int act, void* stream);
+
+/* Upscaler output: x bf16 [P][C] -> out fp32 [C][P] = (x - mean[c]) / std[c]  (PerChannelStatistics.normalize,
+ * video_vae/ops.py:173-186).                                                                             */
+int ltx2_latent_normalize_nchw(const void* x, const float* mean, const float* std, float* out, int C, int64_t P,
+                               void* stream);
 
 /* out_bf16 = norm(x_f32) * (1 + scale) + shift ; scale = scale_tab[d] + scale_emb[row*emb_stride+d].
  * layer_norm = 0: RMS  (transformer.py:16-31 _compiled_adaln_forward; attention.py:88-100 rms_norm)

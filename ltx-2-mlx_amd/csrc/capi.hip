@@ -113,6 +113,15 @@ int ltx2_dequant_fp8_e4m3fn(const void* in, float scale, void* out_bf16, int64_t
     return dequant_fp8_launch((const unsigned char*)in, scale, (bf16*)out_bf16, n, (hipStream_t)stream);
 }
 
+int ltx2_groupnorm_silu(const void* x, const void* res, void* y, int64_t P, int C, int groups, float eps,
+                        const float* gamma, const float* beta, float* sums, int act, void* stream) {
+    return groupnorm_silu_launch((const bf16*)x, (const bf16*)res, (bf16*)y, P, C, groups, eps, gamma, beta, sums, act, (hipStream_t)stream);
+}
+
+int ltx2_latent_normalize_nchw(const void* x, const float* mean, const float* std, float* out, int C, int64_t P, void* stream) {
+    return latent_normalize_nchw_launch((const bf16*)x, mean, std, out, C, P, (hipStream_t)stream);
+}
+
 int ltx2_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
     LTX2_CHECK_ARG(in && out, "cast: null operand");
     return cast_f32_bf16_launch(in, (bf16*)out, n, (hipStream_t)stream);

@@ -108,16 +108,8 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
             const int kh_ = (tap - kt_ * 9) / 3;
             const int kw_ = tap - kt_ * 9 - kh_ * 3;
 #pragma unroll
-            for (int j = 0; j < AL; ++j) {
-                int tt = ct[j] + kt_ - p.pad_front;
-                tt = max(0, min(tt, p.T - 1));
-                int hh = chh[j] + kh_ - 1;
-                hh = hh < 0 ? -hh : (hh >= p.H ? 2 * p.H - 2 - hh : hh);
-                int ww = cww[j] + kw_ - 1;
-                ww = ww < 0 ? -ww : (ww >= p.Wd ? 2 * p.Wd - 2 - ww : ww);
-                const long pos = ((long)tt * p.H + hh) * p.Wd + ww;
-                glds16(a_ptr[j] + pos * p.Cin + c0, sa + j * 1024);
-            }
+            for (int j = 0; j < AL; ++j)
+                glds16(conv_src(p, a_ptr[j], ct[j], chh[j], cww[j], kt_, kh_, kw_, c0), sa + j * 1024);
         } else {
 #pragma unroll
             for (int j = 0; j < AL; ++j) glds16(a_ptr[j] + k0, sa + j * 1024);
@@ -299,8 +291,9 @@ int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream
                    "gemm: N, ldo, ldres and gate_stride must be multiples of 4 (vector epilogue)");
     if (conv) {
         LTX2_CHECK_ARG(p.Cin >= 64 && (p.Cin & (p.Cin - 1)) == 0, "conv3d: Cin=%d must be a power of two >= 64", p.Cin);
-        LTX2_CHECK_ARG(p.K == 27 * p.Cin, "conv3d: K=%d != 27*Cin", p.K);
-        LTX2_CHECK_ARG(p.H >= 2 && p.Wd >= 2 && p.T >= 1, "conv3d: reflect padding needs H,W >= 2");
+        LTX2_CHECK_ARG(p.taps_t == 3 || p.taps_t == 1, "conv3d: temporal kernel size %d (3 or 1)", p.taps_t);
+        LTX2_CHECK_ARG(p.K == 9 * p.taps_t * p.Cin, "conv3d: K=%d != 9*kt*Cin", p.K);
+        LTX2_CHECK_ARG(p.T >= 1 && (p.pad_zero || (p.H >= 2 && p.Wd >= 2)), "conv3d: reflect padding needs H,W >= 2");
         LTX2_CHECK_ARG((long)p.T * p.H * p.Wd == p.M, "conv3d: M != T*H*W");
     } else {
         LTX2_CHECK_ARG(p.lda % 8 == 0, "gemm: lda must be a multiple of 8 elements (16-byte rows)");

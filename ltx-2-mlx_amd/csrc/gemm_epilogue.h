@@ -75,16 +75,24 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, const EpiRow& er
     }
 }
 
-// Conv A-operand source position for output row (t,h,w) and tap (kt,kh,kw): replicate in T,
-// reflect in H/W (reference simple_decoder.py:105-134).
-__device__ __forceinline__ long conv_src_pos(const GemmParams& p, int t, int h, int w, int kt_, int kh_, int kw_) {
-    int tt = t + kt_ - p.pad_front;
-    tt = max(0, min(tt, p.T - 1));
-    int hh = h + kh_ - 1;
-    hh = hh < 0 ? -hh : (hh >= p.H ? 2 * p.H - 2 - hh : hh);
-    int ww = w + kw_ - 1;
-    ww = ww < 0 ? -ww : (ww >= p.Wd ? 2 * p.Wd - 2 - ww : ww);
-    return ((long)tt * p.H + hh) * p.Wd + ww;
+// One 16-byte row of zeros: the LDS-DMA source of out-of-range taps under zero padding.
+__device__ static const unsigned int ltx2_zero_row[32] = {0};
+
+// Conv A-operand source of output position (t,h,w), tap (kt,kh,kw), channel offset c0, for the lane whose
+// staging pointer is a_chunk = A + chunk*8.  pad_zero == 0: replicate in T, reflect in H/W (reference
+// simple_decoder.py:105-134); pad_zero == 1: zero padding in all three dims (upscaler/spatial.py:44-52).
+__device__ __forceinline__ const bf16* conv_src(const GemmParams& p, const bf16* a_chunk, int t, int h, int w, int kt_,
+                                                int kh_, int kw_, int c0) {
+    int tt = t + kt_ - p.pad_front, hh = h + kh_ - 1, ww = w + kw_ - 1;
+    if (p.pad_zero) {
+        if (tt < 0 || tt >= p.T || hh < 0 || hh >= p.H || ww < 0 || ww >= p.Wd)
+            return (const bf16*)ltx2_zero_row + (a_chunk - p.A);
+    } else {
+        tt = max(0, min(tt, p.T - 1));
+        hh = hh < 0 ? -hh : (hh >= p.H ? 2 * p.H - 2 - hh : hh);
+        ww = ww < 0 ? -ww : (ww >= p.Wd ? 2 * p.Wd - 2 - ww : ww);
+    }
+    return a_chunk + (((long)tt * p.H + hh) * p.Wd + ww) * p.Cin + c0;
 }
 
 // Launcher of the 256x256 ping-pong kernel (gemm_pp.hip)

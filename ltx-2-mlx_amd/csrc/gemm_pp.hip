@@ -123,10 +123,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             const int kh_ = (tap - kt_ * 9) / 3;
             const int kw_ = tap - kt_ * 9 - kh_ * 3;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const long pos = conv_src_pos(p, ct[h][j], chh[h][j], cww[h][j], kt_, kh_, kw_);
-                glds16(a_src[h][j] + pos * p.Cin + c0, dst + j * 1024);
-            }
+            for (int j = 0; j < 2; ++j)
+                glds16(conv_src(p, a_src[h][j], ct[h][j], chh[h][j], cww[h][j], kt_, kh_, kw_, c0), dst + j * 1024);
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) glds16(a_src[h][j] + k0, dst + j * 1024);

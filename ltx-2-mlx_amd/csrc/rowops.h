@@ -46,6 +46,13 @@ int x0_from_velocity_launch(const float* latent, const float* vel, const float* 
 int euler_step_launch(const float* x, const float* x0, const float* mask, const float* clean, float sigma,
                       float sigma_next, float* out, int rows, int C, hipStream_t stream);
 
+// ---- spatial upscaler (channels-last bf16 [P][C]) ----
+// y = [silu]( GroupNorm_G(x over (C/G, all positions)) * gamma + beta + res );  sums: 2*G floats scratch
+int groupnorm_silu_launch(const bf16* x, const bf16* res, bf16* y, long P, int C, int G, float eps, const float* gamma,
+                          const float* beta, float* sums, int act, hipStream_t stream);
+// out fp32 [C][P] = (x[P][C] - mean[c]) / std[c]
+int latent_normalize_nchw_launch(const bf16* x, const float* mean, const float* stdv, float* out, int C, long P, hipStream_t stream);
+
 // ---- VAE decoder elementwise ops (channels-last bf16 activations [P][C]) ----
 // latent fp32 NCTHW [C][P] -> bf16 [P][C]: v = latent*std[c] + mean[c]; if noise_scale>0: v = noise*ns + (1-ns)*v
 int vae_prepare_latent_launch(const float* latent, const float* std, const float* mean, const float* noise,

@@ -217,6 +217,94 @@ __global__ void head_gate_kernel(bf16* __restrict__ att, long ld, const float* _
     }
 }
 
+// ---- GroupNorm (spatial upscaler): statistics over (C/G channels x all positions) per group ----
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16* __restrict__ x, float* __restrict__ sums, long P,
+                                                              int C, int G, int rows_per_block) {
+    __shared__ float bins[128];                        // [sum | sumsq] per group, G <= 64
+    if (threadIdx.x < 128) bins[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int cpg = C / G;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < P ? r0 + rows_per_block : P;
+    const int vec_per_row = C / 4;
+    // thread -> one 4-channel vector column, strided over rows
+    for (int v = threadIdx.x; v < vec_per_row; v += 256) {
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (long r = r0; r < r1; ++r) {
+            const bf16x4 q = *(const bf16x4*)(x + r * C + v * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float f = bf2f(q[e]);
+                s1[e] += f;
+                s2[e] += f * f;
+            }
+        }
+        if (cpg % 4 == 0) {          // the 4-channel vector lies inside one group (production widths)
+            const int g = (v * 4) / cpg;
+            atomicAdd(&bins[g], s1[0] + s1[1] + s1[2] + s1[3]);
+            atomicAdd(&bins[64 + g], s2[0] + s2[1] + s2[2] + s2[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int g = (v * 4 + e) / cpg;
+                atomicAdd(&bins[g], s1[e]);
+                atomicAdd(&bins[64 + g], s2[e]);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        atomicAdd(&sums[threadIdx.x], bins[threadIdx.x]);
+        atomicAdd(&sums[G + threadIdx.x], bins[64 + threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ res,
+                                                              bf16* __restrict__ y, const float* __restrict__ sums,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              long n4, int C, int G, float inv_count, float eps, int act) {
+    const int cpg = C / G;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        float mean[4], rstd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            mean[e] = sums[g] * inv_count;
+            rstd[e] = rsqrtf(fmaxf(sums[G + g] * inv_count - mean[e] * mean[e], 0.f) + eps);
+        }
+        const bf16x4 q = *(const bf16x4*)(x + i * 4);
+        const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+        bf16x4 r4 = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+        if (res) r4 = *(const bf16x4*)(res + i * 4);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = (bf2f(q[e]) - mean[e]) * rstd[e] * ga[e] + be[e] + bf2f(r4[e]);
+            o[e] = f2bf(act ? silu_f(v) : v);
+        }
+        *(bf16x4*)(y + i * 4) = o;
+    }
+}
+
+// x bf16 [P][C] -> out fp32 [C][P] = (x - mean[c]) / std[c]
+__global__ __launch_bounds__(256) void latent_normalize_nchw_kernel(const bf16* __restrict__ x, const float* __restrict__ mean,
+                                                                    const float* __restrict__ stdv, float* __restrict__ out,
+                                                                    int C, long P) {
+    __shared__ float tile[64][65];
+    const long p0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int pr = i >> 6, cc = i & 63;
+        tile[pr][cc] = (p0 + pr < P && c0 + cc < C) ? bf2f(x[(p0 + pr) * C + c0 + cc]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int cc = i >> 6, pr = i & 63;
+        if (p0 + pr < P && c0 + cc < C) out[(long)(c0 + cc) * P + p0 + pr] = (tile[pr][cc] - mean[c0 + cc]) / stdv[c0 + cc];
+    }
+}
+
 __global__ void timestep_sinusoid_kernel(const float* __restrict__ t, long t_stride, float t_scalar, float mult, int T,
                                          int dim, float* __restrict__ of, bf16* __restrict__ ob) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -470,6 +558,32 @@ int head_gate_launch(bf16* att, long ld, const float* logits, long ldl, int rows
     const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
     hipLaunchKernelGGL(head_gate_kernel, dim3(grid), dim3(256), 0, stream, att, ld, logits, ldl, n8, per_row8, hd);
     LTX2_CHECK_LAUNCH("head_gate_kernel");
+    return LTX2_OK;
+}
+
+int groupnorm_silu_launch(const bf16* x, const bf16* res, bf16* y, long P, int C, int G, float eps, const float* gamma,
+                          const float* beta, float* sums, int act, hipStream_t stream) {
+    LTX2_CHECK_ARG(x && y && gamma && beta && sums && P > 0, "groupnorm: null operand");
+    LTX2_CHECK_ARG(G >= 1 && G <= 64 && C % G == 0 && C % 4 == 0, "groupnorm: need groups <= 64, C %% groups == 0 and C %% 4 == 0 (C=%d, groups=%d)", C, G);
+    if (hipMemsetAsync(sums, 0, 2 * G * sizeof(float), stream) != hipSuccess) {
+        ltx2_set_error("groupnorm: memset failed");
+        return LTX2_E_HIP;
+    }
+    const int rows_per_block = 16;
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((int)((P + rows_per_block - 1) / rows_per_block)), dim3(256), 0, stream, x, sums, P, C, G, rows_per_block);
+    LTX2_CHECK_LAUNCH("groupnorm_stats_kernel");
+    const long n4 = P * C / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(grid), dim3(256), 0, stream, x, res, y, sums, gamma, beta, n4, C, G,
+                       1.0f / ((float)P * (float)(C / G)), eps, act);
+    LTX2_CHECK_LAUNCH("groupnorm_apply_kernel");
+    return LTX2_OK;
+}
+
+int latent_normalize_nchw_launch(const bf16* x, const float* mean, const float* stdv, float* out, int C, long P, hipStream_t stream) {
+    LTX2_CHECK_ARG(x && mean && stdv && out && C > 0 && P > 0, "latent_normalize: bad argument");
+    hipLaunchKernelGGL(latent_normalize_nchw_kernel, dim3((int)((P + 63) / 64), (C + 63) / 64), dim3(256), 0, stream, x, mean, stdv, out, C, P);
+    LTX2_CHECK_LAUNCH("latent_normalize_nchw_kernel");
     return LTX2_OK;
 }
 

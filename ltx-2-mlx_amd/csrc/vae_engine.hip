@@ -79,7 +79,7 @@ Plan plan_sizes(const ltx2_vae_config& cfg, int T, int H, int W) {
 }
 
 int conv(const bf16* x, const bf16* w, const float* b, void* out, int T, int H, int W, int Cin, int Cout, int causal,
-         int epi, const bf16* res, int ft, int fh, int fw, int residual, hipStream_t st) {
+         int epi, const bf16* res, int ft, int fh, int fw, int residual, hipStream_t st, int pad_zero = 0, int taps_t = 3) {
     GemmParams p{};
     p.A = x;
     p.W = w;
@@ -87,7 +87,9 @@ int conv(const bf16* x, const bf16* w, const float* b, void* out, int T, int H, 
     p.out = out;
     p.M = T * H * W;
     p.N = Cout;
-    p.K = 27 * Cin;
+    p.K = 9 * taps_t * Cin;
+    p.taps_t = taps_t;
+    p.pad_zero = pad_zero;
     p.ldo = Cout;
     p.res = res;
     p.ldres = Cout;
@@ -96,7 +98,7 @@ int conv(const bf16* x, const bf16* w, const float* b, void* out, int T, int H, 
     p.Wd = W;
     p.Cin = Cin;
     p.cin_shift = ilog2(Cin);
-    p.pad_front = causal ? 2 : 1;
+    p.pad_front = taps_t == 1 ? 0 : (causal ? 2 : 1);
     if (epi == EPI_D2S_BF16) {
         const int sp = ft * fh * fw;
         LTX2_CHECK_ARG(Cout % sp == 0, "conv3d d2s: Cout=%d not divisible by stride product %d", Cout, sp);
@@ -120,13 +122,15 @@ extern "C" {
 
 int ltx2_conv3d_fused(const void* x, const void* w, const float* bias, void* out, int T, int H, int W, int Cin,
                       int Cout, int causal, int mode, const void* res, int ft, int fh, int fw, int residual,
-                      void* stream) {
+                      int pad_zero, int kt, void* stream) {
     LTX2_CHECK_ARG(x && w && out, "conv3d: null operand");
+    LTX2_CHECK_ARG(kt == 3 || kt == 1, "conv3d: temporal kernel size %d (3 or 1)", kt);
+    LTX2_CHECK_ARG(!(pad_zero && causal), "conv3d: causal padding is a replicate-pad mode");
     LTX2_CHECK_ARG(mode >= 0 && mode <= 2, "conv3d: mode %d", mode);
     LTX2_CHECK_ARG(mode != 1 || res, "conv3d: mode 1 needs a residual tensor");
     const int epi = mode == 0 ? EPI_BF16 : (mode == 1 ? EPI_ADD_BF16 : EPI_D2S_BF16);
     return conv((const bf16*)x, (const bf16*)w, bias, out, T, H, W, Cin, Cout, causal, epi, (const bf16*)res, ft, fh, fw,
-                residual, (hipStream_t)stream);
+                residual, (hipStream_t)stream, pad_zero, kt);
 }
 
 int ltx2_vae_create(const ltx2_vae_config* cfg, ltx2_vae** out) {

@@ -73,12 +73,16 @@ def conv_bias_to_engine(b: torch.Tensor, d2s_stride: Optional[Tuple[int, int, in
 
 
 def conv3d(x: torch.Tensor, w_engine: torch.Tensor, bias: Optional[torch.Tensor], causal: bool = False, mode: int = 0,
-           res: Optional[torch.Tensor] = None, stride: Tuple[int, int, int] = (1, 1, 1), residual: bool = False) -> torch.Tensor:
-    """x bf16 [T,H,W,Cin] channels-last; w_engine from conv_weight_to_engine."""
+           res: Optional[torch.Tensor] = None, stride: Tuple[int, int, int] = (1, 1, 1), residual: bool = False,
+           pad_zero: bool = False) -> torch.Tensor:
+    """x bf16 [T,H,W,Cin] channels-last; w_engine [Cout][27 or 9][Cin] from conv_weight_to_engine /
+    conv2d_weight_to_engine (9 taps = per-frame 3x3 conv).  pad_zero: zero padding (spatial upscaler)
+    instead of the VAE's reflect/replicate."""
     assert x.dtype == BF16 and x.dim() == 4 and w_engine.dtype == BF16
     x = _c(x)
     T, H, W, Cin = x.shape
     Cout = w_engine.shape[0]
+    kt = w_engine.shape[1] // 9
     ft, fh, fw = stride
     if mode == 2:
         sp = ft * fh * fw
@@ -86,7 +90,55 @@ def conv3d(x: torch.Tensor, w_engine: torch.Tensor, bias: Optional[torch.Tensor]
     else:
         out = torch.empty(T, H, W, Cout, device=x.device, dtype=BF16)
     nv.check(nv.lib().ltx2_conv3d_fused(nv.ptr(x), nv.ptr(w_engine), nv.ptr(bias), nv.ptr(out), T, H, W, Cin, Cout,
-                                        int(causal), mode, nv.ptr(res), ft, fh, fw, int(residual), nv.stream()))
+                                        int(causal), mode, nv.ptr(res), ft, fh, fw, int(residual), int(pad_zero), kt,
+                                        nv.stream()))
+    return out
+
+
+def conv2d_weight_to_engine(w: torch.Tensor, pixel_shuffle: int = 0) -> torch.Tensor:
+    """PyTorch conv2d weight (Cout, Cin, 3, 3) -> engine layout bf16 [Cout][9][Cin] (tap = kh*3+kw).  With
+    pixel_shuffle = r the output rows are permuted from ch = c*r*r + s (PyTorch pixel_shuffle packing
+    (C, r_h, r_w)) to n' = s*Cf + c for the depth-to-space epilogue."""
+    cout, cin = w.shape[0], w.shape[1]
+    e = w.permute(0, 2, 3, 1).reshape(cout, 9, cin)
+    if pixel_shuffle:
+        sp = pixel_shuffle * pixel_shuffle
+        e = e.reshape(cout // sp, sp, 9, cin).permute(1, 0, 2, 3).reshape(cout, 9, cin)
+    return e.to(BF16).contiguous()
+
+
+def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-5,
+                   res: Optional[torch.Tensor] = None, act: bool = True) -> torch.Tensor:
+    """y = [silu](GroupNorm(x over (C/groups, T, H, W)) * gamma + beta + res) on channels-last bf16 [..., C]."""
+    assert x.dtype == BF16 and x.is_contiguous()
+    C = x.shape[-1]
+    P = x.numel() // C
+    y = torch.empty_like(x)
+    sums = torch.empty(2 * groups, device=x.device, dtype=torch.float32)
+    nv.check(nv.lib().ltx2_groupnorm_silu(nv.ptr(x), nv.ptr(res), nv.ptr(y), P, C, groups, eps, nv.ptr(_c(gamma.float())),
+                                          nv.ptr(_c(beta.float())), nv.ptr(sums), int(act), nv.stream()))
+    return y
+
+
+def latent_unnormalize_nhwc(latent: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+    """latent fp32 [C,T,H,W] -> bf16 [T,H,W,C] = latent * std[c] + mean[c]  (PerChannelStatistics.un_normalize,
+    video_vae/ops.py:158-171; same kernel as the VAE decoder's input stage)."""
+    assert latent.dtype == torch.float32 and latent.dim() == 4
+    latent = _c(latent)
+    C, T, H, W = latent.shape
+    out = torch.empty(T, H, W, C, device=latent.device, dtype=BF16)
+    nv.check(nv.lib().ltx2_vae_prepare_latent(nv.ptr(latent), nv.ptr(_c(std.float())), nv.ptr(_c(mean.float())), None, 0.0,
+                                              nv.ptr(out), C, T * H * W, nv.stream()))
+    return out
+
+
+def latent_normalize_nchw(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+    """x bf16 [T,H,W,C] -> fp32 [C,T,H,W] = (x - mean[c]) / std[c]."""
+    assert x.dtype == BF16 and x.dim() == 4 and x.is_contiguous()
+    T, H, W, C = x.shape
+    out = torch.empty(C, T, H, W, device=x.device, dtype=torch.float32)
+    nv.check(nv.lib().ltx2_latent_normalize_nchw(nv.ptr(x), nv.ptr(_c(mean.float())), nv.ptr(_c(std.float())), nv.ptr(out), C,
+                                                 T * H * W, nv.stream()))
     return out
 
 

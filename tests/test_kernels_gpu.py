@@ -314,3 +314,46 @@ def test_dequant_fp8_all_codes(K, dev):
         nan = torch.isnan(ref)
         assert torch.equal(torch.isnan(out), nan)
         assert torch.equal(out[~nan], ref[~nan])
+
+
+@pytest.mark.parametrize("T,H,W,Cin,Cout", [(3, 5, 6, 64, 128), (1, 4, 4, 128, 64), (2, 9, 7, 64, 64)])
+def test_conv3d_zero_pad(K, dev, T, H, W, Cin, Cout):
+    """Spatial upscaler's conv3d: zero padding in T/H/W (reference upscaler/spatial.py:20-87)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(T * 10 + H)
+    x = q(torch.randn(1, Cin, T, H, W, generator=g))
+    w = q(torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin))
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv3d(x, w, b, padding=1)[0].permute(1, 2, 3, 0)
+    xe = x[0].permute(1, 2, 3, 0).contiguous().to(dev, BF)
+    out = K.conv3d(xe, K.conv_weight_to_engine(w).to(dev), b.to(dev), pad_zero=True)
+    assert rel_l2(out.float().cpu(), ref) < 6e-3
+
+
+def test_conv2d_pixel_shuffle(K, dev):
+    """SpatialRationalResampler: per-frame conv2d (C -> 4C, zero pad) + PixelShuffle(2) (upscaler/spatial.py:184-323)."""
+    import torch.nn.functional as F
+    T, H, W, C = 2, 5, 6, 64
+    g = torch.Generator().manual_seed(9)
+    x = q(torch.randn(T, C, H, W, generator=g))
+    w = q(torch.randn(4 * C, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    b = torch.randn(4 * C, generator=g)
+    ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2).permute(0, 2, 3, 1)          # T, 2H, 2W, C
+    xe = x.permute(0, 2, 3, 1).contiguous().to(dev, BF)
+    out = K.conv3d(xe, K.conv2d_weight_to_engine(w, pixel_shuffle=2).to(dev), K.conv_bias_to_engine(b, (1, 2, 2)).to(dev),
+                   mode=2, stride=(1, 2, 2), pad_zero=True)
+    assert out.shape == (T, 2 * H, 2 * W, C)
+    assert rel_l2(out.float().cpu(), ref) < 6e-3
+
+
+@pytest.mark.parametrize("P,C,G,with_res", [(90, 64, 32, False), (1000, 1024, 32, True), (37, 128, 8, True)])
+def test_groupnorm_silu(K, dev, P, C, G, with_res):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(P + C)
+    x = q(torch.randn(P, C, generator=g) * 2 + 0.5)
+    res = q(torch.randn(P, C, generator=g)) if with_res else None
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    y = F.group_norm(x.t()[None], G, gamma, beta, 1e-5)[0].t()          # stats over (C/G, all positions)
+    ref = F.silu(y + (res if with_res else 0))
+    out = K.groupnorm_silu(x.to(dev, BF), gamma.to(dev), beta.to(dev), G, res=res.to(dev, BF) if with_res else None)
+    assert rel_l2(out.float().cpu(), ref) < 6e-3

@@ -199,3 +199,13 @@ def test_av_dit_matches_reference(v23):
             vx0, ax0 = dit_av.av_x0_model(video, audio, w, cfg)
             close(vx0, z[f"{tag}_{tsk}_video_x0"], rtol=2e-4, atol=2e-5)
             close(ax0, z[f"{tag}_{tsk}_audio_x0"], rtol=2e-4, atol=2e-5)
+
+
+def test_upscaler_matches_reference():
+    """Spatial x2 upscaler oracle against the reference's SpatialUpscaler (tiny: 64 -> 64 channels, 2+2 blocks)."""
+    from oracle import upscaler
+    z = g("upscaler_tiny.npz")
+    w = upscaler.make_upscaler_weights(64, 64, 2, seed=41)
+    x = torch.randn(1, 64, 3, 5, 6, generator=torch.Generator().manual_seed(77))
+    with torch.no_grad():
+        close(upscaler.spatial_upscaler(x, w, num_blocks=2), z["upscaled"], rtol=2e-4, atol=2e-5)

@@ -348,3 +348,28 @@ def test_fp8_checkpoint_loader(dev, tmp_path):
     ref = dit.x0_model(lat, ctx, sigma, pos, wq, cfg)
     x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
     assert rel_l2(x0.cpu(), ref) < 2e-2 and pearson(x0.cpu(), ref) > 0.999
+
+
+def test_spatial_upscaler(dev):
+    """BASELINE config 5 building block: SpatialUpscaler (tiny 64-channel, 2+2 blocks) and the un_normalize /
+    normalize bracket on the GPU vs the fp32 oracle and vs the vector recorded from the reference."""
+    import numpy as np
+    import os
+    from oracle import upscaler as oup
+    from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler, upscale_latent
+    w = oup.make_upscaler_weights(64, 64, 2, seed=41)
+    wq = {k: (v.to(torch.bfloat16).float() if v.dim() >= 4 else v) for k, v in w.items()}
+    up = SpatialUpscaler(in_channels=64, mid_channels=64, num_blocks_per_stage=2, device=dev)
+    up.load_state_dict(w)
+    x = torch.randn(1, 64, 3, 5, 6, generator=torch.Generator().manual_seed(77))
+    out = up(x.to(dev))
+    assert out.shape == (1, 64, 3, 10, 12) and out.dtype == torch.float32
+    ref = oup.spatial_upscaler(x, wq, num_blocks=2)
+    assert rel_l2(out.cpu(), ref) < 4e-2 and pearson(out.cpu(), ref) > 0.999
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "upscaler_tiny.npz"))
+    assert rel_l2(out.cpu(), torch.from_numpy(z["upscaled"])) < 5e-2
+    g = torch.Generator().manual_seed(5)
+    mean, std = torch.randn(64, generator=g), 0.5 + torch.rand(64, generator=g)
+    out2 = upscale_latent(x.to(dev), up, mean, std)
+    ref2 = oup.upscale_latent(x, wq, mean, std, num_blocks=2)
+    assert rel_l2(out2.cpu(), ref2) < 4e-2

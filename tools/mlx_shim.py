@@ -146,6 +146,9 @@ class Arr:
     def mean(self, axis=None, keepdims=False):
         return Arr(self.t.mean() if axis is None else self.t.mean(dim=axis, keepdim=keepdims))
 
+    def var(self, axis=None, keepdims=False, ddof=0):        # mx.array.var: population variance by default
+        return Arr(self.t.var(unbiased=bool(ddof)) if axis is None else self.t.var(dim=axis, keepdim=keepdims, unbiased=bool(ddof)))
+
     def max(self, axis=None, keepdims=False):
         return Arr(self.t.max() if axis is None else self.t.amax(dim=axis, keepdim=keepdims))
 
@@ -292,6 +295,11 @@ sum = lambda a, axis=None, keepdims=False: a.sum(axis, keepdims)  # noqa: A001
 matmul = lambda a, b: Arr(_t(a) @ _t(b))
 softmax = lambda a, axis=-1: Arr(torch.softmax(_t(a), dim=axis))
 allclose = lambda a, b, rtol=1e-5, atol=1e-8: bool(torch.allclose(_t(a, b).float(), _t(b, a).float(), rtol=rtol, atol=atol))
+
+
+def _mx_all(a, axis=None, keepdims=False):
+    t = _t(a)
+    return Arr(t.all() if axis is None else t.all(dim=axis, keepdim=keepdims))
 
 
 def std(a, axis=None, keepdims=False):
@@ -464,6 +472,7 @@ def install():
     core.fast = _Fast("mlx.core.fast")
     core.random = _Random("mlx.core.random")
     core.array = array
+    core.all = _mx_all
     core.Dtype = Dtype
     core.metal = types.SimpleNamespace(clear_cache=lambda: None, is_available=lambda: False)
     core.clear_cache = lambda: None

@@ -24,6 +24,7 @@ A = shim.Arr
 
 from oracle import dit as odit  # noqa: E402
 from oracle import dit_av as oav  # noqa: E402
+from oracle import upscaler as oup  # noqa: E402
 from oracle import loop as oloop  # noqa: E402
 from oracle import vae as ovae  # noqa: E402
 
@@ -144,6 +145,31 @@ def pin_dit_av():
             out[f"{tag}_{tsk}_audio_x0"] = tn(ax0.t)
     np.savez_compressed(os.path.join(GOLD, "dit_av_tiny.npz"), **out)
     print("dit_av_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------------ spatial upscaler
+def pin_upscaler():
+    from LTX_2_MLX.model.upscaler.spatial import SpatialUpscaler
+    cin, mid, nb = 64, 64, 2
+    w = oup.make_upscaler_weights(cin, mid, nb, seed=41)
+    up = SpatialUpscaler(in_channels=cin, mid_channels=mid, num_blocks_per_stage=nb, num_groups=32)
+    up.initial_conv_weight, up.initial_conv_bias = A(w["initial_conv.weight"]), A(w["initial_conv.bias"])
+    up.initial_norm.weight, up.initial_norm.bias = A(w["initial_norm.weight"]), A(w["initial_norm.bias"])
+    up.final_conv_weight, up.final_conv_bias = A(w["final_conv.weight"]), A(w["final_conv.bias"])
+    for stage, blocks in (("res_blocks", up.res_blocks), ("post_upsample_res_blocks", up.post_upsample_res_blocks)):
+        for i, blk in enumerate(blocks):
+            blk.conv1_weight, blk.conv1_bias = A(w[f"{stage}.{i}.conv1.weight"]), A(w[f"{stage}.{i}.conv1.bias"])
+            blk.conv2_weight, blk.conv2_bias = A(w[f"{stage}.{i}.conv2.weight"]), A(w[f"{stage}.{i}.conv2.bias"])
+            blk.norm1.weight, blk.norm1.bias = A(w[f"{stage}.{i}.norm1.weight"]), A(w[f"{stage}.{i}.norm1.bias"])
+            blk.norm2.weight, blk.norm2.bias = A(w[f"{stage}.{i}.norm2.weight"]), A(w[f"{stage}.{i}.norm2.bias"])
+    # PyTorch conv2d weight (out, in, kh, kw) -> MLX (out, kh, kw, in), as _load_upsampler_weight does (spatial.py:520-531)
+    up.upsampler.conv_weight = A(w["upsampler.conv.weight"].permute(0, 2, 3, 1).contiguous())
+    up.upsampler.conv_bias = A(w["upsampler.conv.bias"])
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, cin, 3, 5, 6, generator=g)
+    out = {"upscaled": tn(up(A(x)).t)}
+    np.savez_compressed(os.path.join(GOLD, "upscaler_tiny.npz"), **out)
+    print("upscaler_tiny.npz", {k: v.shape for k, v in out.items()})
 
 # ------------------------------------------------------------------------------------------ loop helpers
 def pin_loop():
@@ -284,5 +310,6 @@ if __name__ == "__main__":
         pin_loop()
         pin_dit()
         pin_dit_av()
+        pin_upscaler()
         pin_vae()
     print("golden vectors written to", GOLD)
