@@ -159,6 +159,11 @@ class SimpleVideoDecoder:
                     t = t.to(dev, torch.float32)
                     self._register(k, t.to(BF16) if k.endswith(".weight") else t)
 
+    @property
+    def per_channel_statistics(self) -> "PerChannelStatistics":
+        """Latent-space statistics shipped with the VAE weights (video_vae/ops.py:133-210)."""
+        return PerChannelStatistics(self._w["vae.per_channel_statistics.mean-of-means"], self._w["vae.per_channel_statistics.std-of-means"])
+
     def init_random_weights(self, seed: int = 0) -> None:
         """Synthetic weights generated in HBM in engine layout (bench / smoke)."""
         self._create()
@@ -240,6 +245,19 @@ class SimpleVideoDecoder:
         nv.check(nv.lib().ltx2_vae_decode(self._h, nv.ptr(lat), t, h, w, float(timestep) if tcond else -1.0, nv.ptr(nz),
                                           int(causal), nv.ptr(video), nv.stream()))
         return video[None]
+
+
+class PerChannelStatistics:
+    """mean-of-means / std-of-means of the video VAE latent space (reference video_vae/ops.py:133-210)."""
+
+    def __init__(self, mean_of_means: torch.Tensor, std_of_means: torch.Tensor):
+        self.mean_of_means, self.std_of_means = mean_of_means.float(), std_of_means.float()
+
+    def un_normalize(self, x: torch.Tensor) -> torch.Tensor:
+        return x * self.std_of_means.reshape(1, -1, 1, 1, 1).to(x.device) + self.mean_of_means.reshape(1, -1, 1, 1, 1).to(x.device)
+
+    def normalize(self, x: torch.Tensor) -> torch.Tensor:
+        return (x - self.mean_of_means.reshape(1, -1, 1, 1, 1).to(x.device)) / self.std_of_means.reshape(1, -1, 1, 1, 1).to(x.device)
 
 
 def load_vae_decoder_weights(decoder: SimpleVideoDecoder, weights_path: str) -> None:

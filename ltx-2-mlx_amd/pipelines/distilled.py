@@ -17,6 +17,7 @@ from ..components import (DISTILLED_SIGMA_VALUES, STAGE_2_DISTILLED_SIGMA_VALUES
                           VideoLatentPatchifier)
 from ..conditioning.tools import VideoLatentTools
 from ..model.transformer import LTXModel, LTXModelType, Modality, X0Model
+from ..model.upscaler import SpatialUpscaler, upscale_latent
 from ..model.video_vae import SimpleVideoDecoder, TilingConfig, decode_latent, decode_tiled
 from ..types import LatentState, VideoLatentShape, VideoPixelShape
 from .common import modality_from_state, post_process_latent
@@ -122,16 +123,22 @@ class DistilledPipeline:
         final_latent = state.latent
 
         if self.spatial_upscaler is not None:
-            stats = getattr(self.video_encoder, "per_channel_statistics", None)
+            # un_normalize -> upscaler -> normalize (reference pipelines/distilled.py:394-405); the statistics
+            # ship with the VAE weights, so the decoder serves when no encoder object is passed
+            stats = getattr(self.video_encoder, "per_channel_statistics", None) or getattr(self.video_decoder, "per_channel_statistics", None)
             if stats is None:
-                raise ValueError("spatial_upscaler needs video_encoder.per_channel_statistics (un_normalize/normalize)")
-            up = stats.normalize(self.spatial_upscaler(stats.un_normalize(final_latent)))
+                raise ValueError("spatial_upscaler needs per_channel_statistics (un_normalize/normalize) from the video VAE")
+            if isinstance(self.spatial_upscaler, SpatialUpscaler):
+                up = upscale_latent(final_latent, self.spatial_upscaler, stats.mean_of_means, stats.std_of_means)
+            else:
+                up = stats.normalize(self.spatial_upscaler(stats.un_normalize(final_latent)))
             s2 = VideoPixelShape(batch=1, frames=config.num_frames, height=config.height, width=config.width, fps=config.fps)
             tools2 = self._create_video_tools(VideoLatentShape.from_pixel_shape(s2, latent_channels=128), config.fps)
             state2 = tools2.create_initial_state(dtype=config.dtype, initial_latent=up)
             state2 = noiser(state2, noise_scale=float(STAGE_2_DISTILLED_SIGMA_VALUES[0]))
             cb2 = (lambda s, t: callback("stage2", s, t)) if callback else None
-            state2, _ = self._denoise_loop_av(state2, None, STAGE_2_DISTILLED_SIGMA_VALUES, text_encoding.to(dev), callback=cb2)
+            state2, _ = self._denoise_loop_av(state2, None, STAGE_2_DISTILLED_SIGMA_VALUES, text_encoding.to(dev), callback=cb2,
+                                              use_hip_graph=config.use_hip_graph)
             final_latent = tools2.unpatchify(tools2.clear_conditioning(state2)).latent
 
         if self.video_decoder is None:

@@ -373,3 +373,30 @@ def test_spatial_upscaler(dev):
     out2 = upscale_latent(x.to(dev), up, mean, std)
     ref2 = oup.upscale_latent(x, wq, mean, std, num_blocks=2)
     assert rel_l2(out2.cpu(), ref2) < 4e-2
+
+
+def test_two_stage_pipeline_with_upscaler(dev):
+    """BASELINE config 5 plumbing at toy size: stage 1 (8 steps, half res) -> un_normalize/upscale x2/normalize ->
+    re-noise to sigma 0.909375 -> stage 2 (3 steps, full res); eager per-step API and hipGraph replay agree."""
+    from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler
+    from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline
+    cfg, w, m = make_dit(dev, heads=2, layers=2, cap=128)
+    vcfg, vw, d = make_vae(dev, layers=1)
+    up = SpatialUpscaler(in_channels=128, mid_channels=64, num_blocks_per_stage=1, device=dev)
+    up.init_random_weights(seed=3)
+    g = torch.Generator().manual_seed(2)
+    ctx = 0.1 * torch.randn(1, 64, 128, generator=g)
+    noise = torch.randn(1, 3 * 4 * 6, 128, generator=g)
+    pipe = DistilledPipeline(m, None, None, spatial_upscaler=up)
+    with pytest.raises(ValueError, match="per_channel_statistics"):
+        pipe(ctx.to(dev), None, DistilledConfig(height=256, width=384, num_frames=17, seed=1), initial_noise=noise.to(dev))
+    pipe = DistilledPipeline(m, None, d, spatial_upscaler=up)
+    outs = []
+    for graph in (False, True):
+        conf = DistilledConfig(height=256, width=384, num_frames=17, seed=1, use_hip_graph=graph)
+        pipe.video_decoder = None                       # latent out
+        pipe.video_encoder = d                          # statistics provider (ships with the VAE weights)
+        lat = pipe(ctx.to(dev), None, conf, initial_noise=noise.to(dev))
+        assert lat.shape == (1, 128, 3, 8, 12) and bool(torch.isfinite(lat).all())
+        outs.append(lat)
+    assert rel_l2(outs[1], outs[0]) < 1e-4
