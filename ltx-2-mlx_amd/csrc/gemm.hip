@@ -72,18 +72,14 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
     // ---- per-lane staging addresses ----
     const bf16* a_ptr[AL];
     const bf16* w_ptr[BL];
-    int ct[AL], chh[AL], cww[AL];
+    ConvRow crow[CONV ? AL : 1];
 #pragma unroll
     for (int j = 0; j < AL; ++j) {
         const int rt = (wv * AL + j) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((rt >> 1) & 7);
         const int m = min(m0 + rt, p.M - 1);
         if (CONV) {
-            const int hw = p.H * p.Wd;
-            ct[j] = m / hw;
-            const int r2 = m - ct[j] * hw;
-            chh[j] = r2 / p.Wd;
-            cww[j] = r2 - chh[j] * p.Wd;
+            crow[CONV ? j : 0] = conv_row_setup(p, m);
             a_ptr[j] = p.A + chunk * 8;
         } else {
             a_ptr[j] = p.A + (long)m * p.lda + chunk * 8;
@@ -109,7 +105,7 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
             const int kw_ = tap - kt_ * 9 - kh_ * 3;
 #pragma unroll
             for (int j = 0; j < AL; ++j)
-                glds16(conv_src(p, a_ptr[j], ct[j], chh[j], cww[j], kt_, kh_, kw_, c0), sa + j * 1024);
+                glds16(conv_src_row(p, a_ptr[j], crow[CONV ? j : 0], kt_, kh_, kw_, c0), sa + j * 1024);
         } else {
 #pragma unroll
             for (int j = 0; j < AL; ++j) glds16(a_ptr[j] + k0, sa + j * 1024);
@@ -295,6 +291,7 @@ int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream
         LTX2_CHECK_ARG(p.K == 9 * p.taps_t * p.Cin, "conv3d: K=%d != 9*kt*Cin", p.K);
         LTX2_CHECK_ARG(p.T >= 1 && (p.pad_zero || (p.H >= 2 && p.Wd >= 2)), "conv3d: reflect padding needs H,W >= 2");
         LTX2_CHECK_ARG((long)p.T * p.H * p.Wd == p.M, "conv3d: M != T*H*W");
+        LTX2_CHECK_ARG((long)p.M * p.Cin * 2 < (1L << 31), "conv3d: activation volume must be < 2 GiB (32-bit tap offsets); decode in tiles");
     } else {
         LTX2_CHECK_ARG(p.lda % 8 == 0, "gemm: lda must be a multiple of 8 elements (16-byte rows)");
     }

@@ -78,21 +78,51 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, const EpiRow& er
 // One 16-byte row of zeros: the LDS-DMA source of out-of-range taps under zero padding.
 __device__ static const unsigned int ltx2_zero_row[32] = {0};
 
-// Conv A-operand source of output position (t,h,w), tap (kt,kh,kw), channel offset c0, for the lane whose
-// staging pointer is a_chunk = A + chunk*8.  pad_zero == 0: replicate in T, reflect in H/W (reference
-// simple_decoder.py:105-134); pad_zero == 1: zero padding in all three dims (upscaler/spatial.py:44-52).
-__device__ __forceinline__ const bf16* conv_src(const GemmParams& p, const bf16* a_chunk, int t, int h, int w, int kt_,
-                                                int kh_, int kw_, int c0) {
-    int tt = t + kt_ - p.pad_front, hh = h + kh_ - 1, ww = w + kw_ - 1;
-    if (p.pad_zero) {
-        if (tt < 0 || tt >= p.T || hh < 0 || hh >= p.H || ww < 0 || ww >= p.Wd)
-            return (const bf16*)ltx2_zero_row + (a_chunk - p.A);
-    } else {
-        tt = max(0, min(tt, p.T - 1));
-        hh = hh < 0 ? -hh : (hh >= p.H ? 2 * p.H - 2 - hh : hh);
-        ww = ww < 0 ? -ww : (ww >= p.Wd ? 2 * p.Wd - 2 - ww : ww);
+// Per-output-position tap tables for the conv A-operand gather: BYTE offsets of the three temporal, three
+// vertical and three horizontal neighbours with the padding rule already applied (computed once per row; the
+// per-K-tile address is then three uniform 3-way selects and three adds instead of ~30 VALU instructions of
+// clamp / reflect / 64-bit multiply per LDS-DMA issue).  Padding: replicate in T, reflect in H/W (reference
+// simple_decoder.py:105-134), or zero padding in all three dims when pad_zero (upscaler/spatial.py:44-52), where
+// 0xffffffff marks an out-of-range tap whose LDS-DMA source becomes the zero row.
+struct ConvRow {
+    unsigned ho[3], wo[3];      // vertical / horizontal neighbour offsets (bytes), padding rule applied
+    int t;                      // frame index: the temporal neighbour is one clamp + multiply per use
+};
+
+__device__ __forceinline__ ConvRow conv_row_setup(const GemmParams& p, int m) {
+    const int hw = p.H * p.Wd;
+    const int t = m / hw, r2 = m - t * hw, h = r2 / p.Wd, w = r2 - h * p.Wd;
+    ConvRow r;
+    r.t = t;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int hh = h + k - 1, ww = w + k - 1;
+        bool ho_ok = true, wo_ok = true;
+        if (p.pad_zero) {
+            ho_ok = hh >= 0 && hh < p.H;
+            wo_ok = ww >= 0 && ww < p.Wd;
+        } else {
+            hh = hh < 0 ? -hh : (hh >= p.H ? 2 * p.H - 2 - hh : hh);
+            ww = ww < 0 ? -ww : (ww >= p.Wd ? 2 * p.Wd - 2 - ww : ww);
+        }
+        r.ho[k] = ho_ok ? (unsigned)hh * (unsigned)p.Wd * (unsigned)p.Cin * 2u : 0xffffffffu;
+        r.wo[k] = wo_ok ? (unsigned)ww * (unsigned)p.Cin * 2u : 0xffffffffu;
     }
-    return a_chunk + (((long)tt * p.H + hh) * p.Wd + ww) * p.Cin + c0;
+    return r;
+}
+
+__device__ __forceinline__ unsigned sel3(const unsigned (&a)[3], int k) { return k == 0 ? a[0] : (k == 1 ? a[1] : a[2]); }
+
+// a_chunk = A + chunk*8 (this lane's 16-byte column of the row); kt_/kh_/kw_ are wave-uniform.
+__device__ __forceinline__ const bf16* conv_src_row(const GemmParams& p, const bf16* a_chunk, const ConvRow& r, int kt_, int kh_,
+                                                    int kw_, int c0) {
+    const int tt = r.t + kt_ - p.pad_front;
+    const unsigned a = (unsigned)max(0, min(tt, p.T - 1)) * (unsigned)(p.H * p.Wd * p.Cin * 2);
+    const unsigned b = sel3(r.ho, kh_), c = sel3(r.wo, kw_);
+    const bf16* src = (const bf16*)((const char*)a_chunk + ((unsigned long)a + b + c) + 2u * (unsigned)c0);
+    // bit 31 is set only by the sentinel: the launcher requires the activation volume to be < 2 GiB
+    const bool oob = p.pad_zero && ((int)(b | c) < 0 || tt < 0 || tt >= p.T);
+    return oob ? (const bf16*)ltx2_zero_row + (a_chunk - p.A) : src;
 }
 
 // Launcher of the 256x256 ping-pong kernel (gemm_pp.hip)

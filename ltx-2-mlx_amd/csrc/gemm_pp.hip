@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     // LDS row r' = (wv*2 + j)*8 + lane/8 of the 128-row half-tile; chunk swizzle on the source.
     const bf16* a_src[2][2];
     const bf16* b_src[2][2];
-    int ct[2][2], chh[2][2], cww[2][2];
+    ConvRow crow[CONV ? 2 : 1][CONV ? 2 : 1];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int rp = (wv * 2 + j) * 8 + (lane >> 3);
@@ -97,11 +97,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             const int arow = (rp >> 6) * 128 + h * 64 + (rp & 63);
             const int m = min(m0 + arow, p.M - 1);
             if (CONV) {
-                const int hw = p.H * p.Wd;
-                ct[h][j] = m / hw;
-                const int r2 = m - ct[h][j] * hw;
-                chh[h][j] = r2 / p.Wd;
-                cww[h][j] = r2 - chh[h][j] * p.Wd;
+                crow[CONV ? h : 0][CONV ? j : 0] = conv_row_setup(p, m);
                 a_src[h][j] = p.A + chunk * 8;
             } else {
                 a_src[h][j] = p.A + (long)m * p.lda + chunk * 8;
@@ -124,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             const int kw_ = tap - kt_ * 9 - kh_ * 3;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                glds16(conv_src(p, a_src[h][j], ct[h][j], chh[h][j], cww[h][j], kt_, kh_, kw_, c0), dst + j * 1024);
+                glds16(conv_src_row(p, a_src[h][j], crow[CONV ? h : 0][CONV ? j : 0], kt_, kh_, kw_, c0), dst + j * 1024);
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) glds16(a_src[h][j] + k0, dst + j * 1024);

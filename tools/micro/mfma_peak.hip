@@ -8,7 +8,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int NACC>
-__global__ __launch_bounds__(512) void mfma_loop(float* out, int iters) {
+__global__ void mfma_loop(float* out, int iters) {
     bf16x8 a, b;
     for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(threadIdx.x * 0.001f + e); b[e] = (__bf16)(1.0f - e * 0.01f); }
     f32x16 acc[NACC];
@@ -27,21 +27,25 @@ int main() {
     hipMalloc(&out, 4096 * 512 * sizeof(float));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const int NACC = 4;
-    for (int blocks_per_cu : {1, 2}) {
-        for (int iters : {20000, 200000}) {
-            const int grid = 256 * blocks_per_cu;
-            hipLaunchKernelGGL(mfma_loop<NACC>, dim3(grid), dim3(512), 0, 0, out, 1000);
-            hipDeviceSynchronize();
-            hipEventRecord(e0);
-            hipLaunchKernelGGL(mfma_loop<NACC>, dim3(grid), dim3(512), 0, 0, out, iters);
-            hipEventRecord(e1);
-            hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            const double flops = 2.0 * 32 * 32 * 16 * (double)NACC * iters * (grid * 8.0);
-            printf("grid=%d x 8 waves, %d iters: %.3f ms  %.1f TFLOP/s  (implied clock if 1024 pipes x 1024 flop/clk: %.2f GHz)\n",
-                   grid, iters, ms, flops / ms / 1e9, flops / ms / 1e6 / (1024.0 * 1024.0) / 1e3);
-        }
-    }
+    // waves per SIMD x independent accumulators per wave (a single wave issuing alone is the ping-pong GEMM's case)
+    auto run = [&](auto kern, int nacc, int threads, int blocks_per_cu) {
+        const int grid = 256 * blocks_per_cu, iters = 100000;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, 0, out, 1000);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, 0, out, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double flops = 2.0 * 32 * 32 * 16 * (double)nacc * iters * (grid * (threads / 64.0));
+        printf("waves/SIMD=%.0f  independent accumulators=%d : %7.1f TFLOP/s\n", grid * (threads / 64.0) / 1024.0, nacc, flops / ms / 1e9);
+    };
+    run(mfma_loop<2>, 2, 256, 1);
+    run(mfma_loop<4>, 4, 256, 1);
+    run(mfma_loop<8>, 8, 256, 1);
+    run(mfma_loop<2>, 2, 512, 1);
+    run(mfma_loop<4>, 4, 512, 1);
+    run(mfma_loop<8>, 8, 512, 1);
+    run(mfma_loop<4>, 4, 512, 2);
     return 0;
 }
