@@ -11,9 +11,7 @@ struct AttnParams {
     int Nq, Nkv, Npad, H;
     int head_dim;       // 128 (default when 0) or 64
     float scale_log2e;  // (1/sqrt(d)) * log2(e)
-    void* dbg;          // optional device buffer for interval timestamps (debug)
 };
 
 int attn_launch(const AttnParams& p, hipStream_t stream);
-int attn_pp_launch(const AttnParams& p, hipStream_t stream);   // 8-wave / 256-row variant (attention_pp.hip)
 int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream, int head_dim = 128);

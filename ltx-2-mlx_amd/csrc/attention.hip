@@ -17,9 +17,6 @@
 //    that key order inside every 32-key block (done once by vt_transpose_kernel), which makes the
 //    V^T fragment a single conflict-free 16-byte LDS read.
 //  * online softmax in the exp2 domain (scale * log2(e) folded into the scores), fp32 statistics.
-#include <stdlib.h>
-#include <string.h>
-
 #include "attention.h"
 
 namespace {
@@ -85,17 +82,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         const int vchunk = (lane & 7) ^ ((vr >> 1) & 7);
         v_src[j] = p.VT + (long)head * p.vt_head_stride + (long)vr * p.Npad + vchunk * 8;
     }
-    auto stage = [&](int t, int buf) {
+    // K and V^T staging of one KV tile, issued in separate pieces: a burst of 8 LDS-DMA issues stalls the wave
+    // for ~100 cycles each, spaced issues cost ~25 (measured in the GEMM's M intervals).
+    auto stage_k = [&](int t, int buf) {
         char* sk = smem + buf * STAGE + wv * (NJ * 1024);
-        char* sv = sk + K_TILE;
         const int kv0 = t * KVB;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int kr = min(kv0 + k_rowi[j], p.Nkv - 1);
             glds16(k_src[j] + (long)kr * p.ldk, sk + j * 1024);
         }
+    };
+    auto stage_v = [&](int t, int buf, int j0, int j1) {
+        char* sv = smem + buf * STAGE + wv * (NJ * 1024) + K_TILE;
+        const int kv0 = t * KVB;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) glds16(v_src[j] + kv0, sv + j * 1024);
+        for (int j = j0; j < j1; ++j) glds16(v_src[j] + kv0, sv + j * 1024);
+    };
+    auto stage = [&](int t, int buf) {
+        stage_k(t, buf);
+        stage_v(t, buf, 0, NJ);
     };
 
     f32x16 o[ND];
@@ -112,7 +118,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        const int tn = min(t + 1, nt - 1);          // the tail re-stages the last tile into the idle buffer (branch-free body)
+        stage_k(tn, (t + 1) & 1);
         const char* ks_base = smem + (t & 1) * STAGE;
         const char* vs_base = ks_base + K_TILE;
 
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             SGB_DSR(1);
         }
         SGB_MFMA(AT_DEPTH);
+        stage_v(tn, (t + 1) & 1, 0, NJ / 2);
         // ---- mask the ragged tail, running max (raw score domain; the softmax scale * log2(e) is
         //      folded into one fma in front of v_exp_f32: p = 2^(s*c - m*c)) ----
         const int kv0 = t * KVB;
@@ -182,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             }
         l_run += psum;
 
+        stage_v(tn, (t + 1) & 1, NJ / 2, NJ);
         // ---- O^T += V^T . P^T ----
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
@@ -274,14 +283,6 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.head_dim == 0 || p.head_dim == 128 || p.head_dim == 64, "attention: head_dim=%d, only 128 and 64 are implemented", p.head_dim);
     LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
     LTX2_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
-    {   // large problems: 8-wave software-pipelined variant (LTX2_ATTN=v1|pp overrides the heuristic)
-        static int ov = -1;
-        if (ov < 0) {
-            const char* e = getenv("LTX2_ATTN");
-            ov = !e ? 0 : (!strcmp(e, "v1") ? 1 : (!strcmp(e, "pp") ? 2 : 0));
-        }
-        if (ov == 2 && p.head_dim != 64) return attn_pp_launch(p, stream);   // experimental 8-wave variant: not faster yet
-    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
