@@ -83,10 +83,10 @@ int ltx2_conv3d_fused(const void* x, const void* w, const float* bias, void* out
  * PixelShuffle(2) (SpatialRationalResampler, upscaler/spatial.py:267-323).                               */
 
 /* GroupNorm over (C/groups, T, H, W) on channels-last bf16 x[P][C] (upscaler/spatial.py:89-128), fused with the
- * affine, an optional residual add and SiLU:  y = silu(gn(x) * gamma + beta + res).  sums: 2*groups floats of
- * scratch (zeroed inside).  act = 0 skips the SiLU.                                                      */
+ * affine, an optional residual add and SiLU:  y = silu(gn(x) * gamma + beta + res).  scratch: 2*groups*(1 +
+ * ceil(P/16)) floats (two-level reduction without atomics: bit-reproducible).  act = 0 skips the SiLU.   */
 int ltx2_groupnorm_silu(const void* x, const void* res, void* y, int64_t P, int C, int groups, float eps,
-                        const float* gamma, const float* beta, float* sums, int act, void* stream);
+                        const float* gamma, const float* beta, float* scratch, int act, void* stream);
 
 /* Upscaler output: x bf16 [P][C] -> out fp32 [C][P] = (x - mean[c]) / std[c]  (PerChannelStatistics.normalize,
  * video_vae/ops.py:173-186).                                                                             */

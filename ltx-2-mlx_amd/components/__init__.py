@@ -1,9 +1,9 @@
 from .diffusion_steps import EulerDiffusionStep, to_denoised, to_velocity
 from .noisers import GaussianNoiser
-from .patchifiers import VideoLatentPatchifier, get_pixel_coords
+from .patchifiers import AudioPatchifier, VideoLatentPatchifier, get_pixel_coords
 from .schedulers import (DISTILLED_SIGMA_VALUES, STAGE_2_DISTILLED_SIGMA_VALUES, LTX2Scheduler,
                          get_sigma_schedule)
 
-__all__ = ["EulerDiffusionStep", "to_denoised", "to_velocity", "GaussianNoiser", "VideoLatentPatchifier",
+__all__ = ["EulerDiffusionStep", "to_denoised", "to_velocity", "GaussianNoiser", "AudioPatchifier", "VideoLatentPatchifier",
            "get_pixel_coords", "DISTILLED_SIGMA_VALUES", "STAGE_2_DISTILLED_SIGMA_VALUES", "LTX2Scheduler",
            "get_sigma_schedule"]

@@ -1,1 +1,1 @@
-from .tools import VideoLatentTools
+from .tools import AudioLatentTools, VideoLatentTools

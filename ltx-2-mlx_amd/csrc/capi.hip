@@ -114,8 +114,8 @@ int ltx2_dequant_fp8_e4m3fn(const void* in, float scale, void* out_bf16, int64_t
 }
 
 int ltx2_groupnorm_silu(const void* x, const void* res, void* y, int64_t P, int C, int groups, float eps,
-                        const float* gamma, const float* beta, float* sums, int act, void* stream) {
-    return groupnorm_silu_launch((const bf16*)x, (const bf16*)res, (bf16*)y, P, C, groups, eps, gamma, beta, sums, act, (hipStream_t)stream);
+                        const float* gamma, const float* beta, float* scratch, int act, void* stream) {
+    return groupnorm_silu_launch((const bf16*)x, (const bf16*)res, (bf16*)y, P, C, groups, eps, gamma, beta, scratch, act, (hipStream_t)stream);
 }
 
 int ltx2_latent_normalize_nchw(const void* x, const float* mean, const float* std, float* out, int C, int64_t P, void* stream) {

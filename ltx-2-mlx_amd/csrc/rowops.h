@@ -47,9 +47,9 @@ int euler_step_launch(const float* x, const float* x0, const float* mask, const 
                       float sigma_next, float* out, int rows, int C, hipStream_t stream);
 
 // ---- spatial upscaler (channels-last bf16 [P][C]) ----
-// y = [silu]( GroupNorm_G(x over (C/G, all positions)) * gamma + beta + res );  sums: 2*G floats scratch
+// y = [silu]( GroupNorm_G(x over (C/G, all positions)) * gamma + beta + res );  scratch: 2*G*(1 + ceil(P/16)) floats
 int groupnorm_silu_launch(const bf16* x, const bf16* res, bf16* y, long P, int C, int G, float eps, const float* gamma,
-                          const float* beta, float* sums, int act, hipStream_t stream);
+                          const float* beta, float* scratch, int act, hipStream_t stream);
 // out fp32 [C][P] = (x[P][C] - mean[c]) / std[c]
 int latent_normalize_nchw_launch(const bf16* x, const float* mean, const float* stdv, float* out, int C, long P, hipStream_t stream);
 

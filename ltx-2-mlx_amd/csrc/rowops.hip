@@ -218,16 +218,16 @@ __global__ void head_gate_kernel(bf16* __restrict__ att, long ld, const float* _
 }
 
 // ---- GroupNorm (spatial upscaler): statistics over (C/G channels x all positions) per group ----
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16* __restrict__ x, float* __restrict__ sums, long P,
+// Deterministic two-level reduction (no atomics, fixed summation order => bit-reproducible statistics):
+// block b reduces rows [16b, 16b+16) to per-channel sums in LDS (every channel has exactly one owner thread),
+// then to per-group partials partial[b][2G]; groupnorm_finish_kernel folds the partials in a fixed tree.
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16* __restrict__ x, float* __restrict__ partial, long P,
                                                               int C, int G, int rows_per_block) {
-    __shared__ float bins[128];                        // [sum | sumsq] per group, G <= 64
-    if (threadIdx.x < 128) bins[threadIdx.x] = 0.f;
-    __syncthreads();
+    __shared__ float ch1[2048], ch2[2048];
     const int cpg = C / G;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < P ? r0 + rows_per_block : P;
     const int vec_per_row = C / 4;
-    // thread -> one 4-channel vector column, strided over rows
     for (int v = threadIdx.x; v < vec_per_row; v += 256) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         for (long r = r0; r < r1; ++r) {
@@ -239,24 +239,38 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16* __rest
                 s2[e] += f * f;
             }
         }
-        if (cpg % 4 == 0) {          // the 4-channel vector lies inside one group (production widths)
-            const int g = (v * 4) / cpg;
-            atomicAdd(&bins[g], s1[0] + s1[1] + s1[2] + s1[3]);
-            atomicAdd(&bins[64 + g], s2[0] + s2[1] + s2[2] + s2[3]);
-        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int g = (v * 4 + e) / cpg;
-                atomicAdd(&bins[g], s1[e]);
-                atomicAdd(&bins[64 + g], s2[e]);
-            }
+        for (int e = 0; e < 4; ++e) {
+            ch1[v * 4 + e] = s1[e];
+            ch2[v * 4 + e] = s2[e];
         }
     }
     __syncthreads();
     if (threadIdx.x < G) {
-        atomicAdd(&sums[threadIdx.x], bins[threadIdx.x]);
-        atomicAdd(&sums[G + threadIdx.x], bins[64 + threadIdx.x]);
+        float a = 0.f, b = 0.f;
+        for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
+            a += ch1[c];
+            b += ch2[c];
+        }
+        partial[(long)blockIdx.x * 2 * G + threadIdx.x] = a;
+        partial[(long)blockIdx.x * 2 * G + G + threadIdx.x] = b;
     }
+}
+
+// sums[k] = sum_b partial[b][k], k < 2G: one block per k, strided serial sums + fixed-order LDS tree
+__global__ __launch_bounds__(256) void groupnorm_finish_kernel(const float* __restrict__ partial, float* __restrict__ sums,
+                                                               int nblk, int G2) {
+    __shared__ float red[256];
+    const int k = blockIdx.x;
+    float a = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) a += partial[(long)b * G2 + k];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[k] = red[0];
 }
 
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ res,
@@ -562,16 +576,17 @@ int head_gate_launch(bf16* att, long ld, const float* logits, long ldl, int rows
 }
 
 int groupnorm_silu_launch(const bf16* x, const bf16* res, bf16* y, long P, int C, int G, float eps, const float* gamma,
-                          const float* beta, float* sums, int act, hipStream_t stream) {
-    LTX2_CHECK_ARG(x && y && gamma && beta && sums && P > 0, "groupnorm: null operand");
-    LTX2_CHECK_ARG(G >= 1 && G <= 64 && C % G == 0 && C % 4 == 0, "groupnorm: need groups <= 64, C %% groups == 0 and C %% 4 == 0 (C=%d, groups=%d)", C, G);
-    if (hipMemsetAsync(sums, 0, 2 * G * sizeof(float), stream) != hipSuccess) {
-        ltx2_set_error("groupnorm: memset failed");
-        return LTX2_E_HIP;
-    }
+                          const float* beta, float* scratch, int act, hipStream_t stream) {
+    LTX2_CHECK_ARG(x && y && gamma && beta && scratch && P > 0, "groupnorm: null operand");
+    LTX2_CHECK_ARG(G >= 1 && G <= 64 && C % G == 0 && C % 4 == 0 && C <= 2048, "groupnorm: need groups <= 64, C %% groups == 0, C %% 4 == 0, C <= 2048 (C=%d, groups=%d)", C, G);
     const int rows_per_block = 16;
-    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((int)((P + rows_per_block - 1) / rows_per_block)), dim3(256), 0, stream, x, sums, P, C, G, rows_per_block);
+    const int nblk = (int)((P + rows_per_block - 1) / rows_per_block);
+    float* sums = scratch;                 // [2G]
+    float* partial = scratch + 2 * G;      // [nblk][2G]
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(nblk), dim3(256), 0, stream, x, partial, P, C, G, rows_per_block);
     LTX2_CHECK_LAUNCH("groupnorm_stats_kernel");
+    hipLaunchKernelGGL(groupnorm_finish_kernel, dim3(2 * G), dim3(256), 0, stream, partial, sums, nblk, 2 * G);
+    LTX2_CHECK_LAUNCH("groupnorm_finish_kernel");
     const long n4 = P * C / 4;
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(grid), dim3(256), 0, stream, x, res, y, sums, gamma, beta, n4, C, G,

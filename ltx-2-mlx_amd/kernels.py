@@ -114,7 +114,7 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     C = x.shape[-1]
     P = x.numel() // C
     y = torch.empty_like(x)
-    sums = torch.empty(2 * groups, device=x.device, dtype=torch.float32)
+    sums = torch.empty(2 * groups * (1 + (P + 15) // 16), device=x.device, dtype=torch.float32)
     nv.check(nv.lib().ltx2_groupnorm_silu(nv.ptr(x), nv.ptr(res), nv.ptr(y), P, C, groups, eps, nv.ptr(_c(gamma.float())),
                                           nv.ptr(_c(beta.float())), nv.ptr(sums), int(act), nv.stream()))
     return y

@@ -1,5 +1,5 @@
-from .common import modality_from_state, post_process_latent, timesteps_from_mask
+from .common import audio_modality_from_state, modality_from_state, post_process_latent, timesteps_from_mask
 from .distilled import DistilledConfig, DistilledPipeline, create_distilled_pipeline
 
-__all__ = ["modality_from_state", "post_process_latent", "timesteps_from_mask", "DistilledConfig", "DistilledPipeline",
+__all__ = ["audio_modality_from_state", "modality_from_state", "post_process_latent", "timesteps_from_mask", "DistilledConfig", "DistilledPipeline",
            "create_distilled_pipeline"]

@@ -23,3 +23,8 @@ def modality_from_state(state: LatentState, context: torch.Tensor, sigma: float,
     return Modality(enabled=enabled, latent=state.latent, timesteps=timesteps_from_mask(state.denoise_mask, sigma),
                     positions=state.positions, context=context, context_mask=None,
                     sigma=torch.tensor([sigma], device=state.latent.device))
+
+
+def audio_modality_from_state(state: LatentState, context: torch.Tensor, sigma: float, enabled: bool = True) -> Modality:
+    """Same record for the audio modality (reference pipelines/common.py:235-262)."""
+    return modality_from_state(state, context, sigma, enabled)

@@ -4,7 +4,8 @@ Mirrors reference LTX_2_MLX/pipelines/distilled.py:48-98 (DistilledConfig), :101
 (constructor), :198-272 (_denoise_loop_av, video branch) and :274-505 (__call__): stage 1 at half
 resolution with DISTILLED_SIGMA_VALUES (8 steps), optional latent 2x upscale + stage 2 with
 STAGE_2_DISTILLED_SIGMA_VALUES (3 steps), then VAE decode (tiled above 4000 latent voxels).
-Audio branches and image conditioning are outside this path (scope table).
+The joint audio+video branch runs on AudioVideo transformers and returns the audio latent; audio VAE / vocoder
+decode and image conditioning are outside this path (scope table).
 """
 from __future__ import annotations
 
@@ -13,14 +14,14 @@ from typing import Callable, List, Optional, Sequence, Union
 
 import torch
 
-from ..components import (DISTILLED_SIGMA_VALUES, STAGE_2_DISTILLED_SIGMA_VALUES, EulerDiffusionStep, GaussianNoiser,
-                          VideoLatentPatchifier)
-from ..conditioning.tools import VideoLatentTools
+from ..components import (DISTILLED_SIGMA_VALUES, STAGE_2_DISTILLED_SIGMA_VALUES, AudioPatchifier, EulerDiffusionStep,
+                          GaussianNoiser, VideoLatentPatchifier)
+from ..conditioning.tools import AudioLatentTools, VideoLatentTools
 from ..model.transformer import LTXModel, LTXModelType, Modality, X0Model
 from ..model.upscaler import SpatialUpscaler, upscale_latent
 from ..model.video_vae import SimpleVideoDecoder, TilingConfig, decode_latent, decode_tiled
-from ..types import LatentState, VideoLatentShape, VideoPixelShape
-from .common import modality_from_state, post_process_latent
+from ..types import AudioLatentShape, LatentState, VideoLatentShape, VideoPixelShape
+from .common import audio_modality_from_state, modality_from_state, post_process_latent
 
 
 @dataclass
@@ -34,6 +35,12 @@ class DistilledConfig:
     dtype: torch.dtype = torch.float32
     audio_enabled: bool = False
     use_internal_audio_branch: bool = True
+    audio_vae_channels: int = 8
+    audio_mel_bins: int = 16
+    audio_sample_rate: int = 16000
+    audio_hop_length: int = 160
+    audio_downsample_factor: int = 4
+    audio_output_sample_rate: int = 24000
     use_hip_graph: bool = False    # MI355X addition: replay the captured step loop (uniform sigma only)
 
     def _get_tiling_config(self) -> Optional[TilingConfig]:
@@ -58,7 +65,7 @@ class DistilledPipeline:
         inner = self.transformer.velocity_model
         self.is_av_model = getattr(inner, "model_type", None) == LTXModelType.AudioVideo
         if audio_decoder is not None or vocoder is not None:
-            raise NotImplementedError("audio decode is outside the MI355X hot path")
+            raise NotImplementedError("audio VAE / vocoder decode is outside the MI355X hot path (the audio latent is returned)")
         self.video_encoder = video_encoder
         self.video_decoder = video_decoder
         self.spatial_upscaler = spatial_upscaler
@@ -68,59 +75,106 @@ class DistilledPipeline:
     def _create_video_tools(self, target_shape: VideoLatentShape, fps: float) -> VideoLatentTools:
         return VideoLatentTools(patchifier=self.patchifier, target_shape=target_shape, fps=fps)
 
-    def _denoise_loop_av(self, video_state: LatentState, audio_state, sigmas: Sequence[float], video_context: torch.Tensor,
-                         audio_context=None, stepper: Optional[EulerDiffusionStep] = None,
-                         callback: Optional[Callable[[int, int], None]] = None, use_hip_graph: bool = False):
-        """Per step: Modality(mask*sigma) -> X0 -> post_process -> Euler.  Two equivalent
-        executions: (a) API-faithful, one X0Model call + EulerDiffusionStep per step; (b) fused
-        ltx2_dit_denoise_step / hipGraph replay when no callback needs intermediate states."""
+    def _create_audio_tools(self, target_shape: AudioLatentShape) -> AudioLatentTools:
+        return AudioLatentTools(patchifier=AudioPatchifier(patch_size=1), target_shape=target_shape)
+
+    @staticmethod
+    def _channelwise_normalize_audio(latent: torch.Tensor) -> torch.Tensor:
+        """Length-invariant audio noise (reference pipelines/distilled.py:165-187): global zero-mean / unit-std
+        (population std), then per-feature standardisation over the token axis."""
+        x = (latent - latent.mean()) / (latent.std(unbiased=False) + 1e-8)
+        return (x - x.mean(dim=1, keepdim=True)) / (x.std(dim=1, keepdim=True, unbiased=False) + 1e-8)
+
+    def _denoise_loop_av(self, video_state: LatentState, audio_state: Optional[LatentState], sigmas: Sequence[float],
+                         video_context: torch.Tensor, audio_context: Optional[torch.Tensor] = None,
+                         stepper: Optional[EulerDiffusionStep] = None, callback: Optional[Callable[[int, int], None]] = None,
+                         use_hip_graph: bool = False):
+        """Joint audio+video loop (reference pipelines/distilled.py:198-271).  Per step: Modality(mask*sigma) ->
+        X0 -> post_process -> Euler, per modality.  Two equivalent executions: (a) API-faithful, one X0Model call +
+        EulerDiffusionStep per step; (b) hipGraph replay of the fused steps when the denoise masks are uniform
+        and no callback needs intermediate states."""
         sig = [float(s) for s in sigmas]
         n = len(sig) - 1
         model = self.transformer.velocity_model
+        joint = self.is_av_model and audio_state is not None
+        if self.is_av_model and not joint:
+            raise NotImplementedError("video-only inference on an AudioVideo model: build a VideoOnly LTXModel from the same weights")
+        if joint and audio_context is None:
+            raise ValueError("AudioVideo model: audio_encoding (the audio text context) is required")
         if use_hip_graph and callback is None:
-            lat = video_state.latent[0].float().contiguous()
-            mask = video_state.denoise_mask.reshape(-1)
-            if not bool((mask == 1).all()):
+            states = [video_state] + ([audio_state] if joint else [])
+            if not all(bool((st.denoise_mask == 1).all()) for st in states):
                 raise ValueError("hipGraph replay needs a uniform denoise mask (no conditioning tokens)")
-            model.prepare(video_context, video_state.positions)
+            lat = video_state.latent[0].float().contiguous()
+            alat = audio_state.latent[0].float().contiguous() if joint else None
+            if joint:
+                model.prepare(video_context, video_state.positions, audio_context=audio_context, audio_positions=audio_state.positions)
+            else:
+                model.prepare(video_context, video_state.positions)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                model.capture_denoise_graph(lat, sig)
+                model.capture_denoise_graph(lat, sig, audio_latent=alat)
                 model.replay_denoise_graph()
             torch.cuda.current_stream().wait_stream(side)
-            return video_state.replace(latent=lat[None].to(video_state.latent.dtype)), audio_state
+            video_state = video_state.replace(latent=lat[None].to(video_state.latent.dtype))
+            if joint:
+                audio_state = audio_state.replace(latent=alat[None].to(audio_state.latent.dtype))
+            return video_state, audio_state
+        step = stepper or self.diffusion_step
         for i in range(n):
-            m = modality_from_state(video_state, video_context, sig[i])
-            x0 = self.transformer(m)
-            x0 = post_process_latent(x0, video_state.denoise_mask, video_state.clean_latent)
-            new = (stepper or self.diffusion_step).step(sample=video_state.latent, denoised_sample=x0, sigmas=sig, step_index=i)
-            video_state = video_state.replace(latent=new)
+            vm = modality_from_state(video_state, video_context, sig[i])
+            if joint:
+                vx0, ax0 = self.transformer(vm, audio_modality_from_state(audio_state, audio_context, sig[i]))
+            else:
+                vx0, ax0 = self.transformer(vm), None
+            vx0 = post_process_latent(vx0, video_state.denoise_mask, video_state.clean_latent)
+            video_state = video_state.replace(latent=step.step(sample=video_state.latent, denoised_sample=vx0, sigmas=sig, step_index=i))
+            if joint:
+                ax0 = post_process_latent(ax0, audio_state.denoise_mask, audio_state.clean_latent)
+                audio_state = audio_state.replace(latent=step.step(sample=audio_state.latent, denoised_sample=ax0, sigmas=sig, step_index=i))
             if callback:
                 callback(i + 1, n)
         return video_state, audio_state
 
     def __call__(self, text_encoding: torch.Tensor, text_mask: Optional[torch.Tensor], config: DistilledConfig,
                  images: Optional[List] = None, callback: Optional[Callable[[str, int, int], None]] = None,
-                 audio_encoding=None, initial_noise: Optional[torch.Tensor] = None):
+                 audio_encoding: Optional[torch.Tensor] = None, initial_noise: Optional[torch.Tensor] = None,
+                 initial_audio_noise: Optional[torch.Tensor] = None):
+        """Returns the decoded video (uint8 frames, or the final latent when no decoder is set); with
+        config.audio_enabled on an AudioVideo model, the tuple (video, audio_latent) -- the audio VAE / vocoder
+        that turn the (B, 8, T_a, 16) latent into a waveform are outside this path."""
         if images:
             raise NotImplementedError("image conditioning needs the VAE encoder (scope row f4)")
-        if config.audio_enabled:
-            raise NotImplementedError("audio generation is outside the MI355X hot path")
         dev = self.transformer.velocity_model.device
         gen = torch.Generator(device=dev).manual_seed(config.seed)
         noiser = GaussianNoiser(generator=gen)
+        audio_active = self.is_av_model and (config.use_internal_audio_branch or config.audio_enabled)
+        if config.audio_enabled and not self.is_av_model:
+            raise ValueError("audio_enabled needs an AudioVideo transformer")
+        actx = audio_encoding.to(dev) if audio_encoding is not None else None
+
+        def audio_shape(pix: VideoPixelShape) -> AudioLatentShape:
+            return AudioLatentShape.from_video_pixel_shape(pix, channels=config.audio_vae_channels, mel_bins=config.audio_mel_bins,
+                                                           sample_rate=config.audio_sample_rate, hop_length=config.audio_hop_length,
+                                                           audio_latent_downsample_factor=config.audio_downsample_factor)
 
         s1 = VideoPixelShape(batch=1, frames=config.num_frames, height=config.height // 2, width=config.width // 2, fps=config.fps)
         shape1 = VideoLatentShape.from_pixel_shape(s1, latent_channels=128)
         tools = self._create_video_tools(shape1, config.fps)
         state = tools.create_initial_state(dtype=config.dtype, device=dev)
         state = noiser(state, noise_scale=1.0, noise=initial_noise)
+        astate, atools = None, None
+        if audio_active:
+            atools = self._create_audio_tools(audio_shape(s1))
+            astate = noiser(atools.create_initial_state(dtype=config.dtype, device=dev), noise_scale=1.0, noise=initial_audio_noise)
+            astate = astate.replace(latent=self._channelwise_normalize_audio(astate.latent))
         cb1 = (lambda s, t: callback("stage1", s, t)) if callback else None
-        state, _ = self._denoise_loop_av(state, None, DISTILLED_SIGMA_VALUES, text_encoding.to(dev), callback=cb1,
-                                         use_hip_graph=config.use_hip_graph)
+        state, astate = self._denoise_loop_av(state, astate, DISTILLED_SIGMA_VALUES, text_encoding.to(dev), actx, callback=cb1,
+                                              use_hip_graph=config.use_hip_graph)
         state = tools.unpatchify(tools.clear_conditioning(state))
         final_latent = state.latent
+        audio_latent = atools.unpatchify(atools.clear_conditioning(astate)).latent if astate is not None else None
 
         if self.spatial_upscaler is not None:
             # un_normalize -> upscaler -> normalize (reference pipelines/distilled.py:394-405); the statistics
@@ -135,19 +189,29 @@ class DistilledPipeline:
             s2 = VideoPixelShape(batch=1, frames=config.num_frames, height=config.height, width=config.width, fps=config.fps)
             tools2 = self._create_video_tools(VideoLatentShape.from_pixel_shape(s2, latent_channels=128), config.fps)
             state2 = tools2.create_initial_state(dtype=config.dtype, initial_latent=up)
-            state2 = noiser(state2, noise_scale=float(STAGE_2_DISTILLED_SIGMA_VALUES[0]))
+            sigma0 = float(STAGE_2_DISTILLED_SIGMA_VALUES[0])
+            state2 = noiser(state2, noise_scale=sigma0)
+            astate2, atools2 = None, None
+            if audio_active:        # no spatial upscaling for audio: stage 1's latent is re-noised (reference :441-458)
+                atools2 = self._create_audio_tools(audio_shape(s2))
+                astate2 = noiser(atools2.create_initial_state(dtype=config.dtype, initial_latent=audio_latent), noise_scale=sigma0)
             cb2 = (lambda s, t: callback("stage2", s, t)) if callback else None
-            state2, _ = self._denoise_loop_av(state2, None, STAGE_2_DISTILLED_SIGMA_VALUES, text_encoding.to(dev), callback=cb2,
-                                              use_hip_graph=config.use_hip_graph)
+            state2, astate2 = self._denoise_loop_av(state2, astate2, STAGE_2_DISTILLED_SIGMA_VALUES, text_encoding.to(dev), actx,
+                                                    callback=cb2, use_hip_graph=config.use_hip_graph)
             final_latent = tools2.unpatchify(tools2.clear_conditioning(state2)).latent
+            if astate2 is not None:
+                audio_latent = atools2.unpatchify(atools2.clear_conditioning(astate2)).latent
 
         if self.video_decoder is None:
-            return final_latent
-        tiling = config._get_tiling_config()
-        if tiling:
-            chunks = list(decode_tiled(final_latent, self.video_decoder, tiling))
-            return torch.cat(chunks, dim=2) if len(chunks) > 1 else chunks[0]
-        return decode_latent(final_latent, self.video_decoder)
+            video = final_latent
+        else:
+            tiling = config._get_tiling_config()
+            if tiling:
+                chunks = list(decode_tiled(final_latent, self.video_decoder, tiling))
+                video = torch.cat(chunks, dim=2) if len(chunks) > 1 else chunks[0]
+            else:
+                video = decode_latent(final_latent, self.video_decoder)
+        return (video, audio_latent) if config.audio_enabled else video
 
 
 def create_distilled_pipeline(transformer, video_encoder, video_decoder, spatial_upscaler=None, audio_decoder=None, vocoder=None):

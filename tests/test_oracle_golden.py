@@ -209,3 +209,32 @@ def test_upscaler_matches_reference():
     x = torch.randn(1, 64, 3, 5, 6, generator=torch.Generator().manual_seed(77))
     with torch.no_grad():
         close(upscaler.spatial_upscaler(x, w, num_blocks=2), z["upscaled"], rtol=2e-4, atol=2e-5)
+
+
+def test_audio_host_logic_matches_reference():
+    """Product host-side audio helpers (AudioLatentShape, AudioPatchifier, AudioLatentTools, the length-invariant
+    audio noise normalisation of DistilledPipeline) and the oracle's audio_positions against the reference."""
+    from oracle import dit_av
+    from ltx_2_mlx_amd.components import AudioPatchifier
+    from ltx_2_mlx_amd.conditioning import AudioLatentTools
+    from ltx_2_mlx_amd.pipelines import DistilledPipeline
+    from ltx_2_mlx_amd.types import AudioLatentShape, VideoPixelShape
+    z = g("loop.npz")
+    shp = AudioLatentShape.from_video_pixel_shape(VideoPixelShape(batch=1, frames=65, height=512, width=768, fps=24.0))
+    assert list(shp.to_tuple()) == list(z["audio_shape_65f_24fps"])
+    st = AudioLatentTools(patchifier=AudioPatchifier(patch_size=1), target_shape=AudioLatentShape(1, 8, 11, 16)).create_initial_state()
+    close(st.positions, z["audio_positions_11"], rtol=1e-6, atol=1e-7)
+    close(dit_av.audio_positions(1, 11), z["audio_positions_11"], rtol=1e-6, atol=1e-7)
+    assert st.latent.shape == (1, 11, 128) and st.denoise_mask.shape == (1, 11, 1)
+    gen = torch.Generator().manual_seed(5)
+    # advance the stream exactly as pin_loop does before its audio draws
+    torch.randn(1, 24, 128, generator=gen)
+    torch.randn(1, 24, 128, generator=gen)
+    torch.rand(1, 24, 1, generator=gen)
+    torch.randn(1, 128, 3, 4, 5, generator=gen)
+    alat = torch.randn(1, 8, 11, 16, generator=gen)
+    close(AudioPatchifier(patch_size=1).patchify(alat), z["audio_patchify"], rtol=0, atol=0)
+    tools = AudioLatentTools(patchifier=AudioPatchifier(patch_size=1), target_shape=AudioLatentShape(1, 8, 11, 16))
+    assert torch.equal(AudioPatchifier(patch_size=1).unpatchify(AudioPatchifier(patch_size=1).patchify(alat), tools.target_shape), alat)
+    anoise = torch.randn(1, 37, 128, generator=gen) * 1.7 + 0.3
+    close(DistilledPipeline._channelwise_normalize_audio(anoise), z["audio_channelwise_normalize"], rtol=1e-4, atol=1e-5)

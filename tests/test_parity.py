@@ -400,3 +400,30 @@ def test_two_stage_pipeline_with_upscaler(dev):
         assert lat.shape == (1, 128, 3, 8, 12) and bool(torch.isfinite(lat).all())
         outs.append(lat)
     assert rel_l2(outs[1], outs[0]) < 1e-4
+
+
+@pytest.mark.parametrize("v23", [False, True])
+def test_av_distilled_pipeline(dev, v23):
+    """BASELINE config 4 plumbing at toy size: DistilledPipeline on an AudioVideo transformer -- joint audio+video
+    stage 1, upscale, joint stage 2 with the re-noised stage-1 audio latent -- returns (video latent, audio latent);
+    the per-step API and the hipGraph replay agree."""
+    from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler
+    from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline
+    cfg, w, wq, m = make_av(dev, v23, seed=9)
+    vcfg, vw, d = make_vae(dev, layers=1)
+    up = SpatialUpscaler(in_channels=128, mid_channels=64, num_blocks_per_stage=1, device=dev)
+    up.init_random_weights(seed=3)
+    g = torch.Generator().manual_seed(2)
+    cv, ca = (cfg.caption_channels or cfg.inner_dim), (cfg.caption_channels or cfg.audio_inner_dim)
+    vctx, actx = 0.1 * torch.randn(1, 40, cv, generator=g), 0.1 * torch.randn(1, 40, ca, generator=g)
+    pipe = DistilledPipeline(m, d, None, spatial_upscaler=up)          # decoder object only provides the latent statistics
+    outs = []
+    for graph in (False, True):
+        conf = DistilledConfig(height=256, width=384, num_frames=17, seed=1, fps=24.0, audio_enabled=True, use_hip_graph=graph)
+        video, audio = pipe(vctx.to(dev), None, conf, audio_encoding=actx.to(dev))
+        assert video.shape == (1, 128, 3, 8, 12) and audio.shape == (1, 8, 18, 16)        # 17 frames / 24 fps * 25 latents/s
+        assert bool(torch.isfinite(video).all()) and bool(torch.isfinite(audio).all())
+        outs.append((video, audio))
+    assert rel_l2(outs[1][0], outs[0][0]) < 1e-4 and rel_l2(outs[1][1], outs[0][1]) < 1e-4
+    with pytest.raises(ValueError, match="audio_encoding"):
+        pipe(vctx.to(dev), None, DistilledConfig(height=256, width=384, num_frames=17, audio_enabled=True))

@@ -6,8 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES
 from ltx_2_mlx_amd.model.transformer import LTXModel, LTXModelType, Modality
-from oracle.dit_av import audio_positions          # position helper only (host-side table)
-from oracle.loop import video_positions
+from ltx_2_mlx_amd.components import AudioPatchifier, VideoLatentPatchifier
+from ltx_2_mlx_amd.conditioning import AudioLatentTools, VideoLatentTools
+from ltx_2_mlx_amd.types import AudioLatentShape, VideoLatentShape
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--v1", action="store_true", help="19B-style AV blocks (6-row AdaLN, caption projection, cached text K/V)")
@@ -25,7 +26,8 @@ vlat = torch.randn(N, 128, generator=g, device=dev)
 alat = torch.randn(Na, 128, generator=g, device=dev)
 vctx = 0.1 * torch.randn(1, S, 4096 if v23 else 3840, generator=g, device=dev)
 actx = 0.1 * torch.randn(1, S, 2048 if v23 else 3840, generator=g, device=dev)
-vpos, apos = video_positions(1, 9, 16, 24, 24.0).to(dev), audio_positions(1, Na).to(dev)
+vpos = VideoLatentTools(VideoLatentPatchifier(1), VideoLatentShape(1, 128, 9, 16, 24), fps=24.0).create_initial_state(device=dev).positions
+apos = AudioLatentTools(AudioPatchifier(1), AudioLatentShape(1, 8, Na, 16)).create_initial_state(device=dev).positions
 t0 = time.time()
 m.prepare(vctx, vpos, audio_context=actx, audio_positions=apos)
 torch.cuda.synchronize()

@@ -196,6 +196,19 @@ def pin_loop():
     out["positions_3x4x5_fps24"] = tn(st.positions.t)
     lat5 = torch.randn(1, 128, 3, 4, 5, generator=g)
     out["patchify"] = tn(VideoLatentPatchifier(patch_size=1).patchify(A(lat5)).t)
+    # audio side of the loop helpers (AudioVideo pipelines)
+    from LTX_2_MLX.components.patchifiers import AudioPatchifier
+    from LTX_2_MLX.conditioning.tools import AudioLatentTools
+    from LTX_2_MLX.pipelines.distilled import DistilledPipeline
+    from LTX_2_MLX.types import AudioLatentShape, VideoPixelShape
+    ashape = AudioLatentShape.from_video_pixel_shape(VideoPixelShape(batch=1, frames=65, height=512, width=768, fps=24.0))
+    out["audio_shape_65f_24fps"] = np.array(ashape.to_tuple())
+    ast = AudioLatentTools(patchifier=AudioPatchifier(patch_size=1), target_shape=AudioLatentShape(1, 8, 11, 16)).create_initial_state()
+    out["audio_positions_11"] = tn(ast.positions.t)
+    alat = torch.randn(1, 8, 11, 16, generator=g)
+    out["audio_patchify"] = tn(AudioPatchifier(patch_size=1).patchify(A(alat)).t)
+    anoise = torch.randn(1, 37, 128, generator=g) * 1.7 + 0.3
+    out["audio_channelwise_normalize"] = tn(DistilledPipeline._channelwise_normalize_audio(A(anoise)).t)
     np.savez_compressed(os.path.join(GOLD, "loop.npz"), **out)
     print("loop.npz", {k: v.shape for k, v in out.items()})
 
