@@ -79,6 +79,7 @@ int ltx2_conv3d_fused(const void* x, const void* w, const float* bias, void* out
                       int Cout, int causal, int mode, const void* res, int ft, int fh, int fw, int residual,
                       int pad_zero, int kt, void* stream);
 /* pad_zero = 1: zero padding in T/H/W instead of reflect/replicate (spatial upscaler, upscaler/spatial.py:20-87);
+ * pad_zero = 2: zero padding in H/W, replicated temporal edge (VAE encoder Conv3dSimple, simple_encoder.py:44-75);
  * kt = 1: per-frame 3x3 conv2d (weight [Cout][9*Cin]); with mode 2, ft=1, fh=fw=2 the epilogue is
  * PixelShuffle(2) (SpatialRationalResampler, upscaler/spatial.py:267-323).                               */
 
@@ -87,6 +88,13 @@ int ltx2_conv3d_fused(const void* x, const void* w, const float* bias, void* out
  * ceil(P/16)) floats (two-level reduction without atomics: bit-reproducible).  act = 0 skips the SiLU.   */
 int ltx2_groupnorm_silu(const void* x, const void* res, void* y, int64_t P, int C, int groups, float eps,
                         const float* gamma, const float* beta, float* scratch, int act, void* stream);
+
+/* VAE encoder SpaceToDepthDownsample3d tail (simple_encoder.py:183-257): y = conv(x') [T][H][W][Cc] and the conv
+ * input x' [T][H][W][Cin] (first frame already duplicated when st = 2) ->
+ * out[T/st][H/sh][W/sw][Cc*sp] = space_to_depth(y) + group_mean(space_to_depth(x')), sp = st*sh*sw,
+ * channel c*sp + (a*sh + b)*sw + d, groups of Cin*sp / (Cc*sp) consecutive space-to-depth channels.      */
+int ltx2_s2d_downsample(const void* y, const void* x, void* out, int T, int H, int W, int Cc, int Cin, int st, int sh,
+                        int sw, void* stream);
 
 /* Upscaler output: x bf16 [P][C] -> out fp32 [C][P] = (x - mean[c]) / std[c]  (PerChannelStatistics.normalize,
  * video_vae/ops.py:173-186).                                                                             */

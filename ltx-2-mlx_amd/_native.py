@@ -48,6 +48,7 @@ SIGNATURES = {
     "ltx2_gemv_f32": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "ltx2_conv3d_fused": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ltx2_groupnorm_silu": (i32, [vp, vp, vp, i64, i32, i32, f32, vp, vp, vp, i32, vp]),
+    "ltx2_s2d_downsample": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ltx2_latent_normalize_nchw": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "ltx2_adaln_rmsnorm": (i32, [vp, i64, vp, i64, i32, i32, f32, i32, vp, vp, vp, vp, i64, vp]),
     "ltx2_qknorm_rope": (i32, [vp, i64, i32, i32, i32, i32, vp, i32, vp, f32, vp, vp, vp]),

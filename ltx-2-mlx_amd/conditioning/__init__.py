@@ -1,1 +1,2 @@
+from .latent import ConditioningError, VideoConditionByLatentIndex
 from .tools import AudioLatentTools, VideoLatentTools

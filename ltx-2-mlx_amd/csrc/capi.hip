@@ -118,6 +118,11 @@ int ltx2_groupnorm_silu(const void* x, const void* res, void* y, int64_t P, int 
     return groupnorm_silu_launch((const bf16*)x, (const bf16*)res, (bf16*)y, P, C, groups, eps, gamma, beta, scratch, act, (hipStream_t)stream);
 }
 
+int ltx2_s2d_downsample(const void* y, const void* x, void* out, int T, int H, int W, int Cc, int Cin, int st, int sh,
+                        int sw, void* stream) {
+    return s2d_downsample_launch((const bf16*)y, (const bf16*)x, (bf16*)out, T, H, W, Cc, Cin, st, sh, sw, (hipStream_t)stream);
+}
+
 int ltx2_latent_normalize_nchw(const void* x, const float* mean, const float* std, float* out, int C, int64_t P, void* stream) {
     return latent_normalize_nchw_launch((const bf16*)x, mean, std, out, C, P, (hipStream_t)stream);
 }

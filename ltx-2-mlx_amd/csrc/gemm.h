@@ -26,7 +26,8 @@ struct GemmParams {
     // conv geometry (implicit GEMM): M = T*H*Wd output positions, stride 1, 3x3x3
     int T, H, Wd, Cin, cin_shift, pad_front;
     int taps_t;          // temporal kernel size: 3 (3x3x3) or 1 (per-frame 3x3); K = 9*taps_t*Cin
-    int pad_zero;        // 0: reflect H/W + replicate T (VAE decoder); 1: zero padding in T/H/W (spatial upscaler)
+    int pad_zero;        // 0: reflect H/W + replicate T (VAE decoder); 1: zero padding in T/H/W (spatial upscaler);
+                         // 2: zero padding in H/W + replicate T (VAE encoder)
     // depth-to-space epilogue: column n = s*Cf + c, s = (a*fh + b)*fw + d
     int ft, fh, fw, Cf, cf_shift, drop_first, d2s_residual, c_d2s;
     void* dbg;           // ping-pong kernel: optional device buffer for interval timestamps (debug)      // ping-pong kernel: which wave bit selects the staggered group (tuning knob)

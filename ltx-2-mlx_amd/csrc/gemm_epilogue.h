@@ -82,7 +82,8 @@ __device__ static const unsigned int ltx2_zero_row[32] = {0};
 // vertical and three horizontal neighbours with the padding rule already applied (computed once per row; the
 // per-K-tile address is then three uniform 3-way selects and three adds instead of ~30 VALU instructions of
 // clamp / reflect / 64-bit multiply per LDS-DMA issue).  Padding: replicate in T, reflect in H/W (reference
-// simple_decoder.py:105-134), or zero padding in all three dims when pad_zero (upscaler/spatial.py:44-52), where
+// simple_decoder.py:105-134); pad_zero = 1: zero padding in all three dims (upscaler/spatial.py:44-52); pad_zero = 2:
+// zero padding in H/W with the replicated (causal) temporal edge of the VAE encoder (simple_encoder.py:56-75);
 // 0xffffffff marks an out-of-range tap whose LDS-DMA source becomes the zero row.
 struct ConvRow {
     unsigned ho[3], wo[3];      // vertical / horizontal neighbour offsets (bytes), padding rule applied
@@ -98,7 +99,7 @@ __device__ __forceinline__ ConvRow conv_row_setup(const GemmParams& p, int m) {
     for (int k = 0; k < 3; ++k) {
         int hh = h + k - 1, ww = w + k - 1;
         bool ho_ok = true, wo_ok = true;
-        if (p.pad_zero) {
+        if (p.pad_zero) {           // 1: zero padding in T/H/W; 2: zero padding in H/W, replicate in T
             ho_ok = hh >= 0 && hh < p.H;
             wo_ok = ww >= 0 && ww < p.Wd;
         } else {
@@ -121,8 +122,9 @@ __device__ __forceinline__ const bf16* conv_src_row(const GemmParams& p, const b
     const unsigned b = sel3(r.ho, kh_), c = sel3(r.wo, kw_);
     const bf16* src = (const bf16*)((const char*)a_chunk + ((unsigned long)a + b + c) + 2u * (unsigned)c0);
     // bit 31 is set only by the sentinel: the launcher requires the activation volume to be < 2 GiB
-    const bool oob = p.pad_zero && ((int)(b | c) < 0 || tt < 0 || tt >= p.T);
-    return oob ? (const bf16*)ltx2_zero_row + (a_chunk - p.A) : src;
+    const bool hw_oob = (int)(b | c) < 0;                                   // sentinels exist only when pad_zero != 0
+    const bool t_oob = p.pad_zero == 1 && (tt < 0 || tt >= p.T);
+    return (hw_oob || t_oob) ? (const bf16*)ltx2_zero_row + (a_chunk - p.A) : src;
 }
 
 // Launcher of the 256x256 ping-pong kernel (gemm_pp.hip)

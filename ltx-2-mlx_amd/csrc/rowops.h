@@ -50,6 +50,9 @@ int euler_step_launch(const float* x, const float* x0, const float* mask, const 
 // y = [silu]( GroupNorm_G(x over (C/G, all positions)) * gamma + beta + res );  scratch: 2*G*(1 + ceil(P/16)) floats
 int groupnorm_silu_launch(const bf16* x, const bf16* res, bf16* y, long P, int C, int G, float eps, const float* gamma,
                           const float* beta, float* scratch, int act, hipStream_t stream);
+// VAE encoder downsample tail: out = space_to_depth(y) + group_mean(space_to_depth(x))   (see ltx2hip.h)
+int s2d_downsample_launch(const bf16* y, const bf16* x, bf16* out, int T, int H, int W, int Cc, int Cin, int st, int sh, int sw,
+                          hipStream_t stream);
 // out fp32 [C][P] = (x[P][C] - mean[c]) / std[c]
 int latent_normalize_nchw_launch(const bf16* x, const float* mean, const float* stdv, float* out, int C, long P, hipStream_t stream);
 

@@ -217,6 +217,30 @@ __global__ void head_gate_kernel(bf16* __restrict__ att, long ld, const float* _
     }
 }
 
+// out[t'][h'][w'][co] = y_s2d[co] + mean_{q in group co} x_s2d[q]   (VAE encoder downsample, see ltx2hip.h)
+__global__ __launch_bounds__(256) void s2d_downsample_kernel(const bf16* __restrict__ y, const bf16* __restrict__ x,
+                                                             bf16* __restrict__ out, int T, int H, int W, int Cc, int Cin,
+                                                             int st, int sh, int sw, long n) {
+    const int sp = st * sh * sw, Cout = Cc * sp, gs = Cin / Cc;
+    const int To = T / st, Ho = H / sh, Wo = W / sw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        long pos = i / Cout;
+        const int wo = (int)(pos % Wo);
+        pos /= Wo;
+        const int ho = (int)(pos % Ho), to = (int)(pos / Ho);
+        (void)To;
+        auto src_pos = [&](int s) {
+            const int a = s / (sh * sw), b = (s / sw) % sh, d = s % sw;
+            return ((long)(to * st + a) * H + (ho * sh + b)) * W + (wo * sw + d);
+        };
+        float v = bf2f(y[src_pos(co % sp) * Cc + co / sp]);
+        float m = 0.f;
+        for (int q = co * gs; q < (co + 1) * gs; ++q) m += bf2f(x[src_pos(q % sp) * Cin + q / sp]);
+        out[i] = f2bf(v + m / (float)gs);
+    }
+}
+
 // ---- GroupNorm (spatial upscaler): statistics over (C/G channels x all positions) per group ----
 // Deterministic two-level reduction (no atomics, fixed summation order => bit-reproducible statistics):
 // block b reduces rows [16b, 16b+16) to per-channel sums in LDS (every channel has exactly one owner thread),
@@ -572,6 +596,17 @@ int head_gate_launch(bf16* att, long ld, const float* logits, long ldl, int rows
     const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
     hipLaunchKernelGGL(head_gate_kernel, dim3(grid), dim3(256), 0, stream, att, ld, logits, ldl, n8, per_row8, hd);
     LTX2_CHECK_LAUNCH("head_gate_kernel");
+    return LTX2_OK;
+}
+
+int s2d_downsample_launch(const bf16* y, const bf16* x, bf16* out, int T, int H, int W, int Cc, int Cin, int st, int sh, int sw,
+                          hipStream_t stream) {
+    LTX2_CHECK_ARG(y && x && out && T > 0 && H > 0 && W > 0, "s2d_downsample: bad argument");
+    LTX2_CHECK_ARG(st >= 1 && sh >= 1 && sw >= 1 && T % st == 0 && H % sh == 0 && W % sw == 0, "s2d_downsample: dims must divide by the stride");
+    LTX2_CHECK_ARG(Cc > 0 && Cin % Cc == 0, "s2d_downsample: Cin=%d must be a multiple of the conv width %d", Cin, Cc);
+    const long n = (long)(T / st) * (H / sh) * (W / sw) * Cc * st * sh * sw;
+    hipLaunchKernelGGL(s2d_downsample_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, y, x, out, T, H, W, Cc, Cin, st, sh, sw, n);
+    LTX2_CHECK_LAUNCH("s2d_downsample_kernel");
     return LTX2_OK;
 }
 

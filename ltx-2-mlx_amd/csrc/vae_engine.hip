@@ -125,7 +125,7 @@ int ltx2_conv3d_fused(const void* x, const void* w, const float* bias, void* out
                       int pad_zero, int kt, void* stream) {
     LTX2_CHECK_ARG(x && w && out, "conv3d: null operand");
     LTX2_CHECK_ARG(kt == 3 || kt == 1, "conv3d: temporal kernel size %d (3 or 1)", kt);
-    LTX2_CHECK_ARG(!(pad_zero && causal), "conv3d: causal padding is a replicate-pad mode");
+    LTX2_CHECK_ARG(pad_zero >= 0 && pad_zero <= 2 && !(pad_zero == 1 && causal), "conv3d: pad_zero in {0,1,2}; causal needs a replicate-T mode (0 or 2)");
     LTX2_CHECK_ARG(mode >= 0 && mode <= 2, "conv3d: mode %d", mode);
     LTX2_CHECK_ARG(mode != 1 || res, "conv3d: mode 1 needs a residual tensor");
     const int epi = mode == 0 ? EPI_BF16 : (mode == 1 ? EPI_ADD_BF16 : EPI_D2S_BF16);

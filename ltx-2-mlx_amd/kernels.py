@@ -74,10 +74,10 @@ def conv_bias_to_engine(b: torch.Tensor, d2s_stride: Optional[Tuple[int, int, in
 
 def conv3d(x: torch.Tensor, w_engine: torch.Tensor, bias: Optional[torch.Tensor], causal: bool = False, mode: int = 0,
            res: Optional[torch.Tensor] = None, stride: Tuple[int, int, int] = (1, 1, 1), residual: bool = False,
-           pad_zero: bool = False) -> torch.Tensor:
+           pad_zero: int = 0) -> torch.Tensor:
     """x bf16 [T,H,W,Cin] channels-last; w_engine [Cout][27 or 9][Cin] from conv_weight_to_engine /
-    conv2d_weight_to_engine (9 taps = per-frame 3x3 conv).  pad_zero: zero padding (spatial upscaler)
-    instead of the VAE's reflect/replicate."""
+    conv2d_weight_to_engine (9 taps = per-frame 3x3 conv).  pad_zero: 0 reflect H/W + replicate T (VAE decoder),
+    1 / True zero padding in T/H/W (spatial upscaler), 2 zero padding in H/W + replicate T (VAE encoder)."""
     assert x.dtype == BF16 and x.dim() == 4 and w_engine.dtype == BF16
     x = _c(x)
     T, H, W, Cin = x.shape
@@ -118,6 +118,17 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     nv.check(nv.lib().ltx2_groupnorm_silu(nv.ptr(x), nv.ptr(res), nv.ptr(y), P, C, groups, eps, nv.ptr(_c(gamma.float())),
                                           nv.ptr(_c(beta.float())), nv.ptr(sums), int(act), nv.stream()))
     return y
+
+
+def s2d_downsample(y: torch.Tensor, x: torch.Tensor, stride: Tuple[int, int, int]) -> torch.Tensor:
+    """space_to_depth(y) + group_mean(space_to_depth(x)) on channels-last bf16 [T,H,W,C] (VAE encoder downsample)."""
+    assert y.dtype == BF16 and x.dtype == BF16 and y.shape[:3] == x.shape[:3]
+    y, x = _c(y), _c(x)
+    T, H, W, Cc = y.shape
+    st, sh, sw = stride
+    out = torch.empty(T // st, H // sh, W // sw, Cc * st * sh * sw, device=y.device, dtype=BF16)
+    nv.check(nv.lib().ltx2_s2d_downsample(nv.ptr(y), nv.ptr(x), nv.ptr(out), T, H, W, Cc, x.shape[3], st, sh, sw, nv.stream()))
+    return out
 
 
 def latent_unnormalize_nhwc(latent: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:

@@ -1,5 +1,7 @@
-from .common import audio_modality_from_state, modality_from_state, post_process_latent, timesteps_from_mask
+from .common import (ImageCondition, apply_conditionings, audio_modality_from_state, create_image_conditionings, load_image_tensor,
+                     modality_from_state, post_process_latent, timesteps_from_mask)
 from .distilled import DistilledConfig, DistilledPipeline, create_distilled_pipeline
 
-__all__ = ["audio_modality_from_state", "modality_from_state", "post_process_latent", "timesteps_from_mask", "DistilledConfig", "DistilledPipeline",
+__all__ = ["ImageCondition", "apply_conditionings", "create_image_conditionings", "load_image_tensor",
+           "audio_modality_from_state", "modality_from_state", "post_process_latent", "timesteps_from_mask", "DistilledConfig", "DistilledPipeline",
            "create_distilled_pipeline"]

@@ -5,7 +5,8 @@ Mirrors reference LTX_2_MLX/pipelines/distilled.py:48-98 (DistilledConfig), :101
 resolution with DISTILLED_SIGMA_VALUES (8 steps), optional latent 2x upscale + stage 2 with
 STAGE_2_DISTILLED_SIGMA_VALUES (3 steps), then VAE decode (tiled above 4000 latent voxels).
 The joint audio+video branch runs on AudioVideo transformers and returns the audio latent; audio VAE / vocoder
-decode and image conditioning are outside this path (scope table).
+decode is outside this path (scope table).  Image conditioning encodes the image with the VAE encoder
+and runs the per-token-sigma path of the DiT.
 """
 from __future__ import annotations
 
@@ -21,7 +22,8 @@ from ..model.transformer import LTXModel, LTXModelType, Modality, X0Model
 from ..model.upscaler import SpatialUpscaler, upscale_latent
 from ..model.video_vae import SimpleVideoDecoder, TilingConfig, decode_latent, decode_tiled
 from ..types import AudioLatentShape, LatentState, VideoLatentShape, VideoPixelShape
-from .common import audio_modality_from_state, modality_from_state, post_process_latent
+from .common import (apply_conditionings, audio_modality_from_state, create_image_conditionings, modality_from_state,
+                     post_process_latent)
 
 
 @dataclass
@@ -101,10 +103,9 @@ class DistilledPipeline:
             raise NotImplementedError("video-only inference on an AudioVideo model: build a VideoOnly LTXModel from the same weights")
         if joint and audio_context is None:
             raise ValueError("AudioVideo model: audio_encoding (the audio text context) is required")
-        if use_hip_graph and callback is None:
-            states = [video_state] + ([audio_state] if joint else [])
-            if not all(bool((st.denoise_mask == 1).all()) for st in states):
-                raise ValueError("hipGraph replay needs a uniform denoise mask (no conditioning tokens)")
+        states = [video_state] + ([audio_state] if joint else [])
+        uniform = all(bool((st.denoise_mask == 1).all()) for st in states)        # no conditioning tokens
+        if use_hip_graph and callback is None and uniform:
             lat = video_state.latent[0].float().contiguous()
             alat = audio_state.latent[0].float().contiguous() if joint else None
             if joint:
@@ -144,8 +145,7 @@ class DistilledPipeline:
         """Returns the decoded video (uint8 frames, or the final latent when no decoder is set); with
         config.audio_enabled on an AudioVideo model, the tuple (video, audio_latent) -- the audio VAE / vocoder
         that turn the (B, 8, T_a, 16) latent into a waveform are outside this path."""
-        if images:
-            raise NotImplementedError("image conditioning needs the VAE encoder (scope row f4)")
+        images = images or []
         dev = self.transformer.velocity_model.device
         gen = torch.Generator(device=dev).manual_seed(config.seed)
         noiser = GaussianNoiser(generator=gen)
@@ -163,6 +163,9 @@ class DistilledPipeline:
         shape1 = VideoLatentShape.from_pixel_shape(s1, latent_channels=128)
         tools = self._create_video_tools(shape1, config.fps)
         state = tools.create_initial_state(dtype=config.dtype, device=dev)
+        # image conditioning at stage-1 resolution: encoded latent replaces the tokens of its latent frame and
+        # lowers their denoise mask (reference pipelines/distilled.py:326-333)
+        state = apply_conditionings(state, create_image_conditionings(images, self.video_encoder, s1.height, s1.width, config.dtype), tools)
         state = noiser(state, noise_scale=1.0, noise=initial_noise)
         astate, atools = None, None
         if audio_active:
@@ -189,6 +192,7 @@ class DistilledPipeline:
             s2 = VideoPixelShape(batch=1, frames=config.num_frames, height=config.height, width=config.width, fps=config.fps)
             tools2 = self._create_video_tools(VideoLatentShape.from_pixel_shape(s2, latent_channels=128), config.fps)
             state2 = tools2.create_initial_state(dtype=config.dtype, initial_latent=up)
+            state2 = apply_conditionings(state2, create_image_conditionings(images, self.video_encoder, s2.height, s2.width, config.dtype), tools2)
             sigma0 = float(STAGE_2_DISTILLED_SIGMA_VALUES[0])
             state2 = noiser(state2, noise_scale=sigma0)
             astate2, atools2 = None, None

@@ -238,3 +238,37 @@ def test_audio_host_logic_matches_reference():
     assert torch.equal(AudioPatchifier(patch_size=1).unpatchify(AudioPatchifier(patch_size=1).patchify(alat), tools.target_shape), alat)
     anoise = torch.randn(1, 37, 128, generator=gen) * 1.7 + 0.3
     close(DistilledPipeline._channelwise_normalize_audio(anoise), z["audio_channelwise_normalize"], rtol=1e-4, atol=1e-5)
+
+
+def test_vae_encoder_matches_reference():
+    """VAE encoder oracle (full-size widths, the reference hard-wires them) against the reference's
+    SimpleVideoEncoder on one image and on a 9-frame clip."""
+    from oracle import vae_encoder
+    z = g("vae_encoder.npz")
+    w = vae_encoder.make_encoder_weights(seed=51)
+    gen = torch.Generator().manual_seed(52)
+    img = torch.rand(1, 3, 1, 64, 64, generator=gen) * 2 - 1
+    clip = torch.rand(1, 3, 9, 64, 96, generator=gen) * 2 - 1
+    with torch.no_grad():
+        close(vae_encoder.encoder_forward(img, w), z["image_latent"], rtol=5e-4, atol=5e-5)
+        close(vae_encoder.encoder_forward(clip, w), z["clip_latent"], rtol=5e-4, atol=5e-5)
+    with pytest.raises(ValueError, match="1 \\+ 8\\*k frames"):
+        vae_encoder.encoder_forward(torch.zeros(1, 3, 4, 64, 64), w)
+
+
+def test_latent_index_conditioning_matches_reference():
+    """Product VideoConditionByLatentIndex.apply_to against the reference (strength 0.8 at latent frame 0)."""
+    from ltx_2_mlx_amd.components import VideoLatentPatchifier
+    from ltx_2_mlx_amd.conditioning import ConditioningError, VideoConditionByLatentIndex, VideoLatentTools
+    from ltx_2_mlx_amd.types import VideoLatentShape
+    z = g("vae_encoder.npz")
+    tools = VideoLatentTools(VideoLatentPatchifier(1), VideoLatentShape(1, 128, 3, 2, 2), fps=24.0)
+    st = tools.create_initial_state()
+    st2 = VideoConditionByLatentIndex(latent=torch.from_numpy(z["image_latent"]), strength=0.8, latent_idx=0).apply_to(st, tools)
+    close(st2.latent, z["cond_latent"], rtol=0, atol=0)
+    close(st2.denoise_mask, z["cond_mask"], rtol=1e-6, atol=1e-7)
+    close(st2.clean_latent, z["cond_clean"], rtol=0, atol=0)
+    with pytest.raises(ConditioningError):
+        VideoConditionByLatentIndex(latent=torch.zeros(1, 128, 1, 3, 2), strength=1.0, latent_idx=0).apply_to(st, tools)
+    with pytest.raises(ValueError, match="exceed latent sequence length"):
+        VideoConditionByLatentIndex(latent=torch.zeros(1, 128, 2, 2, 2), strength=1.0, latent_idx=2).apply_to(st, tools)

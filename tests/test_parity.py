@@ -427,3 +427,52 @@ def test_av_distilled_pipeline(dev, v23):
     assert rel_l2(outs[1][0], outs[0][0]) < 1e-4 and rel_l2(outs[1][1], outs[0][1]) < 1e-4
     with pytest.raises(ValueError, match="audio_encoding"):
         pipe(vctx.to(dev), None, DistilledConfig(height=256, width=384, num_frames=17, audio_enabled=True))
+
+
+def test_vae_encoder_and_image_conditioning(dev, tmp_path):
+    """Scope row f4: SimpleVideoEncoder on the GPU vs the fp32 oracle and the reference vectors (one image, one
+    9-frame clip), then image-to-video through DistilledPipeline: with strength 1.0 the conditioned latent frame
+    leaves the loop exactly as encoded; a PNG on disk goes through load_image_tensor."""
+    import numpy as np
+    import os
+    from oracle import vae_encoder as oenc
+    from ltx_2_mlx_amd.model.video_vae_encoder import SimpleVideoEncoder
+    from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline, ImageCondition, load_image_tensor
+    w = oenc.make_encoder_weights(seed=51)
+    wq = {k: (v.to(torch.bfloat16).float() if v.dim() == 5 else v) for k, v in w.items()}
+    enc = SimpleVideoEncoder(device=dev)
+    enc.load_state_dict(w)
+    gen = torch.Generator().manual_seed(52)
+    img = torch.rand(1, 3, 1, 64, 64, generator=gen) * 2 - 1
+    clip = torch.rand(1, 3, 9, 64, 96, generator=gen) * 2 - 1
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vae_encoder.npz"))
+    for name, x in (("image_latent", img), ("clip_latent", clip)):
+        out = enc(x.to(dev))
+        ref = oenc.encoder_forward(x, wq)
+        assert out.shape == ref.shape and out.dtype == torch.float32
+        assert rel_l2(out.cpu(), ref) < 5e-2 and pearson(out.cpu(), ref) > 0.998, name
+        assert rel_l2(out.cpu(), torch.from_numpy(z[name])) < 6e-2, name
+    # image-to-video: 256x384x17 -> stage-1 128x192 image, latent 3x4x6
+    cfg, wd, m = make_dit(dev, heads=2, layers=2, cap=128)
+    g = torch.Generator().manual_seed(2)
+    ctx = 0.1 * torch.randn(1, 64, 128, generator=g)
+    image = torch.rand(1, 3, 1, 128, 192, generator=g) * 2 - 1
+    pipe = DistilledPipeline(m, enc, None)
+    conf = DistilledConfig(height=256, width=384, num_frames=17, seed=1, use_hip_graph=True)     # falls back to per-step (non-uniform mask)
+    lat = pipe(ctx.to(dev), None, conf, images=[ImageCondition(None, 0, 1.0, image=image)])
+    enc_lat = enc(image.to(dev))
+    assert lat.shape == (1, 128, 3, 4, 6)
+    assert rel_l2(lat[:, :, 0], enc_lat[:, :, 0]) < 1e-5                  # frame 0 kept clean
+    assert float((lat[:, :, 1:] - 0).abs().mean()) > 0.05 and bool(torch.isfinite(lat).all())
+    lat2 = pipe(ctx.to(dev), None, conf, images=[ImageCondition(None, 0, 0.5, image=image)])
+    assert rel_l2(lat2[:, :, 0], enc_lat[:, :, 0]) > 1e-3                 # partially denoised
+    from PIL import Image
+    arr = (np.random.RandomState(0).rand(100, 140, 3) * 255).astype(np.uint8)
+    path = str(tmp_path / "cond.png")
+    Image.fromarray(arr).save(path)
+    t = load_image_tensor(path, 128, 192)
+    assert t.shape == (1, 3, 1, 128, 192) and float(t.min()) >= -1.0 and float(t.max()) <= 1.0
+    lat3 = pipe(ctx.to(dev), None, conf, images=[ImageCondition(path, 0, 1.0)])
+    assert lat3.shape == (1, 128, 3, 4, 6) and bool(torch.isfinite(lat3).all())
+    with pytest.raises(FileNotFoundError):
+        pipe(ctx.to(dev), None, conf, images=[ImageCondition(str(tmp_path / "missing.png"), 0, 1.0)])

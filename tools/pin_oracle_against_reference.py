@@ -25,6 +25,7 @@ A = shim.Arr
 from oracle import dit as odit  # noqa: E402
 from oracle import dit_av as oav  # noqa: E402
 from oracle import upscaler as oup  # noqa: E402
+from oracle import vae_encoder as oenc  # noqa: E402
 from oracle import loop as oloop  # noqa: E402
 from oracle import vae as ovae  # noqa: E402
 
@@ -170,6 +171,46 @@ def pin_upscaler():
     out = {"upscaled": tn(up(A(x)).t)}
     np.savez_compressed(os.path.join(GOLD, "upscaler_tiny.npz"), **out)
     print("upscaler_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------------ VAE encoder + conditioning
+def pin_vae_encoder():
+    """The reference hard-wires the encoder widths (128..1024, 28 res blocks), so the full-size encoder runs on
+    tiny inputs: one 64x64 image (image conditioning) and a 9-frame 64x96 clip (temporal downsampling)."""
+    from LTX_2_MLX.components.patchifiers import VideoLatentPatchifier
+    from LTX_2_MLX.conditioning.latent import VideoConditionByLatentIndex
+    from LTX_2_MLX.conditioning.tools import VideoLatentTools
+    from LTX_2_MLX.model.video_vae.simple_encoder import SimpleVideoEncoder
+    from LTX_2_MLX.types import VideoLatentShape
+    w = oenc.make_encoder_weights(seed=51)
+    enc = SimpleVideoEncoder(compute_dtype=mx.float32)
+    enc.per_channel_statistics.mean_of_means = A(w["vae.per_channel_statistics.mean-of-means"])
+    enc.per_channel_statistics.std_of_means = A(w["vae.per_channel_statistics.std-of-means"])
+    for sfx in ("weight", "bias"):
+        setattr(enc.conv_in, sfx, A(w[f"vae.encoder.conv_in.conv.{sfx}"]))
+        setattr(enc.conv_out, sfx, A(w[f"vae.encoder.conv_out.conv.{sfx}"]))
+    for i, (kind, arg) in enumerate(oenc.DEFAULT_BLOCKS):
+        blk = getattr(enc, f"down_blocks_{i}")
+        for sfx in ("weight", "bias"):
+            if kind == "res":
+                for j, rb in enumerate(blk.res_blocks):
+                    setattr(rb.conv1, sfx, A(w[f"vae.encoder.down_blocks.{i}.res_blocks.{j}.conv1.conv.{sfx}"]))
+                    setattr(rb.conv2, sfx, A(w[f"vae.encoder.down_blocks.{i}.res_blocks.{j}.conv2.conv.{sfx}"]))
+            else:
+                setattr(blk.conv, sfx, A(w[f"vae.encoder.down_blocks.{i}.conv.conv.{sfx}"]))
+    g = torch.Generator().manual_seed(52)
+    img = torch.rand(1, 3, 1, 64, 64, generator=g) * 2 - 1
+    clip = torch.rand(1, 3, 9, 64, 96, generator=g) * 2 - 1
+    out = {"image_latent": tn(enc(A(img), show_progress=False).t), "clip_latent": tn(enc(A(clip), show_progress=False).t)}
+    # VideoConditionByLatentIndex on a 3x2x2 latent grid, strength 0.8 at latent frame 0
+    shp = VideoLatentShape(batch=1, channels=128, frames=3, height=2, width=2)
+    tools = VideoLatentTools(patchifier=VideoLatentPatchifier(patch_size=1), target_shape=shp, fps=24.0)
+    st = tools.create_initial_state()
+    cond = VideoConditionByLatentIndex(latent=A(torch.from_numpy(out["image_latent"])), strength=0.8, latent_idx=0)
+    st2 = cond.apply_to(st, tools)
+    out["cond_latent"], out["cond_mask"], out["cond_clean"] = tn(st2.latent.t), tn(st2.denoise_mask.t), tn(st2.clean_latent.t)
+    np.savez_compressed(os.path.join(GOLD, "vae_encoder.npz"), **out)
+    print("vae_encoder.npz", {k: v.shape for k, v in out.items()})
 
 # ------------------------------------------------------------------------------------------ loop helpers
 def pin_loop():
@@ -324,5 +365,6 @@ if __name__ == "__main__":
         pin_dit()
         pin_dit_av()
         pin_upscaler()
+        pin_vae_encoder()
         pin_vae()
     print("golden vectors written to", GOLD)
