@@ -5,7 +5,8 @@ Keeps the flag names and `generate_video(...)` keyword names of the reference's
 scripts/generate.py (argparse block :2364-2641, `generate_video` :933-997) for this path:
 standard single-stage distilled loop (reference :1764-1984) followed by `decode_latent` (:2080-2091).
 Out of this path (and rejected with a clear message): Gemma text encoding, audio, CFG/STG guidance,
-image conditioning, LoRA, ffmpeg muxing.  Text embeddings come from `--embedding file.npz` (keys
+LoRA, ffmpeg muxing.  `--image` conditions latent frame 0 on an image through the VAE encoder (the reference
+routes that through its pipelines, scripts/generate.py:1711-1731).  Text embeddings come from `--embedding file.npz` (keys
 `embedding`, `attention_mask`, as the reference's `load_text_embedding` :730-750) or the reference's
 dummy encoder (`--no-gemma`, :642-661).  Frames are written as `<output>.npz` (uint8 T,H,W,3) and
 the final latent as `<output>_latent.npz` like the reference (:1994-1996).
@@ -24,6 +25,7 @@ sys.path.insert(0, ROOT)
 from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES, VideoLatentPatchifier, get_pixel_coords, get_sigma_schedule  # noqa: E402
 from ltx_2_mlx_amd.model.transformer import LTXModel, Modality, X0Model  # noqa: E402
 from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder, TilingConfig, decode_latent, decode_tiled, load_vae_decoder_weights  # noqa: E402
+from ltx_2_mlx_amd.model.video_vae_encoder import SimpleVideoEncoder, load_vae_encoder_weights  # noqa: E402
 from ltx_2_mlx_amd.types import SpatioTemporalScaleFactors, VideoLatentShape  # noqa: E402
 
 
@@ -64,7 +66,8 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
                    seed: int = 42, output_path: str = "output.mp4", weights_path=None, embedding_path=None,
                    use_gemma: bool = False, model_variant: str = "distilled", skip_vae: bool = False, use_placeholder: bool = False,
                    tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, use_fp8: bool = False, num_layers: int = 48,
-                   num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", **unsupported):
+                   num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", image_path=None,
+                   image_strength: float = 0.95, **unsupported):
     for k, v in unsupported.items():
         if v:
             raise NotImplementedError(f"--{k.replace('_', '-')} is outside the MI355X hot path (see DESIGN.md)")
@@ -107,6 +110,22 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
     if use_placeholder:
         for i in range(len(sigmas) - 1):
             tok = tok + 0.1 * torch.randn_like(tok) * (sigmas[i + 1] - sigmas[i])
+    elif image_path:
+        # image-to-video: encoded image replaces latent frame 0, its tokens keep (1 - strength) of the noise level
+        from ltx_2_mlx_amd.conditioning import VideoLatentTools
+        from ltx_2_mlx_amd.components import GaussianNoiser
+        from ltx_2_mlx_amd.pipelines import DistilledPipeline, ImageCondition, apply_conditionings, create_image_conditionings
+        enc = SimpleVideoEncoder(device=device)
+        if weights_path:
+            load_vae_encoder_weights(enc, weights_path)
+        else:
+            enc.init_random_weights(seed=seed + 2)
+        tools = VideoLatentTools(patchifier, shape, fps=24.0)
+        st = tools.create_initial_state(device=device)
+        st = apply_conditionings(st, create_image_conditionings([ImageCondition(image_path, 0, image_strength)], enc, height, width), tools)
+        st = GaussianNoiser()(st, noise_scale=1.0, noise=tok)
+        st, _ = DistilledPipeline(model, enc, None)._denoise_loop_av(st, None, sigmas, text_encoding, use_hip_graph=use_hip_graph)
+        tok = st.latent
     elif use_hip_graph:
         vm = model.velocity_model
         vm.prepare(text_encoding, positions)
@@ -170,6 +189,7 @@ def main():
     p.add_argument("--fast-mode", action="store_true")
     p.add_argument("--no-hip-graph", action="store_true", help="MI355X: run the step loop eagerly instead of replaying the captured hipGraph")
     p.add_argument("--image", type=str, default=None)
+    p.add_argument("--image-strength", type=float, default=0.95)
     p.add_argument("--lora", type=str, default=None)
     p.add_argument("--generate-audio", action="store_true")
     p.add_argument("--spatial-upscaler-weights", type=str, default=None)
@@ -186,7 +206,7 @@ def main():
                    use_gemma=bool(a.gemma_path) and not a.no_gemma, model_variant=a.model_variant, skip_vae=a.skip_vae,
                    use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, cfg_scale=a.cfg, use_hip_graph=not a.no_hip_graph, use_fp8=a.fp8,
                    num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,
-                   image=a.image, lora=a.lora, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights)
+                   image_path=a.image, image_strength=a.image_strength, lora=a.lora, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights)
 
 
 if __name__ == "__main__":

@@ -27,4 +27,12 @@ def test_generate_cli_plumbing(dev, tmp_path):
     with pytest.raises(ValueError, match="8\\*k \\+ 1"):
         generate.generate_video("x", num_frames=16, **{k: v for k, v in kw.items() if k != "num_frames"})
     with pytest.raises(NotImplementedError):
-        generate.generate_video("x", image="cond.png", **kw)
+        generate.generate_video("x", lora="style.safetensors", **kw)
+    # --image: the conditioned latent frame survives the loop at strength 1.0 (image-to-video through the VAE encoder)
+    from PIL import Image
+    Image.fromarray((np.random.RandomState(1).rand(256, 384, 3) * 255).astype(np.uint8)).save(tmp_path / "cond.png")
+    generate.generate_video("a test prompt", output_path=str(tmp_path / "c.mp4"), image_path=str(tmp_path / "cond.png"),
+                            image_strength=1.0, skip_vae=True, **kw)
+    lc = np.load(tmp_path / "c_latent.npz")["latent"]
+    assert lc.shape == (1, 128, 3, 8, 12) and np.isfinite(lc).all()
+    assert np.abs(lc[:, :, 0] - la[:, :, 0]).mean() > 0.05
