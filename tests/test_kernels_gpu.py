@@ -357,3 +357,17 @@ def test_groupnorm_silu(K, dev, P, C, G, with_res):
     ref = F.silu(y + (res if with_res else 0))
     out = K.groupnorm_silu(x.to(dev, BF), gamma.to(dev), beta.to(dev), G, res=res.to(dev, BF) if with_res else None)
     assert rel_l2(out.float().cpu(), ref) < 6e-3
+
+
+def test_conv3d_baseline_stage_size(K, dev):
+    """The VAE decoder's heaviest stage geometry (H=128, W=192, 128 -> 128 channels at 768x512) on 5 frames against
+    the oracle conv: exercises the multi-row-tile grid and reflect/replicate taps at full spatial size."""
+    from oracle import vae
+    T, H, W, C = 5, 128, 192, 128
+    g = torch.Generator().manual_seed(11)
+    x = q(torch.randn(1, C, T, H, W, generator=g))
+    w = q(torch.randn(C, C, 3, 3, 3, generator=g) / math.sqrt(27 * C))
+    b = torch.randn(C, generator=g)
+    ref = vae.conv3d_simple(x, w, b, causal=False)[0].permute(1, 2, 3, 0)
+    out = K.conv3d(x[0].permute(1, 2, 3, 0).contiguous().to(dev, BF), K.conv_weight_to_engine(w).to(dev), b.to(dev))
+    assert rel_l2(out.float().cpu(), ref) < 6e-3

@@ -91,6 +91,24 @@ def test_dit_full_width_block(dev):
     assert rel_l2(v.cpu(), ref) < 2e-2 and pearson(v.cpu(), ref) > 0.999
 
 
+def test_dit_baseline_size_block(dev):
+    """BASELINE.json config 2 geometry: one full-width block at the full 768x512x65 token count (N=3456, S=1024,
+    D=4096) against the fp32 oracle -- exercises the 224-row ping-pong GEMM grid (16x16 / 16x64 tiles), the
+    attention tail tile (3456 = 54 KV tiles) and the text cross-attention at the sizes bench.py measures."""
+    from oracle import dit
+    from ltx_2_mlx_amd.model.transformer import Modality
+    cfg, w, m = make_dit(dev, heads=32, layers=1, cap=3840, seed=8)
+    lat, ctx, pos = inputs(9, 16, 24, 1024, 3840, seed=77)
+    sigma = torch.tensor([0.725])
+    ref = dit.velocity_model(lat, ctx, sigma, pos, w, cfg)
+    v = m(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
+    assert v.shape == (1, 3456, 128)
+    assert rel_l2(v.cpu(), ref) < 2e-2 and pearson(v.cpu(), ref) > 0.999
+    # determinism: the video path has no atomics -- a second call is bit-identical
+    v2 = m(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
+    assert torch.equal(v, v2)
+
+
 def test_denoise_loop_and_graph(dev):
     """8 distilled steps (CLI loop, scripts/generate.py:1797-1979): API-faithful loop, fused C step
     and hipGraph replay all agree with the oracle (and the two fused forms with each other)."""
