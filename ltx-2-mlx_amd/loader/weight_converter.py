@@ -37,12 +37,15 @@ def is_fp8_checkpoint(weights_path: str) -> bool:
 
 
 def load_transformer_weights(model, weights_path: str, strict: bool = False, use_fp8: bool = False,
-                             include_audio: bool = False, streaming: bool = True, target_dtype: str = "bfloat16") -> None:
+                             include_audio: bool = False, streaming: bool = True, target_dtype: str = "bfloat16",
+                             lora_configs=None) -> None:
     """Load `model.diffusion_model.*` tensors into an LTXModel (weight_converter.py:318-446).
 
     use_fp8: dequantise fp8 weights with their `weight_scale` (ignored `input_scale`, fp8_loader.py:87-97);
     include_audio: keep audio / av_ca / a2v keys (AudioVideo model); `streaming` and `target_dtype` are
-    accepted for signature compatibility (loading always streams; the resident dtype is bf16)."""
+    accepted for signature compatibility (loading always streams; the resident dtype is bf16);
+    lora_configs: LoRAConfig list fused into the checkpoint-keyed weights on the GPU before they are packed
+    (reference loader/lora_loader.py:129-194)."""
     from safetensors import safe_open
     dev = model.device
     sd: Dict[str, torch.Tensor] = {}
@@ -71,6 +74,9 @@ def load_transformer_weights(model, weights_path: str, strict: bool = False, use
                 n_fp8 += 1
             else:
                 sd[key] = t.to(dev, non_blocking=True)
+    if lora_configs:
+        from .lora_loader import fuse_lora_into_weights
+        sd = fuse_lora_into_weights(sd, lora_configs)
     model.load_state_dict(sd, strict=strict)
     print(f"  loaded {len(sd)} transformer tensors ({n_fp8} dequantised from fp8) from {weights_path}")
 

@@ -5,7 +5,7 @@ Keeps the flag names and `generate_video(...)` keyword names of the reference's
 scripts/generate.py (argparse block :2364-2641, `generate_video` :933-997) for this path:
 standard single-stage distilled loop (reference :1764-1984) followed by `decode_latent` (:2080-2091).
 Out of this path (and rejected with a clear message): Gemma text encoding, audio, CFG/STG guidance,
-LoRA, ffmpeg muxing.  `--image` conditions latent frame 0 on an image through the VAE encoder (the reference
+ffmpeg muxing.  `--lora` fuses an adapter into the checkpoint weights at load.  `--image` conditions latent frame 0 on an image through the VAE encoder (the reference
 routes that through its pipelines, scripts/generate.py:1711-1731).  Text embeddings come from `--embedding file.npz` (keys
 `embedding`, `attention_mask`, as the reference's `load_text_embedding` :730-750) or the reference's
 dummy encoder (`--no-gemma`, :642-661).  Frames are written as `<output>.npz` (uint8 T,H,W,3) and
@@ -44,13 +44,18 @@ def load_text_embedding(path: str, device="cuda"):
     return emb.to(device), mask.to(device)
 
 
-def load_transformer(weights_path, num_layers=48, num_heads=32, caption_channels=3840, seed=0, device="cuda", use_fp8=False):
+def load_transformer(weights_path, num_layers=48, num_heads=32, caption_channels=3840, seed=0, device="cuda", use_fp8=False,
+                     lora_path=None, lora_strength=1.0):
     """LTXModel(VideoOnly, 32x128, 48 layers, caption 3840) (reference load_transformer :788-835)."""
     model = LTXModel(num_attention_heads=num_heads, attention_head_dim=128, num_layers=num_layers,
                      caption_channels=caption_channels, device=device)
     if weights_path:
         from ltx_2_mlx_amd.loader import is_fp8_checkpoint, load_transformer_weights
-        load_transformer_weights(model, weights_path, strict=True, use_fp8=use_fp8 or is_fp8_checkpoint(weights_path))
+        from ltx_2_mlx_amd.loader import LoRAConfig
+        load_transformer_weights(model, weights_path, strict=True, use_fp8=use_fp8 or is_fp8_checkpoint(weights_path),
+                                 lora_configs=[LoRAConfig(lora_path, lora_strength)] if lora_path else None)
+    elif lora_path:
+        raise ValueError("--lora needs --weights (an adapter is fused into checkpoint weights)")
     else:
         model.init_random_weights(seed=seed)
     return model
@@ -67,7 +72,7 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
                    use_gemma: bool = False, model_variant: str = "distilled", skip_vae: bool = False, use_placeholder: bool = False,
                    tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, use_fp8: bool = False, num_layers: int = 48,
                    num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", image_path=None,
-                   image_strength: float = 0.95, **unsupported):
+                   image_strength: float = 0.95, lora_path=None, lora_strength: float = 1.0, **unsupported):
     for k, v in unsupported.items():
         if v:
             raise NotImplementedError(f"--{k.replace('_', '-')} is outside the MI355X hot path (see DESIGN.md)")
@@ -84,7 +89,8 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
     print("[1/5] text encoding")
     text_encoding, _ = load_text_embedding(embedding_path, device) if embedding_path else create_dummy_text_encoding(prompt, device=device)
     print("[2/5] transformer")
-    model = X0Model(load_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device, use_fp8=use_fp8))
+    model = X0Model(load_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device, use_fp8=use_fp8,
+                                     lora_path=lora_path, lora_strength=lora_strength))
     print("[3/5] VAE decoder")
     vae_decoder = None
     if not skip_vae:
@@ -191,6 +197,7 @@ def main():
     p.add_argument("--image", type=str, default=None)
     p.add_argument("--image-strength", type=float, default=0.95)
     p.add_argument("--lora", type=str, default=None)
+    p.add_argument("--lora-strength", type=float, default=1.0)
     p.add_argument("--generate-audio", action="store_true")
     p.add_argument("--spatial-upscaler-weights", type=str, default=None)
     p.add_argument("--layers", type=int, default=48, help="debug: number of DiT layers for random-weight runs")
@@ -206,7 +213,7 @@ def main():
                    use_gemma=bool(a.gemma_path) and not a.no_gemma, model_variant=a.model_variant, skip_vae=a.skip_vae,
                    use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, cfg_scale=a.cfg, use_hip_graph=not a.no_hip_graph, use_fp8=a.fp8,
                    num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,
-                   image_path=a.image, image_strength=a.image_strength, lora=a.lora, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights)
+                   image_path=a.image, image_strength=a.image_strength, lora_path=a.lora, lora_strength=a.lora_strength, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights)
 
 
 if __name__ == "__main__":

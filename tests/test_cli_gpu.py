@@ -27,7 +27,9 @@ def test_generate_cli_plumbing(dev, tmp_path):
     with pytest.raises(ValueError, match="8\\*k \\+ 1"):
         generate.generate_video("x", num_frames=16, **{k: v for k, v in kw.items() if k != "num_frames"})
     with pytest.raises(NotImplementedError):
-        generate.generate_video("x", lora="style.safetensors", **kw)
+        generate.generate_video("x", generate_audio=True, **kw)
+    with pytest.raises(ValueError, match="--lora needs --weights"):
+        generate.generate_video("x", lora_path="style.safetensors", **kw)
     # --image: the conditioned latent frame survives the loop at strength 1.0 (image-to-video through the VAE encoder)
     from PIL import Image
     Image.fromarray((np.random.RandomState(1).rand(256, 384, 3) * 255).astype(np.uint8)).save(tmp_path / "cond.png")

@@ -494,3 +494,42 @@ def test_vae_encoder_and_image_conditioning(dev, tmp_path):
     assert lat3.shape == (1, 128, 3, 4, 6) and bool(torch.isfinite(lat3).all())
     with pytest.raises(FileNotFoundError):
         pipe(ctx.to(dev), None, conf, images=[ImageCondition(str(tmp_path / "missing.png"), 0, 1.0)])
+
+
+def test_lora_fusion_at_load(dev, tmp_path):
+    """LoRA adapters (lora_A/lora_B and lora_down/lora_up naming, two adapters with different strengths) are fused
+    on the GPU at load: W + sum s_i * B_i @ A_i, and the model matches the oracle run on the fused weights."""
+    from safetensors.torch import save_file
+    from oracle import dit
+    from ltx_2_mlx_amd.loader import LoRAConfig, load_transformer_weights
+    from ltx_2_mlx_amd.model.transformer import LTXModel, Modality, X0Model
+    cfg = dit.DiTConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, caption_channels=128)
+    w = dit.make_dit_weights(cfg, seed=6)
+    save_file({"model.diffusion_model." + k: (v.to(torch.bfloat16) if v.dim() == 2 else v) for k, v in w.items()}, str(tmp_path / "base.safetensors"))
+    g = torch.Generator().manual_seed(1)
+    l1, l2, wf = {}, {}, {k: (v.to(torch.bfloat16).float() if v.dim() == 2 else v.clone()) for k, v in w.items()}
+    for i, (name, rank) in enumerate((("transformer_blocks.0.attn1.to_q", 16), ("transformer_blocks.1.ff.net.0.proj", 8), ("transformer_blocks.0.attn2.to_v", 32))):
+        o, inn = w[name + ".weight"].shape
+        a, b = (torch.randn(rank, inn, generator=g) * 0.05).to(torch.bfloat16), (torch.randn(o, rank, generator=g) * 0.05).to(torch.bfloat16)
+        if i < 2:
+            l1[f"diffusion_model.{name}.lora_A.weight"], l1[f"diffusion_model.{name}.lora_B.weight"] = a, b
+            wf[name + ".weight"] += 0.8 * (b.float() @ a.float())
+        if i > 0:
+            a2, b2 = (torch.randn(4, inn, generator=g) * 0.1).to(torch.bfloat16), (torch.randn(o, 4, generator=g) * 0.1).to(torch.bfloat16)
+            l2[f"{name}.lora_down.weight"], l2[f"{name}.lora_up.weight"] = a2, b2
+            wf[name + ".weight"] += -0.5 * (b2.float() @ a2.float())
+    save_file(l1, str(tmp_path / "l1.safetensors"))
+    save_file(l2, str(tmp_path / "l2.safetensors"))
+    with pytest.raises(ValueError, match="between -2.0 and 2.0"):
+        LoRAConfig("x", 3.0)
+    m = LTXModel(num_attention_heads=2, attention_head_dim=128, num_layers=2, caption_channels=128, device=dev)
+    load_transformer_weights(m, str(tmp_path / "base.safetensors"), strict=True,
+                             lora_configs=[LoRAConfig(str(tmp_path / "l1.safetensors"), 0.8), LoRAConfig(str(tmp_path / "l2.safetensors"), -0.5)])
+    wq = {k: (v.to(torch.bfloat16).float() if v.dim() == 2 else v) for k, v in wf.items()}
+    lat, ctx, pos = inputs(3, 4, 4, 64, 128)
+    sigma = torch.tensor([0.725])
+    ref = dit.x0_model(lat, ctx, sigma, pos, wq, cfg)
+    base = dit.x0_model(lat, ctx, sigma, pos, {k: (v.to(torch.bfloat16).float() if v.dim() == 2 else v) for k, v in w.items()}, cfg)
+    x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
+    err = rel_l2(x0.cpu(), ref)
+    assert err < 2e-2 and rel_l2(base, ref) > 5 * err        # the adapters matter and are applied
