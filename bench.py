@@ -59,6 +59,65 @@ def cpu_baseline(threads):
                       f"{t_block:.2f} s/block, extrapolated x48 to one step"}
 
 
+def extra_configs(dev, layers):
+    """AudioVideo (LTX-2.3-style) joint step and the two-stage 1536x1024x65 pipeline, random-init weights."""
+    from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES, AudioPatchifier, VideoLatentPatchifier
+    from ltx_2_mlx_amd.conditioning import AudioLatentTools, VideoLatentTools
+    from ltx_2_mlx_amd.model.transformer import LTXModel, LTXModelType
+    from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler
+    from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder, decode_latent
+    from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline
+    from ltx_2_mlx_amd.types import AudioLatentShape, VideoLatentShape
+    res = {}
+    # --- config 4 shape: 48-layer AudioVideo DiT with 9-row AdaLN, prompt-modulated text K/V, per-head gates
+    m = LTXModel(model_type=LTXModelType.AudioVideo, num_layers=layers, caption_channels=None, cross_attention_adaln=True,
+                 apply_gated_attention=True, device=dev)
+    m.init_random_weights(seed=0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    N, Na, S = 3456, 68, 1024
+    vlat, alat = torch.randn(N, 128, generator=g, device=dev), torch.randn(Na, 128, generator=g, device=dev)
+    vctx, actx = 0.1 * torch.randn(1, S, 4096, generator=g, device=dev), 0.1 * torch.randn(1, S, 2048, generator=g, device=dev)
+    vpos = VideoLatentTools(VideoLatentPatchifier(1), VideoLatentShape(1, 128, 9, 16, 24), fps=24.0).create_initial_state(device=dev).positions
+    apos = AudioLatentTools(AudioPatchifier(1), AudioLatentShape(1, 8, Na, 16)).create_initial_state(device=dev).positions
+    m.prepare(vctx, vpos, audio_context=actx, audio_positions=apos)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.capture_denoise_graph(vlat, DISTILLED_SIGMA_VALUES, audio_latent=alat)
+        m.replay_denoise_graph()
+        side.synchronize()
+        t0 = time.perf_counter()
+        m.replay_denoise_graph()
+        side.synchronize()
+        res["ltx23_audiovideo_ms_per_step"] = round((time.perf_counter() - t0) / 8 * 1e3, 2)
+    torch.cuda.current_stream().wait_stream(side)
+    del m
+    torch.cuda.empty_cache()
+    # --- config 5: two-stage distilled, 1536x1024x65 (8 steps @N=3456, upscaler x2, 3 steps @N=13824) + decode
+    m = LTXModel(num_layers=layers, device=dev)
+    m.init_random_weights(seed=0)
+    dec = SimpleVideoDecoder(device=dev)
+    dec.init_random_weights(seed=1)
+    up = SpatialUpscaler(device=dev)
+    up.init_random_weights(seed=2)
+    pipe = DistilledPipeline(m, dec, None, spatial_upscaler=up)
+    conf = DistilledConfig(height=1024, width=1536, num_frames=65, seed=0, use_hip_graph=True)
+    ctx = 0.1 * torch.randn(1, 1024, 3840, generator=g, device=dev)
+    lat = pipe(ctx, None, conf)                       # warm-up: workspaces, kernel attributes
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lat = pipe(ctx, None, conf)
+    torch.cuda.synchronize()
+    res["two_stage_1536x1024x65_denoise_upscale_s"] = round(time.perf_counter() - t0, 3)
+    decode_latent(lat, dec)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fr = decode_latent(lat, dec)
+    torch.cuda.synchronize()
+    res["two_stage_1536x1024x65_decode_frames_per_sec"] = round(fr.shape[0] / (time.perf_counter() - t0), 1)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +126,7 @@ def main():
     ap.add_argument("--layers", type=int, default=48, help="debug only; the headline config is 48")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (AudioVideo step, two-stage pipeline)")
     args = ap.parse_args()
 
     from ltx_2_mlx_amd import _native as nv
@@ -212,6 +272,16 @@ def main():
                      "launches": k_n, "avg_launch_us": round(kern_avg_ms * 1e3, 2),
                      "algorithmic_flops_per_launch": round(k_fl / max(k_n, 1))},
     }
+    if world == 1 and not args.no_extra:
+        # Secondary BASELINE configurations, reported beside the headline (never part of `value`): config 4 shape
+        # (LTX-2.3-style AudioVideo DiT, joint audio+video step) and config 5 (two-stage 1536x1024x65 with the
+        # spatial upscaler).  Any failure here is reported as text and cannot affect the numbers above.
+        try:
+            del model
+            torch.cuda.empty_cache()
+            out["extra_configs"] = extra_configs(dev, L)
+        except Exception as e:  # noqa: BLE001
+            out["extra_configs"] = {"error": str(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
