@@ -129,6 +129,13 @@ int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, cons
 int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const void* gate_w, const float* gate_b,
                         float* logits, int rows, int Dq, int H, int head_dim, void* stream);
 
+/* SPLIT-RoPE tables (precompute_freqs_cis with use_middle_indices_grid, rope.py:214-328,365-418): positions fp32
+ * [n_dims][N][2] = [start, end) per axis, freq_grid [n_freq] = theta^linspace(0,1,n_freq)*pi/2 (host-computed, exact),
+ * max_pos [n_dims]; writes cos/sin fp32 [N][half_dim], slot = pad + f*n_dims + d, pad = half_dim - n_dims*n_freq
+ * identity slots in FRONT.  Replaces the per-step table rebuild of model.py:203-229.                    */
+int ltx2_rope_tables(const float* positions, const float* freq_grid, const float* max_pos, int N, int n_dims, int n_freq,
+                     int half_dim, float* cos_out, float* sin_out, void* stream);
+
 /* [cos | sin] sinusoid, dim 256 (timestep_embedding.py:10-60 with flip_sin_to_cos, shift 0;
  * simple_decoder.py:12-39).  Either output may be NULL.                                       */
 int ltx2_timestep_sinusoid(const float* t, int64_t t_stride, float mult, int T, int dim, float* out_f32,

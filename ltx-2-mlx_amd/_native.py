@@ -55,6 +55,7 @@ SIGNATURES = {
     "ltx2_vt_transpose": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
     "ltx2_flash_attn": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp]),
     "ltx2_attn_head_gate": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ltx2_rope_tables": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "ltx2_timestep_sinusoid": (i32, [vp, i64, f32, i32, i32, vp, vp, vp]),
     "ltx2_dequant_fp8_e4m3fn": (i32, [vp, f32, vp, i64, vp]),
     "ltx2_cast_f32_bf16": (i32, [vp, vp, i64, vp]),

@@ -127,6 +127,11 @@ int ltx2_latent_normalize_nchw(const void* x, const float* mean, const float* st
     return latent_normalize_nchw_launch((const bf16*)x, mean, std, out, C, P, (hipStream_t)stream);
 }
 
+int ltx2_rope_tables(const float* positions, const float* freq_grid, const float* max_pos, int N, int n_dims, int n_freq,
+                     int half_dim, float* cos_out, float* sin_out, void* stream) {
+    return rope_tables_launch(positions, freq_grid, max_pos, N, n_dims, n_freq, half_dim, cos_out, sin_out, (hipStream_t)stream);
+}
+
 int ltx2_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
     LTX2_CHECK_ARG(in && out, "cast: null operand");
     return cast_f32_bf16_launch(in, (bf16*)out, n, (hipStream_t)stream);

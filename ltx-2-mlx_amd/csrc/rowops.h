@@ -29,6 +29,11 @@ int gate_logits_launch(const bf16* X, long ldx, const bf16* Wg, const float* bg,
 // att[row][h*hd + j] *= 2 * sigmoid(logits[row*ldl + h])   (per-head attention gates, attention.py:241-249)
 int head_gate_launch(bf16* att, long ld, const float* logits, long ldl, int rows, int H, int hd, hipStream_t stream);
 
+// SPLIT-RoPE cos/sin tables fp32 [N][half] from positions [n_dims][N][2] (start, end), the frequency grid [n_freq]
+// and max_pos [n_dims]; slot = pad + f*n_dims + d with the identity padding in front (rope.py:214-328)
+int rope_tables_launch(const float* pos, const float* grid, const float* max_pos, int N, int n_dims, int n_freq, int half,
+                       float* cosb, float* sinb, hipStream_t stream);
+
 // [cos | sin] sinusoid of reference get_timestep_embedding(flip_sin_to_cos=True, shift=0), dim 256.
 // t_scaled = (t ? t[i*t_stride] : t_scalar) * mult.  Writes fp32 (out_f32) and/or bf16 (out_bf16) [T][dim].
 int timestep_sinusoid_launch(const float* t, long t_stride, float t_scalar, float mult, int T, int dim, float* out_f32,

@@ -343,6 +343,28 @@ __global__ __launch_bounds__(256) void latent_normalize_nchw_kernel(const bf16* 
     }
 }
 
+// SPLIT-RoPE tables on the GPU (rope.py:214-328,365-418): cos/sin fp32 [N][half], slot pad + f*n_dims + d, identity
+// padding at the FRONT; freq = grid[f] * (2*mid_d/max_pos[d] - 1), mid = (start + end) / 2.  cosf/sinf are the
+// accurate (range-reducing) versions: the argument reaches ~1.6e4 rad.
+__global__ void rope_tables_kernel(const float* __restrict__ pos, const float* __restrict__ grid, const float* __restrict__ max_pos,
+                                   int N, int n_dims, int n_freq, int half, float* __restrict__ cosb, float* __restrict__ sinb) {
+    const long total = (long)N * half;
+    const int pad = half - n_dims * n_freq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / half), slot = (int)(i - (long)n * half);
+        float c = 1.f, s = 0.f;
+        if (slot >= pad) {
+            const int j = slot - pad, f = j / n_dims, d = j - f * n_dims;
+            const float mid = (pos[((long)d * N + n) * 2] + pos[((long)d * N + n) * 2 + 1]) * 0.5f;
+            const float arg = grid[f] * ((mid / max_pos[d]) * 2.f - 1.f);
+            c = cosf(arg);
+            s = sinf(arg);
+        }
+        cosb[i] = c;
+        sinb[i] = s;
+    }
+}
+
 __global__ void timestep_sinusoid_kernel(const float* __restrict__ t, long t_stride, float t_scalar, float mult, int T,
                                          int dim, float* __restrict__ of, bf16* __restrict__ ob) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -634,6 +656,16 @@ int latent_normalize_nchw_launch(const bf16* x, const float* mean, const float* 
     LTX2_CHECK_ARG(x && mean && stdv && out && C > 0 && P > 0, "latent_normalize: bad argument");
     hipLaunchKernelGGL(latent_normalize_nchw_kernel, dim3((int)((P + 63) / 64), (C + 63) / 64), dim3(256), 0, stream, x, mean, stdv, out, C, P);
     LTX2_CHECK_LAUNCH("latent_normalize_nchw_kernel");
+    return LTX2_OK;
+}
+
+int rope_tables_launch(const float* pos, const float* grid, const float* max_pos, int N, int n_dims, int n_freq, int half,
+                       float* cosb, float* sinb, hipStream_t stream) {
+    LTX2_CHECK_ARG(pos && grid && max_pos && cosb && sinb && N > 0, "rope_tables: null operand");
+    LTX2_CHECK_ARG(n_dims >= 1 && n_freq >= 1 && n_dims * n_freq <= half, "rope_tables: n_dims*n_freq=%d exceeds D/2=%d", n_dims * n_freq, half);
+    hipLaunchKernelGGL(rope_tables_kernel, dim3(grid_for((long)N * half, 256, 8192)), dim3(256), 0, stream, pos, grid, max_pos, N, n_dims,
+                       n_freq, half, cosb, sinb);
+    LTX2_CHECK_LAUNCH("rope_tables_kernel");
     return LTX2_OK;
 }
 

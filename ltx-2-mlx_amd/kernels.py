@@ -208,6 +208,22 @@ def attn_head_gate_(att: torch.Tensor, x: torch.Tensor, gate_w: torch.Tensor, ga
     return logits
 
 
+def rope_tables(positions: torch.Tensor, dim: int, theta: float, max_pos) -> Tuple[torch.Tensor, torch.Tensor]:
+    """positions (1, n_dims, N, 2) on the GPU -> SPLIT-RoPE cos, sin fp32 [N, dim/2] (slot h*(d/2)+j for head h)."""
+    pos = _c(positions[0].float())
+    n_dims, N = pos.shape[0], pos.shape[1]
+    if n_dims != len(max_pos):
+        raise ValueError(f"Number of position dimensions ({n_dims}) must match max_pos length ({len(max_pos)})")
+    n_freq = dim // (2 * n_dims)
+    grid = (torch.tensor(float(theta)) ** torch.linspace(0.0, 1.0, n_freq, dtype=torch.float32) * (math.pi / 2)).float().to(pos.device)
+    mp = torch.tensor([float(m) for m in max_pos], device=pos.device)
+    cos = torch.empty(N, dim // 2, device=pos.device, dtype=torch.float32)
+    sin = torch.empty_like(cos)
+    nv.check(nv.lib().ltx2_rope_tables(nv.ptr(pos), nv.ptr(grid), nv.ptr(mp), N, n_dims, n_freq, dim // 2, nv.ptr(cos), nv.ptr(sin),
+                                       nv.stream()))
+    return cos, sin
+
+
 def timestep_sinusoid(t: torch.Tensor, mult: float, dim: int = 256) -> torch.Tensor:
     t = _c(t.float())
     out = torch.empty(t.numel(), dim, device=t.device, dtype=torch.float32)

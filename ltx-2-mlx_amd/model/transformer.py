@@ -59,8 +59,8 @@ def rope_tables_token_major(positions: torch.Tensor, dim: int, heads: int, theta
     Host-side per-prompt setup restating precompute_freqs_cis(SPLIT, use_middle_indices_grid=True)
     (reference model/transformer/rope.py:181-211,242-328,365-418): freq grid
     theta**linspace(0,1,dim//(2*n_dims)) * pi/2, fractional mid positions scaled to [-1,1], slot
-    order f*n_dims + d, identity padding at the FRONT.  Computed on the CPU in fp32 (the argument
-    reaches ~1.6e4 rad, so the table is evaluated once in one place) and uploaded by the caller."""
+    order f*n_dims + d, identity padding at the FRONT.  CPU fp32 restatement kept for host-side tests; the
+    model builds its tables on the GPU with `kernels.rope_tables` (ltx2_rope_tables), same formula."""
     pos = positions.detach().float().cpu()
     assert pos.shape[0] == 1, "batch is 1"
     n_dims = pos.shape[1]
@@ -333,8 +333,8 @@ class LTXModel:
         n, s = positions.shape[2], context.shape[1]
         dev = self.device
         theta = self.positional_embedding_theta
-        cos, sin = (t.to(dev) for t in rope_tables_token_major(positions, self.inner_dim, self.num_attention_heads, theta,
-                                                               self.positional_embedding_max_pos))
+        positions = positions.to(dev)
+        cos, sin = K.rope_tables(positions, self.inner_dim, theta, self.positional_embedding_max_pos)
         ctx = context[0].to(dev, torch.float32).contiguous()
         if not self.is_av:
             self._bind(n, s, per_token)
@@ -347,9 +347,10 @@ class LTXModel:
             self._bind(n, s, per_token, na, sa)
             mp = [self.AUDIO_CROSS_PE_MAX_POS]
             da, ha = self.audio_inner_dim, self.audio_heads
-            acos, asin = (t.to(dev) for t in rope_tables_token_major(audio_positions, da, ha, theta, mp))
-            vcc, vcs = (t.to(dev) for t in rope_tables_token_major(positions[:, 0:1], da, self.num_attention_heads, theta, mp))
-            acc, acs = (t.to(dev) for t in rope_tables_token_major(audio_positions[:, 0:1], da, ha, theta, mp))
+            audio_positions = audio_positions.to(dev)
+            acos, asin = K.rope_tables(audio_positions, da, theta, mp)
+            vcc, vcs = K.rope_tables(positions[:, 0:1], da, theta, mp)
+            acc, acs = K.rope_tables(audio_positions[:, 0:1], da, theta, mp)
             actx = audio_context[0].to(dev, torch.float32).contiguous()
             nv.check(nv.lib().ltx2_dit_prepare_av(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.ptr(vcc), nv.ptr(vcs),
                                                   nv.ptr(actx), sa, nv.ptr(acos), nv.ptr(asin), nv.ptr(acc), nv.ptr(acs),

@@ -371,3 +371,20 @@ def test_conv3d_baseline_stage_size(K, dev):
     ref = vae.conv3d_simple(x, w, b, causal=False)[0].permute(1, 2, 3, 0)
     out = K.conv3d(x[0].permute(1, 2, 3, 0).contiguous().to(dev, BF), K.conv_weight_to_engine(w).to(dev), b.to(dev))
     assert rel_l2(out.float().cpu(), ref) < 6e-3
+
+
+@pytest.mark.parametrize("grid,dim,heads,max_pos", [((9, 16, 24), 4096, 32, [20, 2048, 2048]), ((2, 3, 4), 256, 2, [20, 2048, 2048])])
+def test_rope_tables_gpu(K, dev, grid, dim, heads, max_pos):
+    """GPU SPLIT-RoPE table builder vs the oracle's precompute_freqs_cis restatement (arguments up to ~1.6e4 rad)
+    and the 1-D audio / cross-modal variant."""
+    from oracle import dit, dit_av, loop
+    pos = loop.video_positions(1, *grid, 24.0)
+    cos, sin = K.rope_tables(pos.to(dev), dim, 10000.0, max_pos)
+    rc, rs = dit.rope_split_tables(pos, dim, heads, 10000.0, max_pos)          # [1, H, N, d/2]
+    rc, rs = rc[0].permute(1, 0, 2).reshape(cos.shape), rs[0].permute(1, 0, 2).reshape(sin.shape)
+    assert (cos.cpu() - rc).abs().max() < 2e-5 and (sin.cpu() - rs).abs().max() < 2e-5
+    apos = dit_av.audio_positions(1, 37)
+    c1, s1 = K.rope_tables(apos.to(dev), 2048, 10000.0, [20])
+    r1c, r1s = dit.rope_split_tables(apos, 2048, 32, 10000.0, [20])
+    assert (c1.cpu() - r1c[0].permute(1, 0, 2).reshape(c1.shape)).abs().max() < 2e-5
+    assert (s1.cpu() - r1s[0].permute(1, 0, 2).reshape(s1.shape)).abs().max() < 2e-5
