@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--layers", type=int, default=48, help="debug only; the headline config is 48")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay section (rocprofv3 --pmc passes)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (AudioVideo step, two-stage pipeline)")
     args = ap.parse_args()
 
@@ -200,6 +201,8 @@ def main():
     # ---------------- hipGraph replay of the 8-step loop (reported beside the headline) ----------------
     graph_ms = None
     try:
+        if args.no_graph:
+            raise RuntimeError("skipped (--no-graph)")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
