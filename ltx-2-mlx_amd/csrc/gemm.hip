@@ -19,8 +19,8 @@
 // contiguous run of tiles, walked in groups of row-tiles so co-resident tiles share A/W panels.
 //
 // Conv mode gathers the A operand on the fly from the channels-last activation volume
-// [T][H][W][Cin]: row m = output position, K = tap*Cin + c; reflect padding in H/W and
-// replicate padding in T are index arithmetic on the per-lane source address.
+// [T][H][W][Cin]: row m = output position, K = ((kh*3+kw)*kt_taps + kt)*Cin + c; the padding rules are applied
+// once per row in tap tables and a per-row pointer iterator walks the K-tiles (gemm_epilogue.h).
 #include <stdlib.h>
 #include <string.h>
 
@@ -73,6 +73,8 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
     const bf16* a_ptr[AL];
     const bf16* w_ptr[BL];
     ConvRow crow[CONV ? AL : 1];
+    unsigned coff[CONV ? AL : 1];
+    ConvIter<(CONV ? AL : 1)> cit;          // conv: source pointers of the NEXT K-tile to stage
 #pragma unroll
     for (int j = 0; j < AL; ++j) {
         const int rt = (wv * AL + j) * 8 + (lane >> 3);
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
         const int m = min(m0 + rt, p.M - 1);
         if (CONV) {
             crow[CONV ? j : 0] = conv_row_setup(p, m);
-            a_ptr[j] = p.A + chunk * 8;
+            coff[CONV ? j : 0] = chunk * 16;
+            a_ptr[j] = p.A;
         } else {
             a_ptr[j] = p.A + (long)m * p.lda + chunk * 8;
         }
@@ -97,15 +100,10 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
         char* sa = smem + buf * CFG::STAGE_BYTES + wv * (AL * 1024);
         char* sb = smem + buf * CFG::STAGE_BYTES + CFG::A_BYTES + wv * (BL * 1024);
         const int k0 = kt * BK;
-        if (CONV) {
-            const int tap = k0 >> p.cin_shift;
-            const int c0 = k0 & (p.Cin - 1);
-            const int kt_ = tap / 9;
-            const int kh_ = (tap - kt_ * 9) / 3;
-            const int kw_ = tap - kt_ * 9 - kh_ * 3;
+        if (CONV) {             // K-tiles are staged strictly in order: issue the iterator's tile, step it
 #pragma unroll
-            for (int j = 0; j < AL; ++j)
-                glds16(conv_src_row(p, a_ptr[j], crow[CONV ? j : 0], kt_, kh_, kw_, c0), sa + j * 1024);
+            for (int j = 0; j < AL; ++j) glds16(cit.ptr[CONV ? j : 0], sa + j * 1024);
+            if (kt + 1 < p.K / BK) cit.next(p, crow, coff);
         } else {
 #pragma unroll
             for (int j = 0; j < AL; ++j) glds16(a_ptr[j] + k0, sa + j * 1024);
@@ -130,6 +128,7 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = p.K / BK;
+    if (CONV) cit.init(p, crow, coff);
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -75,19 +75,23 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, const EpiRow& er
     }
 }
 
-// One 16-byte row of zeros: the LDS-DMA source of out-of-range taps under zero padding.
-__device__ static const unsigned int ltx2_zero_row[32] = {0};
+// Zeros: the LDS-DMA source of out-of-range taps under zero padding.  Long enough for a whole channel run
+// (Cin <= 1024 bf16 = 2 KiB) plus the lane's chunk offset, because the iterator below walks it like a real row.
+__device__ static const unsigned int ltx2_zero_row[512 + 32] = {0};
 
-// Per-output-position tap tables for the conv A-operand gather: BYTE offsets of the three temporal, three
-// vertical and three horizontal neighbours with the padding rule already applied (computed once per row; the
-// per-K-tile address is then three uniform 3-way selects and three adds instead of ~30 VALU instructions of
-// clamp / reflect / 64-bit multiply per LDS-DMA issue).  Padding: replicate in T, reflect in H/W (reference
-// simple_decoder.py:105-134); pad_zero = 1: zero padding in all three dims (upscaler/spatial.py:44-52); pad_zero = 2:
-// zero padding in H/W with the replicated (causal) temporal edge of the VAE encoder (simple_encoder.py:56-75);
-// 0xffffffff marks an out-of-range tap whose LDS-DMA source becomes the zero row.
+// ---- conv A-operand gather -------------------------------------------------------------------------------------
+// Conv weights are K-ordered  k = ((kh*3 + kw)*taps_t + kt)*Cin + c : the channel run and the temporal tap are the
+// INNER loops of the K walk.  Per output row the kernels keep small tap tables (byte offsets of the 3 vertical and
+// 3 horizontal neighbours with the padding rule applied) and an iterator that rebuilds the source pointer only when
+// (kh, kw) or kt change; advancing to the next channel run is one 64-bit add per row.  (PMC, 128->128 conv on the
+// 128^2 tile kernel before this: 105 VALU + 86 SALU instructions per K-tile beside 16 MFMAs -- tap decode by integer
+// division, reflect / clamp arithmetic and 64-bit multiplies per LDS-DMA issue -- i.e. issue-bound at 29 % MFMA busy.)
+// Padding: replicate in T, reflect in H/W (reference simple_decoder.py:105-134); pad_zero = 1: zero padding in all
+// three dims (upscaler/spatial.py:44-52); pad_zero = 2: zero padding in H/W with the replicated (causal) temporal
+// edge of the VAE encoder (simple_encoder.py:56-75).  0xffffffff marks a zero-padded tap.
 struct ConvRow {
     unsigned ho[3], wo[3];      // vertical / horizontal neighbour offsets (bytes), padding rule applied
-    int t;                      // frame index: the temporal neighbour is one clamp + multiply per use
+    int t;                      // frame index
 };
 
 __device__ __forceinline__ ConvRow conv_row_setup(const GemmParams& p, int m) {
@@ -114,18 +118,54 @@ __device__ __forceinline__ ConvRow conv_row_setup(const GemmParams& p, int m) {
 
 __device__ __forceinline__ unsigned sel3(const unsigned (&a)[3], int k) { return k == 0 ? a[0] : (k == 1 ? a[1] : a[2]); }
 
-// a_chunk = A + chunk*8 (this lane's 16-byte column of the row); kt_/kh_/kw_ are wave-uniform.
-__device__ __forceinline__ const bf16* conv_src_row(const GemmParams& p, const bf16* a_chunk, const ConvRow& r, int kt_, int kh_,
-                                                    int kw_, int c0) {
-    const int tt = r.t + kt_ - p.pad_front;
-    const unsigned a = (unsigned)max(0, min(tt, p.T - 1)) * (unsigned)(p.H * p.Wd * p.Cin * 2);
-    const unsigned b = sel3(r.ho, kh_), c = sel3(r.wo, kw_);
-    const bf16* src = (const bf16*)((const char*)a_chunk + ((unsigned long)a + b + c) + 2u * (unsigned)c0);
-    // bit 31 is set only by the sentinel: the launcher requires the activation volume to be < 2 GiB
-    const bool hw_oob = (int)(b | c) < 0;                                   // sentinels exist only when pad_zero != 0
-    const bool t_oob = p.pad_zero == 1 && (tt < 0 || tt >= p.T);
-    return (hw_oob || t_oob) ? (const bf16*)ltx2_zero_row + (a_chunk - p.A) : src;
-}
+// Walks the K-tiles of NR rows in K order.  ct / kt / khw are wave-uniform; `chunk_off[j]` = this lane's byte offset
+// of its 16-byte column inside a row (chunk*16).  The launcher requires the activation volume to be < 2 GiB, so
+// bit 31 of an offset is set only by the sentinel.
+template <int NR>
+struct ConvIter {
+    int ct, kt, khw;
+    unsigned hw[NR];            // ho[kh] + wo[kw], or 0xffffffff
+    const bf16* ptr[NR];        // source of the current K-tile's piece
+
+    __device__ __forceinline__ void set_hw(const ConvRow (&rows)[NR]) {
+        const int kh = khw / 3, kw = khw - kh * 3;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const unsigned b = sel3(rows[j].ho, kh), c = sel3(rows[j].wo, kw);
+            hw[j] = (int)(b | c) < 0 ? 0xffffffffu : b + c;
+        }
+    }
+    __device__ __forceinline__ void set_ptr(const GemmParams& p, const ConvRow (&rows)[NR], const unsigned (&chunk_off)[NR]) {
+        const unsigned st = (unsigned)(p.H * p.Wd * p.Cin * 2);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int tt = rows[j].t + kt - p.pad_front;
+            const bool oob = (int)hw[j] < 0 || (p.pad_zero == 1 && (tt < 0 || tt >= p.T));
+            const unsigned long off = (unsigned long)((unsigned)max(0, min(tt, p.T - 1)) * st) + hw[j];
+            ptr[j] = (const bf16*)(oob ? (const char*)ltx2_zero_row + chunk_off[j] : (const char*)p.A + off + chunk_off[j]);
+        }
+    }
+    __device__ __forceinline__ void init(const GemmParams& p, const ConvRow (&rows)[NR], const unsigned (&chunk_off)[NR]) {
+        ct = kt = khw = 0;
+        set_hw(rows);
+        set_ptr(p, rows, chunk_off);
+    }
+    // to the next K-tile (64 channels further, else next temporal tap, else next (kh, kw))
+    __device__ __forceinline__ void next(const GemmParams& p, const ConvRow (&rows)[NR], const unsigned (&chunk_off)[NR]) {
+        if (++ct < (p.Cin >> 6)) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) ptr[j] += 64;
+        } else {
+            ct = 0;
+            if (++kt == p.taps_t) {
+                kt = 0;
+                ++khw;
+                set_hw(rows);
+            }
+            set_ptr(p, rows, chunk_off);
+        }
+    }
+};
 
 // Launcher of the 256x256 ping-pong kernel (gemm_pp.hip)
 int gemm_pp_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream);

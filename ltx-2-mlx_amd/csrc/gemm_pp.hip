@@ -88,6 +88,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const bf16* a_src[2][2];
     const bf16* b_src[2][2];
     ConvRow crow[CONV ? 2 : 1][CONV ? 2 : 1];
+    unsigned coff[CONV ? 2 : 1][CONV ? 2 : 1];
+    // conv: one K-walk iterator per half-tile kind (gemm_epilogue.h) -- cit[1] runs one K-tile ahead of the loop
+    // (A1(t+1) is issued in Ma), cit[0] two ahead (A0(t+2) in Mb); both are stepped inside L intervals, so the M
+    // intervals carry nothing but MFMAs and the LDS-DMA issues themselves.
+    ConvIter<(CONV ? 2 : 1)> cit[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int rp = (wv * 2 + j) * 8 + (lane >> 3);
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             const int m = min(m0 + arow, p.M - 1);
             if (CONV) {
                 crow[CONV ? h : 0][CONV ? j : 0] = conv_row_setup(p, m);
-                a_src[h][j] = p.A + chunk * 8;
+                coff[CONV ? h : 0][CONV ? j : 0] = chunk * 16;
+                a_src[h][j] = p.A;
             } else {
                 a_src[h][j] = p.A + (long)m * p.lda + chunk * 8;
             }
@@ -112,15 +118,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     auto issue_a = [&](int h, int tile) {
         char* dst = smem + (tile & 1) * BUF + h * HALF + wv * 2048;
         const int k0 = min(tile, nk - 1) * BK;
-        if (CONV) {
-            const int tap = k0 >> p.cin_shift;
-            const int c0 = k0 & (p.Cin - 1);
-            const int kt_ = tap / 9;
-            const int kh_ = (tap - kt_ * 9) / 3;
-            const int kw_ = tap - kt_ * 9 - kh_ * 3;
+        if (CONV) {             // the iterator already stands on K-tile min(tile, nk-1)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                glds16(conv_src_row(p, a_src[h][j], crow[CONV ? h : 0][CONV ? j : 0], kt_, kh_, kw_, c0), dst + j * 1024);
+            for (int j = 0; j < 2; ++j) glds16(cit[h].ptr[CONV ? j : 0], dst + j * 1024);
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) glds16(a_src[h][j] + k0, dst + j * 1024);
@@ -183,11 +183,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #define SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
 
     // ---- prologue: tile 0 complete + A0,B0,B1 of tile 1 in flight ----
+    auto step = [&](int h) { cit[h].next(p, crow[CONV ? h : 0], coff[CONV ? h : 0]); };
+    if (CONV) {
+        cit[0].init(p, crow[0], coff[0]);
+        cit[1].init(p, crow[CONV ? 1 : 0], coff[CONV ? 1 : 0]);
+    }
     issue_a(0, 0);
     issue_b(0, 0);
     issue_b(1, 0);
     issue_a(1, 0);
+    if (CONV && nk > 1) {
+        step(0);
+        step(1);            // cit[1] -> K-tile 1 for Ma(0)
+    }
     issue_a(0, 1);
+    if (CONV && nk > 2) step(0);        // cit[0] -> K-tile 2 for Mb(0)
     issue_b(0, 1);
     issue_b(1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -213,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             read_a(cb, 0);
             read_b(cb, 0);
             read_b(cb, 1);
+            if (CONV && t >= 1 && t + 2 < nk) step(0);      // cit[0] -> K-tile t+2 (issued in Mb)
             PP_STAMP();
             PP_LGKM0();
             PP_STAMP();
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             // Lb: fragments of A1; this wave's share of A0,B0,B1(t+1) must have landed before the barrier
             PP_STAMP();
             read_a(cb, 1);
+            if (CONV && t + 2 < nk) step(1);                // cit[1] -> K-tile t+2 (issued in the next Ma)
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             PP_STAMP();
             PP_LGKM0();
@@ -288,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             read_a(cb, 0);
             read_b(cb, 0);
             read_b(cb, 1);
+            if (CONV && t >= 1 && t + 2 < nk) step(0);      // cit[0] -> K-tile t+2 (issued in Mb)
             PP_STAMP();
             PP_LGKM0();
             PP_STAMP();
@@ -322,6 +335,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             // Lb': fragments of b2 (first 32 rows of this group's A1)
             PP_STAMP();
             read_a2(cb);
+            if (CONV && t + 2 < nk) step(1);
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             PP_STAMP();
             PP_LGKM0();
