@@ -68,8 +68,7 @@ int ltx2_gemv_f32(const float* a, int64_t lda, const void* W, const float* bias,
                   int N, int K, int act_in, int act_out, void* stream);
 
 /* 3x3x3 stride-1 conv3d on channels-last bf16 activations x[T][H][W][Cin], weights
- * w[Cout][27][Cin] (tap = (kh*3+kw)*3+kt: temporal tap and channels innermost), reflect pad H/W, replicate pad T
- * (causal: 2 front).
+ * w[Cout][27][Cin] (tap = (kt*3+kh)*3+kw), reflect pad H/W, replicate pad T (causal: 2 front).
  * Replaces Conv3dSimple.__call__ (model/video_vae/simple_decoder.py:90-180).
  *   mode 0: out[T][H][W][Cout] = conv + bias
  *   mode 1: out = conv + bias + res          (ResBlock3d skip, simple_decoder.py:240)

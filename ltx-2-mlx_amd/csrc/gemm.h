@@ -15,7 +15,7 @@ enum GemmEpilogue {
 
 struct GemmParams {
     const bf16* A;       // dense: [M][lda];  conv: activations [T][H][W][Cin] (channels-last)
-    const bf16* W;       // [N][K]  (K contiguous; conv: K = tap*Cin + c, tap = (kh*3+kw)*taps_t + kt)
+    const bf16* W;       // [N][K]  (K contiguous; conv: K = tap*Cin + c, tap = (kt*3+kh)*3+kw)
     const float* bias;   // [N] or null
     void* out;           // bf16 or f32, [M][ldo]  (D2S: [To][Ho][Wo][Cf])
     const float* gate;   // EPI_RESID_GATE_F32: per-row part  gate[m*gate_stride + n]  (may be null)

@@ -19,7 +19,7 @@
 // contiguous run of tiles, walked in groups of row-tiles so co-resident tiles share A/W panels.
 //
 // Conv mode gathers the A operand on the fly from the channels-last activation volume
-// [T][H][W][Cin]: row m = output position, K = ((kh*3+kw)*kt_taps + kt)*Cin + c; the padding rules are applied
+// [T][H][W][Cin]: row m = output position, K = ((kt*3+kh)*3+kw)*Cin + c; the padding rules are applied
 // once per row in tap tables and a per-row pointer iterator walks the K-tiles (gemm_epilogue.h).
 #include <stdlib.h>
 #include <string.h>

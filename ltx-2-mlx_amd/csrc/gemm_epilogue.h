@@ -80,10 +80,12 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, const EpiRow& er
 __device__ static const unsigned int ltx2_zero_row[512 + 32] = {0};
 
 // ---- conv A-operand gather -------------------------------------------------------------------------------------
-// Conv weights are K-ordered  k = ((kh*3 + kw)*taps_t + kt)*Cin + c : the channel run and the temporal tap are the
-// INNER loops of the K walk.  Per output row the kernels keep small tap tables (byte offsets of the 3 vertical and
-// 3 horizontal neighbours with the padding rule applied) and an iterator that rebuilds the source pointer only when
-// (kh, kw) or kt change; advancing to the next channel run is one 64-bit add per row.  (PMC, 128->128 conv on the
+// Conv weights are K-ordered  k = ((kt*3 + kh)*3 + kw)*Cin + c  (for per-frame 3x3 convs kt is absent).  Per output
+// row the kernels keep small tap tables (byte offsets of the 3 vertical and 3 horizontal neighbours with the
+// padding rule applied) and an iterator that rebuilds the source pointer only when the tap changes; advancing
+// inside a channel run is one 64-bit add per row.  (A K order with kt inside (kh, kw) rebuilt pointers less often
+// but walked three frames per (kh, kw): fabric reads of the 128-channel convs rose 5.7x -- the frame-major order
+// keeps all nine spatial taps of a frame together in L2.)  (PMC, 128->128 conv on the
 // 128^2 tile kernel before this: 105 VALU + 86 SALU instructions per K-tile beside 16 MFMAs -- tap decode by integer
 // division, reflect / clamp arithmetic and 64-bit multiplies per LDS-DMA issue -- i.e. issue-bound at 29 % MFMA busy.)
 // Padding: replicate in T, reflect in H/W (reference simple_decoder.py:105-134); pad_zero = 1: zero padding in all
@@ -118,49 +120,54 @@ __device__ __forceinline__ ConvRow conv_row_setup(const GemmParams& p, int m) {
 
 __device__ __forceinline__ unsigned sel3(const unsigned (&a)[3], int k) { return k == 0 ? a[0] : (k == 1 ? a[1] : a[2]); }
 
-// Walks the K-tiles of NR rows in K order.  ct / kt / khw are wave-uniform; `chunk_off[j]` = this lane's byte offset
-// of its 16-byte column inside a row (chunk*16).  The launcher requires the activation volume to be < 2 GiB, so
-// bit 31 of an offset is set only by the sentinel.
+// Walks the K-tiles of NR rows in K order (channel run innermost, then kw, kh, kt).  ct / kw / kh / kt are
+// wave-uniform; `chunk_off[j]` = this lane's byte offset of its 16-byte column inside a row (chunk*16).  The
+// temporal part of the offset is refreshed only when kt changes (every 9*Cin/64 K-tiles), the (kh, kw) part every
+// Cin/64 K-tiles, and a step inside a channel run is one 64-bit add per row.  The launcher requires the
+// activation volume to be < 2 GiB, so bit 31 of an offset is set only by the sentinel.
 template <int NR>
 struct ConvIter {
-    int ct, kt, khw;
-    unsigned hw[NR];            // ho[kh] + wo[kw], or 0xffffffff
+    int ct, kw, kh, kt;
+    unsigned toff[NR];          // clamp(t + kt - pad_front) * frame bytes, or 0xffffffff (zero-padded frame)
     const bf16* ptr[NR];        // source of the current K-tile's piece
 
-    __device__ __forceinline__ void set_hw(const ConvRow (&rows)[NR]) {
-        const int kh = khw / 3, kw = khw - kh * 3;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const unsigned b = sel3(rows[j].ho, kh), c = sel3(rows[j].wo, kw);
-            hw[j] = (int)(b | c) < 0 ? 0xffffffffu : b + c;
-        }
-    }
-    __device__ __forceinline__ void set_ptr(const GemmParams& p, const ConvRow (&rows)[NR], const unsigned (&chunk_off)[NR]) {
+    __device__ __forceinline__ void set_t(const GemmParams& p, const ConvRow (&rows)[NR]) {
         const unsigned st = (unsigned)(p.H * p.Wd * p.Cin * 2);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int tt = rows[j].t + kt - p.pad_front;
-            const bool oob = (int)hw[j] < 0 || (p.pad_zero == 1 && (tt < 0 || tt >= p.T));
-            const unsigned long off = (unsigned long)((unsigned)max(0, min(tt, p.T - 1)) * st) + hw[j];
+            const bool oob = p.pad_zero == 1 && (tt < 0 || tt >= p.T);
+            toff[j] = oob ? 0xffffffffu : (unsigned)max(0, min(tt, p.T - 1)) * st;
+        }
+    }
+    __device__ __forceinline__ void set_ptr(const GemmParams& p, const ConvRow (&rows)[NR], const unsigned (&chunk_off)[NR]) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const unsigned b = sel3(rows[j].ho, kh), c = sel3(rows[j].wo, kw);
+            const bool oob = (int)(b | c | toff[j]) < 0;
+            const unsigned long off = (unsigned long)toff[j] + b + c;
             ptr[j] = (const bf16*)(oob ? (const char*)ltx2_zero_row + chunk_off[j] : (const char*)p.A + off + chunk_off[j]);
         }
     }
     __device__ __forceinline__ void init(const GemmParams& p, const ConvRow (&rows)[NR], const unsigned (&chunk_off)[NR]) {
-        ct = kt = khw = 0;
-        set_hw(rows);
+        ct = kw = kh = kt = 0;
+        set_t(p, rows);
         set_ptr(p, rows, chunk_off);
     }
-    // to the next K-tile (64 channels further, else next temporal tap, else next (kh, kw))
+    // to the next K-tile: 64 channels further, else the next tap
     __device__ __forceinline__ void next(const GemmParams& p, const ConvRow (&rows)[NR], const unsigned (&chunk_off)[NR]) {
         if (++ct < (p.Cin >> 6)) {
 #pragma unroll
             for (int j = 0; j < NR; ++j) ptr[j] += 64;
         } else {
             ct = 0;
-            if (++kt == p.taps_t) {
-                kt = 0;
-                ++khw;
-                set_hw(rows);
+            if (++kw == 3) {
+                kw = 0;
+                if (++kh == 3) {
+                    kh = 0;
+                    ++kt;
+                    set_t(p, rows);
+                }
             }
             set_ptr(p, rows, chunk_off);
         }

@@ -53,12 +53,11 @@ def gemv(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_in:
 
 
 def conv_weight_to_engine(w: torch.Tensor, d2s_stride: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
-    """PyTorch conv3d weight (Cout, Cin, kT, kH, kW) -> engine layout bf16 [Cout][27][Cin] with
-    tap = (kh*3+kw)*3 + kt: the temporal tap and the channel run are the inner loops of the kernels' K walk
-    (gemm_epilogue.h, ConvIter).  For depth-to-space convs the output rows are permuted from
+    """PyTorch conv3d weight (Cout, Cin, 3, 3, 3) -> engine layout bf16 [Cout][27][Cin]
+    (tap = (kt*3+kh)*3+kw).  For depth-to-space convs the output rows are permuted from
     ch = c*sp + s to n' = s*Cf + c so one contiguous channel run lands on one output voxel."""
     cout, cin = w.shape[0], w.shape[1]
-    e = w.permute(0, 3, 4, 2, 1).reshape(cout, 27, cin)
+    e = w.permute(0, 2, 3, 4, 1).reshape(cout, 27, cin)
     if d2s_stride is not None:
         sp = d2s_stride[0] * d2s_stride[1] * d2s_stride[2]
         cf = cout // sp
