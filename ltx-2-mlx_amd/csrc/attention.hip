@@ -18,6 +18,7 @@
 //    V^T fragment a single conflict-free 16-byte LDS read.
 //  * online softmax in the exp2 domain (scale * log2(e) folded into the scores), fp32 statistics.
 #include "attention.h"
+#include <type_traits>
 
 namespace {
 
@@ -36,22 +37,58 @@ struct Geo {
     static constexpr int NJ = HD / 32;          // LDS-DMA instructions per wave per tile (K and V^T each)
 };
 
-#define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
-#define SGB_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
-#define SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
-#ifndef AT_DEPTH
-#define AT_DEPTH 3
+// LDS fragment reads kept in flight ahead of the MFMA that consumes them (AT_DK for K, AT_DV for V^T).
+#ifndef AT_DK
+#define AT_DK 6
+#endif
+#ifndef AT_DV
+#define AT_DV 6
 #endif
 
-__device__ __forceinline__ void glds16(const bf16* g, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const void*)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+__device__ __forceinline__ void glds16(const bf16* g, unsigned lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void*)g, (lds_ptr_t)(uintptr_t)lds_wave_base, 16, 0, 0);
 }
+
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// Hand-issued LDS reads and waits. hipcc only ever emits `s_waitcnt lgkmcnt(0)` around ds_read_b128 in this
+// loop, i.e. every wait drains ALL fragment reads in flight and the LDS latency comes back once per prefetch
+// group (measured: dropping the K reads alone saved as much time as dropping the 16 QK MFMAs). With the read
+// and the counted wait both in asm the compiler tracks neither; lds_wait<N> names the fragment it guards so the
+// consuming MFMA cannot move above it. LGKM returns in order for LDS operations, so "at most N younger
+// operations outstanding" proves the guarded read has landed; extra compiler-issued LGKM traffic only
+// over-waits.
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read16(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     using G = Geo<HD>;
     constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NKS = G::NKS, ND = G::ND, NJ = G::NJ;
+    constexpr int NK = 2 * NKS, NV = 4 * ND;        // K / V^T fragment reads (= MFMAs) per wave per tile
+    constexpr int DK = AT_DK < NK ? AT_DK : NK, DV = AT_DV < NV ? AT_DV : NV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -70,38 +107,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     // ---- staging addresses ----
     const bf16* k_src[NJ];
     const bf16* v_src[NJ];
-    int k_rowi[NJ];
+    unsigned k_off[NJ];                                                // element offset of this lane's K row, next tile to stage
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         // one LDS-DMA instruction covers 1 KiB: 4 K rows of 256 B (HD 128) or 8 rows of 128 B (HD 64)
         const int kr = HD == 128 ? (wv * NJ + j) * 4 + (lane >> 4) : (wv * NJ + j) * 8 + (lane >> 3);   // 0..63
         const int kchunk = HD == 128 ? ((lane & 15) ^ (kr & 15)) : ((lane & 7) ^ ((kr >> 1) & 7));
-        k_rowi[j] = kr;
+        k_off[j] = (unsigned)kr * (unsigned)p.ldk;
         k_src[j] = p.K + head * HD + kchunk * 8;
         const int vr = (wv * NJ + j) * 8 + (lane >> 3);                // 0..HD-1
         const int vchunk = (lane & 7) ^ ((vr >> 1) & 7);
         v_src[j] = p.VT + (long)head * p.vt_head_stride + (long)vr * p.Npad + vchunk * 8;
     }
-    // K and V^T staging of one KV tile, issued in separate pieces: a burst of 8 LDS-DMA issues stalls the wave
-    // for ~100 cycles each, spaced issues cost ~25 (measured in the GEMM's M intervals).
-    auto stage_k = [&](int t, int buf) {
-        char* sk = smem + buf * STAGE + wv * (NJ * 1024);
-        const int kv0 = t * KVB;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int kr = min(kv0 + k_rowi[j], p.Nkv - 1);
-            glds16(k_src[j] + (long)kr * p.ldk, sk + j * 1024);
+    // K tiles are staged strictly in order (0, 1, .., nt-1, and once more into the idle buffer), so the row offset
+    // advances by a constant; clamping the OFFSET to the last row's equals clamping the row (2 VALU per issue
+    // instead of a 64-bit multiply-add chain). The launcher guarantees (Nkv + 2*KVB) * ldk < 2^32.
+    const unsigned k_last = (unsigned)(p.Nkv - 1) * (unsigned)p.ldk, k_step = (unsigned)KVB * (unsigned)p.ldk;
+    // piece i of tile t's staging into buffer `buf`: pieces [0, NJ) are K, [NJ, 2 NJ) are V^T. One LDS-DMA issue
+    // costs the wave ~50 cycles (a burst of 8: ~100 each), so the pieces are spread between the QK MFMAs.
+    auto stage_piece = [&](int t, int buf, int i) {
+        const unsigned dst = lds0 + buf * STAGE + wv * (NJ * 1024);
+        if (i < NJ) {
+            glds16(k_src[i] + min(k_off[i], k_last), dst + i * 1024);
+            k_off[i] += k_step;
+        } else {
+            glds16(v_src[i - NJ] + t * KVB, dst + K_TILE + (i - NJ) * 1024);
         }
-    };
-    auto stage_v = [&](int t, int buf, int j0, int j1) {
-        char* sv = smem + buf * STAGE + wv * (NJ * 1024) + K_TILE;
-        const int kv0 = t * KVB;
-#pragma unroll
-        for (int j = j0; j < j1; ++j) glds16(v_src[j] + kv0, sv + j * 1024);
-    };
-    auto stage = [&](int t, int buf) {
-        stage_k(t, buf);
-        stage_v(t, buf, 0, NJ);
     };
 
     f32x16 o[ND];
@@ -111,45 +142,55 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
+    // per-lane fragment offsets inside a stage (the swizzle of the staging, applied again on the read)
     const int k_xor = HD == 128 ? (l31 & 15) : ((l31 >> 1) & 7);
     const int v_xor = (l31 >> 1) & 7;
+    unsigned k_lane[NKS], v_lane[4];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) k_lane[ks] = l31 * (2 * HD) + (((2 * ks + hi) ^ k_xor) << 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v_lane[i] = K_TILE + l31 * 128 + (((2 * i + hi) ^ v_xor) << 4);
+
     const int nt = (p.Nkv + KVB - 1) / KVB;
-    stage(0, 0);
-    for (int t = 0; t < nt; ++t) {
+#pragma unroll
+    for (int i = 0; i < 2 * NJ; ++i) stage_piece(0, 0, i);
+
+    // One KV tile. MASKED is a compile-time flag: only the ragged last tile carries the key-bound compares (left
+    // in the common body, hipcc if-converts them into ~115 predicated VALU ops on EVERY tile -- SQ_INSTS_VALU
+    // showed 236 non-MFMA VALU per tile against 32 MFMAs).
+    auto tile = [&](const int t, auto masked) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int tn = min(t + 1, nt - 1);          // the tail re-stages the last tile into the idle buffer (branch-free body)
-        stage_k(tn, (t + 1) & 1);
-        const char* ks_base = smem + (t & 1) * STAGE;
-        const char* vs_base = ks_base + K_TILE;
+        const int nbuf = (t + 1) & 1;
+        const unsigned sbase = lds0 + (t & 1) * STAGE;
 
-        // ---- S^T = K . Q^T  (two 32-key blocks) ----
+        // ---- S^T = K . Q^T  (two 32-key blocks); fragment i = b * NKS + ks ----
         f32x16 s[2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
-            const char* krow = ks_base + (b * 32 + l31) * (2 * HD);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(krow + (((2 * ks + hi) ^ k_xor) << 4));
-                s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[b], 0, 0, 0);
-            }
-        }
-        // keep 3 K-fragment reads in flight ahead of the MFMAs (hipcc otherwise serialises
-        // ds_read -> s_waitcnt lgkmcnt(0) -> mfma and exposes the LDS latency per fragment)
-        SGB_DSR(AT_DEPTH);
-#pragma unroll
-        for (int i_ = 0; i_ < 2 * NKS - AT_DEPTH; ++i_) {
-            SGB_MFMA(1);
-            SGB_DSR(1);
-        }
-        SGB_MFMA(AT_DEPTH);
-        stage_v(tn, (t + 1) & 1, 0, NJ / 2);
+        u32x4 kf[NK];
+        auto read_k = [&](auto I) {
+            constexpr int i = decltype(I)::value;
+            kf[i] = lds_read16<(i / NKS) * 32 * 2 * HD>(sbase + k_lane[i % NKS]);
+        };
+        static_for<0, DK>(read_k);
+        static_for<0, NK>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i + DK < NK) read_k(std::integral_constant<int, i + DK>{});
+            lds_wait<(i + DK < NK ? DK : NK - 1 - i)>(kf[i]);
+            s[i / NKS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[i]), qf[i % NKS], s[i / NKS], 0, 0, 0);
+            if constexpr ((i & 1) && i / 2 < 2 * NJ) stage_piece(tn, nbuf, i / 2);
+        });
+        static_for<NK / 2, 2 * NJ>([&](auto I) { stage_piece(tn, nbuf, decltype(I)::value); });
+
         // ---- mask the ragged tail, running max (raw score domain; the softmax scale * log2(e) is
         //      folded into one fma in front of v_exp_f32: p = 2^(s*c - m*c)) ----
-        const int kv0 = t * KVB;
-        if (kv0 + KVB > p.Nkv) {
+        if constexpr (MASKED) {
+            const int kv0 = t * KVB;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -158,9 +199,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                     if (kv >= p.Nkv) s[b][r] = -INFINITY;
                 }
         }
-        float tmax = fmaxf(s[0][0], s[1][0]);
+        // v_max3_f32 directly: fmaxf() lowers to llvm.maxnum, which first canonicalises every MFMA output
+        // (one extra v_max x,x per score)
+        float tmax = s[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
+        for (int r = 0; r < 16; ++r) tmax = max3(tmax, s[0][r], s[1][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         // Deferred rescale: keep the old running max while the tile max exceeds it by at most
         // RESCALE_THR (in exponent units), so P stays <= 2^THR and the O rescale pass is skipped.
@@ -177,40 +220,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
+        // first V^T fragments go out before the exponentials, which hide their LDS latency;
+        // fragment i = d * 4 + (2 b + k2)
+        u32x4 vf[NV];
+        auto read_v = [&](auto I) {
+            constexpr int i = decltype(I)::value;
+            vf[i] = lds_read16<(i / 4) * 32 * 128>(sbase + v_lane[i % 4]);
+        };
+        static_for<0, DV>(read_v);
+
         const float mc = m_run * c;
-        float psum = 0.f;
+        // two scores per VALU op where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32); v_exp_f32 is scalar
+        const f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
+        f32x2 psum2 = {0.f, 0.f};
         bf16x8 pf[2][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][r], c, -mc));
-                psum += pv;
-                pf[b][r >> 3][r & 7] = f2bf(pv);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 sv = {s[b][r], s[b][r + 1]};
+                const f32x2 e = __builtin_elementwise_fma(sv, c2, nmc2);
+                const f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                psum2 += pv;
+                pf[b][r >> 3][r & 7] = f2bf(pv[0]);
+                pf[b][r >> 3][(r & 7) + 1] = f2bf(pv[1]);
             }
-        l_run += psum;
+        l_run += psum2[0] + psum2[1];
 
-        stage_v(tn, (t + 1) & 1, NJ / 2, NJ);
         // ---- O^T += V^T . P^T ----
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const char* vrow = vs_base + (d * 32 + l31) * 128;
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const bf16x8 vf = *(const bf16x8*)(vrow + (((4 * b + 2 * k2 + hi) ^ v_xor) << 4));
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][k2], o[d], 0, 0, 0);
-                }
-        }
-        SGB_DSR(AT_DEPTH);
-#pragma unroll
-        for (int i_ = 0; i_ < 4 * ND - AT_DEPTH; ++i_) {
-            SGB_MFMA(1);
-            SGB_DSR(1);
-        }
-        SGB_MFMA(AT_DEPTH);
-    }
+        static_for<0, NV>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i + DV < NV) read_v(std::integral_constant<int, i + DV>{});
+            lds_wait<(i + DV < NV ? DV : NV - 1 - i)>(vf[i]);
+            o[i / 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[i]), pf[(i % 4) / 2][i % 2], o[i / 4], 0, 0, 0);
+        });
+    };
+
+    const int nfull = p.Nkv / KVB;
+    for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+    if (nfull < nt) tile(nfull, std::true_type{});
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- finalize: lane owns query q0+l31, dims d*32 + (r&3) + 8*(r>>2) + 4*hi ----
@@ -283,6 +331,7 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.head_dim == 0 || p.head_dim == 128 || p.head_dim == 64, "attention: head_dim=%d, only 128 and 64 are implemented", p.head_dim);
     LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
     LTX2_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
+    LTX2_CHECK_ARG(p.ldk > 0 && ((long)p.Nkv + 2 * KVB) * p.ldk < (1L << 32), "attention: Nkv * ldk exceeds the 32-bit K row offset");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
