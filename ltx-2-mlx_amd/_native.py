@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libltx2hip.so")
+# LTX2HIP_LIB: another build of the same library (A/B timing of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("LTX2HIP_LIB") or os.path.join(_HERE, "lib", "libltx2hip.so")
 
 OK, E_INVALID, E_HIP, E_STATE = 0, -1, -2, -3
 DTYPE_BF16, DTYPE_F32 = 0, 1

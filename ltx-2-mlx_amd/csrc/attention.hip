@@ -55,32 +55,8 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return d;
 }
 
-// Hand-issued LDS reads and waits. hipcc only ever emits `s_waitcnt lgkmcnt(0)` around ds_read_b128 in this
-// loop, i.e. every wait drains ALL fragment reads in flight and the LDS latency comes back once per prefetch
-// group (measured: dropping the K reads alone saved as much time as dropping the 16 QK MFMAs). With the read
-// and the counted wait both in asm the compiler tracks neither; lds_wait<N> names the fragment it guards so the
-// consuming MFMA cannot move above it. LGKM returns in order for LDS operations, so "at most N younger
-// operations outstanding" proves the guarded read has landed; extra compiler-issued LGKM traffic only
-// over-waits.
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read16(unsigned addr) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return v;
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(u32x4& v) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
-}
-template <int I0, int I1, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I0 < I1) {
-        f(std::integral_constant<int, I0>{});
-        static_for<I0 + 1, I1>(f);
-    }
-}
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-
+// K / V^T fragments are read with lds_read16 / lds_wait (common.h): measured here, dropping the K reads alone
+// saved as much time as dropping the 16 QK MFMAs while hipcc scheduled them behind lgkmcnt(0).
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     using G = Geo<HD>;

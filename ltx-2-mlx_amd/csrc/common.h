@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -39,6 +40,30 @@ void ltx2_set_error(const char* fmt, ...);
     } while (0)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Hand-issued LDS reads and waits. hipcc only ever emits `s_waitcnt lgkmcnt(0)` around ds_read_b128 in our
+// loops, i.e. every wait drains ALL fragment reads in flight. With the read and the counted wait both in asm the
+// compiler tracks neither; lds_wait<N> names the fragment it guards so the consuming MFMA cannot move above it.
+// LGKM returns in order for LDS operations, so "at most N younger operations outstanding" proves the guarded
+// read has landed; extra compiler-issued LGKM traffic only over-waits.
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read16(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }

@@ -112,12 +112,18 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < BL; ++j) glds16(w_ptr[j] + k0, sb + j * 1024);
     };
 
-    // ---- MFMA fragment read offsets ----
+    // ---- MFMA fragment read offsets (chunk(ks) = (2*ks) ^ xbase, the staging swizzle applied again) ----
     const int wr = wv / WAVES_N, wc = wv % WAVES_N;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int xbase = hi ^ ((l31 >> 1) & 7);          // chunk(ks) = (2*ks) ^ xbase
-    const int a_row_off = (wr * CFG::WM + l31) * 128;
-    const int b_row_off = CFG::A_BYTES + (wc * CFG::WN + l31) * 128;
+    const int xbase = hi ^ ((l31 >> 1) & 7);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    unsigned a_off[4], b_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned c = ((2 * ks) ^ xbase) << 4;
+        a_off[ks] = (wr * CFG::WM + l31) * 128 + c;
+        b_off[ks] = CFG::A_BYTES + (wc * CFG::WN + l31) * 128 + c;
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -127,28 +133,44 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Fragment stream, double-buffered across the four k-steps of a K-tile and issued by hand: hipcc guards
+    // ds_read_b128 results with `s_waitcnt lgkmcnt(0)` only, which drains every read in flight, so a
+    // compiler-scheduled loop pays the LDS latency once per k-step.  Here R(ks+1) goes out before M(ks) and
+    // MFMA (i, j) waits with a counted lgkmcnt for exactly the reads it consumes (LGKM returns in order for
+    // LDS operations; read order inside a k-step: b0, a0, b1.., a1..).
+    constexpr int R = TM + TN;
+    u32x4 fa[2][TM], fb[2][TN];
+    unsigned sbase = lds0;
+    auto read_ks = [&](auto KS) {
+        constexpr int ks = decltype(KS)::value, s = ks & 1;
+        fb[s][0] = lds_read16<0>(sbase + b_off[ks]);
+        fa[s][0] = lds_read16<0>(sbase + a_off[ks]);
+        static_for<1, TN>([&](auto J) { fb[s][decltype(J)::value] = lds_read16<decltype(J)::value * 4096>(sbase + b_off[ks]); });
+        static_for<1, TM>([&](auto I) { fa[s][decltype(I)::value] = lds_read16<decltype(I)::value * 4096>(sbase + a_off[ks]); });
+    };
+    constexpr auto pos_b = [](int j) { return j == 0 ? 0 : 1 + j; };
+    constexpr auto pos_a = [](int i) { return i == 0 ? 1 : TN + i; };
+
     const int nk = p.K / BK;
     if (CONV) cit.init(p, crow, coff);
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        sbase = lds0 + (kt & 1) * CFG::STAGE_BYTES;
+        read_ks(std::integral_constant<int, 0>{});
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char* base = smem + (kt & 1) * CFG::STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int coff = ((2 * ks) ^ xbase) << 4;
-            bf16x8 af[TM], bfr[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(base + a_row_off + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *(const bf16x8*)(base + b_row_off + j * 32 * 128 + coff);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T orientation
-        }
+        static_for<0, 4>([&](auto KS) {
+            constexpr int ks = decltype(KS)::value, s = ks & 1;
+            constexpr int younger = ks < 3 ? R : 0;     // reads of k-step ks+1 issued behind ours
+            if constexpr (ks < 3) read_ks(std::integral_constant<int, ks + 1>{});
+            static_for<0, TM * TN>([&](auto MI) {
+                constexpr int m = decltype(MI)::value, i = m / TN, j = m % TN;
+                if constexpr (i == 0) lds_wait<younger + R - 1 - pos_b(j)>(fb[s][j]);
+                if constexpr (j == 0) lds_wait<younger + R - 1 - pos_a(i)>(fa[s][i]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fb[s][j]), as_bf16x8(fa[s][i]), acc[i][j], 0, 0, 0);   // C^T orientation
+            });
+        });
     }
 
     // ---- epilogue: lane owns rows (l31 per row slot) x 4-column groups (gemm_epilogue.h) ----

@@ -49,25 +49,6 @@ __device__ __forceinline__ void bufl_lds16(const void* base, unsigned lds_wave_b
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(uintptr_t)lds_wave_base, 16, voff, soff, 0, 0);
 }
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read16(unsigned addr) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return v;
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(u32x4& v) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
-}
-template <int I0, int I1, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I0 < I1) {
-        f(std::integral_constant<int, I0>{});
-        static_for<I0 + 1, I1>(f);
-    }
-}
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-
 template <int NWN, int EPI>
 __global__ __launch_bounds__(NWN * 128, NWN == 2 ? 1 : 2) void gemm_sp_kernel(const GemmParams p) {
     constexpr int NW = 2 * NWN;                 // waves: 2 along M x NWN along N
@@ -180,8 +161,11 @@ __global__ __launch_bounds__(NWN * 128, NWN == 2 ? 1 : 2) void gemm_sp_kernel(co
                 if constexpr (i == 0 && SP_ABL != 4) lds_wait<younger + R - 1 - pos_b(j)>(fb[s][j]);
                 if constexpr (j == 0 && SP_ABL != 4) lds_wait<younger + R - 1 - pos_a(i)>(fa[s][i]);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fb[s][j]), as_bf16x8(fa[s][i]), acc[i][j], 0, 0, 0);   // C^T orientation
-                if constexpr (ks < 2 && (m & 1)) {
-                    constexpr int q = (ks * TM * TN + m) / 2;
+#ifndef SP_SPREAD
+#define SP_SPREAD 2         // one LDS-DMA piece per SP_SPREAD MFMAs, starting with M(t,0)
+#endif
+                if constexpr ((ks * TM * TN + m) % SP_SPREAD == SP_SPREAD - 1) {
+                    constexpr int q = (ks * TM * TN + m) / SP_SPREAD;
                     if constexpr (q < AL + BL && SP_ABL != 1 && SP_ABL != 4) stage_piece(SP_ABL == 2 ? 0 : ktn, nbuf, q);
                 }
             });
