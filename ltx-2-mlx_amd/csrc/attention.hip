@@ -49,6 +49,22 @@ __device__ __forceinline__ void glds16(const bf16* g, unsigned lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const void*)g, (lds_ptr_t)(uintptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// v_max3_f32 directly: fmaxf() lowers to llvm.maxnum, which first canonicalises every MFMA output (one extra
+// v_max x,x per score).  The hazard recogniser does not see an asm's operands and an MFMA result has no hardware
+// interlock against a VALU read, so the max3 chain starts with mfma_result_guard(): the software wait states
+// the ISA requires between an XDL write and a VALU read, tied to both accumulators and to the running max so
+// neither the MFMAs nor the max3 chain can cross it.
+// Exchange between the two 32-lane halves with v_permlane32_swap_b32: lo = hi = x on entry; afterwards lo holds
+// x[lane & 31] and hi holds x[32 + (lane & 31)] in every lane.  Issued as asm: with this toolchain
+// __builtin_amdgcn_permlane32_swap returns its first result in both elements.
+__device__ __forceinline__ void half_pair(float x, float& lo, float& hi) {
+    lo = x;
+    hi = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+}
+__device__ __forceinline__ void mfma_result_guard(f32x16& a, f32x16& b, float& tmax) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(tmax));
+}
 __device__ __forceinline__ float max3(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -175,12 +191,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                     if (kv >= p.Nkv) s[b][r] = -INFINITY;
                 }
         }
-        // v_max3_f32 directly: fmaxf() lowers to llvm.maxnum, which first canonicalises every MFMA output
-        // (one extra v_max x,x per score)
-        float tmax = s[0][0];
+        // first V^T fragments go out before the row max and the exponentials, which hide their LDS latency
+        // (and part of the MFMA-result wait below);
+        // fragment i = d * 4 + (2 b + k2)
+        u32x4 vf[NV];
+        auto read_v = [&](auto I) {
+            constexpr int i = decltype(I)::value;
+            vf[i] = lds_read16<(i / 4) * 32 * 128>(sbase + v_lane[i % 4]);
+        };
+        static_for<0, DV>(read_v);
+
+        float tmax = -INFINITY;
+        mfma_result_guard(s[0], s[1], tmax);
 #pragma unroll
         for (int r = 0; r < 16; ++r) tmax = max3(tmax, s[0][r], s[1][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        {   // other lane half: VALU swap, no LDS-queue operation between the counted waits
+            float t_lo, t_hi;
+            half_pair(tmax, t_lo, t_hi);
+            tmax = fmaxf(t_lo, t_hi);
+        }
         // Deferred rescale: keep the old running max while the tile max exceeds it by at most
         // RESCALE_THR (in exponent units), so P stays <= 2^THR and the O rescale pass is skipped.
         // The decision is wave-uniform; when taken, O, l and the new P all move to the new max
@@ -196,15 +225,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
-        // first V^T fragments go out before the exponentials, which hide their LDS latency;
-        // fragment i = d * 4 + (2 b + k2)
-        u32x4 vf[NV];
-        auto read_v = [&](auto I) {
-            constexpr int i = decltype(I)::value;
-            vf[i] = lds_read16<(i / 4) * 32 * 128>(sbase + v_lane[i % 4]);
-        };
-        static_for<0, DV>(read_v);
-
         const float mc = m_run * c;
         // two scores per VALU op where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32); v_exp_f32 is scalar
         const f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
@@ -238,7 +258,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- finalize: lane owns query q0+l31, dims d*32 + (r&3) + 8*(r>>2) + 4*hi ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_lo, l_hi;
+    half_pair(l_run, l_lo, l_hi);
+    const float l_tot = l_lo + l_hi;
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + l31;
     if (qrow < p.Nq) {
