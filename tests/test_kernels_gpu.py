@@ -201,6 +201,33 @@ def test_flash_attn_forced_rescale(K, dev):
     assert (out.float().cpu() - ref).abs().max() < 5e-2
 
 
+@pytest.mark.parametrize("heads,Nq,Nkv,hd", [(32, 3456, 3456, 128), (32, 3456, 1024, 128), (32, 3456, 68, 64), (4, 300, 1000, 128)])
+def test_flash_attn_bit_reproducible(K, dev, heads, Nq, Nkv, hd):
+    """No atomics anywhere: repeated launches on the same operands must agree bit for bit.  At full grid size this
+    is what catches a hand-scheduled instruction that reads an MFMA result before it has landed (the row-max
+    chain is asm) -- the values stay within tolerance, the bits do not."""
+    g = torch.Generator().manual_seed(5)
+    D = heads * hd
+    qq = torch.randn(Nq, D, generator=g).to(dev, BF)
+    kk = torch.randn(Nkv, D, generator=g).to(dev, BF)
+    vt = K.vt_transpose(torch.randn(Nkv, D, generator=g).to(dev, BF), heads, head_dim=hd)
+    ref = K.flash_attn(qq, kk, vt, heads, Nkv).clone()
+    for _ in range(8):
+        assert torch.equal(K.flash_attn(qq, kk, vt, heads, Nkv), ref)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(1024, 8192, 3840), (3456, 4096, 4096), (300, 512, 256)])
+def test_gemm_bit_reproducible(K, dev, M, N, Kd):
+    """Same for the GEMM tile kernels (128x128 tile with hand-issued fragment reads, 224/256-row ping-pong)."""
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(M, Kd, generator=g).to(dev, BF)
+    w = (torch.randn(N, Kd, generator=g) / math.sqrt(Kd)).to(dev, BF)
+    b = torch.randn(N, generator=g).to(dev)
+    ref = K.gemm(a, w, b).clone()
+    for _ in range(8):
+        assert torch.equal(K.gemm(a, w, b), ref)
+
+
 def test_flash_attn_strided_views(K, dev):
     """q/k/v as column slices of one fused qkv buffer (how the engine calls it)."""
     from oracle import dit
