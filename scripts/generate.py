@@ -4,8 +4,8 @@
 Keeps the flag names and `generate_video(...)` keyword names of the reference's
 scripts/generate.py (argparse block :2364-2641, `generate_video` :933-997) for this path:
 standard single-stage distilled loop (reference :1764-1984) followed by `decode_latent` (:2080-2091).
-Out of this path (and rejected with a clear message): Gemma text encoding, audio, CFG/STG guidance,
-ffmpeg muxing.  `--lora` fuses an adapter into the checkpoint weights at load.  `--image` conditions latent frame 0 on an image through the VAE encoder (the reference
+Out of this path (and rejected with a clear message): Gemma text encoding, audio muxing, CFG/STG guidance.
+`save_video` keeps the reference's ffmpeg settings (frames piped as raw RGB; PNG frames when no ffmpeg binary exists).  `--lora` fuses an adapter into the checkpoint weights at load.  `--image` conditions latent frame 0 on an image through the VAE encoder (the reference
 routes that through its pipelines, scripts/generate.py:1711-1731).  Text embeddings come from `--embedding file.npz` (keys
 `embedding`, `attention_mask`, as the reference's `load_text_embedding` :730-750) or the reference's
 dummy encoder (`--no-gemma`, :642-661).  Frames are written as `<output>.npz` (uint8 T,H,W,3) and
@@ -33,6 +33,54 @@ def create_dummy_text_encoding(prompt: str, batch_size: int = 1, max_tokens: int
     """0.1 * N(0,1) embedding seeded by the prompt (reference :642-661; torch RNG instead of MLX's)."""
     g = torch.Generator().manual_seed(hash(prompt) % (2 ** 31))
     return (0.1 * torch.randn(batch_size, max_tokens, embed_dim, generator=g)).to(device), torch.ones(batch_size, max_tokens, device=device)
+
+
+NATIVE_FPS = 24     # the model generates motion at 24 fps
+
+
+def video_filters(fps: int = 24, speed: float = 1.0):
+    """ffmpeg -vf chain of the reference's save_video (scripts/generate.py:2178-2194): speed first (setpts), then
+    motion-compensated interpolation when the target frame rate exceeds the native 24 fps."""
+    filters = []
+    if speed != 1.0:
+        filters.append(f"setpts={1.0 / speed}*PTS")
+    if fps > NATIVE_FPS:
+        filters.append(f"minterpolate=fps={fps}:mi_mode=mci:mc_mode=aobmc:me_mode=bidir:vsbmc=1")
+    return filters
+
+
+def ffmpeg_command(width: int, height: int, output_path: str, fps: int = 24, speed: float = 1.0):
+    """Same encoder settings as the reference (:2201-2222: libx264, yuv420p, crf 18, input at the native 24 fps); the
+    frames arrive as raw RGB on stdin instead of a directory of PNGs."""
+    cmd = ["ffmpeg", "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{width}x{height}", "-framerate", str(NATIVE_FPS), "-i", "-"]
+    filters = video_filters(fps, speed)
+    if filters:
+        cmd += ["-vf", ",".join(filters)]
+    return cmd + ["-c:v", "libx264", "-pix_fmt", "yuv420p", "-crf", "18", "-loglevel", "error", output_path]
+
+
+def save_video(frames, output_path: str, fps: int = 24, speed: float = 1.0):
+    """frames: uint8 (T, H, W, 3) array or list of (H, W, 3) arrays -> output_path via ffmpeg (reference :2153-2226).
+    Without an ffmpeg binary the frames are written as PNGs into `<output stem>_frames/` and that directory is returned
+    (the reference raises there; on a GPU box without ffmpeg the frames are still wanted)."""
+    import shutil
+    import subprocess
+    frames = np.ascontiguousarray(np.stack([np.asarray(f) for f in frames]) if isinstance(frames, (list, tuple)) else np.asarray(frames))
+    if frames.ndim != 4 or frames.shape[-1] != 3 or frames.dtype != np.uint8:
+        raise ValueError(f"save_video expects uint8 frames (T, H, W, 3), got {frames.dtype} {frames.shape}")
+    t, h, w, _ = frames.shape
+    if shutil.which("ffmpeg") is None:
+        from PIL import Image
+        out_dir = os.path.splitext(output_path)[0] + "_frames"
+        os.makedirs(out_dir, exist_ok=True)
+        for i in range(t):
+            Image.fromarray(frames[i]).save(os.path.join(out_dir, f"frame_{i:04d}.png"))
+        print(f"  ffmpeg not found: wrote {t} PNG frames to {out_dir}/")
+        return out_dir
+    result = subprocess.run(ffmpeg_command(w, h, output_path, fps, speed), input=frames.tobytes(), capture_output=True)
+    if result.returncode != 0:
+        raise RuntimeError(f"FFmpeg failed: {result.stderr.decode(errors='replace')}")
+    return output_path
 
 
 def load_text_embedding(path: str, device="cuda"):
@@ -72,7 +120,8 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
                    use_gemma: bool = False, model_variant: str = "distilled", skip_vae: bool = False, use_placeholder: bool = False,
                    tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, use_fp8: bool = False, num_layers: int = 48,
                    num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", image_path=None,
-                   image_strength: float = 0.95, lora_path=None, lora_strength: float = 1.0, **unsupported):
+                   image_strength: float = 0.95, lora_path=None, lora_strength: float = 1.0, fps: int = 24, speed: float = 1.0,
+                   save_mp4: bool = True, **unsupported):
     for k, v in unsupported.items():
         if v:
             raise NotImplementedError(f"--{k.replace('_', '-')} is outside the MI355X hot path (see DESIGN.md)")
@@ -164,7 +213,10 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
             frames = decode_latent(latent, vae_decoder)
         torch.cuda.synchronize()
         print(f"  decode: {(time.time() - t0):.3f} s -> {tuple(frames.shape)}")
-        np.savez_compressed(base + ".npz", frames=frames.cpu().numpy())
+        frames_np = frames.cpu().numpy()
+        np.savez_compressed(base + ".npz", frames=frames_np)
+        if save_mp4:
+            print(f"  video: {save_video(frames_np, output_path, fps=fps, speed=speed)}")
     print(f"Done in {time.time() - t_all:.1f} s: {base}.npz")
     return frames
 
@@ -203,6 +255,9 @@ def main():
     p.add_argument("--layers", type=int, default=48, help="debug: number of DiT layers for random-weight runs")
     p.add_argument("--heads", type=int, default=32, help="debug: attention heads (x128) for random-weight runs")
     p.add_argument("--vae-base-channels", type=int, default=128)
+    p.add_argument("--fps", type=int, default=24, help="output frame rate; > 24 interpolates (reference flag)")
+    p.add_argument("--speed", type=float, default=1.0, help="playback speed multiplier (reference flag)")
+    p.add_argument("--no-video-file", action="store_true", help="keep only the .npz outputs (skip ffmpeg / PNG frames)")
     a = p.parse_args()
     if a.fp32:
         raise NotImplementedError("--fp32: the MI355X path computes in bf16 with fp32 accumulation / residual stream")
@@ -213,7 +268,7 @@ def main():
                    use_gemma=bool(a.gemma_path) and not a.no_gemma, model_variant=a.model_variant, skip_vae=a.skip_vae,
                    use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, cfg_scale=a.cfg, use_hip_graph=not a.no_hip_graph, use_fp8=a.fp8,
                    num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,
-                   image_path=a.image, image_strength=a.image_strength, lora_path=a.lora, lora_strength=a.lora_strength, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights)
+                   image_path=a.image, image_strength=a.image_strength, lora_path=a.lora, lora_strength=a.lora_strength, fps=a.fps, speed=a.speed, save_mp4=not a.no_video_file, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights)
 
 
 if __name__ == "__main__":

@@ -312,3 +312,28 @@ def test_gloo_world2_broadcast_and_sharding(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+def test_save_video_command_and_png_fallback(tmp_path, monkeypatch):
+    """CLI file output (reference scripts/generate.py:2153-2226): the ffmpeg filter chain / encoder settings, and
+    the PNG-frame fallback used on boxes without an ffmpeg binary."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("ltx2_generate_cli", os.path.join(ROOT, "scripts", "generate.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.video_filters(24, 1.0) == []
+    assert gen.video_filters(24, 2.0) == ["setpts=0.5*PTS"]
+    assert gen.video_filters(48, 0.5) == ["setpts=2.0*PTS", "minterpolate=fps=48:mi_mode=mci:mc_mode=aobmc:me_mode=bidir:vsbmc=1"]
+    cmd = gen.ffmpeg_command(768, 512, "out.mp4", fps=48)
+    assert cmd[:2] == ["ffmpeg", "-y"] and "768x512" in cmd and cmd[cmd.index("-framerate") + 1] == "24"
+    assert cmd[-9:] == ["-c:v", "libx264", "-pix_fmt", "yuv420p", "-crf", "18", "-loglevel", "error", "out.mp4"]
+    frames = (np.arange(3 * 8 * 16 * 3) % 251).astype(np.uint8).reshape(3, 8, 16, 3)
+    monkeypatch.setattr("shutil.which", lambda name: None)
+    out = gen.save_video(frames, str(tmp_path / "clip.mp4"))
+    from PIL import Image
+    files = sorted(os.listdir(out))
+    assert files == ["frame_0000.png", "frame_0001.png", "frame_0002.png"]
+    assert np.array_equal(np.asarray(Image.open(os.path.join(out, files[1]))), frames[1])
+    with pytest.raises(ValueError):
+        gen.save_video(frames.astype(np.float32), str(tmp_path / "bad.mp4"))

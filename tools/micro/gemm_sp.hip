@@ -164,10 +164,21 @@ __global__ __launch_bounds__(NWN * 128, NWN == 2 ? 1 : 2) void gemm_sp_kernel(co
 #ifndef SP_SPREAD
 #define SP_SPREAD 2         // one LDS-DMA piece per SP_SPREAD MFMAs, starting with M(t,0)
 #endif
+#ifdef SP_STAGGER
+                // wave w issues in MFMA slots g with g % 4 == w % 4: the four waves of a CU never present their
+                // VMEM instructions to the TA at the same time
+                {
+                    constexpr int g = ks * TM * TN + m, q = g / 4;
+                    if constexpr (q < AL + BL && SP_ABL != 1 && SP_ABL != 4) {
+                        if ((g & 3) == (wv & 3)) stage_piece(SP_ABL == 2 ? 0 : ktn, nbuf, q);
+                    }
+                }
+#else
                 if constexpr ((ks * TM * TN + m) % SP_SPREAD == SP_SPREAD - 1) {
                     constexpr int q = (ks * TM * TN + m) / SP_SPREAD;
                     if constexpr (q < AL + BL && SP_ABL != 1 && SP_ABL != 4) stage_piece(SP_ABL == 2 ? 0 : ktn, nbuf, q);
                 }
+#endif
             });
         });
 #pragma unroll
