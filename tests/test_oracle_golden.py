@@ -272,3 +272,35 @@ def test_latent_index_conditioning_matches_reference():
         VideoConditionByLatentIndex(latent=torch.zeros(1, 128, 1, 3, 2), strength=1.0, latent_idx=0).apply_to(st, tools)
     with pytest.raises(ValueError, match="exceed latent sequence length"):
         VideoConditionByLatentIndex(latent=torch.zeros(1, 128, 2, 2, 2), strength=1.0, latent_idx=2).apply_to(st, tools)
+
+
+def test_text_connector_and_feature_extractors_match_reference():
+    """Embeddings1DConnector (registers, INTERLEAVED RoPE with the fp32 and the float64 grid) and both Gemma feature
+    extractors, from the seeds of tools/pin_oracle_against_reference.py::pin_text_connector."""
+    from oracle import text_connector as tc
+    z = g("text_connector.npz")
+    for tag, dbl in (("f32", False), ("f64", True)):
+        cfg = tc.ConnectorConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, num_learnable_registers=16,
+                                 double_precision_rope=dbl)
+        w = tc.make_connector_weights(cfg, seed=61)
+        x = torch.randn(1, 40, cfg.inner_dim, generator=torch.Generator().manual_seed(62))
+        y, mask = tc.encode_projected(x, torch.ones(1, 40), w, cfg)
+        assert y.shape == (1, 1024, 256) and int(mask.sum()) == 1024
+        close(y[:, :56], z[f"connector_{tag}_head"], rtol=2e-4, atol=2e-5)
+        close(y[:, 992:], z[f"connector_{tag}_tail"], rtol=2e-4, atol=2e-5)
+        close(torch.stack([y.mean(), y.std(unbiased=False), y.abs().max()]), z[f"connector_{tag}_stats"], rtol=1e-4, atol=1e-6)
+    gen = torch.Generator().manual_seed(63)
+    hs = [torch.randn(2, 12, 32, generator=gen) * (1 + 0.3 * i) + 0.1 * i for i in range(5)]
+    am = torch.ones(2, 12)
+    am[1, :5] = 0
+    w1 = 0.05 * torch.randn(32, 160, generator=gen)
+    close(tc.feature_extractor_v1(hs, am, {"aggregate_embed.weight": w1}, "left"), z["fe_v1_left"], rtol=1e-5, atol=1e-6)
+    am_r = torch.ones(2, 12)
+    am_r[1, 7:] = 0
+    close(tc.feature_extractor_v1(hs, am_r, {"aggregate_embed.weight": w1}, "right"), z["fe_v1_right"], rtol=1e-5, atol=1e-6)
+    wv, bv = 0.05 * torch.randn(48, 160, generator=gen), 0.1 * torch.randn(48, generator=gen)
+    wa, ba = 0.05 * torch.randn(24, 160, generator=gen), 0.1 * torch.randn(24, generator=gen)
+    v, a = tc.feature_extractor_v2(hs, am, {"video_aggregate_embed.weight": wv, "video_aggregate_embed.bias": bv,
+                                            "audio_aggregate_embed.weight": wa, "audio_aggregate_embed.bias": ba})
+    close(v, z["fe_v2_video"], rtol=1e-5, atol=1e-6)
+    close(a, z["fe_v2_audio"], rtol=1e-5, atol=1e-6)

@@ -367,6 +367,10 @@ class _Random(types.ModuleType):
             return Arr(t.clone())
         return Arr(torch.randn(tuple(shape), generator=cls.gen).to(_td(dtype)) * scale + loc)
 
+    @classmethod
+    def uniform(cls, low=0.0, high=1.0, shape=(), dtype=float32, key=None):
+        return Arr((torch.rand(tuple(shape), generator=cls.gen) * (high - low) + low).to(_td(dtype)))
+
     @staticmethod
     def key(s):
         return Arr(torch.tensor([0, int(s)]))

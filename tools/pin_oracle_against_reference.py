@@ -28,6 +28,7 @@ from oracle import upscaler as oup  # noqa: E402
 from oracle import vae_encoder as oenc  # noqa: E402
 from oracle import loop as oloop  # noqa: E402
 from oracle import vae as ovae  # noqa: E402
+from oracle import text_connector as otc  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
@@ -171,6 +172,65 @@ def pin_upscaler():
     out = {"upscaled": tn(up(A(x)).t)}
     np.savez_compressed(os.path.join(GOLD, "upscaler_tiny.npz"), **out)
     print("upscaler_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------------ text connector / feature extractors
+def pin_text_connector():
+    """Embeddings1DConnector (2 heads x 128, 2 layers, 16 registers -> 1024 tokens) on a 40-token prompt, with the
+    fp32 and the float64 frequency grid; both Gemma feature extractors on a left-padded 2 x 12 x 32 x 5 stack."""
+    from LTX_2_MLX.model.text_encoder.connector import Embeddings1DConnector
+    from LTX_2_MLX.model.text_encoder.feature_extractor import GemmaFeaturesExtractorProjLinear, GemmaFeaturesExtractorV2
+    import LTX_2_MLX.model.transformer.rope as ref_rope
+    from LTX_2_MLX.model.transformer.rope import LTXRopeType
+    ref_rope._HAS_FUSED_ROPE = False           # the fused variant is a Metal kernel; the reference's own fallback is the definition
+    out = {}
+    for tag, dbl in (("f32", False), ("f64", True)):
+        cfg = otc.ConnectorConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, num_learnable_registers=16,
+                                  double_precision_rope=dbl)
+        w = otc.make_connector_weights(cfg, seed=61)
+        conn = Embeddings1DConnector(attention_head_dim=128, num_attention_heads=2, num_layers=2, num_learnable_registers=16,
+                                     rope_type=LTXRopeType.INTERLEAVED, double_precision_rope=dbl)
+        conn.learnable_registers = A(w["learnable_registers"])
+        for i, blk in enumerate(conn.transformer_1d_blocks):
+            p = f"transformer_1d_blocks.{i}"
+            for n, attr in (("to_q", "to_q"), ("to_k", "to_k"), ("to_v", "to_v"), ("to_out.0", "to_out")):
+                lin = getattr(blk.attn1, attr)
+                lin.weight, lin.bias = A(w[f"{p}.attn1.{n}.weight"]), A(w[f"{p}.attn1.{n}.bias"])
+            blk.attn1.q_norm.weight, blk.attn1.k_norm.weight = A(w[f"{p}.attn1.q_norm.weight"]), A(w[f"{p}.attn1.k_norm.weight"])
+            blk.ff.project_in.proj.weight, blk.ff.project_in.proj.bias = A(w[f"{p}.ff.net.0.proj.weight"]), A(w[f"{p}.ff.net.0.proj.bias"])
+            blk.ff.project_out.weight, blk.ff.project_out.bias = A(w[f"{p}.ff.net.2.weight"]), A(w[f"{p}.ff.net.2.bias"])
+        g = torch.Generator().manual_seed(62)
+        x = torch.randn(1, 40, cfg.inner_dim, generator=g)
+        add_mask = torch.zeros(1, 1, 1, 40)
+        add_mask[..., 30:] = -3.4e38          # ten pad tokens: the connector must clear the mask
+        y, m = conn(A(x), A(add_mask))
+        yt = tn(y.t)                           # keep the prompt rows, the first registers and the last rows (+ global stats)
+        out[f"connector_{tag}_head"], out[f"connector_{tag}_tail"] = yt[:, :56], yt[:, 992:]
+        out[f"connector_{tag}_stats"] = np.array([yt.mean(), yt.std(), np.abs(yt).max()], dtype=np.float32)
+        assert float(np.abs(tn(m.t)).max()) == 0.0 and y.t.shape == (1, 1024, cfg.inner_dim)
+    g = torch.Generator().manual_seed(63)
+    hs = [torch.randn(2, 12, 32, generator=g) * (1 + 0.3 * i) + 0.1 * i for i in range(5)]
+    am = torch.ones(2, 12)
+    am[1, :5] = 0                              # left padding, 7 valid tokens
+    fe1 = GemmaFeaturesExtractorProjLinear(hidden_dim=32, num_layers=5)
+    w1 = 0.05 * torch.randn(32, 160, generator=g)
+    fe1.aggregate_embed.weight = A(w1)
+    out["fe_v1_left"] = tn(fe1.extract_from_hidden_states([A(h) for h in hs], A(am), padding_side="left").t)
+    am_r = torch.ones(2, 12)
+    am_r[1, 7:] = 0
+    out["fe_v1_right"] = tn(fe1.extract_from_hidden_states([A(h) for h in hs], A(am_r), padding_side="right").t)
+    fe2 = GemmaFeaturesExtractorV2(hidden_dim=32, num_layers=5, video_inner_dim=48, audio_inner_dim=24)
+    wv, bv = 0.05 * torch.randn(48, 160, generator=g), 0.1 * torch.randn(48, generator=g)
+    wa, ba = 0.05 * torch.randn(24, 160, generator=g), 0.1 * torch.randn(24, generator=g)
+    fe2.video_aggregate_embed.weight, fe2.video_aggregate_embed.bias = A(wv), A(bv)
+    fe2.audio_aggregate_embed.weight, fe2.audio_aggregate_embed.bias = A(wa), A(ba)
+    v, a = fe2.extract_from_hidden_states([A(h) for h in hs], A(am))
+    out["fe_v2_video"], out["fe_v2_audio"] = tn(v.t), tn(a.t)
+    # the oracle on the same inputs, here and again (from the seeds) in tests/test_oracle_golden.py
+    chk = otc.feature_extractor_v1(hs, am, {"aggregate_embed.weight": w1}, "left")
+    print("  fe_v1 oracle vs reference:", float((chk - torch.from_numpy(out["fe_v1_left"])).abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "text_connector.npz"), **out)
+    print("text_connector.npz", {k: v.shape for k, v in out.items()})
 
 
 # ------------------------------------------------------------------------------------------ VAE encoder + conditioning
@@ -360,6 +420,9 @@ def pin_vae():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "text_connector":
+        pin_text_connector()
+        sys.exit(0)
     with torch.no_grad():
         pin_loop()
         pin_dit()
