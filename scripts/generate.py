@@ -92,6 +92,32 @@ def load_text_embedding(path: str, device="cuda"):
     return emb.to(device), mask.to(device)
 
 
+def encode_text_features(path: str, weights_path=None, device="cuda", seed: int = 0):
+    """`--text-features file.npz`: key `features` = the Gemma feature extractor's output [T, 3840] or [1, T, 3840]
+    (or `hidden_states` [L, T, 3840] = all Gemma layers, run through the extractor first) and `attention_mask` [T].
+    The Embeddings1DConnector (registers, 2 blocks, final RMSNorm) runs on the GPU (reference `encode_projected` /
+    `encode_from_hidden_states`, model/text_encoder/encoder.py:136-215); its weights come from `--weights`
+    (`model.diffusion_model.video_embeddings_connector.*`, `text_embedding_projection.*`) or are random without one."""
+    from ltx_2_mlx_amd.model.text_encoder import create_text_encoder, load_text_encoder_weights
+    z = np.load(path)
+    enc = create_text_encoder(device=device)
+    if weights_path:
+        load_text_encoder_weights(enc, weights_path)
+    else:
+        enc.embeddings_connector.init_random_weights(seed)
+    mask = torch.from_numpy(z["attention_mask"]).float().reshape(1, -1) if "attention_mask" in z else None
+    if "hidden_states" in z:
+        hs = [torch.from_numpy(h).float()[None] for h in z["hidden_states"]]
+        mask = torch.ones(1, hs[0].shape[1]) if mask is None else mask
+        out = enc.encode_from_hidden_states(hs, mask.to(device))
+    else:
+        feats = torch.from_numpy(z["features"]).float()
+        feats = feats[None] if feats.dim() == 2 else feats
+        mask = torch.ones(feats.shape[:2]) if mask is None else mask
+        out = enc.encode_projected(feats.to(device), mask.to(device))
+    return out.video_encoding, out.attention_mask.float()
+
+
 def load_transformer(weights_path, num_layers=48, num_heads=32, caption_channels=3840, seed=0, device="cuda", use_fp8=False,
                      lora_path=None, lora_strength=1.0):
     """LTXModel(VideoOnly, 32x128, 48 layers, caption 3840) (reference load_transformer :788-835)."""
@@ -121,6 +147,7 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
                    tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, use_fp8: bool = False, num_layers: int = 48,
                    num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", image_path=None,
                    image_strength: float = 0.95, lora_path=None, lora_strength: float = 1.0, fps: int = 24, speed: float = 1.0,
+                   text_features_path=None,
                    save_mp4: bool = True, **unsupported):
     for k, v in unsupported.items():
         if v:
@@ -136,7 +163,10 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
     torch.manual_seed(seed)
     t_all = time.time()
     print("[1/5] text encoding")
-    text_encoding, _ = load_text_embedding(embedding_path, device) if embedding_path else create_dummy_text_encoding(prompt, device=device)
+    if text_features_path:
+        text_encoding, _ = encode_text_features(text_features_path, weights_path, device, seed)
+    else:
+        text_encoding, _ = load_text_embedding(embedding_path, device) if embedding_path else create_dummy_text_encoding(prompt, device=device)
     print("[2/5] transformer")
     model = X0Model(load_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device, use_fp8=use_fp8,
                                      lora_path=lora_path, lora_strength=lora_strength))
@@ -232,6 +262,7 @@ def main():
     p.add_argument("--output", "-o", type=str, default="output.mp4")
     p.add_argument("--weights", type=str, default=None)
     p.add_argument("--embedding", type=str, default=None)
+    p.add_argument("--text-features", type=str, default=None, help="npz with Gemma `features` [T,3840] (or `hidden_states` [L,T,3840]) + `attention_mask`: run the text connector on the GPU")
     p.add_argument("--no-gemma", action="store_true", help="dummy text embeddings (reference default without Gemma weights)")
     p.add_argument("--gemma-path", type=str, default=None)
     p.add_argument("--model-variant", choices=["distilled", "dev"], default="distilled")
@@ -264,7 +295,7 @@ def main():
     if a.pipeline not in ("text-to-video", "distilled"):
         raise NotImplementedError(f"--pipeline {a.pipeline} is outside the MI355X hot path")
     generate_video(a.prompt, height=a.height, width=a.width, num_frames=a.frames, num_inference_steps=a.steps, seed=a.seed,
-                   output_path=a.output, weights_path=a.weights, embedding_path=a.embedding,
+                   output_path=a.output, weights_path=a.weights, embedding_path=a.embedding, text_features_path=a.text_features,
                    use_gemma=bool(a.gemma_path) and not a.no_gemma, model_variant=a.model_variant, skip_vae=a.skip_vae,
                    use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, cfg_scale=a.cfg, use_hip_graph=not a.no_hip_graph, use_fp8=a.fp8,
                    num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,

@@ -38,3 +38,12 @@ def test_generate_cli_plumbing(dev, tmp_path):
     lc = np.load(tmp_path / "c_latent.npz")["latent"]
     assert lc.shape == (1, 128, 3, 8, 12) and np.isfinite(lc).all()
     assert np.abs(lc[:, :, 0] - la[:, :, 0]).mean() > 0.05
+    # --text-features: Gemma features -> Embeddings1DConnector on the GPU -> 1024 x 3840 context for the DiT
+    np.savez(tmp_path / "feats.npz", features=(0.1 * np.random.RandomState(2).randn(24, 3840)).astype(np.float32),
+             attention_mask=np.ones(24, dtype=np.float32))
+    generate.generate_video("a test prompt", output_path=str(tmp_path / "d.mp4"), text_features_path=str(tmp_path / "feats.npz"),
+                            skip_vae=True, **kw)
+    ld = np.load(tmp_path / "d_latent.npz")["latent"]
+    assert ld.shape == (1, 128, 3, 8, 12) and np.isfinite(ld).all() and np.abs(ld - la).mean() > 1e-3
+    # a.mp4 went through save_video: an .mp4 with ffmpeg on the box, PNG frames without
+    assert os.path.exists(tmp_path / "a.mp4") or len(os.listdir(tmp_path / "a_frames")) == 17

@@ -533,3 +533,85 @@ def test_lora_fusion_at_load(dev, tmp_path):
     x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
     err = rel_l2(x0.cpu(), ref)
     assert err < 2e-2 and rel_l2(base, ref) > 5 * err        # the adapters matter and are applied
+
+
+def test_text_connector_and_feature_extractors(dev, tmp_path):
+    """Scope row f3: Embeddings1DConnector (registers -> 1024 tokens, INTERLEAVED RoPE run as SPLIT on per-head permuted
+    q/k rows, fp32 and float64 frequency grids) vs the fp32 oracle and the reference vectors; both Gemma feature
+    extractors (layer-major re-ordered projection weights) vs the oracle; the safetensors key scheme round trip."""
+    import numpy as np
+    import os
+    from oracle import text_connector as tc
+    from ltx_2_mlx_amd.model.text_encoder import (Embeddings1DConnector, GemmaFeaturesExtractorProjLinear, GemmaFeaturesExtractorV2,
+                                                  VideoGemmaTextEncoderModel, load_text_encoder_weights)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "text_connector.npz"))
+
+    def qw(w):      # the GPU holds matrices in bf16: give the oracle the same operands
+        return {k: (v.to(torch.bfloat16).float() if v.dim() == 2 and k != "learnable_registers" else v) for k, v in w.items()}
+
+    for tag, dbl in (("f32", False), ("f64", True)):
+        cfg = tc.ConnectorConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, num_learnable_registers=16,
+                                 double_precision_rope=dbl)
+        w = tc.make_connector_weights(cfg, seed=61)
+        conn = Embeddings1DConnector(attention_head_dim=128, num_attention_heads=2, num_layers=2, num_learnable_registers=16,
+                                     double_precision_rope=dbl, device=dev)
+        conn.load_state_dict(w)
+        x = torch.randn(1, 40, cfg.inner_dim, generator=torch.Generator().manual_seed(62))
+        enc = VideoGemmaTextEncoderModel(feature_extractor=object(), embeddings_connector=conn)
+        am = torch.ones(1, 40)
+        am[:, 30:] = 0
+        out = enc.encode_projected(x.to(dev), am.to(dev))
+        ref, _ = tc.encode_projected(x, am, qw(w), cfg)
+        y = out.video_encoding.cpu()
+        assert y.shape == (1, 1024, 256) and y.dtype == torch.float32 and int(out.attention_mask.sum()) == 1024
+        assert rel_l2(y, ref) < 2e-2 and pearson(y, ref) > 0.999, tag
+        assert rel_l2(y[:, :56], torch.from_numpy(z[f"connector_{tag}_head"])) < 3e-2, tag
+        assert rel_l2(y[:, 992:], torch.from_numpy(z[f"connector_{tag}_tail"])) < 3e-2, tag
+    # production width: 30 heads x 128 = 3840, one block, a 100-token prompt
+    cfg = tc.ConnectorConfig(num_layers=1)
+    w = tc.make_connector_weights(cfg, seed=64)
+    conn = Embeddings1DConnector(num_layers=1, device=dev)
+    conn.load_state_dict(w)
+    x = torch.randn(1, 100, 3840, generator=torch.Generator().manual_seed(65))
+    y, m = conn(x.to(dev))
+    ref = tc.embeddings_connector(x, qw(w), cfg)
+    assert y.shape == (1, 1024, 3840) and float(m.abs().max()) == 0.0
+    assert rel_l2(y.cpu(), ref) < 2e-2 and pearson(y.cpu(), ref) > 0.999
+
+    # feature extractors: D = 64, L = 5 layers, left-padded batch of 2
+    gen = torch.Generator().manual_seed(66)
+    hs = [torch.randn(2, 12, 64, generator=gen) * (1 + 0.3 * i) + 0.1 * i for i in range(5)]
+    am = torch.ones(2, 12)
+    am[1, :5] = 0
+    w1 = 0.05 * torch.randn(64, 320, generator=gen)
+    fe1 = GemmaFeaturesExtractorProjLinear(hidden_dim=64, num_layers=5, device=dev)
+    fe1.load_state_dict({"aggregate_embed.weight": w1})
+    o1 = fe1.extract_from_hidden_states([h.to(dev) for h in hs], am.to(dev), padding_side="left").cpu()
+    r1 = tc.feature_extractor_v1(hs, am, {"aggregate_embed.weight": w1.to(torch.bfloat16).float()}, "left")
+    assert o1.shape == (2, 12, 64) and rel_l2(o1, r1) < 1e-2
+    assert float(o1[1, :5].abs().max()) == 0.0                     # pad rows: no bias in V1
+    wv, bv = 0.05 * torch.randn(128, 320, generator=gen), 0.1 * torch.randn(128, generator=gen)
+    wa, ba = 0.05 * torch.randn(64, 320, generator=gen), 0.1 * torch.randn(64, generator=gen)
+    fe2 = GemmaFeaturesExtractorV2(hidden_dim=64, num_layers=5, video_inner_dim=128, audio_inner_dim=64, device=dev)
+    sd2 = {"video_aggregate_embed.weight": wv, "video_aggregate_embed.bias": bv, "audio_aggregate_embed.weight": wa, "audio_aggregate_embed.bias": ba}
+    fe2.load_state_dict(sd2)
+    v, a = fe2.extract_from_hidden_states([h.to(dev) for h in hs], am.to(dev))
+    rv, ra = tc.feature_extractor_v2(hs, am, {k: (t.to(torch.bfloat16).float() if t.dim() == 2 else t) for k, t in sd2.items()})
+    assert rel_l2(v.cpu(), rv) < 1e-2 and rel_l2(a.cpu(), ra) < 1e-2
+    assert torch.allclose(v[1, :5].cpu(), bv.expand(5, -1), atol=1e-6)      # pad rows carry the bias only
+
+    # checkpoint key scheme (reference encoder.py:441-520) through safetensors
+    from safetensors.torch import save_file
+    cfg = tc.ConnectorConfig(num_attention_heads=2, attention_head_dim=128, num_layers=1, num_learnable_registers=16)
+    w = tc.make_connector_weights(cfg, seed=67)
+    sd = {"model.diffusion_model.video_embeddings_connector." + k: t.contiguous() for k, t in w.items()}
+    sd["text_embedding_projection.aggregate_embed.weight"] = w1
+    sd["model.diffusion_model.caption_projection.linear_1.weight"] = torch.zeros(4, 4)      # belongs to the transformer: ignored
+    path = str(tmp_path / "te.safetensors")
+    save_file(sd, path)
+    enc = VideoGemmaTextEncoderModel(feature_extractor=GemmaFeaturesExtractorProjLinear(hidden_dim=64, num_layers=5, device=dev),
+                                     embeddings_connector=Embeddings1DConnector(attention_head_dim=128, num_attention_heads=2, num_layers=1,
+                                                                                num_learnable_registers=16, device=dev))
+    assert load_text_encoder_weights(enc, path) == len(w) + 1
+    with pytest.raises(ValueError):
+        enc.embeddings_connector(torch.zeros(1, 8, 100, device=dev))
