@@ -16,7 +16,10 @@ import torch.distributed as dist
 
 
 def env_rank_world() -> Tuple[int, int, int]:
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    """RANK, WORLD_SIZE, local device index.  LTX2_LOCAL_DEVICE overrides LOCAL_RANK as the device index (several
+    ranks on one GPU: the single-GPU rehearsal of the multi-process path, together with LTX2_DIST_BACKEND=gloo)."""
+    local = int(os.environ.get("LTX2_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), local
 
 
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
@@ -25,7 +28,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("LTX2_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -60,6 +63,8 @@ def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_byt
         while i < len(group):
             # greedily pack whole tensors; a tensor larger than the bucket goes alone, unflattened
             t0 = tensors[group[i]]
+            if not t0.is_contiguous():
+                raise ValueError(f"broadcast_tensors: {group[i]} is not contiguous")
             if t0.numel() >= cap:
                 dist.broadcast(t0, src=src)
                 n_coll += 1
@@ -82,7 +87,7 @@ def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_byt
             if dist.get_rank() != src:
                 for n in group[i:j]:
                     k = tensors[n].numel()
-                    tensors[n].reshape(-1).copy_(flat[off:off + k])
+                    tensors[n].view(-1).copy_(flat[off:off + k])      # view: a non-contiguous tensor must fail, not copy into a temporary
                     off += k
             i = j
     return n_coll
