@@ -47,3 +47,23 @@ def test_generate_cli_plumbing(dev, tmp_path):
     assert ld.shape == (1, 128, 3, 8, 12) and np.isfinite(ld).all() and np.abs(ld - la).mean() > 1e-3
     # a.mp4 went through save_video: an .mp4 with ffmpeg on the box, PNG frames without
     assert os.path.exists(tmp_path / "a.mp4") or len(os.listdir(tmp_path / "a_frames")) == 17
+
+
+def test_bench_two_rank_rehearsal(dev):
+    """The N > 1 path of bench.py (torchrun env, weight broadcast, barrier-bracketed timing, MAX over ranks, rank-0
+    JSON line) with two ranks sharing this box's single GPU over gloo -- what the driver launches with one rank per
+    GPU over RCCL."""
+    import json
+    import subprocess
+    env = dict(os.environ, LTX2_DIST_BACKEND="gloo", LTX2_LOCAL_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "1", "--layers", "2",
+           "--no-vae"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 8 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["weight_broadcast_collectives"] >= 1 and "cpu_baseline" not in out
+    assert abs(out["value"] - 2 * 8 / (out["ms_per_step"] * 8e-3)) < 1e-2 * out["value"]
