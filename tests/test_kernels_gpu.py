@@ -293,6 +293,19 @@ def test_pixnorm_mod_silu(K, dev, C):
     assert rel_l2(out.float().cpu(), ref) < 6e-3
 
 
+@pytest.mark.parametrize("C,P", [(64, 300000), (128, 140000), (1024, 9000)])
+def test_pixnorm_mod_silu_grid_stride(K, dev, C, P):
+    """More positions than one pass of the capped grid covers (8192 blocks x 256 threads / (C/8 or C/16) lanes per position)."""
+    g = torch.Generator(device=dev).manual_seed(C)
+    x = (torch.randn(P, C, generator=g, device=dev) * 2).to(BF)
+    tab = 0.2 * torch.randn(4, C, generator=g, device=dev)
+    xf = x.float()
+    ref = F.silu(xf * torch.rsqrt(xf.pow(2).mean(dim=1, keepdim=True) + 1e-6) * (1 + tab[1]) + tab[0])
+    out = K.pixnorm_mod_silu(x.reshape(1, 1, P, C), tab, None, 0, 1).reshape(P, C)
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 6e-3
+    assert rel_l2(out[-7:].float().cpu(), ref[-7:].cpu()) < 6e-3
+
+
 def test_euler_and_x0(K, dev):
     from oracle import loop
     g = torch.Generator().manual_seed(1)
