@@ -83,6 +83,61 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
     }
 }
 
+// Row-invariant modulation (emb_stride == 0: the scalar-sigma case).  A block walks rows blockIdx.x, +gridDim.x, ..
+// with the combined (1 + scale) and shift vectors in registers -- read per row, the four 16-KiB tables are 64 KiB of
+// L2->L1 traffic beside 24 KiB of data (21.5 -> 18.8 us at 3456 x 4096).  The per-row kernel above stays for per-token
+// modulation and for the plain norm, where more blocks in flight matter more (28.5 vs 32.5 us, 14.0 vs 14.5).
+template <int NV>
+__global__ __launch_bounds__(256) void norm_mod_shared_kernel(const float* __restrict__ x, long ldx, bf16* __restrict__ out,
+                                                              long ldo, int rows, int D, float eps, int layer_norm,
+                                                              const float* __restrict__ scale_tab,
+                                                              const float* __restrict__ shift_tab,
+                                                              const float* __restrict__ scale_emb,
+                                                              const float* __restrict__ shift_emb) {
+    __shared__ float red[8];
+    f32x4 sc1[NV], sh[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int d = threadIdx.x * 4 + i * 1024;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, h = {0.f, 0.f, 0.f, 0.f};
+        if (d < D) {
+            if (scale_tab) sc += *(const f32x4*)(scale_tab + d);
+            if (scale_emb) sc += *(const f32x4*)(scale_emb + d);
+            if (shift_tab) h += *(const f32x4*)(shift_tab + d);
+            if (shift_emb) h += *(const f32x4*)(shift_emb + d);
+        }
+        sc1[i] = sc;
+        sh[i] = h;
+    }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* xr = x + row * ldx;
+        f32x4 v[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int d = threadIdx.x * 4 + i * 1024;
+            v[i] = (d < D) ? *(const f32x4*)(xr + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s1 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            s2 += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+        block_sum2_256(s1, s2, red);
+        const float mean = layer_norm ? s1 / (float)D : 0.f;
+        const float ms = s2 / (float)D;
+        const float var = layer_norm ? fmaxf(ms - mean * mean, 0.f) : ms;
+        const float rstd = rsqrtf(var + eps);
+        bf16* orow = out + row * ldo;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int d = threadIdx.x * 4 + i * 1024;
+            if (d >= D) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf((v[i][e] - mean) * rstd * sc1[i][e] + sh[i][e]);
+            *(bf16x4*)(orow + d) = o;
+        }
+    }
+}
+
 struct QKSegs {
     int off[2];
     const float* w[2];
@@ -91,64 +146,77 @@ struct QKSegs {
 // One block per row, D/2 <= 2048 rotation pairs: thread t owns pairs [8t, 8t+8) of EVERY segment
 // (q and k share the cos/sin row), everything register-resident, one read + one write per element.
 template <int NSEG>
-__global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16* __restrict__ buf, long ld, int D, int head_dim,
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16* __restrict__ buf, long ld, int rows, int D, int head_dim,
                                                           QKSegs segs, float eps, const float* __restrict__ cosp,
                                                           const float* __restrict__ sinp) {
     __shared__ float red[8];
-    const long row = blockIdx.x;
     const int half = head_dim >> 1;
     const int p0 = threadIdx.x * 8;
     const bool act = p0 < D / 2;
     const int ia = act ? (p0 / half) * head_dim + (p0 % half) : 0;
     const int ib = ia + half;
-    bf16x8 va[NSEG], vb[NSEG];
-    float ss[2] = {0.f, 0.f};
+    // the norm weights do not depend on the row: once per block, in registers (a block walks rows blockIdx.x, +gridDim.x, ..)
+    float wa[NSEG][8], wb[NSEG][8];
 #pragma unroll
     for (int g = 0; g < NSEG; ++g) {
-        bf16* xr = buf + row * ld + segs.off[g];
-        if (act) {
-            va[g] = *(const bf16x8*)(xr + ia);
-            vb[g] = *(const bf16x8*)(xr + ib);
+        const float* wt = segs.w[g];
+        const f32x4 a0 = *(const f32x4*)(wt + ia), a1 = *(const f32x4*)(wt + ia + 4);
+        const f32x4 b0 = *(const f32x4*)(wt + ib), b1 = *(const f32x4*)(wt + ib + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            wa[g][e] = a0[e];
+            wa[g][4 + e] = a1[e];
+            wb[g][e] = b0[e];
+            wb[g][4 + e] = b1[e];
+        }
+    }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        bf16x8 va[NSEG], vb[NSEG];
+        float ss[2] = {0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) {
+            bf16* xr = buf + row * ld + segs.off[g];
+            if (act) {
+                va[g] = *(const bf16x8*)(xr + ia);
+                vb[g] = *(const bf16x8*)(xr + ib);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = bf2f(va[g][e]), b = bf2f(vb[g][e]);
+                    ss[g] += a * a + b * b;
+                }
+            }
+        }
+        block_sum2_256(ss[0], ss[1], red);
+        if (!act) continue;
+        f32x4 c4[2], s4[2];
+        if (cosp) {
+            c4[0] = *(const f32x4*)(cosp + row * (D / 2) + p0);
+            c4[1] = *(const f32x4*)(cosp + row * (D / 2) + p0 + 4);
+            s4[0] = *(const f32x4*)(sinp + row * (D / 2) + p0);
+            s4[1] = *(const f32x4*)(sinp + row * (D / 2) + p0 + 4);
+        }
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) {
+            bf16* xr = buf + row * ld + segs.off[g];
+            const float rstd = rsqrtf(ss[g] / (float)D + eps);
+            bf16x8 oa, ob;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float a = bf2f(va[g][e]), b = bf2f(vb[g][e]);
-                ss[g] += a * a + b * b;
+                const float a = bf2f(va[g][e]) * rstd * wa[g][e];
+                const float b = bf2f(vb[g][e]) * rstd * wb[g][e];
+                if (cosp) {
+                    const float c = e < 4 ? c4[0][e & 3] : c4[1][e & 3];
+                    const float sn = e < 4 ? s4[0][e & 3] : s4[1][e & 3];
+                    oa[e] = f2bf(a * c - b * sn);
+                    ob[e] = f2bf(b * c + a * sn);
+                } else {
+                    oa[e] = f2bf(a);
+                    ob[e] = f2bf(b);
+                }
             }
+            *(bf16x8*)(xr + ia) = oa;
+            *(bf16x8*)(xr + ib) = ob;
         }
-    }
-    block_sum2_256(ss[0], ss[1], red);
-    if (!act) return;
-    f32x4 c4[2], s4[2];
-    if (cosp) {
-        c4[0] = *(const f32x4*)(cosp + row * (D / 2) + p0);
-        c4[1] = *(const f32x4*)(cosp + row * (D / 2) + p0 + 4);
-        s4[0] = *(const f32x4*)(sinp + row * (D / 2) + p0);
-        s4[1] = *(const f32x4*)(sinp + row * (D / 2) + p0 + 4);
-    }
-#pragma unroll
-    for (int g = 0; g < NSEG; ++g) {
-        bf16* xr = buf + row * ld + segs.off[g];
-        const float rstd = rsqrtf(ss[g] / (float)D + eps);
-        const float* wt = segs.w[g];
-        const f32x4 wa0 = *(const f32x4*)(wt + ia), wa1 = *(const f32x4*)(wt + ia + 4);
-        const f32x4 wb0 = *(const f32x4*)(wt + ib), wb1 = *(const f32x4*)(wt + ib + 4);
-        bf16x8 oa, ob;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float a = bf2f(va[g][e]) * rstd * (e < 4 ? wa0[e & 3] : wa1[e & 3]);
-            const float b = bf2f(vb[g][e]) * rstd * (e < 4 ? wb0[e & 3] : wb1[e & 3]);
-            if (cosp) {
-                const float c = e < 4 ? c4[0][e & 3] : c4[1][e & 3];
-                const float sn = e < 4 ? s4[0][e & 3] : s4[1][e & 3];
-                oa[e] = f2bf(a * c - b * sn);
-                ob[e] = f2bf(b * c + a * sn);
-            } else {
-                oa[e] = f2bf(a);
-                ob[e] = f2bf(b);
-            }
-        }
-        *(bf16x8*)(xr + ia) = oa;
-        *(bf16x8*)(xr + ib) = ob;
     }
 }
 
@@ -570,12 +638,23 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
                     long emb_stride, hipStream_t stream) {
     LTX2_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "norm_mod: D, ldx, ldo must be multiples of 4");
     LTX2_CHECK_ARG(D <= 8192 && emb_stride % 4 == 0, "norm_mod: D=%d exceeds 8192 or emb_stride not a multiple of 4", D);
-    if (D <= 4096)
+    const bool shared_mod = emb_stride == 0 && (scale_tab || shift_tab || scale_emb || shift_emb) && rows > 1024;
+    if (shared_mod) {
+        const int per_block = (rows + 1023) / 1024;
+        const int grid = (rows + per_block - 1) / per_block;
+        if (D <= 4096)
+            hipLaunchKernelGGL((norm_mod_shared_kernel<4>), dim3(grid), dim3(256), 0, stream, x, ldx, out, ldo, rows, D, eps, layer_norm,
+                               scale_tab, shift_tab, scale_emb, shift_emb);
+        else
+            hipLaunchKernelGGL((norm_mod_shared_kernel<8>), dim3(grid), dim3(256), 0, stream, x, ldx, out, ldo, rows, D, eps, layer_norm,
+                               scale_tab, shift_tab, scale_emb, shift_emb);
+    } else if (D <= 4096) {
         hipLaunchKernelGGL((norm_mod_kernel<4>), dim3(rows), dim3(256), 0, stream, x, ldx, out, ldo, D, eps, layer_norm,
                            scale_tab, shift_tab, scale_emb, shift_emb, emb_stride);
-    else
+    } else {
         hipLaunchKernelGGL((norm_mod_kernel<8>), dim3(rows), dim3(256), 0, stream, x, ldx, out, ldo, D, eps, layer_norm,
                            scale_tab, shift_tab, scale_emb, shift_emb, emb_stride);
+    }
     LTX2_CHECK_LAUNCH("norm_mod_kernel");
     return LTX2_OK;
 }
@@ -592,10 +671,12 @@ int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int ns
         s.w[i] = weights[i];
     }
     LTX2_CHECK_ARG(D <= 4096, "qknorm_rope: inner dim %d exceeds 4096", D);
+    const int per_block = (rows + 2047) / 2048;             // up to 2048 blocks; beyond that a block takes several rows
+    const int grid = (rows + per_block - 1) / per_block;
     if (nseg == 2)
-        hipLaunchKernelGGL((qknorm_rope_kernel<2>), dim3(rows), dim3(256), 0, stream, buf, ld, D, head_dim, s, eps, cos, sin);
+        hipLaunchKernelGGL((qknorm_rope_kernel<2>), dim3(grid), dim3(256), 0, stream, buf, ld, rows, D, head_dim, s, eps, cos, sin);
     else
-        hipLaunchKernelGGL((qknorm_rope_kernel<1>), dim3(rows), dim3(256), 0, stream, buf, ld, D, head_dim, s, eps, cos, sin);
+        hipLaunchKernelGGL((qknorm_rope_kernel<1>), dim3(grid), dim3(256), 0, stream, buf, ld, rows, D, head_dim, s, eps, cos, sin);
     LTX2_CHECK_LAUNCH("qknorm_rope_kernel");
     return LTX2_OK;
 }
