@@ -3,7 +3,9 @@
 // parity tests when wired in), 0.95x the ping-pong kernel.  What it measured on MI355X (8192^3, bf16):
 //   MFMA stream alone 1.56 PF/s; + fragment reads 1.47; + LDS-DMA staging 1.16 -- i.e. the 16 one-KiB
 //   VMEM issues per wave per K-tile cost ~46 cycles each, the same for global_load_lds, buffer_load..lds
-//   and plain global_load_dwordx4, and with one wave per SIMD nothing covers them.  See DESIGN.md.
+//   and plain global_load_dwordx4, and with one wave per SIMD nothing covers them.  Staggering the four waves' issues
+//   (-DSP_STAGGER: wave w issues in MFMA slots g % 4 == w, one specialised K loop per wave) is 4 % slower still, so the
+//   cost is not the waves queueing behind each other at the TA.  See DESIGN.md.
 //
 // Same operands, LDS image, swizzle, tile order and epilogues as gemm.hip / gemm_pp.hip (dense only).
 // What differs is who schedules the inner loop.  hipcc only ever guards ds_read_b128 results with
@@ -142,51 +144,68 @@ __global__ __launch_bounds__(NWN * 128, NWN == 2 ? 1 : 2) void gemm_sp_kernel(co
 #pragma unroll
     for (int q = 0; q < AL + BL; ++q) stage_piece(0, 0, q);
 
+    // SP_STAGGER: one specialised copy of the K loop per wave slot (wv & 3), so that wave w issues its LDS-DMA pieces in
+    // MFMA slots g with g % 4 == w -- statically, no per-MFMA branch -- and the four waves of a SIMD row never present
+    // VMEM instructions to the TA in the same slot.
+    auto run_loop = [&](auto WS) __attribute__((always_inline)) {
+        constexpr int WSLOT = decltype(WS)::value;
+        (void)WSLOT;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (SP_ABL != 3 && SP_ABL != 4) __syncthreads();
-        if (SP_ABL == 5) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (SP_ABL != 3 && SP_ABL != 4) __syncthreads();
+            if (SP_ABL == 5) {
 #pragma unroll
-            for (int q = 0; q < AL + BL; ++q) { asm volatile("" : "+v"(ld[q])); sink ^= ld[q]; }
-        }
-        const int ktn = min(kt + 1, nk - 1);        // the last tile re-stages itself into the idle buffer (branch-free body)
-        const int nbuf = (kt + 1) & 1;
-        if (SP_ABL != 4 || kt == 0) read_ks(std::integral_constant<int, 0>{});
-        static_for<0, 4>([&](auto KS) {
-            constexpr int ks = decltype(KS)::value, s = ks & 1;
-            constexpr int younger = ks < 3 ? R : 0;     // reads of k-step ks+1 issued behind ours
-            if constexpr (ks < 3) { if (SP_ABL != 4 || kt == 0) read_ks(std::integral_constant<int, ks + 1>{}); }
-            static_for<0, TM * TN>([&](auto MI) {
-                constexpr int m = decltype(MI)::value, i = m / TN, j = m % TN;
-                if constexpr (i == 0 && SP_ABL != 4) lds_wait<younger + R - 1 - pos_b(j)>(fb[s][j]);
-                if constexpr (j == 0 && SP_ABL != 4) lds_wait<younger + R - 1 - pos_a(i)>(fa[s][i]);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fb[s][j]), as_bf16x8(fa[s][i]), acc[i][j], 0, 0, 0);   // C^T orientation
+                for (int q = 0; q < AL + BL; ++q) { asm volatile("" : "+v"(ld[q])); sink ^= ld[q]; }
+            }
+            const int ktn = min(kt + 1, nk - 1);        // the last tile re-stages itself into the idle buffer (branch-free body)
+            const int nbuf = (kt + 1) & 1;
+            if (SP_ABL != 4 || kt == 0) read_ks(std::integral_constant<int, 0>{});
+            static_for<0, 4>([&](auto KS) {
+                constexpr int ks = decltype(KS)::value, s = ks & 1;
+                constexpr int younger = ks < 3 ? R : 0;     // reads of k-step ks+1 issued behind ours
+                if constexpr (ks < 3) { if (SP_ABL != 4 || kt == 0) read_ks(std::integral_constant<int, ks + 1>{}); }
+                static_for<0, TM * TN>([&](auto MI) {
+                    constexpr int m = decltype(MI)::value, i = m / TN, j = m % TN;
+                    if constexpr (i == 0 && SP_ABL != 4) lds_wait<younger + R - 1 - pos_b(j)>(fb[s][j]);
+                    if constexpr (j == 0 && SP_ABL != 4) lds_wait<younger + R - 1 - pos_a(i)>(fa[s][i]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fb[s][j]), as_bf16x8(fa[s][i]), acc[i][j], 0, 0, 0);   // C^T orientation
 #ifndef SP_SPREAD
 #define SP_SPREAD 2         // one LDS-DMA piece per SP_SPREAD MFMAs, starting with M(t,0)
 #endif
 #ifdef SP_STAGGER
-                // wave w issues in MFMA slots g with g % 4 == w % 4: the four waves of a CU never present their
-                // VMEM instructions to the TA at the same time
-                {
-                    constexpr int g = ks * TM * TN + m, q = g / 4;
-                    if constexpr (q < AL + BL && SP_ABL != 1 && SP_ABL != 4) {
-                        if ((g & 3) == (wv & 3)) stage_piece(SP_ABL == 2 ? 0 : ktn, nbuf, q);
+                    // wave w issues in MFMA slots g with g % 4 == w % 4: the four waves of a CU never present their
+                    // VMEM instructions to the TA at the same time
+                    {
+                        constexpr int g = ks * TM * TN + m, q = g / 4;
+                        if constexpr (q < AL + BL && SP_ABL != 1 && SP_ABL != 4) {
+                            if constexpr ((g & 3) == WSLOT) stage_piece(SP_ABL == 2 ? 0 : ktn, nbuf, q);
+                        }
                     }
-                }
 #else
-                if constexpr ((ks * TM * TN + m) % SP_SPREAD == SP_SPREAD - 1) {
-                    constexpr int q = (ks * TM * TN + m) / SP_SPREAD;
-                    if constexpr (q < AL + BL && SP_ABL != 1 && SP_ABL != 4) stage_piece(SP_ABL == 2 ? 0 : ktn, nbuf, q);
-                }
+                    if constexpr ((ks * TM * TN + m) % SP_SPREAD == SP_SPREAD - 1) {
+                        constexpr int q = (ks * TM * TN + m) / SP_SPREAD;
+                        if constexpr (q < AL + BL && SP_ABL != 1 && SP_ABL != 4) stage_piece(SP_ABL == 2 ? 0 : ktn, nbuf, q);
+                    }
 #endif
+                });
             });
-        });
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            a_addr[ks] ^= STAGE_BYTES;
-            b_addr[ks] ^= STAGE_BYTES;
+            for (int ks = 0; ks < 4; ++ks) {
+                a_addr[ks] ^= STAGE_BYTES;
+                b_addr[ks] ^= STAGE_BYTES;
+            }
         }
+    };
+#ifdef SP_STAGGER
+    switch (wv & 3) {
+        case 0: run_loop(std::integral_constant<int, 0>{}); break;
+        case 1: run_loop(std::integral_constant<int, 1>{}); break;
+        case 2: run_loop(std::integral_constant<int, 2>{}); break;
+        default: run_loop(std::integral_constant<int, 3>{}); break;
     }
+#else
+    run_loop(std::integral_constant<int, 0>{});
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (SP_ABL == 5 && sink[0] == 0x12345678 && sink[1] == 77 && sink[2] == 5 && sink[3] == 9) acc[0][0][0] += 1.f;
 
