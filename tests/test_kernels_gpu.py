@@ -259,6 +259,31 @@ def test_conv3d(K, dev, causal, T, H, W, Cin, Cout):
     assert rel_l2(out.float().cpu(), ref + res) < 6e-3
 
 
+@pytest.mark.parametrize("T,H,W,C", [(49, 128, 192, 128), (25, 64, 96, 256), (13, 32, 48, 512), (7, 16, 24, 1024)])
+def test_conv3d_decoder_stage_sizes(K, dev, T, H, W, C):
+    """The four res-block conv shapes of one 7-latent-frame chunk at 768x512 (BASELINE config 2): up to 1.2 M output rows,
+    the 128^2 tile kernel at C = 128 and the 256-wide ping-pong conv kernel above.  Reference: plain fp32 torch on the GPU,
+    27 shifted matmuls over the reflect(H, W) / replicate(T) padded volume (simple_decoder.py:146-175)."""
+    g = torch.Generator(device=dev).manual_seed(C)
+    x = torch.randn(T, H, W, C, generator=g, device=dev).to(BF)
+    w = (torch.randn(C, C, 3, 3, 3, generator=g, device=dev) / math.sqrt(27 * C)).to(BF)
+    b = torch.randn(C, generator=g, device=dev)
+    out = K.conv3d(x, K.conv_weight_to_engine(w), b)
+    xp = x.float().permute(3, 0, 1, 2)[None]                                       # 1,C,T,H,W
+    xp = F.pad(xp.reshape(1, C * T, H, W), (1, 1, 1, 1), mode="reflect").reshape(1, C, T, H + 2, W + 2)
+    xp = torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], dim=2)[0].permute(1, 2, 3, 0)   # T+2,H+2,W+2,C
+    ref = b.float().expand(T * H * W, C).clone()
+    wf = w.float()
+    for kt in range(3):
+        for kh in range(3):
+            for kw in range(3):
+                ref += xp[kt:kt + T, kh:kh + H, kw:kw + W].reshape(-1, C) @ wf[:, :, kt, kh, kw].t()
+    ref = ref.reshape(T, H, W, C)
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 6e-3
+    for sl in ((0, 0, 0), (T - 1, H - 1, W - 1), (T // 2, 0, W - 1)):               # corners / edges: the padding rules
+        assert rel_l2(out[sl].float().cpu(), ref[sl].cpu()) < 2e-2
+
+
 @pytest.mark.parametrize("stride,mult,residual", [((2, 2, 2), 2, True), ((2, 2, 2), 1, False), ((1, 2, 2), 2, True), ((2, 1, 1), 2, True)])
 def test_conv3d_depth_to_space(K, dev, stride, mult, residual):
     from oracle import vae

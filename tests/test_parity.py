@@ -615,3 +615,28 @@ def test_text_connector_and_feature_extractors(dev, tmp_path):
     assert load_text_encoder_weights(enc, path) == len(w) + 1
     with pytest.raises(ValueError):
         enc.embeddings_connector(torch.zeros(1, 8, 100, device=dev))
+
+
+def test_vae_full_size_decode(dev):
+    """BASELINE config 2 geometry for the decoder (base_channels 128, default blocks, latent 128 x 9 x 16 x 24 ->
+    65 x 512 x 768, 37.7 TFLOP with the 7/2 chunking).  The fp32 oracle would take minutes on the host cores, so the
+    same oracle code runs in fp32 on the GPU (torch ops only) as the reference; plus bit-for-bit repeatability."""
+    from oracle import vae
+    from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder, decode_latent
+    cfg = vae.VAEConfig()
+    w = vae.make_vae_weights(cfg, seed=21)
+    d = SimpleVideoDecoder(device=dev)
+    d.load_state_dict(w)
+    g = torch.Generator().manual_seed(22)
+    z = torch.randn(1, 128, 9, 16, 24, generator=g)
+    nz = torch.randn(1, 128, 9, 16, 24, generator=g)           # the decode noise is an input here (fixed)
+    a = decode_latent(z.to(dev), d, noise=nz.to(dev))
+    b = decode_latent(z.to(dev), d, noise=nz.to(dev))
+    assert a.shape == (65, 512, 768, 3) and a.dtype == torch.uint8
+    assert torch.equal(a, b)
+    wq = {k: (v.to(torch.bfloat16).float() if (v.dim() == 5 or (v.dim() == 2 and "linear" in k)) else v).to(dev) for k, v in w.items()}
+    with torch.device(dev), torch.no_grad():
+        ref = vae.decode_latent(z.to(dev), wq, cfg, noise=nz.to(dev))
+    assert ref.shape == a.shape
+    diff = (a.int() - ref.int()).abs().float()
+    assert diff.mean() < 2.0 and pearson(a.float().cpu(), ref.float().cpu()) > 0.999
