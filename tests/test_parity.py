@@ -640,3 +640,32 @@ def test_vae_full_size_decode(dev):
     assert ref.shape == a.shape
     diff = (a.int() - ref.int()).abs().float()
     assert diff.mean() < 2.0 and pearson(a.float().cpu(), ref.float().cpu()) > 0.999
+
+
+def test_dit_full_size_denoise_loop(dev):
+    """BASELINE config 2 geometry for the DiT (D = 4096, 32 heads, caption 3840, N = 3456 video tokens, S = 1024 text
+    tokens) with 4 of the 48 layers: the 8-step distilled loop through the hipGraph against the oracle's loop.  The
+    fp32 oracle code runs on the GPU here (torch ops only) -- on the host cores one such step takes a minute."""
+    from oracle import dit, loop
+    from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES
+    cfg, w, m = make_dit(dev, heads=32, layers=4, cap=3840, seed=31)
+    f, h, wd = 9, 16, 24
+    lat, ctx, pos = inputs(f, h, wd, 1024, 3840, seed=32)
+    sig = DISTILLED_SIGMA_VALUES
+    wg = {k: v.to(dev) for k, v in w.items()}
+    with torch.device(dev), torch.no_grad():
+        ctx_g, pos_g = ctx.to(dev), pos.to(dev)
+        ref = loop.denoise_loop_cli(loop.unpatchify(lat.to(dev), f, h, wd),
+                                    lambda tok, s: dit.x0_model(tok, ctx_g, torch.tensor([s]), pos_g, wg, cfg), sig)
+        ref = loop.patchify(ref).cpu()
+    m.prepare(ctx.to(dev), pos.to(dev))
+    z = lat[0].to(dev).contiguous()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.capture_denoise_graph(z, sig)
+        m.replay_denoise_graph()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert z.shape == (3456, 128)
+    assert rel_l2(z.cpu(), ref[0]) < 3e-2 and pearson(z.cpu(), ref[0]) > 0.999
