@@ -669,3 +669,63 @@ def test_dit_full_size_denoise_loop(dev):
     torch.cuda.synchronize()
     assert z.shape == (3456, 128)
     assert rel_l2(z.cpu(), ref[0]) < 3e-2 and pearson(z.cpu(), ref[0]) > 0.999
+
+
+@pytest.mark.parametrize("v23", [False, True])
+def test_av_full_size_step(dev, v23):
+    """BASELINE config 4 geometry: AudioVideo DiT at full width (video 32 x 128, audio 32 x 64), N = 3456 video tokens,
+    68 audio tokens, S = 1024, two layers (19B-style and the V2.3 variant with 9-row AdaLN / prompt modulation / head
+    gates): one joint x0 evaluation against the fp32 oracle executed on the GPU."""
+    from oracle import dit_av, loop
+    from ltx_2_mlx_amd.model.transformer import LTXModel, LTXModelType, X0Model
+    cfg = dit_av.AVConfig(num_attention_heads=32, attention_head_dim=128, audio_heads=32, audio_head_dim=64, num_layers=2,
+                          caption_channels=None if v23 else 3840, cross_attention_adaln=v23, apply_gated_attention=v23)
+    w = dit_av.make_av_weights(cfg, seed=71 + v23)
+    m = LTXModel(model_type=LTXModelType.AudioVideo, num_attention_heads=32, attention_head_dim=128, num_layers=2,
+                 caption_channels=cfg.caption_channels, cross_attention_adaln=v23, apply_gated_attention=v23,
+                 audio_attention_heads=32, device=dev)
+    m.load_state_dict(w)
+    g = torch.Generator().manual_seed(72)
+    f, h, wd, Ta, S = 9, 16, 24, 68, 1024
+    s = torch.tensor([0.725])
+    video = dict(latent=torch.randn(1, f * h * wd, 128, generator=g), context=0.1 * torch.randn(1, S, cfg.caption_channels or cfg.inner_dim, generator=g),
+                 timesteps=s, sigma=s, positions=loop.video_positions(1, f, h, wd, 24.0))
+    audio = dict(latent=torch.randn(1, Ta, 128, generator=g), context=0.1 * torch.randn(1, S, cfg.caption_channels or cfg.audio_inner_dim, generator=g),
+                 timesteps=s, sigma=s, positions=dit_av.audio_positions(1, Ta))
+    vx0, ax0 = X0Model(m)(to_modality(video, dev), to_modality(audio, dev))
+    wg = {k: (v.to(torch.bfloat16).float() if (k.endswith(".weight") and v.dim() == 2) else v).to(dev) for k, v in w.items()}
+    with torch.device(dev), torch.no_grad():
+        rv, ra = dit_av.av_x0_model({k: t.to(dev) for k, t in video.items()}, {k: t.to(dev) for k, t in audio.items()}, wg, cfg)
+    assert vx0.shape == (1, 3456, 128) and ax0.shape == (1, 68, 128)
+    assert rel_l2(vx0.cpu(), rv.cpu()) < 2e-2 and pearson(vx0.cpu(), rv.cpu()) > 0.999
+    assert rel_l2(ax0.cpu(), ra.cpu()) < 2e-2 and pearson(ax0.cpu(), ra.cpu()) > 0.999
+
+
+def test_upscaler_and_encoder_full_size(dev):
+    """BASELINE config 5 building blocks at their real sizes against the fp32 oracle executed on the GPU: the spatial
+    upscaler (128 -> 1024 channels, 4 + 4 blocks) on the 768x512x65 stage-1 latent (9 x 16 x 24 -> 9 x 32 x 48), and the VAE
+    encoder on one 512 x 768 conditioning image."""
+    from oracle import upscaler as oup, vae_encoder as oenc
+    from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler
+    from ltx_2_mlx_amd.model.video_vae_encoder import SimpleVideoEncoder
+    w = oup.make_upscaler_weights(128, 1024, 4, seed=81)
+    up = SpatialUpscaler(device=dev)
+    up.load_state_dict(w)
+    x = torch.randn(1, 128, 9, 16, 24, generator=torch.Generator().manual_seed(82))
+    out = up(x.to(dev))
+    wg = {k: (v.to(torch.bfloat16).float() if v.dim() >= 4 else v).to(dev) for k, v in w.items()}
+    with torch.device(dev), torch.no_grad():
+        ref = oup.spatial_upscaler(x.to(dev), wg, num_blocks=4)
+    assert out.shape == ref.shape == (1, 128, 9, 32, 48)
+    assert rel_l2(out.cpu(), ref.cpu()) < 4e-2 and pearson(out.cpu(), ref.cpu()) > 0.999
+    del up, wg, ref
+    we = oenc.make_encoder_weights(seed=83)
+    enc = SimpleVideoEncoder(device=dev)
+    enc.load_state_dict(we)
+    img = torch.rand(1, 3, 1, 512, 768, generator=torch.Generator().manual_seed(84)) * 2 - 1
+    lat = enc(img.to(dev))
+    weg = {k: (v.to(torch.bfloat16).float() if v.dim() == 5 else v).to(dev) for k, v in we.items()}
+    with torch.device(dev), torch.no_grad():
+        rlat = oenc.encoder_forward(img.to(dev), weg)
+    assert lat.shape == rlat.shape == (1, 128, 1, 16, 24)
+    assert rel_l2(lat.cpu(), rlat.cpu()) < 5e-2 and pearson(lat.cpu(), rlat.cpu()) > 0.998
