@@ -31,8 +31,10 @@ __device__ __forceinline__ bf16x4 pack_bf16x4(float a, float b, float c, float d
 
 // v = 4 raw accumulators for columns col..col+3 of `row`; row < M and col+3 < N guaranteed.
 template <int EPI>
+// gate_tab4 = p.gate_table[col..col+3] (EPI_RESID_GATE_F32; zeros when there is no table): like the bias it depends on
+// the column only, so the caller loads it once per column group instead of once per row.
 __device__ __forceinline__ void epi_store4(const GemmParams& p, const EpiRow& er, int row, int col, f32x4 v,
-                                           f32x4 bias4) {
+                                           f32x4 bias4, f32x4 gate_tab4 = f32x4{0.f, 0.f, 0.f, 0.f}) {
     v += bias4;
     if (EPI == EPI_BF16) {
         *(bf16x4*)((bf16*)p.out + (long)row * p.ldo + col) = pack_bf16x4(v[0], v[1], v[2], v[3]);
@@ -46,9 +48,8 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, const EpiRow& er
     } else if (EPI == EPI_RESID_GATE_F32) {
         f32x4 gt = {1.f, 1.f, 1.f, 1.f};
         if (p.gate || p.gate_table) {
-            gt = f32x4{0.f, 0.f, 0.f, 0.f};
+            gt = gate_tab4;
             if (p.gate) gt += *(const f32x4*)(p.gate + (long)row * p.gate_stride + col);
-            if (p.gate_table) gt += *(const f32x4*)(p.gate_table + col);
         }
         f32x4* o = (f32x4*)((float*)p.out + (long)row * p.ldo + col);
         *o = *o + gt * v;

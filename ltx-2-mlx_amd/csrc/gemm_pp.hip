@@ -386,17 +386,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     // ---- epilogue: lane owns rows (l31 per row slot) x 4-column groups (gemm_epilogue.h) ----
     f32x4 bias4[2][4];
+    f32x4 gate4[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int col = n0 + wc * 64 + qb * 32 + 8 * gq + 4 * hi;
             bias4[qb][gq] = (p.bias && col < p.N) ? *(const f32x4*)(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gate4[qb][gq] = (EPI == EPI_RESID_GATE_F32 && p.gate_table && col < p.N) ? *(const f32x4*)(p.gate_table + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) asm volatile("" : "+v"(bias4[qb][gq]));      // retire the loads once, here
+        for (int gq = 0; gq < 4; ++gq) {
+            asm volatile("" : "+v"(bias4[qb][gq]));      // retire the loads once, here
+            if (EPI == EPI_RESID_GATE_F32) asm volatile("" : "+v"(gate4[qb][gq]));
+        }
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                     if (col >= p.N) continue;
                     const f32x4 v = {acc[qa][i][qb][4 * gq], acc[qa][i][qb][4 * gq + 1], acc[qa][i][qb][4 * gq + 2],
                                      acc[qa][i][qb][4 * gq + 3]};
-                    epi_store4<EPI>(p, er, row, col, v, bias4[qb][gq]);
+                    epi_store4<EPI>(p, er, row, col, v, bias4[qb][gq], gate4[qb][gq]);
                 }
         }
 }

@@ -211,17 +211,22 @@ __global__ __launch_bounds__(NWN * 128, NWN == 2 ? 1 : 2) void gemm_sp_kernel(co
 
     // ---- epilogue: lane owns rows (l31 per row slot) x 4-column groups (gemm_epilogue.h) ----
     f32x4 bias4[TN][4];
+    f32x4 gate4[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int col = n0 + wc * WN + j * 32 + 8 * gq + 4 * hi;
             bias4[j][gq] = (p.bias && col < p.N) ? *(const f32x4*)(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gate4[j][gq] = (EPI == EPI_RESID_GATE_F32 && p.gate_table && col < p.N) ? *(const f32x4*)(p.gate_table + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) asm volatile("" : "+v"(bias4[j][gq]));      // retire the loads once, here
+        for (int gq = 0; gq < 4; ++gq) {
+            asm volatile("" : "+v"(bias4[j][gq]));      // retire the loads once, here
+            if (EPI == EPI_RESID_GATE_F32) asm volatile("" : "+v"(gate4[j][gq]));
+        }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = m0 + wr * 128 + i * 32 + l31;
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(NWN * 128, NWN == 2 ? 1 : 2) void gemm_sp_kernel(co
                 const int col = n0 + wc * WN + j * 32 + 8 * gq + 4 * hi;
                 if (col >= p.N) continue;
                 const f32x4 v = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
-                epi_store4<EPI>(p, er, row, col, v, bias4[j][gq]);
+                epi_store4<EPI>(p, er, row, col, v, bias4[j][gq], gate4[j][gq]);
             }
     }
 }
