@@ -330,11 +330,10 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
     LTX2_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
     LTX2_CHECK_ARG(p.ldk > 0 && ((long)p.Nkv + 2 * KVB) * p.ldk < (1L << 32), "attention: Nkv * ldk exceeds the 32-bit K row offset");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
-        attr_set = true;
     }
     dim3 grid((p.Nq + QB - 1) / QB, p.H);
     if (p.head_dim == 64)

@@ -41,6 +41,20 @@ void ltx2_set_error(const char* fmt, ...);
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// Launchers raise a kernel's dynamic-LDS limit once per DEVICE (hipFuncSetAttribute acts on the current device): returns
+// true the first time a given flag set sees the current device.
+struct PerDeviceOnce {
+    bool seen[64] = {};
+    bool first() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) return true;
+        const bool f = !seen[dev];
+        seen[dev] = true;
+        return f;
+    }
+};
+
 // Hand-issued LDS reads and waits. hipcc only ever emits `s_waitcnt lgkmcnt(0)` around ds_read_b128 in our
 // loops, i.e. every wait drains ALL fragment reads in flight. With the read and the counted wait both in asm the
 // compiler tracks neither; lds_wait<N> names the fragment it guards so the consuming MFMA cannot move above it.

@@ -214,11 +214,10 @@ using CfgNarrow = TileCfg<128, 64, 2, 2>;      // N <= 64 (the decoder's 128 -> 
 
 template <class CFG, int EPI, bool CONV>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_kernel<CFG, EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   CFG::LDS_BYTES);
-        attr_set = true;
     }
     constexpr int TBM = CFG::A_BYTES / (BK * 2), TBN = CFG::B_BYTES / (BK * 2);
     const int Mt = (p.M + TBM - 1) / TBM, Nt = (p.N + TBN - 1) / TBN;

@@ -425,10 +425,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
 template <int EPI, bool CONV, int BM>
 int launch_pp(const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, CONV, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
     }
     const int Mt = (p.M + BM - 1) / BM, Nt = (p.N + TBN - 1) / TBN;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, BM>), dim3(Mt * Nt), dim3(512), LDS_BYTES, stream, p);
