@@ -19,6 +19,10 @@ def env_rank_world() -> Tuple[int, int, int]:
     """RANK, WORLD_SIZE, local device index.  LTX2_LOCAL_DEVICE overrides LOCAL_RANK as the device index (several
     ranks on one GPU: the single-GPU rehearsal of the multi-process path, together with LTX2_DIST_BACKEND=gloo)."""
     local = int(os.environ.get("LTX2_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if "LTX2_LOCAL_DEVICE" not in os.environ and torch.cuda.is_available():
+        n = torch.cuda.device_count()
+        if n and local >= n:      # the launcher narrowed device visibility per rank (HIP_VISIBLE_DEVICES): index within what is visible
+            local %= n
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), local
 
 
