@@ -266,6 +266,15 @@ def test_no_cpu_fallback():
         K.gemm(torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(128, 64, dtype=torch.bfloat16))
     with pytest.raises(RuntimeError):
         LTXModel(num_attention_heads=2, num_layers=1, device="cpu")
+    # every other model class on the path refuses a CPU device the same way
+    from ltx_2_mlx_amd.model.text_encoder import Embeddings1DConnector, GemmaFeaturesExtractorProjLinear, GemmaFeaturesExtractorV2
+    from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler
+    from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder
+    from ltx_2_mlx_amd.model.video_vae_encoder import SimpleVideoEncoder
+    for ctor in (Embeddings1DConnector, GemmaFeaturesExtractorProjLinear, GemmaFeaturesExtractorV2, SpatialUpscaler, SimpleVideoDecoder,
+                 SimpleVideoEncoder):
+        with pytest.raises(RuntimeError):
+            ctor(device="cpu")
 
 
 # ---------------------------------------------------------------- multi-process (gloo, world_size 2)
