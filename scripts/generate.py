@@ -147,7 +147,7 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
                    tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, use_fp8: bool = False, num_layers: int = 48,
                    num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", image_path=None,
                    image_strength: float = 0.95, lora_path=None, lora_strength: float = 1.0, fps: int = 24, speed: float = 1.0,
-                   text_features_path=None,
+                   text_features_path=None, spatial_upscaler_weights=None, pipeline: str = "text-to-video",
                    save_mp4: bool = True, **unsupported):
     for k, v in unsupported.items():
         if v:
@@ -178,6 +178,37 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
             load_vae_decoder_weights(vae_decoder, weights_path)
         else:
             vae_decoder.init_random_weights(seed=seed + 1)
+    if spatial_upscaler_weights or pipeline == "distilled":
+        # `--pipeline distilled` + `--spatial-upscaler-weights`: the reference's two-stage DistilledPipeline
+        # (pipelines/distilled.py:274-505; scripts/generate.py:1622-1700): 8 steps at half resolution, x2 latent
+        # upscale, 3 steps at full resolution.  "random" as the path builds a random-weight upscaler (no checkpoint here).
+        if not spatial_upscaler_weights:
+            raise ValueError("--pipeline distilled needs --spatial-upscaler-weights (two-stage pipeline)")
+        if vae_decoder is None:
+            raise ValueError("the two-stage pipeline needs the VAE weights (per-channel statistics): drop --skip-vae")
+        from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler, load_spatial_upscaler_weights
+        from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline
+        mid = 1024 if vae_base_channels == 128 else 64
+        up = SpatialUpscaler(mid_channels=mid, device=device) if spatial_upscaler_weights != "random" else \
+            SpatialUpscaler(mid_channels=mid, num_blocks_per_stage=4 if mid == 1024 else 1, device=device)
+        if spatial_upscaler_weights == "random":
+            up.init_random_weights(seed=seed + 2)
+        else:
+            load_spatial_upscaler_weights(up, spatial_upscaler_weights)
+        pipe = DistilledPipeline(model, vae_decoder, vae_decoder, spatial_upscaler=up)
+        conf = DistilledConfig(height=height, width=width, num_frames=num_frames, seed=seed, fps=24.0, use_hip_graph=use_hip_graph)
+        print("[4/5] two-stage distilled pipeline (8 steps at half resolution, x2 upscale, 3 steps)")
+        t0 = time.time()
+        frames = pipe(text_encoding, None, conf)
+        torch.cuda.synchronize()
+        print(f"  two-stage: {(time.time() - t0):.3f} s -> {tuple(frames.shape)}")
+        base = os.path.splitext(output_path)[0]
+        frames_np = frames.cpu().numpy()
+        np.savez_compressed(base + ".npz", frames=frames_np)
+        if save_mp4:
+            print(f"  video: {save_video(frames_np, output_path, fps=fps, speed=speed)}")
+        print(f"Done in {time.time() - t_all:.1f} s: {base}.npz")
+        return frames
     print("[4/5] latent noise")
     lf, lh, lw = (num_frames - 1) // 8 + 1, height // 32, width // 32
     g = torch.Generator(device=device).manual_seed(seed)
@@ -299,7 +330,7 @@ def main():
                    use_gemma=bool(a.gemma_path) and not a.no_gemma, model_variant=a.model_variant, skip_vae=a.skip_vae,
                    use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, cfg_scale=a.cfg, use_hip_graph=not a.no_hip_graph, use_fp8=a.fp8,
                    num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,
-                   image_path=a.image, image_strength=a.image_strength, lora_path=a.lora, lora_strength=a.lora_strength, fps=a.fps, speed=a.speed, save_mp4=not a.no_video_file, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights)
+                   image_path=a.image, image_strength=a.image_strength, lora_path=a.lora, lora_strength=a.lora_strength, fps=a.fps, speed=a.speed, save_mp4=not a.no_video_file, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights, pipeline=a.pipeline)
 
 
 if __name__ == "__main__":

@@ -67,3 +67,16 @@ def test_bench_two_rank_rehearsal(dev):
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["scaling"] == "weak" and out["value"] > 0
     assert out["weight_broadcast_collectives"] >= 1 and "cpu_baseline" not in out
     assert abs(out["value"] - 2 * 8 / (out["ms_per_step"] * 8e-3)) < 1e-2 * out["value"]
+
+
+def test_generate_cli_two_stage(dev, tmp_path):
+    """`--spatial-upscaler-weights` routes the CLI through the two-stage DistilledPipeline (reference generate.py:1622-1700)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import generate
+    kw = dict(height=256, width=384, num_frames=17, num_inference_steps=8, seed=3, num_layers=2, num_heads=2, vae_base_channels=64)
+    f = generate.generate_video("a test prompt", output_path=str(tmp_path / "t.mp4"), spatial_upscaler_weights="random", **kw)
+    assert f.shape == (17, 256, 384, 3) and f.dtype == torch.uint8
+    with pytest.raises(ValueError, match="per-channel statistics"):
+        generate.generate_video("x", spatial_upscaler_weights="random", skip_vae=True, **kw)
+    with pytest.raises(ValueError, match="two-stage"):
+        generate.generate_video("x", pipeline="distilled", **kw)
