@@ -4,7 +4,9 @@
 Keeps the flag names and `generate_video(...)` keyword names of the reference's
 scripts/generate.py (argparse block :2364-2641, `generate_video` :933-997) for this path:
 standard single-stage distilled loop (reference :1764-1984) followed by `decode_latent` (:2080-2091).
-Out of this path (and rejected with a clear message): Gemma text encoding, audio muxing, CFG/STG guidance.
+Out of this path (and rejected with a clear message): Gemma text encoding, audio VAE / vocoder / muxing, CFG/STG guidance.
+`--pipeline distilled --spatial-upscaler-weights W` runs the two-stage DistilledPipeline; adding `--generate-audio` runs it on
+the AudioVideo transformer and saves the audio LATENT beside the frames.
 `save_video` keeps the reference's ffmpeg settings (frames piped as raw RGB; PNG frames when no ffmpeg binary exists).  `--lora` fuses an adapter into the checkpoint weights at load.  `--image` conditions latent frame 0 on an image through the VAE encoder (the reference
 routes that through its pipelines, scripts/generate.py:1711-1731).  Text embeddings come from `--embedding file.npz` (keys
 `embedding`, `attention_mask`, as the reference's `load_text_embedding` :730-750) or the reference's
@@ -135,6 +137,19 @@ def load_transformer(weights_path, num_layers=48, num_heads=32, caption_channels
     return model
 
 
+def load_av_transformer(weights_path, num_layers=48, num_heads=32, caption_channels=3840, seed=0, device="cuda", use_fp8=False):
+    """AudioVideo LTXModel (video 32x128 + audio 32x64 heads; reference load_av_transformer :838-902)."""
+    from ltx_2_mlx_amd.model.transformer import LTXModelType
+    model = LTXModel(model_type=LTXModelType.AudioVideo, num_attention_heads=num_heads, attention_head_dim=128, num_layers=num_layers,
+                     caption_channels=caption_channels, audio_attention_heads=num_heads, device=device)
+    if weights_path:
+        from ltx_2_mlx_amd.loader import is_fp8_checkpoint, load_av_transformer_weights
+        load_av_transformer_weights(model, weights_path, strict=True, use_fp8=use_fp8 or is_fp8_checkpoint(weights_path))
+    else:
+        model.init_random_weights(seed=seed)
+    return model
+
+
 def euler_step_x0(sample, denoised, sigma, sigma_next):
     from ltx_2_mlx_amd import kernels as K
     c = sample.shape[-1]
@@ -147,7 +162,7 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
                    tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, use_fp8: bool = False, num_layers: int = 48,
                    num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", image_path=None,
                    image_strength: float = 0.95, lora_path=None, lora_strength: float = 1.0, fps: int = 24, speed: float = 1.0,
-                   text_features_path=None, spatial_upscaler_weights=None, pipeline: str = "text-to-video",
+                   text_features_path=None, spatial_upscaler_weights=None, pipeline: str = "text-to-video", generate_audio: bool = False,
                    save_mp4: bool = True, **unsupported):
     for k, v in unsupported.items():
         if v:
@@ -168,8 +183,15 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
     else:
         text_encoding, _ = load_text_embedding(embedding_path, device) if embedding_path else create_dummy_text_encoding(prompt, device=device)
     print("[2/5] transformer")
-    model = X0Model(load_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device, use_fp8=use_fp8,
-                                     lora_path=lora_path, lora_strength=lora_strength))
+    if generate_audio:
+        if not spatial_upscaler_weights:
+            raise ValueError("--generate-audio runs the joint audio+video DistilledPipeline: it needs --spatial-upscaler-weights")
+        if lora_path:
+            raise NotImplementedError("--lora with --generate-audio")
+        model = X0Model(load_av_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device, use_fp8=use_fp8))
+    else:
+        model = X0Model(load_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device, use_fp8=use_fp8,
+                                         lora_path=lora_path, lora_strength=lora_strength))
     print("[3/5] VAE decoder")
     vae_decoder = None
     if not skip_vae:
@@ -196,13 +218,23 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
         else:
             load_spatial_upscaler_weights(up, spatial_upscaler_weights)
         pipe = DistilledPipeline(model, vae_decoder, vae_decoder, spatial_upscaler=up)
-        conf = DistilledConfig(height=height, width=width, num_frames=num_frames, seed=seed, fps=24.0, use_hip_graph=use_hip_graph)
-        print("[4/5] two-stage distilled pipeline (8 steps at half resolution, x2 upscale, 3 steps)")
+        conf = DistilledConfig(height=height, width=width, num_frames=num_frames, seed=seed, fps=24.0, use_hip_graph=use_hip_graph,
+                               audio_enabled=generate_audio)
+        print("[4/5] two-stage distilled pipeline (8 steps at half resolution, x2 upscale, 3 steps)" + (" with the audio branch" if generate_audio else ""))
         t0 = time.time()
-        frames = pipe(text_encoding, None, conf)
+        base = os.path.splitext(output_path)[0]
+        if generate_audio:
+            # the audio text context: `audio_embedding` of the --embedding file when present, else the video context
+            actx = text_encoding
+            if embedding_path and "audio_embedding" in np.load(embedding_path):
+                actx = torch.from_numpy(np.load(embedding_path)["audio_embedding"]).float().to(device)
+                actx = actx[None] if actx.dim() == 2 else actx
+            frames, audio_latent = pipe(text_encoding, None, conf, audio_encoding=actx)
+            np.savez(base + "_audio_latent.npz", latent=audio_latent.float().cpu().numpy())     # audio VAE / vocoder are outside this path
+        else:
+            frames = pipe(text_encoding, None, conf)
         torch.cuda.synchronize()
         print(f"  two-stage: {(time.time() - t0):.3f} s -> {tuple(frames.shape)}")
-        base = os.path.splitext(output_path)[0]
         frames_np = frames.cpu().numpy()
         np.savez_compressed(base + ".npz", frames=frames_np)
         if save_mp4:

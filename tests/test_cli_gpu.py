@@ -26,7 +26,7 @@ def test_generate_cli_plumbing(dev, tmp_path):
     assert os.path.exists(tmp_path / "a.npz")
     with pytest.raises(ValueError, match="8\\*k \\+ 1"):
         generate.generate_video("x", num_frames=16, **{k: v for k, v in kw.items() if k != "num_frames"})
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="spatial-upscaler-weights"):
         generate.generate_video("x", generate_audio=True, **kw)
     with pytest.raises(ValueError, match="--lora needs --weights"):
         generate.generate_video("x", lora_path="style.safetensors", **kw)
@@ -80,3 +80,9 @@ def test_generate_cli_two_stage(dev, tmp_path):
         generate.generate_video("x", spatial_upscaler_weights="random", skip_vae=True, **kw)
     with pytest.raises(ValueError, match="two-stage"):
         generate.generate_video("x", pipeline="distilled", **kw)
+    # --generate-audio: AudioVideo transformer, joint audio+video loop in both stages, audio latent saved beside the frames
+    fa = generate.generate_video("a test prompt", output_path=str(tmp_path / "av.mp4"), spatial_upscaler_weights="random",
+                                 generate_audio=True, **kw)
+    assert fa.shape == (17, 256, 384, 3)
+    al = np.load(tmp_path / "av_audio_latent.npz")["latent"]
+    assert al.ndim == 4 and al.shape[1] == 8 and al.shape[3] == 16 and np.isfinite(al).all()
