@@ -729,3 +729,23 @@ def test_upscaler_and_encoder_full_size(dev):
         rlat = oenc.encoder_forward(img.to(dev), weg)
     assert lat.shape == rlat.shape == (1, 128, 1, 16, 24)
     assert rel_l2(lat.cpu(), rlat.cpu()) < 5e-2 and pearson(lat.cpu(), rlat.cpu()) > 0.998
+
+
+def test_dit_full_size_per_token_timesteps(dev):
+    """Image-to-video at the BASELINE geometry: per-token timesteps (B, N, 1) = mask * sigma with the first latent frame
+    conditioned (sigma 0), D = 4096, N = 3456, S = 1024, two layers -- the per-token AdaLN path (N x 6D modulation
+    rows, norm_mod with a row stride) against the fp32 oracle executed on the GPU."""
+    from oracle import dit
+    from ltx_2_mlx_amd.model.transformer import Modality, X0Model
+    cfg, w, m = make_dit(dev, heads=32, layers=2, cap=3840, seed=41)
+    lat, ctx, pos = inputs(9, 16, 24, 1024, 3840, seed=42)
+    N = lat.shape[1]
+    mask = torch.ones(1, N, 1)
+    mask[:, :16 * 24] = 0.05                    # conditioned first latent frame (strength 0.95)
+    ts = mask * 0.909375
+    x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=pos.to(dev)))
+    wg = {k: v.to(dev) for k, v in w.items()}
+    with torch.device(dev), torch.no_grad():
+        ref = dit.x0_model(lat.to(dev), ctx.to(dev), ts.to(dev), pos.to(dev), wg, cfg).cpu()
+    assert x0.shape == (1, 3456, 128)
+    assert rel_l2(x0.cpu(), ref) < 2e-2 and pearson(x0.cpu(), ref) > 0.999
