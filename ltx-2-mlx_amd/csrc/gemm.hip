@@ -233,6 +233,17 @@ inline bool use_big_tile(const GemmParams& p) {
     return tiles_big >= 160;
 }
 
+// LTX2_V4_LAYOUT = 0 | 1 | 2 selects the wave layout of the 4-wave asm-loop kernel (gemm_v4.hip; default 2), -1 disables it
+inline int v4_layout() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("LTX2_V4_LAYOUT");
+        v = e ? atoi(e) : 2;
+        if (v < -1 || v > 2) v = 2;
+    }
+    return v;
+}
+
 // 0 = heuristic, 1 = force 128x128, 2 = force plain 256x256, 3 = force ping-pong 256x256 (A/B testing)
 inline int tile_override() {
     static int v = -1;
@@ -252,6 +263,7 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ov = tile_override();
     if (ov == 2) return launch_cfg<CfgBig, EPI, CONV>(p, stream);
     if (ov == 1) return launch_cfg<CfgSmall, EPI, CONV>(p, stream);
+    if (ov == 0 && !CONV && v4_layout() >= 0 && use_big_tile(p) && gemm_v4_supported(p, EPI, CONV)) return gemm_v4_launch(p, EPI, stream, v4_layout(), 0);
     if (ov == 3 || use_big_tile(p)) return gemm_pp_launch(p, EPI, CONV, stream);
     if (p.N <= 64 && p.M >= 4096 && ov != 7) return launch_cfg<CfgNarrow, EPI, CONV>(p, stream);
     return launch_cfg<CfgSmall, EPI, CONV>(p, stream);

@@ -455,8 +455,9 @@ bool prefer_224(const GemmParams& p) {
 int gemm_pp_launch(const GemmParams& p_in, int epilogue, bool conv, hipStream_t stream) {
     GemmParams p = p_in;
     {
-        const char* d = getenv("LTX2_PP_DBG");
-        p.dbg = d ? (void*)strtoull(d, nullptr, 0) : nullptr;
+        static const char* d = getenv("LTX2_PP_DBG");      // read once: this launcher sits on the denoise hot path
+        static void* dbg = d ? (void*)strtoull(d, nullptr, 0) : nullptr;
+        p.dbg = dbg;
     }
     const bool b224 = !conv && prefer_224(p);
 #define CASE(E)                                                                            \

@@ -1,0 +1,316 @@
+// 4-wave bf16 MFMA GEMM for gfx950 with a hand-scheduled K loop: tile (224|256) x 256 x 64, one wave per SIMD, accumulators
+// in AGPRs.  The whole K loop is ONE asm block generated and order-checked by gen_gemm_v4.py (gemm_v4_loop.inc): hipcc
+// schedules nothing in it.  Wave layouts (template LAYOUT):
+//   0  1x4, v_mfma_f32_32x32x16_bf16: wave w owns columns [64w, 64w+64) and all 7|8 row blocks (balanced for 224 rows)
+//   1  2x2, v_mfma_f32_32x32x16_bf16: wave (wr, wc) owns a 128 x 128 quadrant (4 x 4 blocks; with 224-row tiles the second
+//      wave row owns 96 rows = 3 row blocks and runs a shorter program with the same barriers)
+//   2  2x2, v_mfma_f32_16x16x32_bf16: 8 x 8 blocks of 16 (6 x 8 for the second wave row of a 224-row tile)
+// What the measurements on MI355X say: with random operands the chip is POWER-limited -- the K loop of
+// layout 0 issues an MFMA every 34 cycles (2170 cycles per K-tile of 64 MFMAs) but the chip clocks at 1.45-1.55 GHz, an
+// MFMA-only loop at 2.0 GHz -- so what counts is energy per flop: LDS fragment reads (160 / 128 KiB per K-tile and CU for
+// layouts 0 / 1+2, 192 for the 8-wave ping-pong kernel), L2->LDS traffic and fabric re-reads, not issue slots.
+// Dense operands only (activations [M][lda] bf16, weights [N][K] bf16, K contiguous), N % 256 == 0, K % 128 == 0,
+// K >= 256; everything else stays on gemm_pp.hip / gemm.hip.  Same LDS image, swizzle, tile order and fused epilogues
+// (gemm_epilogue.h) as those kernels; with 32x32x16 blocks the fp32 summation order is theirs too (ks ascending), so the
+// outputs are bit-identical to the ping-pong kernel's (tested).
+#include <stdlib.h>
+
+#include "gemm_epilogue.h"
+#include "gemm_v4_loop.inc"
+
+namespace {
+
+typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int V4_LDS_BYTES = 131072;
+
+#define V4_INS : "{v[0:7]}"(voffA), "{v[8:15]}"(voffB), "{v[16:19]}"(addrA), "{v[20:23]}"(addrB), [ra] "s"(ra), [rw] "s"(rw), \
+                 [nk] "s"(nk), [la] "s"(la), [lw] "s"(lw)
+#define V4_OUT16                                                                                                          \
+    "={a[0:15]}"(acc[0]), "={a[16:31]}"(acc[1]), "={a[32:47]}"(acc[2]), "={a[48:63]}"(acc[3]), "={a[64:79]}"(acc[4]),   \
+        "={a[80:95]}"(acc[5]), "={a[96:111]}"(acc[6]), "={a[112:127]}"(acc[7]), "={a[128:143]}"(acc[8]),                 \
+        "={a[144:159]}"(acc[9]), "={a[160:175]}"(acc[10]), "={a[176:191]}"(acc[11]), "={a[192:207]}"(acc[12]),          \
+        "={a[208:223]}"(acc[13]), "={a[224:239]}"(acc[14]), "={a[240:255]}"(acc[15])
+#define V4_ASM(LOOP) asm volatile(LOOP : V4_OUT16 V4_INS : LTX2_V4_CLOBBERS)
+
+template <int EPI, int LAYOUT, int BM, int VAR>
+__global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
+    static_assert(BM == 224 || BM == 256, "224 or 256 rows");
+    static_assert(LAYOUT >= 0 && LAYOUT <= 2, "wave layout");
+    constexpr int TBN = 256, NPA = BM / 32;
+    constexpr int MB = LAYOUT == 2 ? 16 : 32;               // MFMA block
+    constexpr int WM = LAYOUT == 0 ? BM : 128, WN = LAYOUT == 0 ? 64 : 128;
+    constexpr int RBW = (WM + MB - 1) / MB, CBW = WN / MB;  // blocks per wave (first wave row)
+    constexpr int NKS = LAYOUT == 2 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = LAYOUT == 0 ? 0 : (w >> 1), wc = LAYOUT == 0 ? w : (w & 1);
+#ifdef LTX2_V4_PROBE
+    const unsigned long long t_k0 = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- block -> tile (XCD-contiguous, grouped row-tiles; as gemm_pp.hip) ----
+    const int Mt = (p.M + BM - 1) / BM, Nt = p.N / TBN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * Nt;
+    const int g = id / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = min(Mt - first_m, GROUP);
+    const int rem = id - g * per_group;
+    const int m0 = (first_m + rem % gsz) * BM;
+    const int n0 = (rem / gsz) * TBN;
+
+    // ---- LDS-DMA sources: piece j of this wave = 8 tile rows x 128 B; chunk swizzle on the source, row clamp at the ragged edge ----
+    u32x8 voffA = {0, 0, 0, 0, 0, 0, 0, 0}, voffB = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int r = (w * NPA + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        voffA[j] = (unsigned)min(m0 + r, p.M - 1) * (unsigned)(p.lda * 2) + chunk * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = (w * 8 + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        voffB[j] = (unsigned)(n0 + r) * (unsigned)(p.K * 2) + chunk * 16;
+    }
+    // ---- fragment read addresses (stage 0, first block of the wave): row lr, 16-byte chunk (kchunk(ks) + kq) ^ ((row >> 1) & 7) ----
+    const int lr = lane & (MB - 1), kq = lane / MB;         // row in block, k-quarter (32x32x16: 0..1, 16x16x32: 0..3)
+    const int xbase = kq ^ ((lr >> 1) & 7);
+    u32x4 addrA = {0, 0, 0, 0}, addrB = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const unsigned c = (unsigned)(((MB == 32 ? 2 : 4) * ks) ^ xbase) << 4;
+        addrA[ks] = lds0 + (wr * WM + lr) * 128 + c;
+        addrB[ks] = lds0 + 65536 + (wc * WN + lr) * 128 + c;
+    }
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + w * NPA * 1024);
+    const unsigned lw = __builtin_amdgcn_readfirstlane(lds0 + 65536 + w * 8 * 1024);
+    const unsigned nk = __builtin_amdgcn_readfirstlane(p.K / 64);
+
+    f32x16 acc[16];
+#ifdef LTX2_V4_PROBE
+    const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
+    if constexpr (LAYOUT == 0) {
+        if constexpr (BM == 224) V4_ASM(LTX2_V4_L14_RB7);
+        else {
+#ifdef LTX2_V4_PROBE
+            if constexpr (VAR == 1) V4_ASM(LTX2_V4_L14_RB8_NODMA);
+            else if constexpr (VAR == 2) V4_ASM(LTX2_V4_L14_RB8_NOREAD);
+            else
+#endif
+                V4_ASM(LTX2_V4_L14_RB8);
+        }
+    } else if constexpr (LAYOUT == 1) {
+        if constexpr (BM == 224) {
+            if (wr == 0) V4_ASM(LTX2_V4_L22_RB4_224);
+            else V4_ASM(LTX2_V4_L22_RB3_224);
+        } else {
+#ifdef LTX2_V4_PROBE
+            if constexpr (VAR == 1) V4_ASM(LTX2_V4_L22_RB4_NODMA);
+            else if constexpr (VAR == 2) V4_ASM(LTX2_V4_L22_RB4_NOREAD);
+            else
+#endif
+                V4_ASM(LTX2_V4_L22_RB4);
+        }
+    } else {
+        if constexpr (BM == 224) {
+            if (wr == 0) V4_ASM(LTX2_V4_L22_M16_RB8_224);
+            else V4_ASM(LTX2_V4_L22_M16_RB6_224);
+        } else {
+#ifdef LTX2_V4_PROBE
+            if constexpr (VAR == 1) V4_ASM(LTX2_V4_M16_NODMA);
+            else if constexpr (VAR == 2) V4_ASM(LTX2_V4_M16_NOREAD);
+            else if constexpr (VAR == 3) V4_ASM(LTX2_V4_M16_V3);
+            else if constexpr (VAR == 4) V4_ASM(LTX2_V4_M16_V4);
+            else if constexpr (VAR == 5) V4_ASM(LTX2_V4_M16_V5);
+            else if constexpr (VAR == 6) V4_ASM(LTX2_V4_M16_V6);
+            else if constexpr (VAR == 7) V4_ASM(LTX2_V4_M16_V7);
+            else if constexpr (VAR == 8) V4_ASM(LTX2_V4_M16_V8);
+            else
+#endif
+                V4_ASM(LTX2_V4_L22_M16_RB8);
+        }
+    }
+#ifdef LTX2_V4_PROBE
+    const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
+    if (p.dbg && blockIdx.x == 0 && tid == 0) {
+        ((unsigned long long*)p.dbg)[0] = t_loop1 - t_loop0;
+        ((unsigned long long*)p.dbg)[2] = t_loop0 - t_k0;
+    }
+#endif
+
+    // ---- epilogue (gemm_epilogue.h): a lane owns ONE row of every row block and 4-column groups of it ----
+    // 32x32 block: row lr, groups gq = 0..3 at columns 8 gq + 4 kq (accumulator registers 4 gq .. 4 gq + 3)
+    // 16x16 block: row lr, one group at columns 4 kq (accumulator registers 0..3)
+    constexpr int NG = MB == 32 ? 4 : 1;
+    f32x4 bias4[CBW][NG];
+    f32x4 gate4[CBW][NG];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            const int col = n0 + wc * WN + cb * MB + 8 * gq + 4 * kq;
+            bias4[cb][gq] = p.bias ? *(const f32x4*)(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gate4[cb][gq] = (EPI == EPI_RESID_GATE_F32 && p.gate_table) ? *(const f32x4*)(p.gate_table + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            asm volatile("" : "+v"(bias4[cb][gq]));      // retire the loads once, here
+            if (EPI == EPI_RESID_GATE_F32) asm volatile("" : "+v"(gate4[cb][gq]));
+        }
+    auto acc_group = [&](int rb, int cb, int gq) -> f32x4 {
+        // accumulator block index as the generator numbers it: rb * cbw + cb (both wave rows share cbw = CBW)
+        const int blk = rb * CBW + cb;
+        if constexpr (MB == 32) {
+            const f32x16& a = acc[blk];
+            return f32x4{a[4 * gq], a[4 * gq + 1], a[4 * gq + 2], a[4 * gq + 3]};
+        } else {
+            const f32x16& a = acc[blk >> 2];
+            const int o = (blk & 3) * 4;
+            return f32x4{a[o], a[o + 1], a[o + 2], a[o + 3]};
+        }
+    };
+    if constexpr (EPI == EPI_RESID_GATE_F32) {
+        // x += gate * (acc + bias).  The accumulators live in AGPRs and the fragment registers are dead, so the VGPR file
+        // is free: the residual tile is read HALF A WAVE TILE AT A TIME with every load in flight at once (32 x 16 B per
+        // lane), i.e. the HBM latency is paid twice per tile instead of once per row block (measured: one row block per
+        // round trip cost 46-75 k cycles of a 165 k-cycle block).
+        constexpr int RBH = (RBW + 1) / 2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 xs[RBH][CBW][NG];
+#pragma unroll
+            for (int r = 0; r < RBH; ++r) {
+                const int rb = half * RBH + r;
+                if (rb >= RBW || wr * WM + rb * MB >= BM) continue;
+                const int row = min(m0 + wr * WM + rb * MB + lr, p.M - 1);        // clamped for the load; the store checks
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int gq = 0; gq < NG; ++gq)
+                        xs[r][cb][gq] = *(const f32x4*)((const float*)p.out + (long)row * p.ldo + (n0 + wc * WN + cb * MB + 8 * gq + 4 * kq));
+            }
+#pragma unroll
+            for (int r = 0; r < RBH; ++r) {
+                const int rb = half * RBH + r;
+                if (rb >= RBW || wr * WM + rb * MB >= BM) continue;
+                const int row = m0 + wr * WM + rb * MB + lr;
+                const bool ok = row < p.M;
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int gq = 0; gq < NG; ++gq) {
+                        asm volatile("" : "+v"(xs[r][cb][gq]));       // consume in issue order: counted waits, not vmcnt(0)
+                        const int col = n0 + wc * WN + cb * MB + 8 * gq + 4 * kq;
+                        const f32x4 v = acc_group(rb, cb, gq) + bias4[cb][gq];
+                        f32x4 gt = {1.f, 1.f, 1.f, 1.f};
+                        if (p.gate || p.gate_table) {
+                            gt = gate4[cb][gq];
+                            if (p.gate && ok) gt += *(const f32x4*)(p.gate + (long)row * p.gate_stride + col);
+                        }
+                        if (ok) *(f32x4*)((float*)p.out + (long)row * p.ldo + col) = xs[r][cb][gq] + gt * v;
+                    }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) {
+            if (wr * WM + rb * MB >= BM) continue;          // second wave row of a 224-row tile: rows [224, 256) belong to the next tile
+            const int row = m0 + wr * WM + rb * MB + lr;
+            if (row >= p.M) continue;
+            const EpiRow er = epi_row_setup<EPI>(p, row);
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                for (int gq = 0; gq < NG; ++gq) {
+                    const int col = n0 + wc * WN + cb * MB + 8 * gq + 4 * kq;
+                    epi_store4<EPI>(p, er, row, col, acc_group(rb, cb, gq), bias4[cb][gq], gate4[cb][gq]);
+                }
+        }
+    }
+#ifdef LTX2_V4_PROBE
+    if (p.dbg && blockIdx.x == 0 && tid == 0) ((unsigned long long*)p.dbg)[1] = __builtin_amdgcn_s_memtime() - t_k0;
+#endif
+}
+
+template <int EPI, int LAYOUT, int BM, int VAR = 0>
+int launch_v4(const GemmParams& p, hipStream_t stream) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES);
+    }
+    const int Mt = (p.M + BM - 1) / BM, Nt = p.N / 256;
+    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, VAR>), dim3(Mt * Nt), dim3(256), V4_LDS_BYTES, stream, p);
+    LTX2_CHECK_LAUNCH("gemm_v4_kernel");
+    return LTX2_OK;
+}
+
+// 224-row tiles when they need fewer CU-rounds of work than 256-row tiles
+inline bool v4_prefer_224(const GemmParams& p) {
+    const long nt = p.N / 256, cus = 256;
+    const long t256 = ((long)(p.M + 255) / 256) * nt, t224 = ((long)(p.M + 223) / 224) * nt;
+    const long cost256 = (t256 + cus - 1) / cus * 256, cost224 = (t224 + cus - 1) / cus * 224;
+    return cost224 < cost256;
+}
+
+}  // namespace
+
+bool gemm_v4_supported(const GemmParams& p, int epilogue, bool conv) {
+    if (conv || epilogue == EPI_D2S_BF16) return false;
+    if (p.N % 256 != 0 || p.K % 128 != 0 || p.K < 256 || p.M < 1024) return false;
+    if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.K * 2 >= (1L << 31)) return false;     // 32-bit buffer offsets
+    return true;
+}
+
+// layout: 0 / 1 / 2 (see the file comment); bm: 0 = pick, 224, 256
+int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int layout, int bm) {
+    const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
+#define CASE_L(E, L) return b224 ? launch_v4<E, L, 224>(p, stream) : launch_v4<E, L, 256>(p, stream);
+#define CASE(E)                           \
+    case E:                               \
+        if (layout == 0) { CASE_L(E, 0) } \
+        if (layout == 1) { CASE_L(E, 1) } \
+        CASE_L(E, 2)
+    switch (epilogue) {
+        CASE(EPI_BF16)
+        CASE(EPI_GELU_BF16)
+        CASE(EPI_SILU_BF16)
+        CASE(EPI_F32)
+        CASE(EPI_RESID_GATE_F32)
+        CASE(EPI_ADD_BF16)
+        default:
+            ltx2_set_error("gemm_v4: unsupported epilogue %d", epilogue);
+            return LTX2_E_INVALID;
+    }
+#undef CASE
+#undef CASE_L
+}
+
+#ifdef LTX2_V4_PROBE
+// ablations of the 256-row kernels: var 1 = no DMA in the loop, 2 = no fragment reads
+int gemm_v4_probe_launch(const GemmParams& p, int layout, int var, hipStream_t stream) {
+    if (layout == 0) return var == 1 ? launch_v4<EPI_BF16, 0, 256, 1>(p, stream) : launch_v4<EPI_BF16, 0, 256, 2>(p, stream);
+    if (layout == 1) return var == 1 ? launch_v4<EPI_BF16, 1, 256, 1>(p, stream) : launch_v4<EPI_BF16, 1, 256, 2>(p, stream);
+    switch (var) {
+        case 1: return launch_v4<EPI_BF16, 2, 256, 1>(p, stream);
+        case 2: return launch_v4<EPI_BF16, 2, 256, 2>(p, stream);
+        case 3: return launch_v4<EPI_BF16, 2, 256, 3>(p, stream);
+        case 4: return launch_v4<EPI_BF16, 2, 256, 4>(p, stream);
+        case 5: return launch_v4<EPI_BF16, 2, 256, 5>(p, stream);
+        case 6: return launch_v4<EPI_BF16, 2, 256, 6>(p, stream);
+        case 7: return launch_v4<EPI_BF16, 2, 256, 7>(p, stream);
+        case 8: return launch_v4<EPI_BF16, 2, 256, 8>(p, stream);
+    }
+    return LTX2_E_INVALID;
+}
+#endif

@@ -1,0 +1,389 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled K loops of the 4-wave bf16 GEMM (gemm_v4.hip) for gfx950.
+
+Writes gemm_v4_loop.inc: one C string literal per variant holding the whole K loop as ONE asm block
+(prologue DMA, software-pipelined loop, drain).  hipcc never sees inside it: every register is named
+here, every wait count is derived here, and `check()` replays the instruction stream against a model
+of the LDS stages / fragment register sets to prove the RAW / WAR ordering before anything runs.
+
+Geometry: tile BM x 256 x 64 (BM = 256 or 224), 4 waves = one per SIMD, wave grid WR x WC (1x4 or 2x2),
+MFMA block MB = 32 (v_mfma_f32_32x32x16_bf16, 4 k-steps per K-tile) or 16 (v_mfma_f32_16x16x32_bf16,
+2 k-steps), C^T orientation (A operand = weight fragment, B operand = activation fragment).  A wave
+owns rbw x cbw blocks -> rbw*cbw accumulators in AGPRs.  LDS: [A stage0 32K][A stage1 32K][W stage0 32K]
+[W stage1 32K], rows of 128 B (64 bf16), 16-byte chunks XOR-swizzled with (row>>1)&7 on the DMA source.
+
+Per K-tile and wave: NKS k-steps of rbw*cbw MFMAs; the rbw+cbw fragment reads of k-step q+1 are issued
+in MFMA slots of k-step q into the other fragment register set; the LDS-DMA pieces of tile t+2 are issued
+in the slots of (t, last k-step) and (t+1, ks0); ONE s_barrier per K-tile, before the last k-step:
+
+  (t,ks0) .. (t,ksN-2) | lgkmcnt(0) vmcnt(0) s_barrier | (t,ksN-1) (t+1,ks0) ...
+     reads of stage s=t&1 all retired before the barrier -> DMA(t+2) may overwrite stage s after it;
+     own pieces of tile t+1 retired before the barrier -> every wave may read stage 1-s after it.
+
+Fixed registers (the .hip passes them with physical-register constraints):
+  v[0:7]   voffA[j]  byte offset of this lane's 16 B in activation piece j (row clamp + source swizzle applied)
+  v[8:15]  voffW[j]
+  v[16:19] addrA[ks] LDS byte address of this lane's activation fragment chunk for k-step ks (stage 0, block 0 of the wave)
+  v[20:23] addrW[ks] same for the weight fragment
+  v[32:..] fragment set P, then set Q  (rbw activation fragments, then cbw weight fragments, 4 VGPRs each)
+  a[(rb*cbw+cb)*ACC ...] accumulators (ACC = 16 for 32x32 blocks, 4 for 16x16)
+Operands: %[ra] %[rw] buffer resources (SGPR quads), %[nk] K-tiles, %[la] %[lw] LDS byte base of this
+wave's activation / weight DMA pieces in stage 0.
+"""
+import sys
+
+P_BASE = 32
+S_K = ("s92", "s93")      # K byte offset (soffset) of the tile being DMA'd into stage 0 / 1
+S_T, S_NK1, S_TMP = "s94", "s95", "s96"
+SCRATCH_S = ["s92", "s93", "s94", "s95", "s96"]
+A_STAGE, W_BASE = 32768, 65536
+
+
+class Gen:
+    def __init__(self, rbw, cbw, mb=32, npa=8, dma_last=None, dma_ks0=None, reads_every=1, m0_early=False,
+                 no_dma=False, no_read=False, no_barrier=False):
+        self.rbw, self.cbw, self.mb = rbw, cbw, mb
+        self.nks = 4 if mb == 32 else 2
+        self.accsz = 16 if mb == 32 else 4
+        self.blk_bytes = mb * 128                 # LDS bytes between consecutive row blocks
+        self.npa = npa                            # activation DMA pieces per wave (BM / 32)
+        self.NPIECE = npa + 8
+        self.nmf = rbw * cbw
+        self.nfrag = rbw + cbw
+        self.q_base = P_BASE + 4 * self.nfrag
+        self.vgpr_top = self.q_base + 4 * self.nfrag
+        assert self.vgpr_top <= 160
+        assert rbw * cbw * self.accsz <= 256
+        n = self.NPIECE
+        if dma_last is None:
+            # one piece every `st` slots; first half in the last k-step of tile t, the rest in ks0 of tile t+1
+            st = max(1, (2 * self.nmf) // (n + 1))
+            slots = list(range(st - 1, self.nmf, st))
+            n1 = min(len(slots), (n + 1) // 2)
+            dma_last = slots[:n1]
+            rest = n - n1
+            dma_ks0 = slots[:rest] if rest <= len(slots) else list(range(rest))
+        self.dma_last, self.dma_ks0 = dma_last, dma_ks0
+        assert len(dma_last) + len(dma_ks0) == n, (dma_last, dma_ks0, n)
+        self.reads_every = reads_every
+        self.m0_early = m0_early
+        assert (self.nfrag - 1) * reads_every < self.nmf
+        self.no_dma, self.no_read, self.no_barrier = no_dma, no_read, no_barrier
+        self.out = []
+        self.trace = []
+
+    def emit(self, s):
+        self.out.append(s)
+
+    def frag(self, setbase, idx):       # idx < rbw: activation fragment rb ; rbw + cb: weight fragment cb
+        return setbase + 4 * idx
+
+    def acc(self, rb, cb):
+        return (rb * self.cbw + cb) * self.accsz
+
+    def dma(self, piece, stage, tile_tag):
+        if piece < self.npa:
+            m0 = f"s_add_u32 m0, %[la], {stage * A_STAGE + piece * 1024}"
+            ins = f"buffer_load_dwordx4 v{piece}, %[ra], {S_K[stage]} offen lds"
+        else:
+            j = piece - self.npa
+            m0 = f"s_add_u32 m0, %[lw], {stage * A_STAGE + j * 1024}"
+            ins = f"buffer_load_dwordx4 v{8 + j}, %[rw], {S_K[stage]} offen lds"
+        self.trace.append(("dma", (piece, stage, tile_tag)))
+        if self.no_dma and tile_tag != "prologue":
+            return [], None
+        return [m0], ins
+
+    def read(self, setbase, idx, stage, ks, tile_tag):
+        f = self.frag(setbase, idx)
+        if idx < self.rbw:
+            a = f"ds_read_b128 v[{f}:{f + 3}], v{16 + ks} offset:{stage * A_STAGE + idx * self.blk_bytes}"
+        else:
+            a = f"ds_read_b128 v[{f}:{f + 3}], v{20 + ks} offset:{stage * A_STAGE + (idx - self.rbw) * self.blk_bytes}"
+        self.trace.append(("read", (setbase, idx, stage, ks, tile_tag)))
+        if self.no_read and tile_tag != "prologue":
+            return None
+        return a
+
+    def mfma(self, setbase, rb, cb):
+        a = self.acc(rb, cb)
+        w = self.frag(setbase, self.rbw + cb)
+        x = self.frag(setbase, rb)
+        self.trace.append(("mfma", (setbase, rb, cb)))
+        op = "v_mfma_f32_32x32x16_bf16" if self.mb == 32 else "v_mfma_f32_16x16x32_bf16"
+        return f"{op} a[{a}:{a + self.accsz - 1}], v[{w}:{w + 3}], v[{x}:{x + 3}], a[{a}:{a + self.accsz - 1}]"
+
+    def read_order(self):
+        return [self.rbw] + list(range(self.rbw)) + list(range(self.rbw + 1, self.nfrag))     # W0, A0..A(rbw-1), W1..
+
+    # one k-step: MFMAs on `cur`, reads of (rstage, rks) into `nxt`, DMA pieces in the given slots
+    def kstep(self, cur, nxt, rstage, rks, rtag, dma_list, dma_slots, dstage, dtag):
+        order = [(rb, cb) for cb in range(self.cbw) for rb in range(self.rbw)]
+        reads = self.read_order()
+        read_at = {i * self.reads_every: r for i, r in enumerate(reads)}
+        dma_at = dict(zip(dma_slots, dma_list))
+        pre_slot = {}           # instructions to place in the slot BEFORE a DMA's own slot (M0 set early: no s_nop needed)
+        for i, (rb, cb) in enumerate(order):
+            mf = self.mfma(cur, rb, cb)
+            pre, ins = ([], None)
+            if i in dma_at:
+                pre, ins = self.dma(dma_at[i], dstage, dtag)
+            if self.m0_early and ins and i == 0:
+                for s in pre:
+                    self.emit(s)
+                pre = []
+            self.emit(mf)
+            r = None
+            if i in read_at:
+                r = self.read(nxt, read_at[i], rstage, rks, rtag)
+            if self.m0_early:
+                if ins:
+                    self.emit(ins)          # M0 was written one slot earlier
+                if r:
+                    self.emit(r)
+                nxt_dma = dma_at.get(i + 1)
+                if nxt_dma is not None and not (self.no_dma and dtag != "prologue"):
+                    piece = nxt_dma
+                    base = "%[la]" if piece < self.npa else "%[lw]"
+                    j = piece if piece < self.npa else piece - self.npa
+                    self.emit(f"s_add_u32 m0, {base}, {dstage * A_STAGE + j * 1024}")
+            else:
+                for s in pre:
+                    self.emit(s)
+                if r:
+                    self.emit(r)
+                elif ins:
+                    self.emit("s_nop 0")          # SALU write of M0 -> LDS-DMA needs one wait state
+                if ins:
+                    self.emit(ins)
+        self.emit("s_waitcnt lgkmcnt(0)")
+        self.trace.append(("lgkm0", None))
+
+    def tile(self, s):
+        """K-tile living in stage s.  tags: 'T' this tile, 'T+1', 'T+2'."""
+        n1 = len(self.dma_last)
+        p1, p2 = list(range(n1)), list(range(n1, self.NPIECE))
+        o = 1 - s
+        sets = (P_BASE, self.q_base)
+        self.trace.append(("tile", s))
+        for ks in range(self.nks - 1):
+            cur, nxt = sets[ks & 1], sets[(ks + 1) & 1]
+            if ks == 0:         # second part of DMA(T+1) -> stage o
+                self.kstep(cur, nxt, s, ks + 1, "T", p2, self.dma_ks0, o, "T+1")
+            else:
+                self.kstep(cur, nxt, s, ks + 1, "T", [], [], 0, "")
+        self.emit("s_waitcnt vmcnt(0)")
+        self.trace.append(("vm", 0))
+        if not self.no_barrier:
+            self.emit("s_barrier")
+        self.trace.append(("barrier", None))
+        # K offset of tile T+2 (clamped to the last tile: dead data into dead slots, uniform counts)
+        self.emit(f"s_add_u32 {S_TMP}, {S_T}, {2 + s}")
+        self.emit(f"s_min_u32 {S_TMP}, {S_TMP}, {S_NK1}")
+        self.emit(f"s_lshl_b32 {S_K[s]}, {S_TMP}, 7")
+        # last k-step: reads (T+1, ks0) from stage o ; first part of DMA(T+2) -> stage s
+        ks = self.nks - 1
+        self.kstep(sets[ks & 1], sets[(ks + 1) & 1], o, 0, "T+1", p1, self.dma_last, s, "T+2")
+
+    def build(self):
+        NP = self.NPIECE
+        n1 = len(self.dma_last)
+        e = self.emit
+        e(f"s_sub_u32 {S_NK1}, %[nk], 1")
+        e(f"s_mov_b32 {S_K[0]}, 0")
+        e(f"s_min_u32 {S_TMP}, 1, {S_NK1}")
+        e(f"s_lshl_b32 {S_K[1]}, {S_TMP}, 7")
+        # tile 0 -> stage 0 (all pieces), first part of tile 1 -> stage 1
+        for stage, pieces in ((0, range(NP)), (1, range(n1))):
+            for p in pieces:
+                pre, ins = self.dma(p, stage, "prologue")
+                for s in pre:
+                    e(s)
+                e("s_nop 0")
+                e(ins)
+        for r in range(self.rbw * self.cbw * self.accsz):
+            e(f"v_accvgpr_write_b32 a{r}, 0")
+        e(f"s_waitcnt vmcnt({n1})")
+        self.trace.append(("vm", n1))
+        e("s_barrier")
+        self.trace.append(("barrier", None))
+        for idx in self.read_order():
+            e(self.read(P_BASE, idx, 0, 0, "prologue"))
+        e("s_waitcnt lgkmcnt(0)")
+        self.trace.append(("lgkm0", None))
+        e(f"s_mov_b32 {S_T}, 0")
+        e("LTX2_V4_LOOP_%=:")
+        self.trace.append(("loop", None))
+        self.tile(0)
+        self.tile(1)
+        e(f"s_add_u32 {S_T}, {S_T}, 2")
+        e(f"s_cmp_lt_u32 {S_T}, %[nk]")
+        e("s_cbranch_scc1 LTX2_V4_LOOP_%=")
+        e("s_waitcnt vmcnt(0)")
+        e("s_nop 15")        # XDL write -> v_accvgpr_read of the epilogue: hipcc cannot see the MFMAs in here
+        e("s_nop 15")
+        return self.out
+
+
+def check(g, iters=3):
+    """Replay the prologue and `iters` loop iterations of the trace with absolute tile numbers and verify:
+       RAW(LDS)  a fragment read of tile X is issued only after all of this wave's pieces of X were issued, a counted
+                 vmcnt retired them, and an s_barrier followed (the other waves ran the same program up to it);
+       WAR(LDS)  a DMA piece of tile X into stage X&1 is issued only after every read of tile X-2 was retired by an
+                 lgkmcnt(0) that precedes an s_barrier that precedes the DMA;
+       RAW(reg)  an MFMA consumes fragments whose reads were retired, both of the same (tile, ks), and every
+                 (tile, ks, rb, cb) product is issued exactly once;
+       WAR(reg)  a read overwrites a fragment register only after at least one further MFMA was issued behind the last
+                 MFMA that consumed it."""
+    tr = g.trace
+    li = [i for i, (k, _) in enumerate(tr) if k == "loop"][0]
+    body = tr[li + 1:]
+    NP, nfrag, nks = g.NPIECE, g.nfrag, g.nks
+    ev = list(tr[:li])
+    for it in range(iters):
+        base = 2 * it
+        cur = None
+        for k, pl in body:
+            if k == "tile":
+                cur = base + pl
+                continue
+            if k == "dma":
+                piece, stage, tag = pl
+                ev.append((k, (piece, stage, cur + {"T+1": 1, "T+2": 2}[tag])))
+            elif k == "read":
+                setb, idx, stage, ks, tag = pl
+                ev.append((k, (setb, idx, stage, ks, cur + {"T": 0, "T+1": 1}[tag])))
+            else:
+                ev.append((k, pl))
+    errors = []
+    dma_order = []
+    retired_upto = 0
+    landed_pos = {}
+    barriers = []
+    reads_by_tile = {}
+    pending_reads = []
+    frag = {}
+    frag_last_use = {}
+    n_mfma = 0
+    done = {}
+    stage_tile = {}
+    for pos, (k, pl) in enumerate(ev):
+        if k == "dma":
+            piece, stage, tile = pl
+            if isinstance(tile, str):
+                tile = stage          # prologue: tile == stage
+            if tile % 2 != stage:
+                errors.append(f"tile {tile} DMA'd into stage {stage}")
+            prev = tile - 2
+            if prev >= 0:
+                for ip, rp in reads_by_tile.get(prev, []):
+                    if rp[0] is None or not any(rp[0] < b < pos for b in barriers):
+                        errors.append(f"DMA of tile {tile} piece {piece} at {pos} before reads of tile {prev} retired + barrier")
+                        break
+                if len(reads_by_tile.get(prev, [])) != nks * nfrag:
+                    errors.append(f"DMA of tile {tile} at {pos}: tile {prev} has only {len(reads_by_tile.get(prev, []))} reads issued so far")
+            dma_order.append((pos, tile, piece))
+            stage_tile[stage] = tile
+        elif k == "vm":
+            upto = len(dma_order) - pl
+            for i in range(retired_upto, max(retired_upto, upto)):
+                landed_pos[(dma_order[i][1], dma_order[i][2])] = pos
+            retired_upto = max(retired_upto, upto)
+        elif k == "barrier":
+            barriers.append(pos)
+        elif k == "read":
+            setb, idx, stage, ks, tile = pl
+            if isinstance(tile, str):
+                tile = 0
+            if tile % 2 != stage or stage_tile.get(stage) != tile:
+                errors.append(f"read of tile {tile} from stage {stage} (holds {stage_tile.get(stage)})")
+            for p in range(NP):
+                lp = landed_pos.get((tile, p))
+                if lp is None or not any(lp < b < pos for b in barriers):
+                    errors.append(f"read of tile {tile} ks{ks} at {pos}: piece {p} not landed + barrier")
+                    break
+            if (setb, idx) in frag_last_use and n_mfma - frag_last_use[(setb, idx)] < 1:
+                errors.append(f"read into ({setb},{idx}) at {pos} right behind its last consumer")
+            frag.pop((setb, idx), None)
+            rec = [None]
+            reads_by_tile.setdefault(tile, []).append((pos, rec))
+            pending_reads.append((setb, idx, tile, ks, rec))
+        elif k == "lgkm0":
+            for setb, idx, tile, ks, rec in pending_reads:
+                rec[0] = pos
+                frag[(setb, idx)] = (tile, ks)
+            pending_reads = []
+        elif k == "mfma":
+            setb, rb, cb = pl
+            n_mfma += 1
+            ca, cw = frag.get((setb, rb)), frag.get((setb, g.rbw + cb))
+            if ca is None or cw is None:
+                errors.append(f"MFMA at {pos} consumes an unretired fragment")
+            elif ca != cw:
+                errors.append(f"MFMA at {pos} mixes {ca} and {cw}")
+            else:
+                key = (ca[0], ca[1], rb, cb)
+                done[key] = done.get(key, 0) + 1
+            frag_last_use[(setb, rb)] = n_mfma
+            frag_last_use[(setb, g.rbw + cb)] = n_mfma
+    for t in range(2 * iters):
+        for ks in range(nks):
+            for rb in range(g.rbw):
+                for cb in range(g.cbw):
+                    if done.get((t, ks, rb, cb), 0) != 1:
+                        errors.append(f"product tile {t} ks{ks} rb{rb} cb{cb} issued {done.get((t, ks, rb, cb), 0)} times")
+    return errors
+
+
+def variant(name, rbw, cbw, **kw):
+    g = Gen(rbw, cbw, **kw)
+    lines = g.build()
+    abl = kw.get("no_dma") or kw.get("no_read") or kw.get("no_barrier")
+    errs = check(g)
+    if errs and not abl:
+        raise SystemExit(f"{name}: pipeline check failed:\n  " + "\n  ".join(errs[:20]))
+    body = "".join(f'    "{ln}\\n"\n' for ln in lines)
+    hdr = f"// {name}: rbw={rbw} cbw={cbw} mb={g.mb} npa={g.npa} dma_last={g.dma_last} dma_ks0={g.dma_ks0} reads_every={g.reads_every} vgpr_top={g.vgpr_top}"
+    return hdr + f"\n#define {name} \\\n" + body.replace('\n', ' \\\n').rstrip(' \\\n') + "\n\n"
+
+
+def main():
+    out = ["// GENERATED by gen_gemm_v4.py -- do not edit.  One asm string per K-loop variant (see the generator's docstring).\n",
+           "#pragma once\n\n",
+           "#define LTX2_V4_CLOBBERS \\\n    " +
+           ", ".join(f'"v{i}"' for i in range(24, 160)) + ", \\\n    " +
+           ", ".join(f'"{s}"' for s in SCRATCH_S) + ', "scc", "memory"\n\n']
+    odd16, odd14 = list(range(1, 16, 2)), list(range(1, 14, 2))
+    # layout 1x4 (wave = all row blocks x 2 column blocks), 32x32x16
+    out.append(variant("LTX2_V4_L14_RB7", 7, 2, npa=7, dma_last=odd14, dma_ks0=[0, 2, 4, 6, 8, 10, 12, 13]))
+    out.append(variant("LTX2_V4_L14_RB8", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16))
+    # layout 2x2 (wave = 128 x 128), 32x32x16: 4x4 blocks; the second wave row of a 224-row tile owns 3 row blocks
+    out.append(variant("LTX2_V4_L22_RB4", 4, 4, npa=8, dma_last=odd16, dma_ks0=odd16))
+    out.append(variant("LTX2_V4_L22_RB4_224", 4, 4, npa=7, dma_last=odd16, dma_ks0=odd14))
+    out.append(variant("LTX2_V4_L22_RB3_224", 3, 4, npa=7, dma_last=[0, 2, 3, 5, 6, 8, 9, 11], dma_ks0=[1, 2, 4, 5, 7, 8, 10]))
+    # layout 2x2, 16x16x32: 8x8 blocks (6x8 for the second wave row of a 224-row tile)
+    out.append(variant("LTX2_V4_L22_M16_RB8", 8, 8, mb=16, npa=8, dma_last=list(range(3, 64, 4)), dma_ks0=[]))
+    out.append(variant("LTX2_V4_L22_M16_RB8_224", 8, 8, mb=16, npa=7, dma_last=list(range(3, 60, 4)), dma_ks0=[]))
+    out.append(variant("LTX2_V4_L22_M16_RB6_224", 6, 8, mb=16, npa=7, dma_last=list(range(2, 47, 3)), dma_ks0=[]))
+    if "--probe" in sys.argv:
+        out.append(variant("LTX2_V4_L14_RB8_NODMA", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, no_dma=True))
+        out.append(variant("LTX2_V4_L14_RB8_NOREAD", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, no_read=True))
+        out.append(variant("LTX2_V4_L22_RB4_NODMA", 4, 4, npa=8, dma_last=odd16, dma_ks0=odd16, no_dma=True))
+        out.append(variant("LTX2_V4_L22_RB4_NOREAD", 4, 4, npa=8, dma_last=odd16, dma_ks0=odd16, no_read=True))
+        e4, e8 = list(range(3, 64, 4)), list(range(7, 64, 8))
+        out.append(variant("LTX2_V4_M16_NODMA", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], no_dma=True))
+        out.append(variant("LTX2_V4_M16_NOREAD", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], no_read=True))
+        out.append(variant("LTX2_V4_M16_V3", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True))
+        out.append(variant("LTX2_V4_M16_V4", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True, reads_every=2))
+        out.append(variant("LTX2_V4_M16_V5", 8, 8, mb=16, npa=8, dma_last=e8, dma_ks0=e8, m0_early=True))
+        out.append(variant("LTX2_V4_M16_V6", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True, reads_every=3))
+        out.append(variant("LTX2_V4_M16_V7", 8, 8, mb=16, npa=8, dma_last=e8, dma_ks0=e8))
+        out.append(variant("LTX2_V4_M16_V8", 8, 8, mb=16, npa=8, dma_last=e8, dma_ks0=e8, m0_early=True, reads_every=2))
+    path = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "gemm_v4_loop.inc"
+    with open(path, "w") as f:
+        f.write("".join(out))
+    print(f"wrote {path}")
+
+
+if __name__ == "__main__":
+    main()

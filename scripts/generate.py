@@ -156,25 +156,122 @@ def euler_step_x0(sample, denoised, sigma, sigma_next):
     return K.euler_step(sample.reshape(-1, c).float(), denoised.reshape(-1, c).float(), sigma, sigma_next).reshape(sample.shape)
 
 
-def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames: int = 97, num_inference_steps: int = 8,
-                   seed: int = 42, output_path: str = "output.mp4", weights_path=None, embedding_path=None,
-                   use_gemma: bool = False, model_variant: str = "distilled", skip_vae: bool = False, use_placeholder: bool = False,
-                   tiled_vae: bool = False, cfg_scale: float = 1.0, use_hip_graph: bool = True, use_fp8: bool = False, num_layers: int = 48,
-                   num_heads: int = 32, vae_base_channels: int = 128, device: str = "cuda", image_path=None,
-                   image_strength: float = 0.95, lora_path=None, lora_strength: float = 1.0, fps: int = 24, speed: float = 1.0,
-                   text_features_path=None, spatial_upscaler_weights=None, pipeline: str = "text-to-video", generate_audio: bool = False,
-                   save_mp4: bool = True, **unsupported):
-    for k, v in unsupported.items():
-        if v:
-            raise NotImplementedError(f"--{k.replace('_', '-')} is outside the MI355X hot path (see DESIGN.md)")
+# Keyword surface of the reference's generate_video (scripts/generate.py:933-997), names and defaults verbatim, so a caller of
+# the reference can switch without touching its call site.  Options outside the MI355X hot path are accepted at their
+# reference defaults and raise NotImplementedError only when set to something else.
+_OUT_OF_PATH_DEFAULTS = dict(
+    upscale_temporal=False, temporal_upscaler_weights=None, early_layers_only=False, enhance_prompt_flag=False,
+    cross_attn_scale=1.0, distilled_lora=None, stg_scale=0.0, apg_scale=1.0, control_video=None, save_control=False,
+    ge_gamma=0.0, keyframes=None, ic_lora_weights=None, negative_prompt=None)
+
+
+def generate_video(
+    prompt: str,
+    height: int = 480,
+    width: int = 704,
+    num_frames: int = 97,
+    num_steps: int = 7,
+    cfg_scale: float = 5.0,
+    guidance_rescale: float = 0.7,
+    steps_stage1: int = 15,
+    steps_stage2: int = 3,
+    cfg_stage1=None,
+    seed: int = 42,
+    weights_path=None,
+    output_path: str = "gens/output.mp4",
+    use_placeholder: bool = False,
+    skip_vae: bool = False,
+    embedding_path=None,
+    gemma_path: str = "weights/gemma-3-12b",
+    use_gemma: bool = True,
+    use_fp16: bool = True,
+    use_fp8: bool = False,
+    model_variant: str = "distilled",
+    upscale_spatial: bool = False,
+    spatial_upscaler_weights=None,
+    upscale_temporal: bool = False,
+    temporal_upscaler_weights=None,
+    generate_audio: bool = False,
+    low_memory: bool = False,
+    fast_mode: bool = False,
+    image_path=None,
+    image_strength: float = 0.95,
+    lora_path=None,
+    lora_strength: float = 1.0,
+    tiled_vae: bool = False,
+    pipeline_type: str = "text-to-video",
+    early_layers_only: bool = False,
+    enhance_prompt_flag: bool = False,
+    cross_attn_scale: float = 1.0,
+    distilled_lora=None,
+    distilled_lora_scale: float = 1.0,
+    stg_scale: float = 0.0,
+    stg_mode: str = "video",
+    apg_scale: float = 1.0,
+    apg_eta: float = 1.0,
+    apg_norm_threshold: float = 0.0,
+    apg_momentum: float = 0.0,
+    control_video=None,
+    control_type: str = "raw",
+    canny_low: int = 100,
+    canny_high: int = 200,
+    control_strength: float = 0.95,
+    save_control: bool = False,
+    ge_gamma: float = 0.0,
+    output_fps: int = 24,
+    output_speed: float = 1.0,
+    keyframes=None,
+    ic_lora_weights=None,
+    audio_cfg_scale=None,
+    rescale_scale=None,
+    negative_prompt=None,
+    *,
+    # MI355X additions (keyword-only; the reference has no counterpart)
+    use_hip_graph: bool = True,
+    num_layers: int = 48,
+    num_heads: int = 32,
+    vae_base_channels: int = 128,
+    device: str = "cuda",
+    text_features_path=None,
+    save_mp4: bool = True,
+):
+    """Generate video from a text prompt: distilled denoise loop + VAE decode on MI355X behind the reference's signature."""
+    given = dict(upscale_temporal=upscale_temporal, temporal_upscaler_weights=temporal_upscaler_weights, early_layers_only=early_layers_only,
+                 enhance_prompt_flag=enhance_prompt_flag and use_gemma, cross_attn_scale=cross_attn_scale, distilled_lora=distilled_lora,
+                 stg_scale=stg_scale, apg_scale=apg_scale, control_video=control_video, save_control=save_control, ge_gamma=ge_gamma,
+                 keyframes=keyframes, ic_lora_weights=ic_lora_weights, negative_prompt=negative_prompt)
+    for k, v in given.items():
+        if v != _OUT_OF_PATH_DEFAULTS[k]:
+            raise NotImplementedError(f"{k}={v!r} is outside the MI355X hot path (see DESIGN.md); leave it at its default {_OUT_OF_PATH_DEFAULTS[k]!r}")
+    if pipeline_type not in ("text-to-video", "distilled", "one-stage", "two-stage"):
+        raise NotImplementedError(f"pipeline_type={pipeline_type!r} is outside the MI355X hot path (see DESIGN.md)")
+    output_dir = os.path.dirname(output_path)
+    if output_dir:
+        os.makedirs(output_dir, exist_ok=True)          # reference :1000-1003
     if num_frames % 8 != 1:
         raise ValueError(f"num_frames must be 8*k + 1, got {num_frames}")
     if height % 32 != 0 or width % 32 != 0:
         raise ValueError(f"Resolution ({height}x{width}) must be divisible by 32")
-    if use_gemma:
-        raise NotImplementedError("Gemma text encoding is outside the hot path: pass --embedding or --no-gemma")
-    if model_variant == "distilled" and cfg_scale != 1.0:
-        print("  distilled model: cfg forced to 1.0 (reference :1207-1216)")
+    if not use_fp16:
+        raise NotImplementedError("use_fp16=False (fp32 compute): the MI355X path computes in bf16 with fp32 accumulation and an fp32 residual stream")
+    print("Compute dtype: bf16 operands / fp32 accumulate / fp32 residual stream (use_fp16=True selects the reduced-precision path; "
+          "fp16 operands are not built)", file=sys.stderr)
+    if use_gemma and not (embedding_path or text_features_path):
+        if not os.path.exists(gemma_path):              # the reference prints this and returns (:1085-1092)
+            print(f"\n  ERROR: Gemma weights not found at {gemma_path}\n  Use use_gemma=False (--no-gemma) for dummy embeddings, or pass "
+                  f"embedding_path / text_features_path")
+            return None
+        raise NotImplementedError("Gemma-3 text encoding is outside the hot path: pass embedding_path / text_features_path (or use_gemma=False)")
+    if model_variant == "distilled" and cfg_scale > 1.2 and pipeline_type != "two-stage":
+        print(f"  WARNING: Distilled model requires CFG=1.0 (no guidance). You requested {cfg_scale}.\n  Forcing CFG=1.0 (reference :1207-1216).")
+        cfg_scale, guidance_rescale = 1.0, 0.0
+    if cfg_scale > 1.0:
+        raise NotImplementedError(f"cfg_scale={cfg_scale}: classifier-free guidance is outside the MI355X hot path (distilled single-pass only)")
+    if low_memory or fast_mode:
+        print("  low_memory / fast_mode: no effect here (weights and caches stay resident in HBM, the loop is one hipGraph)")
+    num_inference_steps = num_steps
+    pipeline = "distilled" if (pipeline_type in ("distilled", "two-stage") or upscale_spatial) else "text-to-video"
+    fps, speed = output_fps, output_speed
     torch.manual_seed(seed)
     t_all = time.time()
     print("[1/5] text encoding")
@@ -206,6 +303,8 @@ def generate_video(prompt: str, height: int = 480, width: int = 704, num_frames:
         # upscale, 3 steps at full resolution.  "random" as the path builds a random-weight upscaler (no checkpoint here).
         if not spatial_upscaler_weights:
             raise ValueError("--pipeline distilled needs --spatial-upscaler-weights (two-stage pipeline)")
+        if image_path or tiled_vae:
+            raise NotImplementedError("the two-stage pipeline here takes neither --image nor --tiled-vae (single-stage text-to-video does)")
         if vae_decoder is None:
             raise ValueError("the two-stage pipeline needs the VAE weights (per-channel statistics): drop --skip-vae")
         from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler, load_spatial_upscaler_weights
@@ -331,7 +430,7 @@ def main():
     p.add_argument("--model-variant", choices=["distilled", "dev"], default="distilled")
     p.add_argument("--pipeline", type=str, default="text-to-video")
     p.add_argument("--cfg", type=float, default=1.0)
-    p.add_argument("--fp16", action="store_true", help="accepted for compatibility; compute is bf16 / fp32-accumulate")
+    p.add_argument("--fp16", action="store_true", help="reference default; here: bf16 operands, fp32 accumulate (a notice is printed)")
     p.add_argument("--fp32", action="store_true")
     p.add_argument("--fp8", action="store_true")
     p.add_argument("--skip-vae", action="store_true")
@@ -353,16 +452,19 @@ def main():
     p.add_argument("--speed", type=float, default=1.0, help="playback speed multiplier (reference flag)")
     p.add_argument("--no-video-file", action="store_true", help="keep only the .npz outputs (skip ffmpeg / PNG frames)")
     a = p.parse_args()
-    if a.fp32:
-        raise NotImplementedError("--fp32: the MI355X path computes in bf16 with fp32 accumulation / residual stream")
-    if a.pipeline not in ("text-to-video", "distilled"):
+    if a.pipeline not in ("text-to-video", "distilled", "one-stage", "two-stage"):
         raise NotImplementedError(f"--pipeline {a.pipeline} is outside the MI355X hot path")
-    generate_video(a.prompt, height=a.height, width=a.width, num_frames=a.frames, num_inference_steps=a.steps, seed=a.seed,
+    if a.model_variant == "dev" and a.cfg != 1.0:
+        raise NotImplementedError("--model-variant dev with --cfg != 1: classifier-free guidance is not built on this path")
+    generate_video(a.prompt, height=a.height, width=a.width, num_frames=a.frames, num_steps=a.steps, seed=a.seed, cfg_scale=a.cfg,
                    output_path=a.output, weights_path=a.weights, embedding_path=a.embedding, text_features_path=a.text_features,
-                   use_gemma=bool(a.gemma_path) and not a.no_gemma, model_variant=a.model_variant, skip_vae=a.skip_vae,
-                   use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, cfg_scale=a.cfg, use_hip_graph=not a.no_hip_graph, use_fp8=a.fp8,
-                   num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,
-                   image_path=a.image, image_strength=a.image_strength, lora_path=a.lora, lora_strength=a.lora_strength, fps=a.fps, speed=a.speed, save_mp4=not a.no_video_file, generate_audio=a.generate_audio, spatial_upscaler_weights=a.spatial_upscaler_weights, pipeline=a.pipeline)
+                   gemma_path=a.gemma_path or "weights/gemma-3-12b", use_gemma=not a.no_gemma and not (a.embedding or a.text_features) and bool(a.gemma_path),
+                   use_fp16=not a.fp32, model_variant=a.model_variant, skip_vae=a.skip_vae,
+                   use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, use_hip_graph=not a.no_hip_graph, use_fp8=a.fp8,
+                   low_memory=a.low_memory, fast_mode=a.fast_mode, num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,
+                   image_path=a.image, image_strength=a.image_strength, lora_path=a.lora, lora_strength=a.lora_strength,
+                   output_fps=a.fps, output_speed=a.speed, save_mp4=not a.no_video_file, generate_audio=a.generate_audio,
+                   spatial_upscaler_weights=a.spatial_upscaler_weights, pipeline_type=a.pipeline)
 
 
 if __name__ == "__main__":

@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_generate_cli_plumbing(dev, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import generate
-    kw = dict(height=256, width=384, num_frames=17, num_inference_steps=8, seed=3, num_layers=2, num_heads=2,
-              vae_base_channels=64)
+    kw = dict(height=256, width=384, num_frames=17, num_steps=8, seed=3, num_layers=2, num_heads=2,
+              vae_base_channels=64, use_gemma=False)
     f1 = generate.generate_video("a test prompt", output_path=str(tmp_path / "a.mp4"), use_hip_graph=True, **kw)
     f2 = generate.generate_video("a test prompt", output_path=str(tmp_path / "b.mp4"), use_hip_graph=False, **kw)
     assert f1.shape == (17, 256, 384, 3) and f1.dtype == torch.uint8
@@ -73,16 +73,32 @@ def test_generate_cli_two_stage(dev, tmp_path):
     """`--spatial-upscaler-weights` routes the CLI through the two-stage DistilledPipeline (reference generate.py:1622-1700)."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import generate
-    kw = dict(height=256, width=384, num_frames=17, num_inference_steps=8, seed=3, num_layers=2, num_heads=2, vae_base_channels=64)
+    kw = dict(height=256, width=384, num_frames=17, num_steps=8, seed=3, num_layers=2, num_heads=2, vae_base_channels=64, use_gemma=False)
     f = generate.generate_video("a test prompt", output_path=str(tmp_path / "t.mp4"), spatial_upscaler_weights="random", **kw)
     assert f.shape == (17, 256, 384, 3) and f.dtype == torch.uint8
     with pytest.raises(ValueError, match="per-channel statistics"):
         generate.generate_video("x", spatial_upscaler_weights="random", skip_vae=True, **kw)
     with pytest.raises(ValueError, match="two-stage"):
-        generate.generate_video("x", pipeline="distilled", **kw)
+        generate.generate_video("x", pipeline_type="distilled", **kw)
     # --generate-audio: AudioVideo transformer, joint audio+video loop in both stages, audio latent saved beside the frames
     fa = generate.generate_video("a test prompt", output_path=str(tmp_path / "av.mp4"), spatial_upscaler_weights="random",
                                  generate_audio=True, **kw)
     assert fa.shape == (17, 256, 384, 3)
     al = np.load(tmp_path / "av_audio_latent.npz")["latent"]
     assert al.ndim == 4 and al.shape[1] == 8 and al.shape[3] == 16 and np.isfinite(al).all()
+
+
+def test_generate_video_with_reference_default_kwargs(dev, tmp_path):
+    """`generate_video(**reference_defaults, weights_path=None, use_gemma=False)`: the reference's own keyword set (names and
+    defaults from tests/golden/generate_video_signature.json) runs unchanged -- 480x704x97, 7 distilled steps, cfg 5.0 forced
+    to 1.0 for the distilled model, fp16 flag -> bf16 notice -- on a random-init model (2 layers via the keyword-only MI355X
+    extra so the test stays short)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import generate
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "generate_video_signature.json")))["params"]
+    kw = {r["name"]: r["default"] for r in ref if not r["required"]}
+    kw.update(weights_path=None, use_gemma=False, output_path=str(tmp_path / "gens" / "output.mp4"))
+    frames = generate.generate_video("a cat walking through tall grass", **kw, num_layers=2, save_mp4=False)
+    assert frames.shape == (97, 480, 704, 3) and frames.dtype == torch.uint8
+    assert os.path.exists(tmp_path / "gens" / "output_latent.npz")

@@ -346,3 +346,38 @@ def test_save_video_command_and_png_fallback(tmp_path, monkeypatch):
     assert np.array_equal(np.asarray(Image.open(os.path.join(out, files[1]))), frames[1])
     with pytest.raises(ValueError):
         gen.save_video(frames.astype(np.float32), str(tmp_path / "bad.mp4"))
+
+
+def test_generate_video_keeps_the_reference_keyword_surface(tmp_path, capsys):
+    """Drop-in boundary: `generate_video` takes the reference's parameters, in order, with the reference's
+    defaults (tests/golden/generate_video_signature.json, written from /root/reference/scripts/generate.py:933-997 by
+    tools/pin_generate_signature.py); MI355X extras are keyword-only and come after them.  Out-of-path options raise only
+    when they are moved off their reference default."""
+    import inspect
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import generate
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "generate_video_signature.json")))["params"]
+    ours = list(inspect.signature(generate.generate_video).parameters.values())
+    assert [p.name for p in ours[:len(ref)]] == [r["name"] for r in ref]
+    for p, r in zip(ours, ref):
+        assert p.kind == inspect.Parameter.POSITIONAL_OR_KEYWORD
+        assert (p.default is inspect.Parameter.empty) == r["required"], p.name
+        if not r["required"]:
+            assert p.default == r["default"] and type(p.default) is type(r["default"]), (p.name, p.default, r["default"])
+    assert all(p.kind == inspect.Parameter.KEYWORD_ONLY for p in ours[len(ref):])
+    # every reference default is accepted as given: with use_gemma=True (the default) and no Gemma weights on disk the
+    # reference prints an error and returns None (:1085-1092) -- so does this one, before touching the GPU
+    kw = {r["name"]: r["default"] for r in ref if not r["required"]}
+    kw["output_path"] = str(tmp_path / "gens" / "o.mp4")
+    assert generate.generate_video("a prompt", **kw) is None
+    assert "Gemma weights not found" in capsys.readouterr().out and os.path.isdir(tmp_path / "gens")
+    # an out-of-path option off its default is refused by name; frames / resolution errors keep the reference's wording
+    with pytest.raises(NotImplementedError, match="stg_scale"):
+        generate.generate_video("a prompt", **dict(kw, stg_scale=1.0))
+    with pytest.raises(NotImplementedError, match="use_fp16=False"):
+        generate.generate_video("a prompt", **dict(kw, use_fp16=False))
+    with pytest.raises(ValueError, match="8\\*k \\+ 1"):
+        generate.generate_video("a prompt", **dict(kw, num_frames=96))
+    with pytest.raises(ValueError, match="divisible by 32"):
+        generate.generate_video("a prompt", **dict(kw, height=250))
