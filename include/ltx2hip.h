@@ -230,19 +230,21 @@ int ltx2_dit_prepare_av(ltx2_dit* ctx, const float* v_context, int S, const floa
 /* velocity[N][out_channels] (fp32) = LTXModel(latent[N][in_channels] fp32, timesteps).
  * n_timesteps = 1: one sigma for all tokens (Modality.timesteps shape (B,), scripts/generate.py:1946);
  * n_timesteps = N: per-token sigma (pipelines/common.py:193-232).                           */
-int ltx2_dit_forward(ltx2_dit* ctx, const float* latent, const float* timesteps, int n_timesteps, float* velocity,
-                     void* stream);
+int ltx2_dit_forward(ltx2_dit* ctx, const float* latent, const float* timesteps, int n_timesteps, const float* sigma,
+                     float* velocity, void* stream);
 /* AudioVideo forward (model.py:776-881).  *_sigma: one device float per modality = Modality.sigma
  * (drives the prompt AdaLN of its own modality and the cross-modal AdaLN of the OTHER one,
- * model.py:151-161,392-404).  The VideoOnly entry uses timesteps[0] for it.                  */
+ * model.py:151-161,392-404).  The VideoOnly entries take it as `sigma` / `sigma_dev` (one device float; NULL =
+ * timesteps[0], which is only right when no token carries a conditioning mask: with image conditioning
+ * timesteps = mask * sigma, model.py:151-158).                                                 */
 int ltx2_dit_forward_av(ltx2_dit* ctx, const float* v_latent, const float* v_timesteps, int n_v_timesteps,
                         const float* v_sigma, const float* a_latent, const float* a_timesteps, int n_a_timesteps,
                         const float* a_sigma, float* v_velocity, float* a_velocity, void* stream);
 
 /* One sampling step: forward -> x0 = latent - ts*v -> post_process -> Euler, latent updated in
  * place (pipelines/distilled.py:214-253; scripts/generate.py:1942-1979).  x0_out may be NULL.  */
-int ltx2_dit_denoise_step(ltx2_dit* ctx, float* latent, const float* timesteps, int n_timesteps, const float* mask,
-                          const float* clean, float sigma, float sigma_next, float* x0_out, void* stream);
+int ltx2_dit_denoise_step(ltx2_dit* ctx, float* latent, const float* timesteps, int n_timesteps, const float* sigma_dev,
+                          const float* mask, const float* clean, float sigma, float sigma_next, float* x0_out, void* stream);
 /* Joint audio+video step (pipelines/distilled.py:198-271): both latents updated in place;
  * sigma_dev = device copy of sigma.                                                          */
 int ltx2_dit_denoise_step_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* v_timesteps,

@@ -78,8 +78,8 @@ SIGNATURES = {
     "ltx2_dit_forward_av": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "ltx2_dit_denoise_step_av": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp]),
     "ltx2_dit_graph_capture_av": (i32, [vp, vp, vp, C.POINTER(f32), i32, vp]),
-    "ltx2_dit_forward": (i32, [vp, vp, vp, i32, vp, vp]),
-    "ltx2_dit_denoise_step": (i32, [vp, vp, vp, i32, vp, vp, f32, f32, vp, vp]),
+    "ltx2_dit_forward": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "ltx2_dit_denoise_step": (i32, [vp, vp, vp, i32, vp, vp, vp, f32, f32, vp, vp]),
     "ltx2_dit_graph_capture": (i32, [vp, vp, C.POINTER(f32), i32, vp]),
     "ltx2_dit_graph_launch": (i32, [vp, vp]),
     "ltx2_dit_profile_begin": (i32, [vp, i32]),

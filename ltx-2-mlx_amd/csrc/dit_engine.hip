@@ -833,11 +833,11 @@ int ltx2_dit_prepare_av(ltx2_dit* c, const float* v_context, int S, const float*
     return LTX2_OK;
 }
 
-int ltx2_dit_forward(ltx2_dit* c, const float* latent, const float* timesteps, int n_timesteps, float* velocity,
-                     void* stream) {
+int ltx2_dit_forward(ltx2_dit* c, const float* latent, const float* timesteps, int n_timesteps, const float* sigma,
+                     float* velocity, void* stream) {
     LTX2_CHECK_ARG(latent && timesteps && velocity, "dit_forward: null argument");
     TRY(check_ready(c, "dit_forward", false));
-    ModIn in[1] = {{latent, timesteps, n_timesteps, timesteps, velocity}};
+    ModIn in[1] = {{latent, timesteps, n_timesteps, sigma ? sigma : timesteps, velocity}};
     return forward(c, in, (hipStream_t)stream);
 }
 
@@ -852,11 +852,11 @@ int ltx2_dit_forward_av(ltx2_dit* c, const float* v_latent, const float* v_times
     return forward(c, in, (hipStream_t)stream);
 }
 
-int ltx2_dit_denoise_step(ltx2_dit* c, float* latent, const float* timesteps, int n_timesteps, const float* mask,
-                          const float* clean, float sigma, float sigma_next, float* x0_out, void* stream) {
+int ltx2_dit_denoise_step(ltx2_dit* c, float* latent, const float* timesteps, int n_timesteps, const float* sigma_dev,
+                          const float* mask, const float* clean, float sigma, float sigma_next, float* x0_out, void* stream) {
     LTX2_CHECK_ARG(latent && timesteps, "dit_denoise_step: null argument");
     TRY(check_ready(c, "dit_denoise_step", false));
-    ModIn in[1] = {{latent, timesteps, n_timesteps, timesteps, nullptr}};
+    ModIn in[1] = {{latent, timesteps, n_timesteps, sigma_dev ? sigma_dev : timesteps, nullptr}};
     const StepIo io[1] = {{latent, mask, clean, x0_out}};
     return denoise_step(c, in, io, sigma, sigma_next, (hipStream_t)stream);
 }

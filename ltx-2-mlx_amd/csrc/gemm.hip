@@ -233,13 +233,13 @@ inline bool use_big_tile(const GemmParams& p) {
     return tiles_big >= 160;
 }
 
-// LTX2_V4_LAYOUT = 0 | 1 | 2 selects the wave layout of the 4-wave asm-loop kernel (gemm_v4.hip; default 2), -1 disables it
+// LTX2_V4_LAYOUT = 0 | 1 | 2 | 3 selects the wave layout of the 4-wave asm-loop kernel (gemm_v4.hip; default 3), -1 disables it
 inline int v4_layout() {
     static int v = -2;
     if (v == -2) {
         const char* e = getenv("LTX2_V4_LAYOUT");
-        v = e ? atoi(e) : 2;
-        if (v < -1 || v > 2) v = 2;
+        v = e ? atoi(e) : 3;
+        if (v < -1 || v > 3) v = 3;
     }
     return v;
 }

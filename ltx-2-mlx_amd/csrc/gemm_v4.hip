@@ -5,6 +5,7 @@
 //   1  2x2, v_mfma_f32_32x32x16_bf16: wave (wr, wc) owns a 128 x 128 quadrant (4 x 4 blocks; with 224-row tiles the second
 //      wave row owns 96 rows = 3 row blocks and runs a shorter program with the same barriers)
 //   2  2x2, v_mfma_f32_16x16x32_bf16: 8 x 8 blocks of 16 (6 x 8 for the second wave row of a 224-row tile)
+//   3  1x4, v_mfma_f32_16x16x32_bf16: 14|16 x 4 blocks of 16 (balanced for 224 rows)
 // What the measurements on MI355X say: with random operands the chip is POWER-limited -- the K loop of
 // layout 0 issues an MFMA every 34 cycles (2170 cycles per K-tile of 64 MFMAs) but the chip clocks at 1.45-1.55 GHz, an
 // MFMA-only loop at 2.0 GHz -- so what counts is energy per flop: LDS fragment reads (160 / 128 KiB per K-tile and CU for
@@ -36,18 +37,19 @@ constexpr int V4_LDS_BYTES = 131072;
 template <int EPI, int LAYOUT, int BM, int VAR>
 __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     static_assert(BM == 224 || BM == 256, "224 or 256 rows");
-    static_assert(LAYOUT >= 0 && LAYOUT <= 2, "wave layout");
+    static_assert(LAYOUT >= 0 && LAYOUT <= 3, "wave layout");
     constexpr int TBN = 256, NPA = BM / 32;
-    constexpr int MB = LAYOUT == 2 ? 16 : 32;               // MFMA block
-    constexpr int WM = LAYOUT == 0 ? BM : 128, WN = LAYOUT == 0 ? 64 : 128;
+    constexpr int MB = LAYOUT >= 2 ? 16 : 32;               // MFMA block
+    constexpr bool L14 = LAYOUT == 0 || LAYOUT == 3;        // 1x4 waves (else 2x2)
+    constexpr int WM = L14 ? BM : 128, WN = L14 ? 64 : 128;
     constexpr int RBW = (WM + MB - 1) / MB, CBW = WN / MB;  // blocks per wave (first wave row)
-    constexpr int NKS = LAYOUT == 2 ? 2 : 4;
+    constexpr int NKS = MB == 16 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = LAYOUT == 0 ? 0 : (w >> 1), wc = LAYOUT == 0 ? w : (w & 1);
+    const int wr = L14 ? 0 : (w >> 1), wc = L14 ? w : (w & 1);
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_k0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -120,6 +122,15 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #endif
                 V4_ASM(LTX2_V4_L22_RB4);
         }
+    } else if constexpr (LAYOUT == 3) {
+        if constexpr (BM == 224) {
+#ifdef LTX2_V4_PROBE
+            if constexpr (VAR == 10) V4_ASM(LTX2_V4_L14_M16_RB14_RD2);
+            else if constexpr (VAR == 11) V4_ASM(LTX2_V4_L14_M16_RB14_D4);
+            else
+#endif
+                V4_ASM(LTX2_V4_L14_M16_RB14);
+        } else V4_ASM(LTX2_V4_L14_M16_RB16);
     } else {
         if constexpr (BM == 224) {
             if (wr == 0) V4_ASM(LTX2_V4_L22_M16_RB8_224);
@@ -222,6 +233,32 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                     }
             }
         }
+    } else if constexpr (LAYOUT == 3 && VAR != 9 && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_SILU_BF16)) {
+        // bf16 outputs of the 1x4 layout leave through LDS: a lane's accumulator groups are 4 columns of 16 different rows
+        // (8-byte stores into 32-byte row segments); transposed through this wave's 32 KiB of the (now dead) stage buffers
+        // every store instruction writes 8 rows x 128 contiguous bytes.  LDS image [BM rows][128 B], 16-byte chunks
+        // XOR-swizzled with (row >> 1) & 7: conflict-free for the 8-byte writes (16 rows x one column group per lane
+        // group) and for the 16-byte row reads.
+        __syncthreads();                                    // every wave has finished its fragment reads
+        char* wl = smem + w * 32768;
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) {
+            const int r = rb * MB + lr;
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                f32x4 v = acc_group(rb, cb, 0) + bias4[cb][0];
+                if (EPI == EPI_GELU_BF16) v = f32x4{gelu_tanh(v[0]), gelu_tanh(v[1]), gelu_tanh(v[2]), gelu_tanh(v[3])};
+                if (EPI == EPI_SILU_BF16) v = f32x4{silu_f(v[0]), silu_f(v[1]), silu_f(v[2]), silu_f(v[3])};
+                const int chunk = (cb * 2 + (kq >> 1)) ^ ((r >> 1) & 7);
+                *(bf16x4*)(wl + r * 128 + chunk * 16 + (kq & 1) * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < BM / 8; ++it) {
+            const int r = it * 8 + (lane >> 3), c = lane & 7;
+            const u32x4 v = *(const u32x4*)(wl + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            if (m0 + r < p.M) *(u32x4*)((bf16*)p.out + (long)(m0 + r) * p.ldo + n0 + w * 64 + c * 8) = v;
+        }
     } else {
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
@@ -269,6 +306,7 @@ bool gemm_v4_supported(const GemmParams& p, int epilogue, bool conv) {
     if (conv || epilogue == EPI_D2S_BF16) return false;
     if (p.N % 256 != 0 || p.K % 128 != 0 || p.K < 256 || p.M < 1024) return false;
     if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.K * 2 >= (1L << 31)) return false;     // 32-bit buffer offsets
+    if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15)) return false;                                       // 16-byte output rows
     return true;
 }
 
@@ -280,6 +318,7 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
     case E:                               \
         if (layout == 0) { CASE_L(E, 0) } \
         if (layout == 1) { CASE_L(E, 1) } \
+        if (layout == 3) { CASE_L(E, 3) } \
         CASE_L(E, 2)
     switch (epilogue) {
         CASE(EPI_BF16)
@@ -301,6 +340,11 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
 int gemm_v4_probe_launch(const GemmParams& p, int layout, int var, hipStream_t stream) {
     if (layout == 0) return var == 1 ? launch_v4<EPI_BF16, 0, 256, 1>(p, stream) : launch_v4<EPI_BF16, 0, 256, 2>(p, stream);
     if (layout == 1) return var == 1 ? launch_v4<EPI_BF16, 1, 256, 1>(p, stream) : launch_v4<EPI_BF16, 1, 256, 2>(p, stream);
+    if (layout == 3) {
+        if (var == 10) return launch_v4<EPI_BF16, 3, 224, 10>(p, stream);
+        if (var == 11) return launch_v4<EPI_BF16, 3, 224, 11>(p, stream);
+        return launch_v4<EPI_BF16, 3, 224, 9>(p, stream);         // direct (untransposed) bf16 epilogue
+    }
     switch (var) {
         case 1: return launch_v4<EPI_BF16, 2, 256, 1>(p, stream);
         case 2: return launch_v4<EPI_BF16, 2, 256, 2>(p, stream);

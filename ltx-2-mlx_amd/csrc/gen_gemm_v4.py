@@ -52,7 +52,7 @@ class Gen:
         self.nfrag = rbw + cbw
         self.q_base = P_BASE + 4 * self.nfrag
         self.vgpr_top = self.q_base + 4 * self.nfrag
-        assert self.vgpr_top <= 160
+        assert self.vgpr_top <= 192
         assert rbw * cbw * self.accsz <= 256
         n = self.NPIECE
         if dma_last is None:
@@ -351,7 +351,7 @@ def main():
     out = ["// GENERATED by gen_gemm_v4.py -- do not edit.  One asm string per K-loop variant (see the generator's docstring).\n",
            "#pragma once\n\n",
            "#define LTX2_V4_CLOBBERS \\\n    " +
-           ", ".join(f'"v{i}"' for i in range(24, 160)) + ", \\\n    " +
+           ", ".join(f'"v{i}"' for i in range(24, 192)) + ", \\\n    " +
            ", ".join(f'"{s}"' for s in SCRATCH_S) + ', "scc", "memory"\n\n']
     odd16, odd14 = list(range(1, 16, 2)), list(range(1, 14, 2))
     # layout 1x4 (wave = all row blocks x 2 column blocks), 32x32x16
@@ -362,9 +362,12 @@ def main():
     out.append(variant("LTX2_V4_L22_RB4_224", 4, 4, npa=7, dma_last=odd16, dma_ks0=odd14))
     out.append(variant("LTX2_V4_L22_RB3_224", 3, 4, npa=7, dma_last=[0, 2, 3, 5, 6, 8, 9, 11], dma_ks0=[1, 2, 4, 5, 7, 8, 10]))
     # layout 2x2, 16x16x32: 8x8 blocks (6x8 for the second wave row of a 224-row tile)
-    out.append(variant("LTX2_V4_L22_M16_RB8", 8, 8, mb=16, npa=8, dma_last=list(range(3, 64, 4)), dma_ks0=[]))
-    out.append(variant("LTX2_V4_L22_M16_RB8_224", 8, 8, mb=16, npa=7, dma_last=list(range(3, 60, 4)), dma_ks0=[]))
-    out.append(variant("LTX2_V4_L22_M16_RB6_224", 6, 8, mb=16, npa=7, dma_last=list(range(2, 47, 3)), dma_ks0=[]))
+    out.append(variant("LTX2_V4_L22_M16_RB8", 8, 8, mb=16, npa=8, dma_last=list(range(3, 64, 4)), dma_ks0=[], m0_early=True))
+    out.append(variant("LTX2_V4_L22_M16_RB8_224", 8, 8, mb=16, npa=7, dma_last=list(range(3, 60, 4)), dma_ks0=[], m0_early=True))
+    out.append(variant("LTX2_V4_L22_M16_RB6_224", 6, 8, mb=16, npa=7, dma_last=list(range(2, 47, 3)), dma_ks0=[], m0_early=True))
+    # layout 1x4, 16x16x32: 14|16 x 4 blocks (balanced for 224 rows)
+    out.append(variant("LTX2_V4_L14_M16_RB14", 14, 4, mb=16, npa=7, dma_last=list(range(0, 56, 4)) + [55], dma_ks0=[], m0_early=True))
+    out.append(variant("LTX2_V4_L14_M16_RB16", 16, 4, mb=16, npa=8, dma_last=list(range(3, 64, 4)), dma_ks0=[], m0_early=True))
     if "--probe" in sys.argv:
         out.append(variant("LTX2_V4_L14_RB8_NODMA", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, no_dma=True))
         out.append(variant("LTX2_V4_L14_RB8_NOREAD", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, no_read=True))
@@ -373,12 +376,15 @@ def main():
         e4, e8 = list(range(3, 64, 4)), list(range(7, 64, 8))
         out.append(variant("LTX2_V4_M16_NODMA", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], no_dma=True))
         out.append(variant("LTX2_V4_M16_NOREAD", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], no_read=True))
-        out.append(variant("LTX2_V4_M16_V3", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True))
-        out.append(variant("LTX2_V4_M16_V4", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True, reads_every=2))
-        out.append(variant("LTX2_V4_M16_V5", 8, 8, mb=16, npa=8, dma_last=e8, dma_ks0=e8, m0_early=True))
-        out.append(variant("LTX2_V4_M16_V6", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True, reads_every=3))
-        out.append(variant("LTX2_V4_M16_V7", 8, 8, mb=16, npa=8, dma_last=e8, dma_ks0=e8))
-        out.append(variant("LTX2_V4_M16_V8", 8, 8, mb=16, npa=8, dma_last=e8, dma_ks0=e8, m0_early=True, reads_every=2))
+        e2 = list(range(1, 32, 2))
+        out.append(variant("LTX2_V4_M16_V3", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[]))
+        out.append(variant("LTX2_V4_M16_V4", 8, 8, mb=16, npa=8, dma_last=e2, dma_ks0=[], m0_early=True))
+        out.append(variant("LTX2_V4_M16_V5", 8, 8, mb=16, npa=8, dma_last=list(range(2, 48, 3)), dma_ks0=[], m0_early=True))
+        out.append(variant("LTX2_V4_M16_V6", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True, reads_every=2))
+        out.append(variant("LTX2_V4_M16_V7", 8, 8, mb=16, npa=8, dma_last=list(range(19, 64, 3)) + [63], dma_ks0=[], m0_early=True))
+        out.append(variant("LTX2_V4_M16_V8", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True, reads_every=3))
+        out.append(variant("LTX2_V4_L14_M16_RB14_RD2", 14, 4, mb=16, npa=7, dma_last=list(range(2, 47, 3)), dma_ks0=[], m0_early=True, reads_every=2))
+        out.append(variant("LTX2_V4_L14_M16_RB14_D4", 14, 4, mb=16, npa=7, dma_last=list(range(0, 56, 4)) + [55], dma_ks0=[], m0_early=True))
     path = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "gemm_v4_loop.inc"
     with open(path, "w") as f:
         f.write("".join(out))

@@ -412,7 +412,9 @@ class LTXModel:
         out = torch.empty(lat.shape[0], self.out_channels, device=self.device, dtype=torch.float32)
         if not self.is_av:
             self._ensure_prepared(video, per_token=(n_ts != 1))
-            nv.check(nv.lib().ltx2_dit_forward(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(out), nv.stream()))
+            # prompt AdaLN (V2.3) takes Modality.sigma, not timesteps[0]: with image conditioning timesteps = mask * sigma
+            sg = self._sigma(video) if self.cross_attention_adaln else None
+            nv.check(nv.lib().ltx2_dit_forward(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(sg), nv.ptr(out), nv.stream()))
             return out[None]
         ats, n_ats = self._timesteps(audio)
         self._ensure_prepared(video, per_token=(n_ts != 1 or n_ats != 1), audio=audio)
@@ -434,7 +436,8 @@ class LTXModel:
         assert latent.dtype == torch.float32 and latent.is_contiguous() and latent.dim() == 2
         if not self.is_av:
             self._ensure_prepared(video, per_token=(n_ts != 1))
-            nv.check(nv.lib().ltx2_dit_denoise_step(self._h, nv.ptr(latent), nv.ptr(ts), n_ts, nv.ptr(denoise_mask),
+            sg = torch.tensor([float(sigma)], device=self.device, dtype=torch.float32) if self.cross_attention_adaln else None
+            nv.check(nv.lib().ltx2_dit_denoise_step(self._h, nv.ptr(latent), nv.ptr(ts), n_ts, nv.ptr(sg), nv.ptr(denoise_mask),
                                                     nv.ptr(clean_latent), float(sigma), float(sigma_next), None, nv.stream()))
             return
         assert audio is not None and audio_latent is not None and audio_latent.dtype == torch.float32 and audio_latent.is_contiguous()

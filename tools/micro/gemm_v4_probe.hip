@@ -62,7 +62,7 @@ static void one_shape(int M, int N, int K, bool ablations) {
     p.out = o_ref; hipMemset(o_ref, 0, no * 2);
     Ctx cpp{0, 0, 0, EPI_BF16}; run(p, &cpp); hipDeviceSynchronize();
     hipMemcpy(href.data(), o_ref, no * 2, hipMemcpyDeviceToHost);
-    for (int cfg = 0; cfg < 6; ++cfg) {
+    for (int cfg = 0; cfg < 8; ++cfg) {
         const int layout = cfg >> 1, rb = (cfg & 1) ? 256 : 224;
         p.out = o_new; hipMemset(o_new, 0xff, no * 2);
         Ctx c{2, layout, rb, EPI_BF16}; int rc = run(p, &c); hipError_t e = hipDeviceSynchronize();
@@ -104,19 +104,21 @@ static void one_shape(int M, int N, int K, bool ablations) {
     vs.push_back({"v4 L22 256  bf16", {2, 1, 256, EPI_BF16}, o_new});
     vs.push_back({"v4 M16 auto bf16", {2, 2, 0, EPI_BF16}, o_new});
     vs.push_back({"v4 M16 256  bf16", {2, 2, 256, EPI_BF16}, o_new});
+    vs.push_back({"v4 M16x14 auto bf16", {2, 3, 0, EPI_BF16}, o_new});
+    vs.push_back({"v4 M16x14 256 bf16", {2, 3, 256, EPI_BF16}, o_new});
+    vs.push_back({"pp  auto  gelu", {0, 0, 0, EPI_GELU_BF16}, o_ref});
+    vs.push_back({"v4 M16x14 auto gelu", {2, 3, 0, EPI_GELU_BF16}, o_new});
     vs.push_back({"pp  auto  resid", {0, 0, 0, EPI_RESID_GATE_F32}, x0});
     vs.push_back({"v4 L14 auto resid", {2, 0, 0, EPI_RESID_GATE_F32}, x1});
     vs.push_back({"v4 L22 auto resid", {2, 1, 0, EPI_RESID_GATE_F32}, x1});
     vs.push_back({"v4 M16 auto resid", {2, 2, 0, EPI_RESID_GATE_F32}, x1});
+    vs.push_back({"v4 M16x14 auto resid", {2, 3, 0, EPI_RESID_GATE_F32}, x1});
     if (ablations) {
         vs.push_back({"v4 M16 256 no-DMA", {1, 2, 1, EPI_BF16}, o_new});
         vs.push_back({"v4 M16 256 no-read", {1, 2, 2, EPI_BF16}, o_new});
-        vs.push_back({"v4 M16 V3 m0early", {1, 2, 3, EPI_BF16}, o_new});
-        vs.push_back({"v4 M16 V4 m0e+rd2", {1, 2, 4, EPI_BF16}, o_new});
-        vs.push_back({"v4 M16 V5 m0e+dma8/8", {1, 2, 5, EPI_BF16}, o_new});
-        vs.push_back({"v4 M16 V6 m0e+rd3", {1, 2, 6, EPI_BF16}, o_new});
-        vs.push_back({"v4 M16 V7 dma8/8", {1, 2, 7, EPI_BF16}, o_new});
-        vs.push_back({"v4 M16 V8 m0e+rd2+8/8", {1, 2, 8, EPI_BF16}, o_new});
+        vs.push_back({"v4 M16x14 224 direct epi", {1, 3, 9, EPI_BF16}, o_new});
+        vs.push_back({"v4 M16x14 224 rd/2", {1, 3, 10, EPI_BF16}, o_new});
+        vs.push_back({"v4 M16x14 224 dma/4", {1, 3, 11, EPI_BF16}, o_new});
     }
     for (int round = 0; round < 5; ++round)
         for (auto& v : vs) {
