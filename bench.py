@@ -2,18 +2,24 @@
 """Headline benchmark: LTX-2 19B distilled, 768x512x65, bf16 -- denoise steps/s (+ VAE-decode frames/s).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+With N > 1 and no torchrun environment the script re-launches itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, RCCL); under a
+launcher (RANK / WORLD_SIZE set) it runs as the rank it is.
 
 A "step" is one denoise step of the hot path over one prompt's latent: LTXModel forward
 (48 blocks, D=4096, N=3456 video tokens, S=1024 text tokens) + x0 + Euler update, with inputs
 and weights resident in HBM.  Each rank runs its own (prompt, seed); weights are broadcast once
 from rank 0 over RCCL; there is no per-step communication (weak scaling over prompts).
-Prints ONE JSON line on rank 0.
+The headline K steps are timed with NO instrumentation; the dominant GEMM's launch time comes from a second,
+untimed pass of K steps with HIP events around every launch of that kernel.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
-import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -24,6 +30,10 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+# one 768x512x65 decode with the reference's 7/2 chunking
+VAE_ALG_TFLOP, VAE_ALG_GB = 37.73, 17.2
+CPU_THREADS = 32               # the oracle's fp32 block is fastest around 32 threads on the boxes' 2 x 64-core hosts
+                               # (measured s/block: 32 thr 2.4, 64 thr 2.8, 128 thr 4.5, 256 thr 13.9)
 
 
 def dit_algorithmic_flops(N, S, D, L):
@@ -33,30 +43,66 @@ def dit_algorithmic_flops(N, S, D, L):
 
 
 def cpu_baseline(threads):
-    """Oracle (fp32 PyTorch CPU port of the reference arithmetic) timed on the host cores:
-    ONE full-width transformer block (N=3456, S=1024, D=4096) of one denoise step; a step is 48
-    such blocks, so steps/s = 1 / (48 * t_block).  Bounded sample (about 10-30 s)."""
-    from oracle import dit, loop
+    """The oracle (fp32 PyTorch CPU port of the reference's arithmetic, kind "port") timed on the host cores, as SURVEY.md
+    8(d) defines the CPU leg -- bounded to about half a minute:
+      (i)   DiT: ONE denoise step of an L=2 model at full width (D=4096, N=3456, S=1024), median of 3 after one warm-up,
+            x24 linear extrapolation to the 48-layer step (labelled);
+      (ii)  the plumbing config un-extrapolated: 256x384x17 (N=288), S=256, 2-layer DiT, the whole 8-step distilled loop;
+      (iii) VAE: decode of ONE 2-latent-frame chunk (1,128,2,16,24) -> 9 frames at 512x768 with the default decoder
+            (base_channels 128), scaled by algorithmic FLOPs to the chunked 65-frame decode (labelled)."""
+    from oracle import dit, loop, vae
     torch.set_num_threads(threads)
-    cfg = dit.DiTConfig(num_layers=1)
-    D = cfg.inner_dim
-    g = torch.Generator().manual_seed(0)
-    w = {}
-    for name, shape in dit.dit_weight_shapes(cfg).items():
-        if name.startswith("transformer_blocks.0."):
-            w[name] = torch.randn(shape, generator=g) * (0.02 if len(shape) == 2 else 1.0)
-    N, S = 3456, 1024
-    x = torch.randn(1, N, D, generator=g)
-    ctx = torch.randn(1, S, D, generator=g) * 0.1
-    emb = torch.randn(1, 1, 6, D, generator=g) * 0.1
-    pe = dit.rope_split_tables(loop.video_positions(1, 9, 16, 24, 24.0), D, 32, 10000.0, [20, 2048, 2048])
+    g = torch.Generator().manual_seed(1234)
+    out = {"unit": "steps/s", "cores": threads, "kind": "port"}
     with torch.no_grad():
+        # (i) full-width L=2 step
+        cfg = dit.DiTConfig(num_layers=2)
+        w = dit.make_dit_weights(cfg, seed=0)
+        N, S = 3456, 1024
+        lat = torch.randn(1, N, 128, generator=g)
+        ctx = 0.1 * torch.randn(1, S, cfg.caption_channels, generator=g)
+        pos = loop.video_positions(1, 9, 16, 24, 24.0)
+        ts = torch.tensor([1.0])
+        runs = []
+        for i in range(4):
+            t0 = time.time()
+            dit.x0_model(lat, ctx, ts, pos, w, cfg)
+            runs.append(time.time() - t0)
+        t_l2 = statistics.median(runs[1:])
+        del w
+        # (ii) plumbing config, whole loop
+        lat5 = torch.randn(1, 128, 3, 8, 12, generator=g)
+        ctx2 = 0.1 * torch.randn(1, 256, cfg.caption_channels, generator=g)
+        w2 = dit.make_dit_weights(cfg, seed=1)
+        pos2 = loop.video_positions(1, 3, 8, 12, 24.0)
         t0 = time.time()
-        dit.transformer_block(x, ctx, emb, pe, w, 0, cfg)
-        t_block = time.time() - t0
-    return {"value": 1.0 / (48 * t_block), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"1 of 48 full-width DiT blocks (N=3456,S=1024,D=4096) fp32 on {threads} host threads: "
-                      f"{t_block:.2f} s/block, extrapolated x48 to one step"}
+        loop.denoise_loop_cli(lat5, lambda tok, s: dit.x0_model(tok, ctx2, torch.tensor([s]), pos2, w2, cfg), loop.DISTILLED_SIGMA_VALUES)
+        t_plumb = time.time() - t0
+        del w2
+        # (iii) one VAE chunk
+        vcfg = vae.VAEConfig()
+        vw = vae.make_vae_weights(vcfg, seed=2)
+        z = torch.randn(1, 128, 2, 16, 24, generator=g)
+        t0 = time.time()
+        vid = vae.decoder_forward(z, vw, vcfg, timestep=0.05)
+        t_vae = time.time() - t0
+        frames = vid.shape[2]
+    # algorithmic FLOPs of a T'-latent-frame decoder pass scale with the output frame count 8T'-7 (SURVEY 8d: 32.65 TF at 65)
+    chunk_tf = 32.65 * frames / 65.0
+    t_decode = t_vae * VAE_ALG_TFLOP / chunk_tf
+    out.update({
+        "value": 1.0 / (24 * t_l2),
+        "sample": f"one denoise step of a 2-layer full-width DiT (D=4096, N=3456, S=1024) in fp32 on {threads} host threads: "
+                  f"median of 3 after a warm-up {t_l2:.2f} s (runs {[round(r, 2) for r in runs]}), x24 -> 48 layers",
+        "dit_l2_step_s": round(t_l2, 3),
+        "plumbing_config_8_steps_s": round(t_plumb, 3),
+        "plumbing_config": "256x384x17 (N=288), S=256, 2-layer DiT, 8 distilled steps, un-extrapolated",
+        "vae_chunk_s": round(t_vae, 2), "vae_chunk_frames": int(frames),
+        "vae_decode_frames_per_sec": round(65.0 / t_decode, 3),
+        "vae_sample": f"decoder pass of one (1,128,2,16,24) chunk -> {frames} frames at 512x768 (base_channels 128) in {t_vae:.1f} s, "
+                      f"scaled by algorithmic FLOPs ({chunk_tf:.2f} of {VAE_ALG_TFLOP} TF) to the 7/2-chunked 65-frame decode",
+    })
+    return out
 
 
 def extra_configs(dev, layers):
@@ -118,6 +164,16 @@ def extra_configs(dev, layers):
     return res
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` with no launcher environment: become the launcher (one rank per GPU, 127.0.0.1 rendezvous)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,7 +184,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay section (rocprofv3 --pmc passes)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (AudioVideo step, two-stage pipeline)")
+    ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (instrumented) pass that times the dominant GEMM")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus))
 
     from ltx_2_mlx_amd import _native as nv
     from ltx_2_mlx_amd import distributed as D
@@ -150,9 +209,14 @@ def main():
     L = args.layers
     model = LTXModel(num_layers=L, device=dev)
     model.init_random_weights(seed=0 if rank == 0 else 1000 + rank)
-    t0 = time.time()
-    n_coll = D.broadcast_tensors(model.weight_tensors(), src=0, bucket_bytes=1 << 30)
+    wt = model.weight_tensors()
+    w_bytes = sum(t.numel() * t.element_size() for t in wt.values())
     torch.cuda.synchronize()
+    D.barrier()
+    t0 = time.time()
+    n_coll = D.broadcast_tensors(wt, src=0, bucket_bytes=1 << 30)
+    torch.cuda.synchronize()
+    D.barrier()
     bcast_s = time.time() - t0
 
     # ---------------- per-rank prompt / seed ----------------
@@ -172,8 +236,9 @@ def main():
     sig = DISTILLED_SIGMA_VALUES
     K, W = args.steps, args.warmup
     lat = noise.clone()
+    ts_dev = torch.tensor(sig[:8], device=dev)
 
-    def run_steps(n, profile=False):
+    def run_steps(n):
         for i in range(n):
             s0, s1 = sig[i % 8], sig[i % 8 + 1]
             if i % 8 == 0:
@@ -181,22 +246,26 @@ def main():
             m = Modality(latent=lat[None], context=ctx, context_mask=None, timesteps=ts_dev[i % 8:i % 8 + 1], positions=state.positions)
             model.denoise_step_(lat, m, s0, s1)
 
-    ts_dev = torch.tensor(sig[:8], device=dev)
     run_steps(W)
     torch.cuda.synchronize()
 
-    # ---------------- timed region: exactly K steps, dominant GEMM bracketed by HIP events ----------------
-    DOM_EPI = nv.EPI_RESID_GATE_F32     # gemm_pp_kernel<4,false,224>: attn1.to_out, attn2.to_out, ff.net.2 (+ gated residual)
+    # ---------------- timed region: exactly K steps, nothing else on the stream ----------------
     D.barrier()
     torch.cuda.synchronize()
-    model.profile_begin(DOM_EPI)
     t0 = time.perf_counter()
     run_steps(K)
     torch.cuda.synchronize()
     D.barrier()
-    dt = time.perf_counter() - t0
-    k_ms, k_n, k_fl = model.profile_end()
-    dt = D.max_over_ranks(dt, dev)
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # ---------------- second pass (not part of `value`): HIP events around every launch of the dominant GEMM ----------------
+    DOM_EPI = nv.EPI_RESID_GATE_F32     # gemm_v4_kernel<EPI_RESID_GATE_F32, 3, 224>: attn1.to_out, attn2.to_out, ff.net.2
+    k_ms, k_n, k_fl = 0.0, 0, 0.0
+    if not args.no_kernel_pass:
+        model.profile_begin(DOM_EPI)
+        run_steps(K)
+        torch.cuda.synchronize()
+        k_ms, k_n, k_fl = model.profile_end()
 
     # ---------------- hipGraph replay of the 8-step loop (reported beside the headline) ----------------
     graph_ms = None
@@ -246,16 +315,17 @@ def main():
     steps_per_s = world * K / dt
     ms_per_step = dt / K * 1e3
     alg = dit_algorithmic_flops(N, S, Dm, L)
-    # HBM/fabric traffic of the dominant kernel cannot be collected from inside the process; it comes
-    # from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), null if absent.
-    traffic = None
+    # HBM/fabric traffic of the dominant kernel cannot be collected from inside the process: it comes from the committed
+    # rocprofv3 --pmc passes of THIS kernel version (profiles/r02_pmc_traffic.json names the commit), null if absent.
+    traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            traffic = json.load(f).get("per_launch_avg_bytes")
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            tj = json.load(f)
+            traffic, traffic_src = tj.get("per_launch_avg_bytes"), tj.get("commit")
     except Exception:  # noqa: BLE001
         pass
     kern_avg_ms = k_ms / max(k_n, 1)
-    kern_tflops = (k_fl / max(k_n, 1)) / (kern_avg_ms * 1e-3) / 1e12
+    kern_tflops = (k_fl / max(k_n, 1)) / (kern_avg_ms * 1e-3) / 1e12 if k_n else None
     out = {
         "metric": "denoise_steps_per_sec", "value": round(steps_per_s, 4), "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 3),
@@ -268,13 +338,27 @@ def main():
         "step_algorithmic_tflop": round(alg / 1e12, 3),
         "step_mfma_roofline_frac": round(alg / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "hipgraph_ms_per_step": graph_ms if not isinstance(graph_ms, float) else round(graph_ms, 3),
-        "prompt_setup_ms": round(prep_ms, 1), "weight_broadcast_s": round(bcast_s, 3), "weight_broadcast_collectives": n_coll,
-        "roofline": {"kernel": "gemm_pp_kernel<4,false,224> (224x256x64 ping-pong bf16 MFMA GEMM, EPI_RESID_GATE_F32: attn1/attn2 to_out and ff.net.2 + bias + gate*residual)",
-                     "bound": "mfma", "achieved": round(kern_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+        "prompt_setup_ms": round(prep_ms, 1),
+        "rccl_ranks": world, "weight_bytes": w_bytes, "weight_broadcast_s": round(bcast_s, 3),
+        "weight_broadcast_collectives": n_coll,
+        "weight_broadcast_gbps": round(w_bytes / bcast_s / 1e9, 1) if world > 1 and bcast_s > 0 else None,
+        "roofline": {"kernel": "gemm_v4_kernel<EPI_RESID_GATE_F32, layout 3, 224> (224x256x64 tile, 4 waves, generated asm K loop, "
+                               "v_mfma_f32_16x16x32_bf16: attn1/attn2 to_out and ff.net.2 + bias + gate * (.) added into the fp32 residual)",
+                     "bound": "mfma", "achieved": None if kern_tflops is None else round(kern_tflops, 1), "peak": PEAK_BF16_TFLOPS,
+                     "unit": "TFLOP/s", "frac": None if kern_tflops is None else round(kern_tflops / PEAK_BF16_TFLOPS, 4),
+                     "traffic": traffic, "traffic_source_commit": traffic_src,
                      "launches": k_n, "avg_launch_us": round(kern_avg_ms * 1e3, 2),
-                     "algorithmic_flops_per_launch": round(k_fl / max(k_n, 1))},
+                     "algorithmic_flops_per_launch": round(k_fl / max(k_n, 1)),
+                     "measured": "HIP events around every launch of this kernel in a separate pass of the same K steps (not in `value`)"},
     }
+    if vae_ms is not None:
+        t = vae_ms * 1e-3 / 1.0
+        out["vae_roofline"] = {
+            "workload": "decode_latent 768x512x65 (7/2 temporal chunking, cross-fade, uint8), latent and frames in HBM",
+            "algorithmic_tflop": VAE_ALG_TFLOP, "algorithmic_gb": VAE_ALG_GB,
+            "mfma": {"achieved": round(VAE_ALG_TFLOP / t, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(VAE_ALG_TFLOP / t / PEAK_BF16_TFLOPS, 4)},
+            "hbm": {"achieved": round(VAE_ALG_GB / t, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(VAE_ALG_GB / t / PEAK_HBM_GBS, 4)},
+            "bound": "mfma", "note": "the conv stack is MFMA-bound (arithmetic intensity ~2000 F/B); the HBM fraction cannot exceed ~0.15 (SURVEY 8d)"}
     if world == 1 and not args.no_extra:
         # Secondary BASELINE configurations, reported beside the headline (never part of `value`): config 4 shape
         # (LTX-2.3-style AudioVideo DiT, joint audio+video step) and config 5 (two-stage 1536x1024x65 with the
@@ -285,9 +369,9 @@ def main():
             out["extra_configs"] = extra_configs(dev, L)
         except Exception as e:  # noqa: BLE001
             out["extra_configs"] = {"error": str(e)}
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(min(CPU_THREADS, os.cpu_count() or 1))
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"error": str(e)}
     print(json.dumps(out))

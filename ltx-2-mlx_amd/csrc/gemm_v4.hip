@@ -1,19 +1,20 @@
-// 4-wave bf16 MFMA GEMM for gfx950 with a hand-scheduled K loop: tile (224|256) x 256 x 64, one wave per SIMD, accumulators
-// in AGPRs.  The whole K loop is ONE asm block generated and order-checked by gen_gemm_v4.py (gemm_v4_loop.inc): hipcc
-// schedules nothing in it.  Wave layouts (template LAYOUT):
-//   0  1x4, v_mfma_f32_32x32x16_bf16: wave w owns columns [64w, 64w+64) and all 7|8 row blocks (balanced for 224 rows)
-//   1  2x2, v_mfma_f32_32x32x16_bf16: wave (wr, wc) owns a 128 x 128 quadrant (4 x 4 blocks; with 224-row tiles the second
-//      wave row owns 96 rows = 3 row blocks and runs a shorter program with the same barriers)
-//   2  2x2, v_mfma_f32_16x16x32_bf16: 8 x 8 blocks of 16 (6 x 8 for the second wave row of a 224-row tile)
-//   3  1x4, v_mfma_f32_16x16x32_bf16: 14|16 x 4 blocks of 16 (balanced for 224 rows)
-// What the measurements on MI355X say: with random operands the chip is POWER-limited -- the K loop of
-// layout 0 issues an MFMA every 34 cycles (2170 cycles per K-tile of 64 MFMAs) but the chip clocks at 1.45-1.55 GHz, an
-// MFMA-only loop at 2.0 GHz -- so what counts is energy per flop: LDS fragment reads (160 / 128 KiB per K-tile and CU for
-// layouts 0 / 1+2, 192 for the 8-wave ping-pong kernel), L2->LDS traffic and fabric re-reads, not issue slots.
-// Dense operands only (activations [M][lda] bf16, weights [N][K] bf16, K contiguous), N % 256 == 0, K % 128 == 0,
-// K >= 256; everything else stays on gemm_pp.hip / gemm.hip.  Same LDS image, swizzle, tile order and fused epilogues
-// (gemm_epilogue.h) as those kernels; with 32x32x16 blocks the fp32 summation order is theirs too (ks ascending), so the
-// outputs are bit-identical to the ping-pong kernel's (tested).
+// 4-wave bf16 MFMA GEMM / implicit-GEMM conv3d for gfx950 with a hand-scheduled K loop: one wave per SIMD, accumulators in
+// AGPRs.  The whole K loop is ONE asm block generated and order-checked by gen_gemm_v4.py (gemm_v4_loop.inc): hipcc schedules
+// nothing in it.  Wave layouts (template LAYOUT), tile BM x BN x 64:
+//   0  BN 256, 1x4 waves, v_mfma_f32_32x32x16_bf16: wave w owns columns [64w, 64w+64) and all 7|8 row blocks
+//   1  BN 256, 2x2 waves, 32x32x16: wave (wr, wc) owns a 128 x 128 quadrant (with 224-row tiles the second wave row owns
+//      96 rows and runs a shorter program with the same barriers)
+//   2  BN 256, 2x2 waves, v_mfma_f32_16x16x32_bf16: 8 x 8 blocks of 16 (6 x 8 for the second wave row of a 224-row tile)
+//   3  BN 256, 1x4 waves, 16x16x32: 14|16 x 4 blocks of 16 (BM 224|256; balanced for 224 rows) -- the DiT default
+//   4  BN 128, 4x1 waves, 16x16x32: wave w owns rows [BM/4 w, +BM/4) x all 128 columns, 7|8 x 8 blocks (BM 448|512) -- the
+//      VAE decoder's 128-channel convs
+// What the measurements on MI355X say: with random operands the chip is POWER-limited -- the 32x32x16
+// K loop issues an MFMA every 34 cycles but the chip clocks at 1.45-1.55 GHz, an MFMA-only loop at 2.0 GHz -- and the
+// 16x16x32 instruction (half the accumulator-register traffic per flop) sustains 12-20 % more on the same shapes.
+// Operands: activations [M][lda] bf16 (dense) or a PADDED channels-last volume [T+2][H+2][W+2][Cin] (conv: every tap of a
+// row is the row's base address plus one wave-uniform offset, see the generator), weights [N][K] bf16, K contiguous.
+// N % BN == 0, K % 128 == 0, K >= 256; everything else stays on gemm_pp.hip / gemm.hip.  Same LDS image, swizzle, tile order
+// and fused epilogues (gemm_epilogue.h) as those kernels; outputs are bit-identical to the ping-pong kernel's (tested).
 #include <stdlib.h>
 
 #include "gemm_epilogue.h"
@@ -22,34 +23,47 @@
 namespace {
 
 typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int V4_LDS_BYTES = 131072;
-
-#define V4_INS : "{v[0:7]}"(voffA), "{v[8:15]}"(voffB), "{v[16:19]}"(addrA), "{v[20:23]}"(addrB), [ra] "s"(ra), [rw] "s"(rw), \
-                 [nk] "s"(nk), [la] "s"(la), [lw] "s"(lw)
+#define V4_INS_DENSE : "{v[0:15]}"(voffA), "{v[16:23]}"(voffB), "{v[24:27]}"(addrA), "{v[28:31]}"(addrB), [ra] "s"(ra), [rw] "s"(rw), \
+                       [nk] "s"(nk), [la] "s"(la), [lw] "s"(lw)
+#define V4_INS_CONV V4_INS_DENSE, "{v32}"(tapv), [lcpt] "s"(lcpt), [cptm1] "s"(cptm1)
 #define V4_OUT16                                                                                                          \
     "={a[0:15]}"(acc[0]), "={a[16:31]}"(acc[1]), "={a[32:47]}"(acc[2]), "={a[48:63]}"(acc[3]), "={a[64:79]}"(acc[4]),   \
         "={a[80:95]}"(acc[5]), "={a[96:111]}"(acc[6]), "={a[112:127]}"(acc[7]), "={a[128:143]}"(acc[8]),                 \
         "={a[144:159]}"(acc[9]), "={a[160:175]}"(acc[10]), "={a[176:191]}"(acc[11]), "={a[192:207]}"(acc[12]),          \
         "={a[208:223]}"(acc[13]), "={a[224:239]}"(acc[14]), "={a[240:255]}"(acc[15])
-#define V4_ASM(LOOP) asm volatile(LOOP : V4_OUT16 V4_INS : LTX2_V4_CLOBBERS)
+#define V4_ASM(LOOP) asm volatile(LOOP : V4_OUT16 V4_INS_DENSE : LTX2_V4_CLOBBERS)
+#define V4_ASM_CONV(LOOP) asm volatile(LOOP : V4_OUT16 V4_INS_CONV : LTX2_V4_CLOBBERS)
 
-template <int EPI, int LAYOUT, int BM, int VAR>
+template <int LAYOUT, int BM>
+struct V4Geo {
+    static constexpr int BN = LAYOUT == 4 ? 128 : 256;
+    static constexpr int MB = LAYOUT >= 2 ? 16 : 32;               // MFMA block
+    static constexpr bool L14 = LAYOUT == 0 || LAYOUT == 3;        // 1x4 waves
+    static constexpr int WM = LAYOUT == 4 ? BM / 4 : (L14 ? BM : 128);
+    static constexpr int WN = LAYOUT == 4 ? 128 : (L14 ? 64 : 128);
+    static constexpr int RBW = (WM + MB - 1) / MB, CBW = WN / MB;  // blocks per wave (first wave row)
+    static constexpr int NKS = MB == 16 ? 2 : 4;
+    static constexpr int NPA = BM / 32, NPW = BN / 32;             // 1-KiB LDS-DMA pieces per wave and K-tile
+    static constexpr int A_STAGE = LAYOUT == 4 ? BM * 128 : 32768, W_BASE = 2 * A_STAGE, W_STAGE = BN * 128;
+    static constexpr int LDS_BYTES = W_BASE + 2 * W_STAGE;
+    static_assert(LAYOUT == 4 ? (BM == 448 || BM == 512) : (BM == 224 || BM == 256), "tile rows");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int EPI, int LAYOUT, int BM, bool CONV, int VAR>
 __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
-    static_assert(BM == 224 || BM == 256, "224 or 256 rows");
-    static_assert(LAYOUT >= 0 && LAYOUT <= 3, "wave layout");
-    constexpr int TBN = 256, NPA = BM / 32;
-    constexpr int MB = LAYOUT >= 2 ? 16 : 32;               // MFMA block
-    constexpr bool L14 = LAYOUT == 0 || LAYOUT == 3;        // 1x4 waves (else 2x2)
-    constexpr int WM = L14 ? BM : 128, WN = L14 ? 64 : 128;
-    constexpr int RBW = (WM + MB - 1) / MB, CBW = WN / MB;  // blocks per wave (first wave row)
-    constexpr int NKS = MB == 16 ? 2 : 4;
+    static_assert(LAYOUT >= 0 && LAYOUT <= 4, "wave layout");
+    using G = V4Geo<LAYOUT, BM>;
+    constexpr int TBN = G::BN, NPA = G::NPA, NPW = G::NPW, MB = G::MB, WM = G::WM, WN = G::WN, RBW = G::RBW, CBW = G::CBW, NKS = G::NKS;
+    static_assert(!CONV || LAYOUT >= 3, "conv runs on the 16x16x32 layouts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = L14 ? 0 : (w >> 1), wc = L14 ? w : (w & 1);
+    const int wr = LAYOUT == 4 ? w : (G::L14 ? 0 : (w >> 1)), wc = LAYOUT == 4 ? 0 : (G::L14 ? w : (w & 1));
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_k0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -67,40 +81,75 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     const int n0 = (rem / gsz) * TBN;
 
     // ---- LDS-DMA sources: piece j of this wave = 8 tile rows x 128 B; chunk swizzle on the source, row clamp at the ragged edge ----
-    u32x8 voffA = {0, 0, 0, 0, 0, 0, 0, 0}, voffB = {0, 0, 0, 0, 0, 0, 0, 0};
+    u32x16 voffA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u32x8 voffB = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int Hp = p.H + 2, Wp = p.Wd + 2;
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
         const int r = (w * NPA + j) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        voffA[j] = (unsigned)min(m0 + r, p.M - 1) * (unsigned)(p.lda * 2) + chunk * 16;
+        const int m = min(m0 + r, p.M - 1);
+        if constexpr (CONV) {       // output position (t, h, w) = padded position of its (0,0,0) tap
+            const int hw = p.H * p.Wd;
+            const int t = m / hw, r2 = m - t * hw, h = r2 / p.Wd, x = r2 - h * p.Wd;
+            voffA[j] = (unsigned)((t * Hp + h) * Wp + x) * (unsigned)(p.Cin * 2) + chunk * 16;
+        } else {
+            voffA[j] = (unsigned)m * (unsigned)(p.lda * 2) + chunk * 16;
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = (w * 8 + j) * 8 + (lane >> 3);
+    for (int j = 0; j < NPW; ++j) {
+        const int r = (w * NPW + j) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         voffB[j] = (unsigned)(n0 + r) * (unsigned)(p.K * 2) + chunk * 16;
     }
-    // ---- fragment read addresses (stage 0, first block of the wave): row lr, 16-byte chunk (kchunk(ks) + kq) ^ ((row >> 1) & 7) ----
+    // ---- fragment read addresses (first block of the wave): row lr, 16-byte chunk (kchunk(ks) + kq) ^ ((row >> 1) & 7) ----
     const int lr = lane & (MB - 1), kq = lane / MB;         // row in block, k-quarter (32x32x16: 0..1, 16x16x32: 0..3)
     const int xbase = kq ^ ((lr >> 1) & 7);
     u32x4 addrA = {0, 0, 0, 0}, addrB = {0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const unsigned c = (unsigned)(((MB == 32 ? 2 : 4) * ks) ^ xbase) << 4;
-        addrA[ks] = lds0 + (wr * WM + lr) * 128 + c;
-        addrB[ks] = lds0 + 65536 + (wc * WN + lr) * 128 + c;
+        const unsigned a0 = lds0 + (wr * WM + lr) * 128 + c, b0 = lds0 + G::W_BASE + (wc * WN + lr) * 128 + c;
+        if constexpr (MB == 16) {       // per-stage bases: [ks + 2 * stage]
+            addrA[ks] = a0;
+            addrA[ks + 2] = a0 + G::A_STAGE;
+            addrB[ks] = b0;
+            addrB[ks + 2] = b0 + G::W_STAGE;
+        } else {
+            addrA[ks] = a0;
+            addrB[ks] = b0;
+        }
     }
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
     const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + w * NPA * 1024);
-    const unsigned lw = __builtin_amdgcn_readfirstlane(lds0 + 65536 + w * 8 * 1024);
+    const unsigned lw = __builtin_amdgcn_readfirstlane(lds0 + G::W_BASE + w * NPW * 1024);
     const unsigned nk = __builtin_amdgcn_readfirstlane(p.K / 64);
+    // conv: lane i holds the byte offset of tap i = (a*3 + b)*3 + c (a absent for per-frame 3x3 convs) in the padded volume
+    unsigned tapv = 0;
+    unsigned lcpt = 0, cptm1 = 0;
+    if constexpr (CONV) {
+        const int ntap = 9 * p.taps_t;
+        const int a = p.taps_t == 3 ? lane / 9 : 0, bc = p.taps_t == 3 ? lane % 9 : lane;
+        tapv = lane < ntap ? (unsigned)((a * Hp + bc / 3) * Wp + bc % 3) * (unsigned)(p.Cin * 2) : 0u;
+        lcpt = __builtin_amdgcn_readfirstlane(p.cin_shift - 6);
+        cptm1 = __builtin_amdgcn_readfirstlane((p.Cin >> 6) - 1);
+    }
 
     f32x16 acc[16];
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (LAYOUT == 0) {
+    if constexpr (CONV) {
+        if constexpr (LAYOUT == 3) {
+            if constexpr (BM == 224) V4_ASM_CONV(LTX2_V4_L14_M16_RB14_CONV);
+            else V4_ASM_CONV(LTX2_V4_L14_M16_RB16_CONV);
+        } else {
+            if constexpr (BM == 448) V4_ASM_CONV(LTX2_V4_L41_M16_RB7_CONV);
+            else V4_ASM_CONV(LTX2_V4_L41_M16_RB8_CONV);
+        }
+    } else if constexpr (LAYOUT == 0) {
         if constexpr (BM == 224) V4_ASM(LTX2_V4_L14_RB7);
         else {
 #ifdef LTX2_V4_PROBE
@@ -115,22 +164,14 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             if (wr == 0) V4_ASM(LTX2_V4_L22_RB4_224);
             else V4_ASM(LTX2_V4_L22_RB3_224);
         } else {
-#ifdef LTX2_V4_PROBE
-            if constexpr (VAR == 1) V4_ASM(LTX2_V4_L22_RB4_NODMA);
-            else if constexpr (VAR == 2) V4_ASM(LTX2_V4_L22_RB4_NOREAD);
-            else
-#endif
-                V4_ASM(LTX2_V4_L22_RB4);
+            V4_ASM(LTX2_V4_L22_RB4);
         }
     } else if constexpr (LAYOUT == 3) {
-        if constexpr (BM == 224) {
-#ifdef LTX2_V4_PROBE
-            if constexpr (VAR == 10) V4_ASM(LTX2_V4_L14_M16_RB14_RD2);
-            else if constexpr (VAR == 11) V4_ASM(LTX2_V4_L14_M16_RB14_D4);
-            else
-#endif
-                V4_ASM(LTX2_V4_L14_M16_RB14);
-        } else V4_ASM(LTX2_V4_L14_M16_RB16);
+        if constexpr (BM == 224) V4_ASM(LTX2_V4_L14_M16_RB14);
+        else V4_ASM(LTX2_V4_L14_M16_RB16);
+    } else if constexpr (LAYOUT == 4) {
+        if constexpr (BM == 448) V4_ASM(LTX2_V4_L41_M16_RB7);
+        else V4_ASM(LTX2_V4_L41_M16_RB8);
     } else {
         if constexpr (BM == 224) {
             if (wr == 0) V4_ASM(LTX2_V4_L22_M16_RB8_224);
@@ -139,12 +180,6 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #ifdef LTX2_V4_PROBE
             if constexpr (VAR == 1) V4_ASM(LTX2_V4_M16_NODMA);
             else if constexpr (VAR == 2) V4_ASM(LTX2_V4_M16_NOREAD);
-            else if constexpr (VAR == 3) V4_ASM(LTX2_V4_M16_V3);
-            else if constexpr (VAR == 4) V4_ASM(LTX2_V4_M16_V4);
-            else if constexpr (VAR == 5) V4_ASM(LTX2_V4_M16_V5);
-            else if constexpr (VAR == 6) V4_ASM(LTX2_V4_M16_V6);
-            else if constexpr (VAR == 7) V4_ASM(LTX2_V4_M16_V7);
-            else if constexpr (VAR == 8) V4_ASM(LTX2_V4_M16_V8);
             else
 #endif
                 V4_ASM(LTX2_V4_L22_M16_RB8);
@@ -191,6 +226,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             return f32x4{a[o], a[o + 1], a[o + 2], a[o + 3]};
         }
     };
+    constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_SILU_BF16;
     if constexpr (EPI == EPI_RESID_GATE_F32) {
         // x += gate * (acc + bias).  The accumulators live in AGPRs and the fragment registers are dead, so the VGPR file
         // is free: the residual tile is read HALF A WAVE TILE AT A TIME with every load in flight at once (32 x 16 B per
@@ -233,31 +269,35 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                     }
             }
         }
-    } else if constexpr (LAYOUT == 3 && VAR != 9 && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_SILU_BF16)) {
-        // bf16 outputs of the 1x4 layout leave through LDS: a lane's accumulator groups are 4 columns of 16 different rows
-        // (8-byte stores into 32-byte row segments); transposed through this wave's 32 KiB of the (now dead) stage buffers
-        // every store instruction writes 8 rows x 128 contiguous bytes.  LDS image [BM rows][128 B], 16-byte chunks
-        // XOR-swizzled with (row >> 1) & 7: conflict-free for the 8-byte writes (16 rows x one column group per lane
-        // group) and for the 16-byte row reads.
+    } else if constexpr ((LAYOUT == 3 || LAYOUT == 4) && VAR != 9 && BF16_OUT) {
+        // bf16 outputs of the row-slab layouts leave through LDS: a lane's accumulator groups are 4 columns of 16 different
+        // rows (8-byte stores into 32-byte row segments); transposed through this wave's share of the (now dead) stage
+        // buffers every store instruction writes whole rows: 8 rows x 128 B (layout 3) or 4 rows x 256 B (layout 4).
+        // LDS image [WM rows][WN bf16], 16-byte chunks XOR-swizzled with the row: conflict-free for the 8-byte writes
+        // (16 rows x one column group per lane group) and for the 16-byte row reads.
+        constexpr int ROWB = WN * 2, CPR = ROWB / 16, RPI = 64 / CPR;          // bytes per row, chunks per row, rows per instruction
         __syncthreads();                                    // every wave has finished its fragment reads
-        char* wl = smem + w * 32768;
+        char* wl = smem + w * (WM * ROWB);
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
             const int r = rb * MB + lr;
+            const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) {
                 f32x4 v = acc_group(rb, cb, 0) + bias4[cb][0];
                 if (EPI == EPI_GELU_BF16) v = f32x4{gelu_tanh(v[0]), gelu_tanh(v[1]), gelu_tanh(v[2]), gelu_tanh(v[3])};
                 if (EPI == EPI_SILU_BF16) v = f32x4{silu_f(v[0]), silu_f(v[1]), silu_f(v[2]), silu_f(v[3])};
-                const int chunk = (cb * 2 + (kq >> 1)) ^ ((r >> 1) & 7);
-                *(bf16x4*)(wl + r * 128 + chunk * 16 + (kq & 1) * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+                const int chunk = (cb * 2 + (kq >> 1)) ^ sw;
+                *(bf16x4*)(wl + r * ROWB + chunk * 16 + (kq & 1) * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
             }
         }
 #pragma unroll
-        for (int it = 0; it < BM / 8; ++it) {
-            const int r = it * 8 + (lane >> 3), c = lane & 7;
-            const u32x4 v = *(const u32x4*)(wl + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
-            if (m0 + r < p.M) *(u32x4*)((bf16*)p.out + (long)(m0 + r) * p.ldo + n0 + w * 64 + c * 8) = v;
+        for (int it = 0; it < WM / RPI; ++it) {
+            const int r = it * RPI + lane / CPR, c = lane % CPR;
+            const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
+            const u32x4 v = *(const u32x4*)(wl + r * ROWB + ((c ^ sw) << 4));
+            const int row = m0 + wr * WM + r;
+            if (row < p.M) *(u32x4*)((bf16*)p.out + (long)row * p.ldo + n0 + wc * WN + c * 8) = v;
         }
     } else {
 #pragma unroll
@@ -280,14 +320,15 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #endif
 }
 
-template <int EPI, int LAYOUT, int BM, int VAR = 0>
+template <int EPI, int LAYOUT, int BM, bool CONV = false, int VAR = 0>
 int launch_v4(const GemmParams& p, hipStream_t stream) {
+    using G = V4Geo<LAYOUT, BM>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     }
-    const int Mt = (p.M + BM - 1) / BM, Nt = p.N / 256;
-    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, VAR>), dim3(Mt * Nt), dim3(256), V4_LDS_BYTES, stream, p);
+    const int Mt = (p.M + BM - 1) / BM, Nt = p.N / G::BN;
+    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt), dim3(256), G::LDS_BYTES, stream, p);
     LTX2_CHECK_LAUNCH("gemm_v4_kernel");
     return LTX2_OK;
 }
@@ -310,8 +351,23 @@ bool gemm_v4_supported(const GemmParams& p, int epilogue, bool conv) {
     return true;
 }
 
-// layout: 0 / 1 / 2 (see the file comment); bm: 0 = pick, 224, 256
+// layout: 0..4 (see the file comment); bm: 0 = pick, 224 | 256 (layouts 0-3), 448 | 512 (layout 4)
 int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int layout, int bm) {
+    if (layout == 4) {
+        LTX2_CHECK_ARG(p.N % 128 == 0, "gemm_v4 layout 4: N %% 128");
+        const bool b448 = bm == 448;
+#define CASE4(E) \
+    case E:      \
+        return b448 ? launch_v4<E, 4, 448>(p, stream) : launch_v4<E, 4, 512>(p, stream);
+        switch (epilogue) {
+            CASE4(EPI_BF16)
+            CASE4(EPI_ADD_BF16)
+            default:
+                ltx2_set_error("gemm_v4 layout 4: unsupported epilogue %d", epilogue);
+                return LTX2_E_INVALID;
+        }
+#undef CASE4
+    }
     const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
 #define CASE_L(E, L) return b224 ? launch_v4<E, L, 224>(p, stream) : launch_v4<E, L, 256>(p, stream);
 #define CASE(E)                           \
@@ -335,26 +391,36 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
 #undef CASE_L
 }
 
+// Implicit-GEMM 3x3x3 (or per-frame 3x3) conv over a PADDED channels-last activation volume: p.A = [T+2][H+2][Wd+2][Cin] with
+// the padding rule already applied by the producer (replicate in T with `pad_front` leading frames, reflect in H / W), p.T /
+// p.H / p.Wd = the OUTPUT extent, M = T*H*Wd, K = 9*taps_t*Cin, weights [Cout][taps][Cin].
+bool gemm_v4_conv_supported(const GemmParams& p, int epilogue) {
+    if (epilogue != EPI_BF16 && epilogue != EPI_ADD_BF16) return false;
+    if (p.Cin < 128 || (p.Cin & (p.Cin - 1)) || p.N % 128 != 0) return false;          // an even number of K-tiles: 27 * Cin / 64
+    if (p.taps_t != 3 && p.taps_t != 1) return false;
+    if (p.M < 4096) return false;
+    if ((long)(p.T + 2) * (p.H + 2) * (p.Wd + 2) * p.Cin * 2 >= (1L << 31) || (long)p.N * p.K * 2 >= (1L << 31)) return false;
+    if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15)) return false;
+    return true;
+}
+
+int gemm_v4_conv_launch(const GemmParams& p, int epilogue, hipStream_t stream) {
+    LTX2_CHECK_ARG(gemm_v4_conv_supported(p, epilogue), "gemm_v4 conv: unsupported problem (Cin=%d N=%d M=%d epilogue=%d)", p.Cin, p.N, p.M, epilogue);
+    if (p.N % 256 != 0) {       // 128-channel outputs: 512 x 128 tiles
+        if (epilogue == EPI_BF16) return launch_v4<EPI_BF16, 4, 512, true>(p, stream);
+        return launch_v4<EPI_ADD_BF16, 4, 512, true>(p, stream);
+    }
+    const long t256 = ((long)(p.M + 255) / 256) * (p.N / 256), t224 = ((long)(p.M + 223) / 224) * (p.N / 256);
+    const bool b224 = (t224 + 255) / 256 * 224 < (t256 + 255) / 256 * 256;
+    if (epilogue == EPI_BF16) return b224 ? launch_v4<EPI_BF16, 3, 224, true>(p, stream) : launch_v4<EPI_BF16, 3, 256, true>(p, stream);
+    return b224 ? launch_v4<EPI_ADD_BF16, 3, 224, true>(p, stream) : launch_v4<EPI_ADD_BF16, 3, 256, true>(p, stream);
+}
+
 #ifdef LTX2_V4_PROBE
-// ablations of the 256-row kernels: var 1 = no DMA in the loop, 2 = no fragment reads
+// ablations of the 256-row kernels: var 1 = no DMA in the loop, 2 = no fragment reads; layout 3: var 9 = direct (untransposed) epilogue
 int gemm_v4_probe_launch(const GemmParams& p, int layout, int var, hipStream_t stream) {
-    if (layout == 0) return var == 1 ? launch_v4<EPI_BF16, 0, 256, 1>(p, stream) : launch_v4<EPI_BF16, 0, 256, 2>(p, stream);
-    if (layout == 1) return var == 1 ? launch_v4<EPI_BF16, 1, 256, 1>(p, stream) : launch_v4<EPI_BF16, 1, 256, 2>(p, stream);
-    if (layout == 3) {
-        if (var == 10) return launch_v4<EPI_BF16, 3, 224, 10>(p, stream);
-        if (var == 11) return launch_v4<EPI_BF16, 3, 224, 11>(p, stream);
-        return launch_v4<EPI_BF16, 3, 224, 9>(p, stream);         // direct (untransposed) bf16 epilogue
-    }
-    switch (var) {
-        case 1: return launch_v4<EPI_BF16, 2, 256, 1>(p, stream);
-        case 2: return launch_v4<EPI_BF16, 2, 256, 2>(p, stream);
-        case 3: return launch_v4<EPI_BF16, 2, 256, 3>(p, stream);
-        case 4: return launch_v4<EPI_BF16, 2, 256, 4>(p, stream);
-        case 5: return launch_v4<EPI_BF16, 2, 256, 5>(p, stream);
-        case 6: return launch_v4<EPI_BF16, 2, 256, 6>(p, stream);
-        case 7: return launch_v4<EPI_BF16, 2, 256, 7>(p, stream);
-        case 8: return launch_v4<EPI_BF16, 2, 256, 8>(p, stream);
-    }
-    return LTX2_E_INVALID;
+    if (layout == 0) return var == 1 ? launch_v4<EPI_BF16, 0, 256, false, 1>(p, stream) : launch_v4<EPI_BF16, 0, 256, false, 2>(p, stream);
+    if (layout == 3) return launch_v4<EPI_BF16, 3, 224, false, 9>(p, stream);
+    return var == 1 ? launch_v4<EPI_BF16, 2, 256, false, 1>(p, stream) : launch_v4<EPI_BF16, 2, 256, false, 2>(p, stream);
 }
 #endif

@@ -21,38 +21,55 @@ in the slots of (t, last k-step) and (t+1, ks0); ONE s_barrier per K-tile, befor
      own pieces of tile t+1 retired before the barrier -> every wave may read stage 1-s after it.
 
 Fixed registers (the .hip passes them with physical-register constraints):
-  v[0:7]   voffA[j]  byte offset of this lane's 16 B in activation piece j (row clamp + source swizzle applied)
-  v[8:15]  voffW[j]
-  v[16:19] addrA[ks] LDS byte address of this lane's activation fragment chunk for k-step ks (stage 0, block 0 of the wave)
-  v[20:23] addrW[ks] same for the weight fragment
-  v[32:..] fragment set P, then set Q  (rbw activation fragments, then cbw weight fragments, 4 VGPRs each)
+  v[0:15]  voffA[j]  byte offset of this lane's 16 B in activation piece j (row clamp + source swizzle applied)
+  v[16:23] voffW[j]
+  v[24:27] addrA     LDS byte address of this lane's activation fragment chunk (block 0 of the wave):
+                     32x32 blocks: [ks] for ks = 0..3 in stage 0 (the stage is an immediate offset);
+                     16x16 blocks: [ks + 2*stage] for ks = 0..1 (per-stage bases: immediate offsets stay < 64 KiB)
+  v[28:31] addrW     same for the weight fragment
+  v32      conv only: lane i holds the byte offset of tap i in the padded activation volume
+  v[36:..] fragment set P, then set Q  (rbw activation fragments, then cbw weight fragments, 4 VGPRs each)
   a[(rb*cbw+cb)*ACC ...] accumulators (ACC = 16 for 32x32 blocks, 4 for 16x16)
 Operands: %[ra] %[rw] buffer resources (SGPR quads), %[nk] K-tiles, %[la] %[lw] LDS byte base of this
-wave's activation / weight DMA pieces in stage 0.
+wave's activation / weight DMA pieces in stage 0; conv: %[lcpt] log2(K-tiles per tap), %[cptm1] K-tiles per tap - 1.
+
+Implicit-GEMM conv (conv=True): the activation operand is a PADDED channels-last volume, so tap (kt, kh, kw) of every
+output row is the row's own base address plus ONE wave-uniform byte offset; K-tile X covers channels
+[64 (X mod cpt), +64) of tap X div cpt.  The activation soffset of tile X is v_readlane(v32, X >> lcpt) + ((X & cptm1) << 7)
+(read one k-step before its first use), the weight soffset stays X << 7 (weights are [Cout][taps][Cin], K-contiguous).
 """
 import sys
 
-P_BASE = 32
-S_K = ("s92", "s93")      # K byte offset (soffset) of the tile being DMA'd into stage 0 / 1
+VOFF_A, VOFF_W, ADDR_A, ADDR_W, V_TAB, P_BASE = 0, 16, 24, 28, 32, 36
+S_KA = ("s92", "s93")     # activation K byte offset (soffset) of the tile being DMA'd into stage 0 / 1
+S_KW = ("s88", "s89")     # weight K byte offset (conv only; dense: the same register as S_KA)
 S_T, S_NK1, S_TMP = "s94", "s95", "s96"
-SCRATCH_S = ["s92", "s93", "s94", "s95", "s96"]
-A_STAGE, W_BASE = 32768, 65536
+S_TAP, S_C0, S_TAPOFF = "s97", ("s98", "s99"), ("s90", "s91")
+SCRATCH_S = ["s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"]
+VGPR_TOP_MAX = 200
 
 
 class Gen:
-    def __init__(self, rbw, cbw, mb=32, npa=8, dma_last=None, dma_ks0=None, reads_every=1, m0_early=False,
+    def __init__(self, rbw, cbw, mb=32, npa=8, npw=8, a_stage=32768, w_base=65536, w_stage=32768, conv=False,
+                 dma_last=None, dma_ks0=None, reads_every=1, m0_early=False,
                  no_dma=False, no_read=False, no_barrier=False):
         self.rbw, self.cbw, self.mb = rbw, cbw, mb
+        self.npw, self.a_stage, self.w_base, self.w_stage, self.conv = npw, a_stage, w_base, w_stage, conv
+        assert npa <= 16 and npw <= 8
+        assert w_base >= 2 * a_stage and w_base + 2 * w_stage <= 160 * 1024
+        if mb == 32:
+            assert a_stage + 8 * 4096 <= 65536 and w_stage + 8 * 4096 <= 65536
+        self.s_kw = S_KW if conv else S_KA
         self.nks = 4 if mb == 32 else 2
         self.accsz = 16 if mb == 32 else 4
         self.blk_bytes = mb * 128                 # LDS bytes between consecutive row blocks
         self.npa = npa                            # activation DMA pieces per wave (BM / 32)
-        self.NPIECE = npa + 8
+        self.NPIECE = npa + npw
         self.nmf = rbw * cbw
         self.nfrag = rbw + cbw
         self.q_base = P_BASE + 4 * self.nfrag
         self.vgpr_top = self.q_base + 4 * self.nfrag
-        assert self.vgpr_top <= 192
+        assert self.vgpr_top <= VGPR_TOP_MAX
         assert rbw * cbw * self.accsz <= 256
         n = self.NPIECE
         if dma_last is None:
@@ -81,14 +98,17 @@ class Gen:
     def acc(self, rb, cb):
         return (rb * self.cbw + cb) * self.accsz
 
-    def dma(self, piece, stage, tile_tag):
+    def m0_for(self, piece, stage):
         if piece < self.npa:
-            m0 = f"s_add_u32 m0, %[la], {stage * A_STAGE + piece * 1024}"
-            ins = f"buffer_load_dwordx4 v{piece}, %[ra], {S_K[stage]} offen lds"
+            return f"s_add_u32 m0, %[la], {stage * self.a_stage + piece * 1024}"
+        return f"s_add_u32 m0, %[lw], {stage * self.w_stage + (piece - self.npa) * 1024}"
+
+    def dma(self, piece, stage, tile_tag):
+        m0 = self.m0_for(piece, stage)
+        if piece < self.npa:
+            ins = f"buffer_load_dwordx4 v{VOFF_A + piece}, %[ra], {S_KA[stage]} offen lds"
         else:
-            j = piece - self.npa
-            m0 = f"s_add_u32 m0, %[lw], {stage * A_STAGE + j * 1024}"
-            ins = f"buffer_load_dwordx4 v{8 + j}, %[rw], {S_K[stage]} offen lds"
+            ins = f"buffer_load_dwordx4 v{VOFF_W + piece - self.npa}, %[rw], {self.s_kw[stage]} offen lds"
         self.trace.append(("dma", (piece, stage, tile_tag)))
         if self.no_dma and tile_tag != "prologue":
             return [], None
@@ -96,10 +116,13 @@ class Gen:
 
     def read(self, setbase, idx, stage, ks, tile_tag):
         f = self.frag(setbase, idx)
-        if idx < self.rbw:
-            a = f"ds_read_b128 v[{f}:{f + 3}], v{16 + ks} offset:{stage * A_STAGE + idx * self.blk_bytes}"
+        is_a = idx < self.rbw
+        blk = (idx if is_a else idx - self.rbw) * self.blk_bytes
+        base = ADDR_A if is_a else ADDR_W
+        if self.mb == 16:         # per-stage base registers
+            a = f"ds_read_b128 v[{f}:{f + 3}], v{base + ks + 2 * stage} offset:{blk}"
         else:
-            a = f"ds_read_b128 v[{f}:{f + 3}], v{20 + ks} offset:{stage * A_STAGE + (idx - self.rbw) * self.blk_bytes}"
+            a = f"ds_read_b128 v[{f}:{f + 3}], v{base + ks} offset:{stage * (self.a_stage if is_a else self.w_stage) + blk}"
         self.trace.append(("read", (setbase, idx, stage, ks, tile_tag)))
         if self.no_read and tile_tag != "prologue":
             return None
@@ -143,10 +166,7 @@ class Gen:
                     self.emit(r)
                 nxt_dma = dma_at.get(i + 1)
                 if nxt_dma is not None and not (self.no_dma and dtag != "prologue"):
-                    piece = nxt_dma
-                    base = "%[la]" if piece < self.npa else "%[lw]"
-                    j = piece if piece < self.npa else piece - self.npa
-                    self.emit(f"s_add_u32 m0, {base}, {dstage * A_STAGE + j * 1024}")
+                    self.emit(self.m0_for(nxt_dma, dstage))
             else:
                 for s in pre:
                     self.emit(s)
@@ -159,6 +179,28 @@ class Gen:
         self.emit("s_waitcnt lgkmcnt(0)")
         self.trace.append(("lgkm0", None))
 
+    def koff_prefetch(self, s):
+        """conv: tile X = min(T + 2, nk - 1) for the tile T living in stage s; tap offset fetched one k-step early."""
+        e = self.emit
+        e(f"s_add_u32 {S_TMP}, {S_T}, {2 + s}")
+        e(f"s_min_u32 {S_TMP}, {S_TMP}, {S_NK1}")
+        e(f"s_lshl_b32 {S_KW[s]}, {S_TMP}, 7")
+        e(f"s_and_b32 {S_C0[s]}, {S_TMP}, %[cptm1]")
+        e(f"s_lshl_b32 {S_C0[s]}, {S_C0[s]}, 7")
+        e(f"s_lshr_b32 {S_TAP}, {S_TMP}, %[lcpt]")
+        e("s_nop 3")                                      # SALU write of the lane select -> v_readlane
+        e(f"v_readlane_b32 {S_TAPOFF[s]}, v{V_TAB}, {S_TAP}")
+
+    def koff_commit(self, s):
+        e = self.emit
+        if self.conv:
+            e(f"s_add_u32 {S_KA[s]}, {S_TAPOFF[s]}, {S_C0[s]}")
+        else:
+            # K offset of tile T+2 (clamped to the last tile: dead data into dead slots, uniform counts)
+            e(f"s_add_u32 {S_TMP}, {S_T}, {2 + s}")
+            e(f"s_min_u32 {S_TMP}, {S_TMP}, {S_NK1}")
+            e(f"s_lshl_b32 {S_KA[s]}, {S_TMP}, 7")
+
     def tile(self, s):
         """K-tile living in stage s.  tags: 'T' this tile, 'T+1', 'T+2'."""
         n1 = len(self.dma_last)
@@ -166,6 +208,9 @@ class Gen:
         o = 1 - s
         sets = (P_BASE, self.q_base)
         self.trace.append(("tile", s))
+        if self.conv:
+            assert not self.dma_ks0, "conv: S_KW/S_C0 of stage s are rewritten at the top of its tile, so every piece goes out in the last k-step"
+            self.koff_prefetch(s)
         for ks in range(self.nks - 1):
             cur, nxt = sets[ks & 1], sets[(ks + 1) & 1]
             if ks == 0:         # second part of DMA(T+1) -> stage o
@@ -177,10 +222,7 @@ class Gen:
         if not self.no_barrier:
             self.emit("s_barrier")
         self.trace.append(("barrier", None))
-        # K offset of tile T+2 (clamped to the last tile: dead data into dead slots, uniform counts)
-        self.emit(f"s_add_u32 {S_TMP}, {S_T}, {2 + s}")
-        self.emit(f"s_min_u32 {S_TMP}, {S_TMP}, {S_NK1}")
-        self.emit(f"s_lshl_b32 {S_K[s]}, {S_TMP}, 7")
+        self.koff_commit(s)
         # last k-step: reads (T+1, ks0) from stage o ; first part of DMA(T+2) -> stage s
         ks = self.nks - 1
         self.kstep(sets[ks & 1], sets[(ks + 1) & 1], o, 0, "T+1", p1, self.dma_last, s, "T+2")
@@ -190,9 +232,24 @@ class Gen:
         n1 = len(self.dma_last)
         e = self.emit
         e(f"s_sub_u32 {S_NK1}, %[nk], 1")
-        e(f"s_mov_b32 {S_K[0]}, 0")
-        e(f"s_min_u32 {S_TMP}, 1, {S_NK1}")
-        e(f"s_lshl_b32 {S_K[1]}, {S_TMP}, 7")
+        if self.conv:
+            # tile 0: tap 0, channels [0, 64); tile 1: tap 1 >> lcpt, channels 64 * (1 & cptm1)
+            e(f"v_readlane_b32 {S_KA[0]}, v{V_TAB}, 0")
+            e(f"s_mov_b32 {S_KW[0]}, 0")
+            e(f"s_min_u32 {S_TMP}, 1, {S_NK1}")
+            e(f"s_lshl_b32 {S_KW[1]}, {S_TMP}, 7")
+            e(f"s_and_b32 {S_C0[1]}, {S_TMP}, %[cptm1]")
+            e(f"s_lshl_b32 {S_C0[1]}, {S_C0[1]}, 7")
+            e(f"s_lshr_b32 {S_TAP}, {S_TMP}, %[lcpt]")
+            e("s_nop 3")
+            e(f"v_readlane_b32 {S_KA[1]}, v{V_TAB}, {S_TAP}")
+            e("s_nop 3")                                  # VALU write of an SGPR -> SALU / VMEM read
+            e(f"s_add_u32 {S_KA[1]}, {S_KA[1]}, {S_C0[1]}")
+            e("s_nop 3")
+        else:
+            e(f"s_mov_b32 {S_KA[0]}, 0")
+            e(f"s_min_u32 {S_TMP}, 1, {S_NK1}")
+            e(f"s_lshl_b32 {S_KA[1]}, {S_TMP}, 7")
         # tile 0 -> stage 0 (all pieces), first part of tile 1 -> stage 1
         for stage, pieces in ((0, range(NP)), (1, range(n1))):
             for p in pieces:
@@ -343,7 +400,7 @@ def variant(name, rbw, cbw, **kw):
     if errs and not abl:
         raise SystemExit(f"{name}: pipeline check failed:\n  " + "\n  ".join(errs[:20]))
     body = "".join(f'    "{ln}\\n"\n' for ln in lines)
-    hdr = f"// {name}: rbw={rbw} cbw={cbw} mb={g.mb} npa={g.npa} dma_last={g.dma_last} dma_ks0={g.dma_ks0} reads_every={g.reads_every} vgpr_top={g.vgpr_top}"
+    hdr = f"// {name}: rbw={rbw} cbw={cbw} mb={g.mb} npa={g.npa} npw={g.npw} a_stage={g.a_stage} w_base={g.w_base} w_stage={g.w_stage} conv={g.conv} dma_last={g.dma_last} dma_ks0={g.dma_ks0} reads_every={g.reads_every} vgpr_top={g.vgpr_top}"
     return hdr + f"\n#define {name} \\\n" + body.replace('\n', ' \\\n').rstrip(' \\\n') + "\n\n"
 
 
@@ -351,40 +408,37 @@ def main():
     out = ["// GENERATED by gen_gemm_v4.py -- do not edit.  One asm string per K-loop variant (see the generator's docstring).\n",
            "#pragma once\n\n",
            "#define LTX2_V4_CLOBBERS \\\n    " +
-           ", ".join(f'"v{i}"' for i in range(24, 192)) + ", \\\n    " +
+           ", ".join(f'"v{i}"' for i in range(33, VGPR_TOP_MAX)) + ", \\\n    " +
            ", ".join(f'"{s}"' for s in SCRATCH_S) + ', "scc", "memory"\n\n']
     odd16, odd14 = list(range(1, 16, 2)), list(range(1, 14, 2))
-    # layout 1x4 (wave = all row blocks x 2 column blocks), 32x32x16
+    # layout 0: 1x4 waves (wave = all row blocks x 2 column blocks), 32x32x16
     out.append(variant("LTX2_V4_L14_RB7", 7, 2, npa=7, dma_last=odd14, dma_ks0=[0, 2, 4, 6, 8, 10, 12, 13]))
     out.append(variant("LTX2_V4_L14_RB8", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16))
-    # layout 2x2 (wave = 128 x 128), 32x32x16: 4x4 blocks; the second wave row of a 224-row tile owns 3 row blocks
+    # layout 1: 2x2 waves (wave = 128 x 128), 32x32x16: 4x4 blocks; the second wave row of a 224-row tile owns 3 row blocks
     out.append(variant("LTX2_V4_L22_RB4", 4, 4, npa=8, dma_last=odd16, dma_ks0=odd16))
     out.append(variant("LTX2_V4_L22_RB4_224", 4, 4, npa=7, dma_last=odd16, dma_ks0=odd14))
     out.append(variant("LTX2_V4_L22_RB3_224", 3, 4, npa=7, dma_last=[0, 2, 3, 5, 6, 8, 9, 11], dma_ks0=[1, 2, 4, 5, 7, 8, 10]))
-    # layout 2x2, 16x16x32: 8x8 blocks (6x8 for the second wave row of a 224-row tile)
+    # layout 2: 2x2 waves, 16x16x32: 8x8 blocks (6x8 for the second wave row of a 224-row tile)
     out.append(variant("LTX2_V4_L22_M16_RB8", 8, 8, mb=16, npa=8, dma_last=list(range(3, 64, 4)), dma_ks0=[], m0_early=True))
     out.append(variant("LTX2_V4_L22_M16_RB8_224", 8, 8, mb=16, npa=7, dma_last=list(range(3, 60, 4)), dma_ks0=[], m0_early=True))
     out.append(variant("LTX2_V4_L22_M16_RB6_224", 6, 8, mb=16, npa=7, dma_last=list(range(2, 47, 3)), dma_ks0=[], m0_early=True))
-    # layout 1x4, 16x16x32: 14|16 x 4 blocks (balanced for 224 rows)
-    out.append(variant("LTX2_V4_L14_M16_RB14", 14, 4, mb=16, npa=7, dma_last=list(range(0, 56, 4)) + [55], dma_ks0=[], m0_early=True))
-    out.append(variant("LTX2_V4_L14_M16_RB16", 16, 4, mb=16, npa=8, dma_last=list(range(3, 64, 4)), dma_ks0=[], m0_early=True))
+    # layout 3: 1x4 waves, 16x16x32: 14|16 x 4 blocks (balanced for 224 rows); dense and conv
+    d14, d16 = list(range(0, 56, 4)) + [55], list(range(3, 64, 4))
+    for conv in (False, True):
+        sfx = "_CONV" if conv else ""
+        out.append(variant("LTX2_V4_L14_M16_RB14" + sfx, 14, 4, mb=16, npa=7, dma_last=d14, dma_ks0=[], m0_early=True, conv=conv))
+        out.append(variant("LTX2_V4_L14_M16_RB16" + sfx, 16, 4, mb=16, npa=8, dma_last=d16, dma_ks0=[], m0_early=True, conv=conv))
+        # layout 4: BN = 128, 4x1 waves, 16x16x32: 7|8 x 8 blocks per wave (tile 448|512 x 128)
+        out.append(variant("LTX2_V4_L41_M16_RB7" + sfx, 7, 8, mb=16, npa=14, npw=4, a_stage=57344, w_base=114688, w_stage=16384,
+                           dma_last=list(range(0, 54, 3)), dma_ks0=[], m0_early=True, conv=conv))
+        out.append(variant("LTX2_V4_L41_M16_RB8" + sfx, 8, 8, mb=16, npa=16, npw=4, a_stage=65536, w_base=131072, w_stage=16384,
+                           dma_last=list(range(0, 60, 3)), dma_ks0=[], m0_early=True, conv=conv))
     if "--probe" in sys.argv:
+        e4 = list(range(3, 64, 4))
         out.append(variant("LTX2_V4_L14_RB8_NODMA", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, no_dma=True))
         out.append(variant("LTX2_V4_L14_RB8_NOREAD", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, no_read=True))
-        out.append(variant("LTX2_V4_L22_RB4_NODMA", 4, 4, npa=8, dma_last=odd16, dma_ks0=odd16, no_dma=True))
-        out.append(variant("LTX2_V4_L22_RB4_NOREAD", 4, 4, npa=8, dma_last=odd16, dma_ks0=odd16, no_read=True))
-        e4, e8 = list(range(3, 64, 4)), list(range(7, 64, 8))
         out.append(variant("LTX2_V4_M16_NODMA", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], no_dma=True))
         out.append(variant("LTX2_V4_M16_NOREAD", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], no_read=True))
-        e2 = list(range(1, 32, 2))
-        out.append(variant("LTX2_V4_M16_V3", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[]))
-        out.append(variant("LTX2_V4_M16_V4", 8, 8, mb=16, npa=8, dma_last=e2, dma_ks0=[], m0_early=True))
-        out.append(variant("LTX2_V4_M16_V5", 8, 8, mb=16, npa=8, dma_last=list(range(2, 48, 3)), dma_ks0=[], m0_early=True))
-        out.append(variant("LTX2_V4_M16_V6", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True, reads_every=2))
-        out.append(variant("LTX2_V4_M16_V7", 8, 8, mb=16, npa=8, dma_last=list(range(19, 64, 3)) + [63], dma_ks0=[], m0_early=True))
-        out.append(variant("LTX2_V4_M16_V8", 8, 8, mb=16, npa=8, dma_last=e4, dma_ks0=[], m0_early=True, reads_every=3))
-        out.append(variant("LTX2_V4_L14_M16_RB14_RD2", 14, 4, mb=16, npa=7, dma_last=list(range(2, 47, 3)), dma_ks0=[], m0_early=True, reads_every=2))
-        out.append(variant("LTX2_V4_L14_M16_RB14_D4", 14, 4, mb=16, npa=7, dma_last=list(range(0, 56, 4)) + [55], dma_ks0=[], m0_early=True))
     path = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "gemm_v4_loop.inc"
     with open(path, "w") as f:
         f.write("".join(out))

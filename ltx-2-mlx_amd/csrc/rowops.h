@@ -68,6 +68,10 @@ int vae_prepare_latent_launch(const float* latent, const float* std, const float
 // y = silu( x * rsqrt(mean_c(x^2)+eps) * (1 + scale) + shift ), scale/shift = tab[row_idx*C + c] (+ te[row_idx*C + c])
 int pixnorm_mod_silu_launch(const bf16* x, bf16* y, long P, int C, float eps, const float* tab, const float* te,
                             int shift_row, int scale_row, hipStream_t stream);
+// same, writing the PADDED volume [T+2][H+2][W+2][C] (replicate T with pad_front leading frames, reflect H / W) that the
+// implicit-GEMM conv of gemm_v4.hip reads
+int pixnorm_mod_silu_padded_launch(const bf16* x, bf16* y, int T, int H, int W, int C, float eps, const float* tab, const float* te,
+                                   int shift_row, int scale_row, int pad_front, hipStream_t stream);
 // conv_out [T][H][W][48] bf16 -> video fp32 [3][T][4H][4W]  (reference ops.unpatchify packing (c, r_w, r_h))
 int vae_unpatchify_launch(const bf16* x, float* video, int T, int H, int W, hipStream_t stream);
 // video fp32 [3][T][H][W] -> frames uint8 [T][H][W][3] = trunc(clip((v+1)/2,0,1)*255)

@@ -545,12 +545,15 @@ __global__ void vae_prepare_latent_kernel(const float* __restrict__ latent, cons
 // LP lanes per position, each lane owns C/LP contiguous channels (8 or 16).  A thread keeps its channels' (1+scale) and
 // shift values in registers and walks positions with a grid stride: loaded per position, the four 16-byte table reads
 // per 16 bytes of data made the kernel VMEM-issue-bound (3.85 TB/s at C = 128).
-template <int E>
+// PAD: the output is the PADDED channels-last volume [T+2][H+2][W+2][C] the implicit-GEMM conv of gemm_v4.hip reads (replicate
+// in T with `pad_front` leading frames, reflect in H / W -- reference simple_decoder.py:105-134): the loop walks padded
+// positions and normalises the source position each one mirrors (a few % more rows than the interior).
+template <int E, bool PAD>
 __global__ __launch_bounds__(256) void pixnorm_mod_silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long P,
                                                                int C, int lp_shift, float eps,
                                                                const float* __restrict__ tab,
                                                                const float* __restrict__ te, int shift_row,
-                                                               int scale_row) {
+                                                               int scale_row, int T, int H, int W, int pad_front) {
     const int LP = 1 << lp_shift;
     const long gthread = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long pos_stride = ((long)gridDim.x * blockDim.x) >> lp_shift;
@@ -572,16 +575,26 @@ __global__ __launch_bounds__(256) void pixnorm_mod_silu_kernel(const bf16* __res
         }
     }
     const float inv_c = 1.f / (float)C;
+    const int Hp = H + 2, Wp = W + 2;
     // the LP lanes of a position share `pos`, so a shuffle group is always wholly inside or wholly outside the loop
     for (long pos = gthread >> lp_shift; pos < P; pos += pos_stride) {
+        long src = pos;
+        if (PAD) {
+            const int tp = (int)(pos / ((long)Hp * Wp)), r2 = (int)(pos - (long)tp * Hp * Wp), hp = r2 / Wp, wp = r2 - hp * Wp;
+            const int t = min(max(tp - pad_front, 0), T - 1);
+            int h = hp - 1, w = wp - 1;
+            h = h < 0 ? -h : (h >= H ? 2 * H - 2 - h : h);
+            w = w < 0 ? -w : (w >= W ? 2 * W - 2 - w : w);
+            src = ((long)t * H + h) * W + w;
+        }
         float v[E];
         float s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < E / 8; ++i) {
-            const bf16x8 t = *(const bf16x8*)(x + pos * C + c0 + i * 8);
+            const bf16x8 t8 = *(const bf16x8*)(x + src * C + c0 + i * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                v[i * 8 + e] = bf2f(t[e]);
+                v[i * 8 + e] = bf2f(t8[e]);
                 s2 += v[i * 8 + e] * v[i * 8 + e];
             }
         }
@@ -810,8 +823,8 @@ int vae_prepare_latent_launch(const float* latent, const float* std, const float
     return LTX2_OK;
 }
 
-int pixnorm_mod_silu_launch(const bf16* x, bf16* y, long P, int C, float eps, const float* tab, const float* te,
-                            int shift_row, int scale_row, hipStream_t stream) {
+static int pixnorm_launch_impl(const bf16* x, bf16* y, long P, int C, float eps, const float* tab, const float* te,
+                               int shift_row, int scale_row, bool pad, int T, int H, int W, int pad_front, hipStream_t stream) {
     LTX2_CHECK_ARG(C >= 64 && (C & (C - 1)) == 0 && C <= 1024, "pixnorm: C=%d must be a power of two in [64,1024]", C);
     const int E = (C >= 1024) ? 16 : 8;
     const int LP = C / E;
@@ -820,12 +833,30 @@ int pixnorm_mod_silu_launch(const bf16* x, bf16* y, long P, int C, float eps, co
     const long threads = P * LP;
     const long want = (threads + 255) / 256;
     const unsigned grid = (unsigned)(want < 8192 ? want : 8192);        // 32 blocks per CU; the kernel walks the rest
-    if (E == 16)
-        hipLaunchKernelGGL((pixnorm_mod_silu_kernel<16>), dim3(grid), dim3(256), 0, stream, x, y, P, C, lp_shift, eps, tab, te, shift_row, scale_row);
-    else
-        hipLaunchKernelGGL((pixnorm_mod_silu_kernel<8>), dim3(grid), dim3(256), 0, stream, x, y, P, C, lp_shift, eps, tab, te, shift_row, scale_row);
+#define PIX_LAUNCH(EE, PP) \
+    hipLaunchKernelGGL((pixnorm_mod_silu_kernel<EE, PP>), dim3(grid), dim3(256), 0, stream, x, y, P, C, lp_shift, eps, tab, te, shift_row, scale_row, T, H, W, pad_front)
+    if (E == 16) {
+        if (pad) PIX_LAUNCH(16, true);
+        else PIX_LAUNCH(16, false);
+    } else {
+        if (pad) PIX_LAUNCH(8, true);
+        else PIX_LAUNCH(8, false);
+    }
+#undef PIX_LAUNCH
     LTX2_CHECK_LAUNCH("pixnorm_mod_silu_kernel");
     return LTX2_OK;
+}
+
+int pixnorm_mod_silu_launch(const bf16* x, bf16* y, long P, int C, float eps, const float* tab, const float* te,
+                            int shift_row, int scale_row, hipStream_t stream) {
+    return pixnorm_launch_impl(x, y, P, C, eps, tab, te, shift_row, scale_row, false, 0, 0, 0, 0, stream);
+}
+
+// y = the padded volume [T+2][H+2][W+2][C] (see the kernel comment)
+int pixnorm_mod_silu_padded_launch(const bf16* x, bf16* y, int T, int H, int W, int C, float eps, const float* tab, const float* te,
+                                   int shift_row, int scale_row, int pad_front, hipStream_t stream) {
+    LTX2_CHECK_ARG(H >= 2 && W >= 2 && T >= 1 && (pad_front == 1 || pad_front == 2), "pixnorm (padded): reflect padding needs H, W >= 2");
+    return pixnorm_launch_impl(x, y, (long)(T + 2) * (H + 2) * (W + 2), C, eps, tab, te, shift_row, scale_row, true, T, H, W, pad_front, stream);
 }
 
 int vae_unpatchify_launch(const bf16* x, float* video, int T, int H, int W, hipStream_t stream) {

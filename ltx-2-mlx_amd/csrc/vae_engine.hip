@@ -8,7 +8,9 @@
 #include <vector>
 
 #include "../../include/ltx2hip.h"
-#include "gemm.h"
+#include <stdlib.h>
+
+#include "gemm_epilogue.h"
 #include "rowops.h"
 
 #define TRY(expr)                       \
@@ -63,7 +65,7 @@ struct Plan {
 };
 Plan plan_sizes(const ltx2_vae_config& cfg, int T, int H, int W) {
     long ch = (long)cfg.base_channels * 8;
-    long mx = (long)T * H * W * (ch > cfg.latent_channels ? ch : cfg.latent_channels);
+    long mx = (long)(T + 2) * (H + 2) * (W + 2) * (ch > cfg.latent_channels ? ch : cfg.latent_channels);
     for (int i = 0; i < cfg.n_blocks; ++i) {
         if (cfg.kind[i] == LTX2_VAE_UPSAMPLE) {
             const int ft = cfg.stride[i][0], fh = cfg.stride[i][1], fw = cfg.stride[i][2];
@@ -72,10 +74,50 @@ Plan plan_sizes(const ltx2_vae_config& cfg, int T, int H, int W) {
             W *= fw;
             ch /= cfg.multiplier[i];
         }
-        const long e = (long)T * H * W * ch;
+        const long e = (long)(T + 2) * (H + 2) * (W + 2) * ch;      // the padded volume the v4 conv reads
         if (e > mx) mx = e;
     }
     return Plan{mx, T, H, W, (int)ch};
+}
+
+// LTX2_VAE_V4=0 keeps every conv on the tap-iterator kernels (A/B testing)
+bool vae_v4_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LTX2_VAE_V4");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
+GemmParams conv_params(const bf16* x, const bf16* w, const float* b, void* out, int T, int H, int W, int Cin, int Cout, int causal,
+                       const bf16* res) {
+    GemmParams p{};
+    p.A = x;
+    p.W = w;
+    p.bias = b;
+    p.out = out;
+    p.M = T * H * W;
+    p.N = Cout;
+    p.K = 27 * Cin;
+    p.taps_t = 3;
+    p.ldo = Cout;
+    p.res = res;
+    p.ldres = Cout;
+    p.T = T;
+    p.H = H;
+    p.Wd = W;
+    p.Cin = Cin;
+    p.cin_shift = ilog2(Cin);
+    p.pad_front = causal ? 2 : 1;
+    return p;
+}
+
+// res-block conv on the padded-volume kernel (gemm_v4.hip)?  The producer (pixel norm) must then write the padded layout.
+bool conv_on_v4(int T, int H, int W, int Cin, int Cout, int epi, void* out) {
+    if (!vae_v4_enabled()) return false;
+    const GemmParams p = conv_params(nullptr, nullptr, nullptr, out, T, H, W, Cin, Cout, 0, nullptr);
+    return gemm_v4_conv_supported(p, epi);
 }
 
 int conv(const bf16* x, const bf16* w, const float* b, void* out, int T, int H, int W, int Cin, int Cout, int causal,
@@ -266,10 +308,19 @@ int ltx2_vae_decode(ltx2_vae* c, const float* latent, int T, int H, int W, float
                 const float* b2 = W_F32(rb + ".conv2.conv.bias", ch);
                 NEED(b2);
                 // rows: shift1, scale1, shift2, scale2 (simple_decoder.py:216-238)
-                TRY(pixnorm_mod_silu_launch(X, Y, P, ch, eps, tab, tep, 0, 1, st));
-                TRY(conv(Y, w1, b1, Z, T, H, W, ch, ch, causal, EPI_BF16, nullptr, 1, 1, 1, 0, st));
-                TRY(pixnorm_mod_silu_launch(Z, Y, P, ch, eps, tab, tep, 2, 3, st));
-                TRY(conv(Y, w2, b2, X, T, H, W, ch, ch, causal, EPI_ADD_BF16, X, 1, 1, 1, 0, st));
+                if (conv_on_v4(T, H, W, ch, ch, EPI_BF16, Z) && conv_on_v4(T, H, W, ch, ch, EPI_ADD_BF16, X)) {
+                    // pixel norm writes the PADDED volume; the conv is a GEMM with one wave-uniform offset per tap
+                    const int pf = causal ? 2 : 1;
+                    TRY(pixnorm_mod_silu_padded_launch(X, Y, T, H, W, ch, eps, tab, tep, 0, 1, pf, st));
+                    TRY(gemm_v4_conv_launch(conv_params(Y, w1, b1, Z, T, H, W, ch, ch, causal, nullptr), EPI_BF16, st));
+                    TRY(pixnorm_mod_silu_padded_launch(Z, Y, T, H, W, ch, eps, tab, tep, 2, 3, pf, st));
+                    TRY(gemm_v4_conv_launch(conv_params(Y, w2, b2, X, T, H, W, ch, ch, causal, X), EPI_ADD_BF16, st));
+                } else {
+                    TRY(pixnorm_mod_silu_launch(X, Y, P, ch, eps, tab, tep, 0, 1, st));
+                    TRY(conv(Y, w1, b1, Z, T, H, W, ch, ch, causal, EPI_BF16, nullptr, 1, 1, 1, 0, st));
+                    TRY(pixnorm_mod_silu_launch(Z, Y, P, ch, eps, tab, tep, 2, 3, st));
+                    TRY(conv(Y, w2, b2, X, T, H, W, ch, ch, causal, EPI_ADD_BF16, X, 1, 1, 1, 0, st));
+                }
             }
         } else {
             const int ft = cfg.stride[i][0], fh = cfg.stride[i][1], fw = cfg.stride[i][2];

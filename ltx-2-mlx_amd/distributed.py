@@ -33,7 +33,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("LTX2_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
+        if torch.cuda.is_available():       # whatever the backend: every rank works on ITS device (LOCAL_RANK / LTX2_LOCAL_DEVICE)
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():

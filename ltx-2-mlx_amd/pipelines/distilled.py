@@ -141,7 +141,7 @@ class DistilledPipeline:
     def __call__(self, text_encoding: torch.Tensor, text_mask: Optional[torch.Tensor], config: DistilledConfig,
                  images: Optional[List] = None, callback: Optional[Callable[[str, int, int], None]] = None,
                  audio_encoding: Optional[torch.Tensor] = None, initial_noise: Optional[torch.Tensor] = None,
-                 initial_audio_noise: Optional[torch.Tensor] = None):
+                 initial_audio_noise: Optional[torch.Tensor] = None, stage2_noise: Optional[torch.Tensor] = None):
         """Returns the decoded video (uint8 frames, or the final latent when no decoder is set); with
         config.audio_enabled on an AudioVideo model, the tuple (video, audio_latent) -- the audio VAE / vocoder
         that turn the (B, 8, T_a, 16) latent into a waveform are outside this path."""
@@ -182,7 +182,12 @@ class DistilledPipeline:
         if self.spatial_upscaler is not None:
             # un_normalize -> upscaler -> normalize (reference pipelines/distilled.py:394-405); the statistics
             # ship with the VAE weights, so the decoder serves when no encoder object is passed
-            stats = getattr(self.video_encoder, "per_channel_statistics", None) or getattr(self.video_decoder, "per_channel_statistics", None)
+            # the encoder's statistics only when it actually carries loaded weights (an unloaded SimpleVideoEncoder holds the
+            # identity placeholder zeros / ones, which would silently mis-scale stage 2); else the decoder's
+            enc_stats = getattr(self.video_encoder, "per_channel_statistics", None)
+            if enc_stats is not None and not getattr(self.video_encoder, "_loaded", True):
+                enc_stats = None
+            stats = enc_stats or getattr(self.video_decoder, "per_channel_statistics", None)
             if stats is None:
                 raise ValueError("spatial_upscaler needs per_channel_statistics (un_normalize/normalize) from the video VAE")
             if isinstance(self.spatial_upscaler, SpatialUpscaler):
@@ -194,7 +199,7 @@ class DistilledPipeline:
             state2 = tools2.create_initial_state(dtype=config.dtype, initial_latent=up)
             state2 = apply_conditionings(state2, create_image_conditionings(images, self.video_encoder, s2.height, s2.width, config.dtype), tools2)
             sigma0 = float(STAGE_2_DISTILLED_SIGMA_VALUES[0])
-            state2 = noiser(state2, noise_scale=sigma0)
+            state2 = noiser(state2, noise_scale=sigma0, noise=stage2_noise)
             astate2, atools2 = None, None
             if audio_active:        # no spatial upscaling for audio: stage 1's latent is re-noised (reference :441-458)
                 atools2 = self._create_audio_tools(audio_shape(s2))

@@ -58,15 +58,35 @@ def test_bench_two_rank_rehearsal(dev):
     env = dict(os.environ, LTX2_DIST_BACKEND="gloo", LTX2_LOCAL_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "1", "--layers", "2",
-           "--no-vae"]
+           "--no-vae", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["weight_broadcast_collectives"] >= 1 and "cpu_baseline" not in out
+    assert out["weight_broadcast_collectives"] >= 1 and out["rccl_ranks"] == 2 and out["weight_broadcast_gbps"] > 0
     assert abs(out["value"] - 2 * 8 / (out["ms_per_step"] * 8e-3)) < 1e-2 * out["value"]
+
+
+def test_bench_self_launch(dev):
+    """`python bench.py --gpus 2 ...` as a PLAIN process (the form the driver uses for --gpus 1): with no launcher environment
+    it re-launches itself under torch.distributed.run; rank 0 prints the one JSON line, cpu_baseline included (both ranks on
+    this box's single GPU over gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LTX2_DIST_BACKEND="gloo", LTX2_LOCAL_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "1", "--layers", "2",
+                        "--no-vae", "--no-graph"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["plumbing_config_8_steps_s"] > 0 and cb["vae_decode_frames_per_sec"] > 0
+    assert out["roofline"]["launches"] > 0 and out["roofline"]["frac"] is not None
 
 
 def test_generate_cli_two_stage(dev, tmp_path):

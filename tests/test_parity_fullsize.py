@@ -1,0 +1,155 @@
+"""Parity at the sizes bench.py times ("depth and size never parity-checked"): the fp32 oracle is far too
+slow on host cores at these sizes, so the SAME oracle code (torch ops only) is executed in fp32 on the GPU as the checker
+-- it stays test infrastructure, never the thing measured.
+
+  * the 48-layer full-width step bench.py's headline times (D = 4096, N = 3456, S = 1024), distinct weights per layer
+  * BASELINE config 5 at its real size: a stage-2 step on N = 13 824 tokens, `decode_tiled` of a full-width decoder with
+    overlapping spatial AND temporal tiles, and the two-stage pipeline's upscale / re-noise / stage-2 logic against an
+    oracle loop (not against itself)
+Tolerances as tests/test_parity.py (bf16 operands, fp32 accumulate, fp32 residual stream vs an fp32 oracle)."""
+import pytest
+import torch
+
+from conftest import rel_l2
+from test_parity import inputs, make_dit, make_vae, pearson
+
+pytestmark = pytest.mark.gpu
+
+
+def dit_weights_on_gpu(cfg, dev, seed):
+    """oracle.dit.make_dit_weights' recipe with the tensors drawn on the GPU (19 G parameters are minutes of host RNG);
+    2-D linear weights are rounded to bf16 values so oracle and engine see identical numbers."""
+    from oracle import dit
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = {}
+    for name, shape in dit.dit_weight_shapes(cfg).items():
+        t = torch.randn(shape, generator=g, device=dev)
+        if name.endswith("_norm.weight"):
+            t = 1.0 + 0.1 * t
+        elif name.endswith(".bias"):
+            t = 0.02 * t
+        elif name.endswith("scale_shift_table"):
+            t = 0.1 * t
+        else:
+            t = 0.02 * t
+        if name.endswith(".weight") and t.dim() == 2:
+            t = t.to(torch.bfloat16).float()
+        out[name] = t
+    return out
+
+
+def test_dit_48_layer_step(dev):
+    """ONE full denoise-step forward of the headline model: 48 layers, D = 4096, 32 heads, caption 3840, N = 3456, S = 1024."""
+    from oracle import dit
+    from ltx_2_mlx_amd.model.transformer import LTXModel, Modality, X0Model
+    cfg = dit.DiTConfig(num_layers=48)
+    w = dit_weights_on_gpu(cfg, dev, seed=48)
+    m = LTXModel(num_layers=48, device=dev)
+    m.load_state_dict(w)
+    lat, ctx, pos = inputs(9, 16, 24, 1024, 3840, seed=49)
+    for sigma in (1.0, 0.421875):
+        ts = torch.tensor([sigma])
+        with torch.device(dev), torch.no_grad():
+            ref = dit.x0_model(lat.to(dev), ctx.to(dev), ts.to(dev), pos.to(dev), w, cfg).cpu()
+        x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=pos.to(dev)))
+        assert x0.shape == (1, 3456, 128)
+        assert rel_l2(x0.cpu(), ref) < 3e-2 and pearson(x0.cpu(), ref) > 0.999, sigma
+    del w, m
+    torch.cuda.empty_cache()
+
+
+def test_dit_stage2_size_step(dev):
+    """BASELINE config 5, stage 2: 1536x1024x65 -> latent 9 x 32 x 48 = 13 824 tokens; 2 full-width layers, the three stage-2
+    steps through the hipGraph against the oracle's loop."""
+    from oracle import dit, loop
+    from ltx_2_mlx_amd.components import STAGE_2_DISTILLED_SIGMA_VALUES
+    cfg, w, m = make_dit(dev, heads=32, layers=2, cap=3840, seed=51)
+    f, h, wd = 9, 32, 48
+    lat, ctx, pos = inputs(f, h, wd, 1024, 3840, seed=52)
+    sig = list(STAGE_2_DISTILLED_SIGMA_VALUES)
+    wg = {k: v.to(dev) for k, v in w.items()}
+    with torch.device(dev), torch.no_grad():
+        ctx_g, pos_g = ctx.to(dev), pos.to(dev)
+        ref = loop.denoise_loop_cli(loop.unpatchify(lat.to(dev), f, h, wd),
+                                    lambda tok, s: dit.x0_model(tok, ctx_g, torch.tensor([s]), pos_g, wg, cfg), sig)
+        ref = loop.patchify(ref).cpu()
+    m.prepare(ctx.to(dev), pos.to(dev))
+    z = lat[0].to(dev).contiguous()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.capture_denoise_graph(z, sig)
+        m.replay_denoise_graph()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert z.shape == (13824, 128)
+    assert rel_l2(z.cpu(), ref[0]) < 3e-2 and pearson(z.cpu(), ref[0]) > 0.999
+
+
+def test_decode_tiled_full_width(dev):
+    """`decode_tiled` with the reference's default tiling (512 px / 64 overlap, 64 frames / 24 overlap) and the full-width
+    decoder (base_channels 128, default blocks) on a 9 x 16 x 40 latent = 65 x 512 x 1280 px: 3 spatial x 2 temporal
+    overlapping tiles and their trapezoid blend, against the oracle's decode_tiled (tiling.py:252-412)."""
+    from oracle import vae
+    from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder, TilingConfig, decode_tiled, generate_tile_specs
+    cfg = vae.VAEConfig()
+    w = vae.make_vae_weights(cfg, seed=61)
+    d = SimpleVideoDecoder(device=dev)
+    d.load_state_dict(w)
+    g = torch.Generator().manual_seed(62)
+    z = torch.randn(1, 128, 9, 16, 40, generator=g)
+    tc = TilingConfig.default()
+    specs = list(generate_tile_specs(z.shape, tc))
+    assert len(specs) >= 4 and len({(s.in_w_start, s.in_w_end) for s in specs}) >= 2 and len({(s.in_t_start, s.in_t_end) for s in specs}) >= 2
+    zeros = {}          # decode noise fixed to zero on both sides (only the (1 - 0.025) scaling applies, simple_decoder.py:496-498)
+
+    def dec(t, timestep=0.05):
+        return d(t, timestep=timestep, noise=zeros.setdefault(tuple(t.shape), torch.zeros(t.shape, device=dev)))
+
+    out = next(decode_tiled(z.to(dev), dec, tc))
+    wq = {k: (v.to(torch.bfloat16).float() if (v.dim() == 5 or (v.dim() == 2 and "linear" in k)) else v).to(dev) for k, v in w.items()}
+    with torch.device(dev), torch.no_grad():
+        ref = vae.decode_tiled(z.to(dev), lambda t: vae.decoder_forward(t, wq, cfg, timestep=0.05, noise=None))
+    assert out.shape == ref.shape == (1, 3, 65, 512, 1280)
+    assert rel_l2(out.cpu(), ref.cpu()) < 4e-2 and pearson(out.cpu(), ref.cpu()) > 0.999
+
+
+def test_two_stage_pipeline_against_oracle_loop(dev):
+    """Stage 1 (8 steps at half resolution) -> un_normalize / upscale x2 / normalize -> re-noise to sigma 0.909375 with a
+    SUPPLIED noise tensor -> stage 2 (3 steps) against the same sequence written with the oracle's pieces
+    (pipelines/distilled.py:394-470); eager and hipGraph paths."""
+    from oracle import dit, loop, upscaler as oup
+    from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler
+    from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline
+    cfg, w, m = make_dit(dev, heads=2, layers=2, cap=128, seed=71)
+    vcfg, vw, d = make_vae(dev, layers=1, seed=72)
+    uw = oup.make_upscaler_weights(128, 64, 1, seed=73)
+    up = SpatialUpscaler(in_channels=128, mid_channels=64, num_blocks_per_stage=1, device=dev)
+    up.load_state_dict(uw)
+    uwq = {k: (v.to(torch.bfloat16).float() if v.dim() >= 4 else v) for k, v in uw.items()}
+    g = torch.Generator().manual_seed(74)
+    f, h1, w1 = 3, 4, 6
+    ctx = 0.1 * torch.randn(1, 64, 128, generator=g)
+    noise1 = torch.randn(1, f * h1 * w1, 128, generator=g)
+    noise2 = torch.randn(1, f * 2 * h1 * 2 * w1, 128, generator=g)
+    # ---- oracle sequence
+    pos1, pos2 = loop.video_positions(1, f, h1, w1, 24.0), loop.video_positions(1, f, 2 * h1, 2 * w1, 24.0)
+    ones1, ones2 = torch.ones(1, f * h1 * w1, 1), torch.ones(1, f * 4 * h1 * w1, 1)
+    tok = loop.gaussian_noiser(torch.zeros_like(noise1), ones1, noise1, 1.0)
+    tok = loop.denoise_loop_pipeline(tok, ones1, torch.zeros_like(noise1), lambda x, ts, s: dit.x0_model(x, ctx, ts, pos1, w, cfg),
+                                     loop.DISTILLED_SIGMA_VALUES)
+    lat1 = loop.unpatchify(tok, f, h1, w1)
+    mean, std = vw["vae.per_channel_statistics.mean-of-means"].float(), vw["vae.per_channel_statistics.std-of-means"].float()
+    lat_up = oup.upscale_latent(lat1, uwq, mean, std, num_blocks=1)
+    s0 = float(loop.STAGE_2_DISTILLED_SIGMA_VALUES[0])
+    tok2 = loop.gaussian_noiser(loop.patchify(lat_up), ones2, noise2, s0)
+    tok2 = loop.denoise_loop_pipeline(tok2, ones2, torch.zeros_like(noise2), lambda x, ts, s: dit.x0_model(x, ctx, ts, pos2, w, cfg),
+                                      loop.STAGE_2_DISTILLED_SIGMA_VALUES)
+    ref = loop.unpatchify(tok2, f, 2 * h1, 2 * w1)
+    # ---- product pipeline
+    pipe = DistilledPipeline(m, d, None, spatial_upscaler=up)         # decoder object as the statistics provider, latent out
+    for graph in (False, True):
+        conf = DistilledConfig(height=256, width=384, num_frames=17, seed=1, use_hip_graph=graph)
+        lat = pipe(ctx.to(dev), None, conf, initial_noise=noise1.to(dev), stage2_noise=noise2.to(dev))
+        assert lat.shape == ref.shape == (1, 128, 3, 8, 12)
+        assert rel_l2(lat.cpu(), ref) < 4e-2 and pearson(lat.cpu(), ref) > 0.999, graph
