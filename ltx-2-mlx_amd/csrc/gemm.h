@@ -30,6 +30,7 @@ struct GemmParams {
                          // 2: zero padding in H/W + replicate T (VAE encoder)
     // depth-to-space epilogue: column n = s*Cf + c, s = (a*fh + b)*fw + d
     int ft, fh, fw, Cf, cf_shift, drop_first, d2s_residual, c_d2s;
+    int splitk;          // gemm_v4.hip: K split over this many blocks per tile (fp32 slabs + reduce); 0 / 1 = off
     void* dbg;           // ping-pong kernel: optional device buffer for interval timestamps (debug)      // ping-pong kernel: which wave bit selects the staggered group (tuning knob)
 };
 

@@ -185,4 +185,5 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
 // implicit-GEMM conv over a PADDED activation volume (p.A = [T+2][H+2][Wd+2][Cin], padding rule applied by the producer;
 // p.T / p.H / p.Wd = output extent): EPI_BF16 / EPI_ADD_BF16, Cin >= 128, Cout % 128 == 0
 bool gemm_v4_conv_supported(const GemmParams& p, int epilogue);
-int gemm_v4_conv_launch(const GemmParams& p, int epilogue, hipStream_t stream);
+// splitk_ws: optional fp32 scratch ([splits][M][N]) that lets small-M / long-K convs split K deterministically
+int gemm_v4_conv_launch(const GemmParams& p, int epilogue, hipStream_t stream, void* splitk_ws = nullptr, long ws_bytes = 0);

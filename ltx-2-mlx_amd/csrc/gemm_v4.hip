@@ -26,7 +26,7 @@ typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 
 #define V4_INS_DENSE : "{v[0:15]}"(voffA), "{v[16:23]}"(voffB), "{v[24:27]}"(addrA), "{v[28:31]}"(addrB), [ra] "s"(ra), [rw] "s"(rw), \
-                       [nk] "s"(nk), [la] "s"(la), [lw] "s"(lw)
+                       [nk] "s"(nk), [la] "s"(la), [lw] "s"(lw), [kb] "s"(kb)
 #define V4_INS_CONV V4_INS_DENSE, "{v32}"(tapv), [lcpt] "s"(lcpt), [cptm1] "s"(cptm1)
 #define V4_OUT16                                                                                                          \
     "={a[0:15]}"(acc[0]), "={a[16:31]}"(acc[1]), "={a[32:47]}"(acc[2]), "={a[48:63]}"(acc[3]), "={a[64:79]}"(acc[4]),   \
@@ -69,8 +69,12 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #endif
 
     // ---- block -> tile (XCD-contiguous, grouped row-tiles; as gemm_pp.hip) ----
+    // split-K (p.splitk > 1): blockIdx = split * tiles + tile; this block accumulates K-tiles [split * nk, +nk) and writes an
+    // fp32 partial tile into slab `split` of p.out ([splitk][M][ldo] fp32); splitk_reduce_kernel adds the slabs
     const int Mt = (p.M + BM - 1) / BM, Nt = p.N / TBN;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntiles = Mt * Nt;
+    const int split = p.splitk > 1 ? (int)blockIdx.x / ntiles : 0;
+    const int id = xcd_remap((int)blockIdx.x - split * ntiles, ntiles);
     constexpr int GROUP = 8;
     const int per_group = GROUP * Nt;
     const int g = id / per_group;
@@ -125,7 +129,8 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
     const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + w * NPA * 1024);
     const unsigned lw = __builtin_amdgcn_readfirstlane(lds0 + G::W_BASE + w * NPW * 1024);
-    const unsigned nk = __builtin_amdgcn_readfirstlane(p.K / 64);
+    const unsigned nk = __builtin_amdgcn_readfirstlane(p.K / 64 / (p.splitk > 1 ? p.splitk : 1));
+    const unsigned kb = __builtin_amdgcn_readfirstlane(split * nk);
     // conv: lane i holds the byte offset of tap i = (a*3 + b)*3 + c (a absent for per-frame 3x3 convs) in the padded volume
     unsigned tapv = 0;
     unsigned lcpt = 0, cptm1 = 0;
@@ -193,6 +198,8 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     }
 #endif
 
+    GemmParams pe = p;
+    if (EPI == EPI_F32 && p.splitk > 1) pe.out = (float*)p.out + (long)split * p.M * p.ldo;
     // ---- epilogue (gemm_epilogue.h): a lane owns ONE row of every row block and 4-column groups of it ----
     // 32x32 block: row lr, groups gq = 0..3 at columns 8 gq + 4 kq (accumulator registers 4 gq .. 4 gq + 3)
     // 16x16 block: row lr, one group at columns 4 kq (accumulator registers 0..3)
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #pragma unroll
                 for (int gq = 0; gq < NG; ++gq) {
                     const int col = n0 + wc * WN + cb * MB + 8 * gq + 4 * kq;
-                    epi_store4<EPI>(p, er, row, col, acc_group(rb, cb, gq), bias4[cb][gq], gate4[cb][gq]);
+                    epi_store4<EPI>(pe, er, row, col, acc_group(rb, cb, gq), bias4[cb][gq], gate4[cb][gq]);
                 }
         }
     }
@@ -328,9 +335,26 @@ int launch_v4(const GemmParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     }
     const int Mt = (p.M + BM - 1) / BM, Nt = p.N / G::BN;
-    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt), dim3(256), G::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt * (p.splitk > 1 ? p.splitk : 1)), dim3(256), G::LDS_BYTES, stream, p);
     LTX2_CHECK_LAUNCH("gemm_v4_kernel");
     return LTX2_OK;
+}
+
+// out_bf16[m][n] = sum_s part[s][m][n] + bias[n] (+ res[m][n]): the slabs are added in slab order, so the result does not depend
+// on which block finished first (deterministic split-K)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long mn, int N, const float* __restrict__ bias,
+                                                            const bf16* __restrict__ res, bf16* __restrict__ out) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < mn; i += (long)gridDim.x * blockDim.x * 4) {
+        f32x4 a = *(const f32x4*)(part + i);
+        for (int s = 1; s < splits; ++s) a += *(const f32x4*)(part + (long)s * mn + i);
+        const int n = (int)(i % N);
+        if (bias) a += *(const f32x4*)(bias + n);
+        if (res) {
+            const bf16x4 r = *(const bf16x4*)(res + i);
+            a += f32x4{bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
+        }
+        *(bf16x4*)(out + i) = pack_bf16x4(a[0], a[1], a[2], a[3]);
+    }
 }
 
 // 224-row tiles when they need fewer CU-rounds of work than 256-row tiles
@@ -398,20 +422,51 @@ bool gemm_v4_conv_supported(const GemmParams& p, int epilogue) {
     if (epilogue != EPI_BF16 && epilogue != EPI_ADD_BF16) return false;
     if (p.Cin < 128 || (p.Cin & (p.Cin - 1)) || p.N % 128 != 0) return false;          // an even number of K-tiles: 27 * Cin / 64
     if (p.taps_t != 3 && p.taps_t != 1) return false;
-    if (p.M < 4096) return false;
+    if (p.M < 512) return false;
     if ((long)(p.T + 2) * (p.H + 2) * (p.Wd + 2) * p.Cin * 2 >= (1L << 31) || (long)p.N * p.K * 2 >= (1L << 31)) return false;
     if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15)) return false;
     return true;
 }
 
-int gemm_v4_conv_launch(const GemmParams& p, int epilogue, hipStream_t stream) {
+// splits for a conv with `tiles` output tiles and nk K-tiles: the largest power of two that keeps an even number (>= 8) of
+// K-tiles per block and does not push the grid past ~1.2 rounds of the 256 CUs; 1 when the grid already fills the chip
+static int conv_splits(long tiles, int nk, long mn, long ws_bytes) {
+    int best = 1;
+    for (int s = 2; s <= 16; s *= 2) {
+        if (nk % (2 * s) != 0 || nk / s < 8) break;
+        if (tiles * s > 308) break;
+        if ((long)s * mn * 4 > ws_bytes) break;
+        best = s;
+    }
+    return tiles >= 160 ? 1 : best;
+}
+
+int gemm_v4_conv_launch(const GemmParams& p_in, int epilogue, hipStream_t stream, void* splitk_ws, long ws_bytes) {
+    GemmParams p = p_in;
     LTX2_CHECK_ARG(gemm_v4_conv_supported(p, epilogue), "gemm_v4 conv: unsupported problem (Cin=%d N=%d M=%d epilogue=%d)", p.Cin, p.N, p.M, epilogue);
+    p.splitk = 1;
     if (p.N % 256 != 0) {       // 128-channel outputs: 512 x 128 tiles
         if (epilogue == EPI_BF16) return launch_v4<EPI_BF16, 4, 512, true>(p, stream);
         return launch_v4<EPI_ADD_BF16, 4, 512, true>(p, stream);
     }
     const long t256 = ((long)(p.M + 255) / 256) * (p.N / 256), t224 = ((long)(p.M + 223) / 224) * (p.N / 256);
-    const bool b224 = (t224 + 255) / 256 * 224 < (t256 + 255) / 256 * 256;
+    const bool b224 = (t224 + 255) / 256 * 224 < (t256 + 255) / 256 * 256 || t224 < 256;
+    const long mn = (long)p.M * p.N;
+    const int splits = (splitk_ws && p.ldo == p.N) ? conv_splits(b224 ? t224 : t256, p.K / 64, mn, ws_bytes) : 1;
+    if (splits > 1) {
+        GemmParams q = p;
+        q.splitk = splits;
+        q.out = splitk_ws;
+        q.bias = nullptr;
+        q.res = nullptr;
+        const int rc = b224 ? launch_v4<EPI_F32, 3, 224, true>(q, stream) : launch_v4<EPI_F32, 3, 256, true>(q, stream);
+        if (rc != LTX2_OK) return rc;
+        const long want = (mn / 4 + 255) / 256;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, stream, (const float*)splitk_ws, splits, mn,
+                           p.N, p.bias, epilogue == EPI_ADD_BF16 ? p.res : nullptr, (bf16*)p.out);
+        LTX2_CHECK_LAUNCH("splitk_reduce_kernel");
+        return LTX2_OK;
+    }
     if (epilogue == EPI_BF16) return b224 ? launch_v4<EPI_BF16, 3, 224, true>(p, stream) : launch_v4<EPI_BF16, 3, 256, true>(p, stream);
     return b224 ? launch_v4<EPI_ADD_BF16, 3, 224, true>(p, stream) : launch_v4<EPI_ADD_BF16, 3, 256, true>(p, stream);
 }

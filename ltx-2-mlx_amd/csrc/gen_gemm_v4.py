@@ -31,7 +31,7 @@ Fixed registers (the .hip passes them with physical-register constraints):
   v[36:..] fragment set P, then set Q  (rbw activation fragments, then cbw weight fragments, 4 VGPRs each)
   a[(rb*cbw+cb)*ACC ...] accumulators (ACC = 16 for 32x32 blocks, 4 for 16x16)
 Operands: %[ra] %[rw] buffer resources (SGPR quads), %[nk] K-tiles, %[la] %[lw] LDS byte base of this
-wave's activation / weight DMA pieces in stage 0; conv: %[lcpt] log2(K-tiles per tap), %[cptm1] K-tiles per tap - 1.
+wave's activation / weight DMA pieces in stage 0, %[kb] first K-tile of this block (split-K; 0 otherwise); conv: %[lcpt] log2(K-tiles per tap), %[cptm1] K-tiles per tap - 1.
 
 Implicit-GEMM conv (conv=True): the activation operand is a PADDED channels-last volume, so tap (kt, kh, kw) of every
 output row is the row's own base address plus ONE wave-uniform byte offset; K-tile X covers channels
@@ -184,6 +184,7 @@ class Gen:
         e = self.emit
         e(f"s_add_u32 {S_TMP}, {S_T}, {2 + s}")
         e(f"s_min_u32 {S_TMP}, {S_TMP}, {S_NK1}")
+        e(f"s_add_u32 {S_TMP}, {S_TMP}, %[kb]")          # split-K: this block's first K-tile
         e(f"s_lshl_b32 {S_KW[s]}, {S_TMP}, 7")
         e(f"s_and_b32 {S_C0[s]}, {S_TMP}, %[cptm1]")
         e(f"s_lshl_b32 {S_C0[s]}, {S_C0[s]}, 7")
@@ -199,6 +200,7 @@ class Gen:
             # K offset of tile T+2 (clamped to the last tile: dead data into dead slots, uniform counts)
             e(f"s_add_u32 {S_TMP}, {S_T}, {2 + s}")
             e(f"s_min_u32 {S_TMP}, {S_TMP}, {S_NK1}")
+            e(f"s_add_u32 {S_TMP}, {S_TMP}, %[kb]")      # split-K: this block's first K-tile
             e(f"s_lshl_b32 {S_KA[s]}, {S_TMP}, 7")
 
     def tile(self, s):
@@ -233,10 +235,17 @@ class Gen:
         e = self.emit
         e(f"s_sub_u32 {S_NK1}, %[nk], 1")
         if self.conv:
-            # tile 0: tap 0, channels [0, 64); tile 1: tap 1 >> lcpt, channels 64 * (1 & cptm1)
-            e(f"v_readlane_b32 {S_KA[0]}, v{V_TAB}, 0")
-            e(f"s_mov_b32 {S_KW[0]}, 0")
+            # tile X (X = kb, kb + 1): tap X >> lcpt, channels 64 * (X & cptm1)
+            e(f"s_lshl_b32 {S_KW[0]}, %[kb], 7")
+            e(f"s_and_b32 {S_C0[0]}, %[kb], %[cptm1]")
+            e(f"s_lshl_b32 {S_C0[0]}, {S_C0[0]}, 7")
+            e(f"s_lshr_b32 {S_TAP}, %[kb], %[lcpt]")
+            e("s_nop 3")
+            e(f"v_readlane_b32 {S_KA[0]}, v{V_TAB}, {S_TAP}")
+            e("s_nop 3")
+            e(f"s_add_u32 {S_KA[0]}, {S_KA[0]}, {S_C0[0]}")
             e(f"s_min_u32 {S_TMP}, 1, {S_NK1}")
+            e(f"s_add_u32 {S_TMP}, {S_TMP}, %[kb]")
             e(f"s_lshl_b32 {S_KW[1]}, {S_TMP}, 7")
             e(f"s_and_b32 {S_C0[1]}, {S_TMP}, %[cptm1]")
             e(f"s_lshl_b32 {S_C0[1]}, {S_C0[1]}, 7")
@@ -247,8 +256,9 @@ class Gen:
             e(f"s_add_u32 {S_KA[1]}, {S_KA[1]}, {S_C0[1]}")
             e("s_nop 3")
         else:
-            e(f"s_mov_b32 {S_KA[0]}, 0")
+            e(f"s_lshl_b32 {S_KA[0]}, %[kb], 7")
             e(f"s_min_u32 {S_TMP}, 1, {S_NK1}")
+            e(f"s_add_u32 {S_TMP}, {S_TMP}, %[kb]")
             e(f"s_lshl_b32 {S_KA[1]}, {S_TMP}, 7")
         # tile 0 -> stage 0 (all pieces), first part of tile 1 -> stage 1
         for stage, pieces in ((0, range(NP)), (1, range(n1))):

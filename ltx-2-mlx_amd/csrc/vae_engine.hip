@@ -20,6 +20,7 @@
     } while (0)
 
 namespace {
+constexpr long SPLITK_WS_BYTES = 64L << 20;        // fp32 partial slabs of the small-M / long-K convs (gemm_v4.hip split-K)
 struct Wt {
     const void* p;
     int dtype;
@@ -217,7 +218,7 @@ int64_t ltx2_vae_workspace_bytes(const ltx2_vae* c, int T, int H, int W) {
     if (!c || T <= 0 || H <= 0 || W <= 0) return -1;
     const Plan p = plan_sizes(c->cfg, T, H, W);
     const long maxc = (long)c->cfg.base_channels * 8;
-    return 3 * align_up(2 * p.max_elems) + align_up(4L * 256) + 2 * align_up(4L * 4 * maxc) + 1024;
+    return 3 * align_up(2 * p.max_elems) + align_up(4L * 256) + 2 * align_up(4L * 4 * maxc) + align_up(SPLITK_WS_BYTES) + 1024;
 }
 
 int ltx2_vae_bind_workspace(ltx2_vae* c, void* ptr, int64_t bytes) {
@@ -248,6 +249,7 @@ int ltx2_vae_decode(ltx2_vae* c, const float* latent, int T, int H, int W, float
     const long maxc = (long)cfg.base_channels * 8;
     float* te_h = (float*)((char*)sinus + align_up(4L * 256));
     float* te = (float*)((char*)te_h + align_up(4L * 4 * maxc));
+    void* skws = (char*)te + align_up(4L * 4 * maxc);
     const bool tcond = cfg.timestep_conditioning && timestep >= 0.f;
     const int CL = cfg.latent_channels;
     const float eps = 1e-6f;
@@ -312,9 +314,9 @@ int ltx2_vae_decode(ltx2_vae* c, const float* latent, int T, int H, int W, float
                     // pixel norm writes the PADDED volume; the conv is a GEMM with one wave-uniform offset per tap
                     const int pf = causal ? 2 : 1;
                     TRY(pixnorm_mod_silu_padded_launch(X, Y, T, H, W, ch, eps, tab, tep, 0, 1, pf, st));
-                    TRY(gemm_v4_conv_launch(conv_params(Y, w1, b1, Z, T, H, W, ch, ch, causal, nullptr), EPI_BF16, st));
+                    TRY(gemm_v4_conv_launch(conv_params(Y, w1, b1, Z, T, H, W, ch, ch, causal, nullptr), EPI_BF16, st, skws, SPLITK_WS_BYTES));
                     TRY(pixnorm_mod_silu_padded_launch(Z, Y, T, H, W, ch, eps, tab, tep, 2, 3, pf, st));
-                    TRY(gemm_v4_conv_launch(conv_params(Y, w2, b2, X, T, H, W, ch, ch, causal, X), EPI_ADD_BF16, st));
+                    TRY(gemm_v4_conv_launch(conv_params(Y, w2, b2, X, T, H, W, ch, ch, causal, X), EPI_ADD_BF16, st, skws, SPLITK_WS_BYTES));
                 } else {
                     TRY(pixnorm_mod_silu_launch(X, Y, P, ch, eps, tab, tep, 0, 1, st));
                     TRY(conv(Y, w1, b1, Z, T, H, W, ch, ch, causal, EPI_BF16, nullptr, 1, 1, 1, 0, st));
