@@ -115,6 +115,30 @@ def extra_configs(dev, layers):
     from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline
     from ltx_2_mlx_amd.types import AudioLatentShape, VideoLatentShape
     res = {}
+    # --- config 3: the same 19B step with fp8-RESIDENT weights (e4m3fn codes + scale in HBM, expanded inside the GEMM; outputs
+    #     bit-identical to dequantising at load -- tests/test_parity_fullsize.py)
+    from ltx_2_mlx_amd.conditioning import VideoLatentTools as _VLT
+    m = LTXModel(num_layers=layers, device=dev)
+    m.init_random_weights(seed=0, fp8_resident=True)
+    g3 = torch.Generator(device=dev).manual_seed(3)
+    lat3 = torch.randn(3456, 128, generator=g3, device=dev)
+    ctx3 = 0.1 * torch.randn(1, 1024, 3840, generator=g3, device=dev)
+    pos3 = _VLT(VideoLatentPatchifier(1), VideoLatentShape(1, 128, 9, 16, 24), fps=24.0).create_initial_state(device=dev).positions
+    m.prepare(ctx3, pos3)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.capture_denoise_graph(lat3, DISTILLED_SIGMA_VALUES)
+        m.replay_denoise_graph()
+        side.synchronize()
+        t0 = time.perf_counter()
+        m.replay_denoise_graph()
+        side.synchronize()
+        res["fp8_resident_ms_per_step"] = round((time.perf_counter() - t0) / 8 * 1e3, 2)
+        res["fp8_resident_weight_gb"] = round(sum(t.numel() * t.element_size() for t in m.weight_tensors().values()) / 1e9, 2)
+    torch.cuda.current_stream().wait_stream(side)
+    del m
+    torch.cuda.empty_cache()
     # --- config 4 shape: 48-layer AudioVideo DiT with 9-row AdaLN, prompt-modulated text K/V, per-head gates
     m = LTXModel(model_type=LTXModelType.AudioVideo, num_layers=layers, caption_channels=None, cross_attention_adaln=True,
                  apply_gated_attention=True, device=dev)

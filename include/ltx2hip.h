@@ -34,6 +34,7 @@ extern "C" {
 
 #define LTX2_DTYPE_BF16 0
 #define LTX2_DTYPE_F32 1
+#define LTX2_DTYPE_FP8_E4M3FN 2   /* ltx2_dit_set_weight: codes of a fp8-resident linear weight; `<name>_scale` (fp32 [out]) must be set too */
 
 const char* ltx2_last_error(void);
 int ltx2_abi_version(void);
@@ -59,6 +60,14 @@ int ltx2_abi_version(void);
 int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M,
                    int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table,
                    const void* res, int64_t ldres, void* stream);
+
+/* fp8-RESIDENT weights (reference loader/fp8_loader.py:14-51,54-130 dequantises at load; BASELINE config 3): W8 = float8_e4m3fn
+ * codes [N][K], wscale[N] fp32 = the checkpoint's per-tensor `weight_scale` repeated per output row (fused q/k/v carry one
+ * value per part).  The kernel expands bf16(f32(code) * wscale[n]) on the way from LDS to the MFMA -- exactly
+ * ltx2_dequant_fp8_e4m3fn's arithmetic -- so out is BIT-IDENTICAL to ltx2_gemm_bf16 on the dequantised weights.
+ * N % 256 == 0, K % 128 == 0, K >= 256; epilogues BF16 / GELU_BF16 / F32 / RESID_GATE_F32.                          */
+int ltx2_gemm_w8a16(const void* A, int64_t lda, const void* W8, const float* wscale, const float* bias, void* out, int64_t ldo, int M,
+                    int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table, void* stream);
 
 /* Skinny fp32-activation path (M <= 16): out_f32 = act_out(act_in(a) @ W^T + bias); act: 0 none,
  * 1 silu, 2 gelu_tanh.  Replaces TimestepEmbedding / AdaLayerNormSingle linears for a scalar
@@ -163,6 +172,17 @@ int ltx2_pixnorm_mod_silu(const void* x, void* y, int64_t P, int C, float eps, c
                           int shift_row, int scale_row, void* stream);
 int ltx2_vae_unpatchify(const void* x, float* video, int T, int H, int W, void* stream);
 int ltx2_video_to_uint8(const float* video, uint8_t* frames, int T, int H, int W, void* stream);
+/* decode_latent's chunk cross-fade, trim and uint8 conversion in one pass (simple_decoder.py:760-798): frame j of the chunk
+ * `cur` [3][Tc][H][W] lands on output frame t_dst0 + j of `frames` [T_out][H][W][3]; with `prev` (the previous chunk,
+ * [3][prev_T][H][W]) the first `ov` frames are prev_tail * (1 - ramp[j]) + cur * ramp[j] (ramp = torch.linspace(0, 1, ov) on the
+ * device), rounded like the separate reference ops.                                                                  */
+int ltx2_video_chunk_to_uint8(const float* cur, const float* prev, const float* ramp, uint8_t* frames, int Tc, int prev_T, int ov, int H,
+                              int W, int t_dst0, int T_out, void* stream);
+/* decode_tiled's trapezoid blend (video_vae/tiling.py:380-412): out[3][OT][OH][OW] += tile[3][dt][dh][dw](cropped to nt,nh,nw) *
+ * mt[t] mh[h] mw[w] and wsum += mask at offset (t0,h0,w0); ltx2_tile_blend_finish divides by clamp(wsum, 1e-8).       */
+int ltx2_tile_blend_accumulate(const float* tile, int dt, int dh, int dw, int nt, int nh, int nw, const float* mt, const float* mh,
+                               const float* mw, float* out, float* wsum, int OT, int OH, int OW, int t0, int h0, int w0, void* stream);
+int ltx2_tile_blend_finish(float* out, const float* wsum, int64_t plane, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * DiT engine: LTXModel forward behind one call, VideoOnly or AudioVideo, 19B-style blocks or the

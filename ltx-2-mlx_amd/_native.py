@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LTX2HIP_LIB") or os.path.join(_HERE, "lib", "libltx2hip.so")
 
 OK, E_INVALID, E_HIP, E_STATE = 0, -1, -2, -3
-DTYPE_BF16, DTYPE_F32 = 0, 1
+DTYPE_BF16, DTYPE_F32, DTYPE_FP8_E4M3FN = 0, 1, 2
 MODEL_VIDEO_ONLY, MODEL_AUDIO_VIDEO = 0, 1
 EPI_BF16, EPI_GELU_BF16, EPI_SILU_BF16, EPI_F32, EPI_RESID_GATE_F32, EPI_ADD_BF16 = range(6)
 VAE_RES, VAE_UPSAMPLE = 0, 1
@@ -46,6 +46,7 @@ SIGNATURES = {
     "ltx2_last_error": (C.c_char_p, []),
     "ltx2_abi_version": (i32, []),
     "ltx2_gemm_bf16": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp, i64, vp]),
+    "ltx2_gemm_w8a16": (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
     "ltx2_gemv_f32": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "ltx2_conv3d_fused": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ltx2_groupnorm_silu": (i32, [vp, vp, vp, i64, i32, i32, f32, vp, vp, vp, i32, vp]),
@@ -66,6 +67,9 @@ SIGNATURES = {
     "ltx2_pixnorm_mod_silu": (i32, [vp, vp, i64, i32, f32, vp, vp, i32, i32, vp]),
     "ltx2_vae_unpatchify": (i32, [vp, vp, i32, i32, i32, vp]),
     "ltx2_video_to_uint8": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ltx2_video_chunk_to_uint8": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ltx2_tile_blend_accumulate": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ltx2_tile_blend_finish": (i32, [vp, vp, i64, vp]),
     "ltx2_dit_create": (i32, [C.POINTER(DitConfig), C.POINTER(vp)]),
     "ltx2_dit_destroy": (None, [vp]),
     "ltx2_dit_set_weight": (i32, [vp, C.c_char_p, vp, i32, i64]),

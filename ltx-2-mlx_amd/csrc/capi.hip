@@ -45,6 +45,26 @@ int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
     return gemm_launch(p, epilogue, false, (hipStream_t)stream);
 }
 
+int ltx2_gemm_w8a16(const void* A, int64_t lda, const void* W8, const float* wscale, const float* bias, void* out, int64_t ldo, int M,
+                    int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table, void* stream) {
+    LTX2_CHECK_ARG(A && W8 && wscale && out, "gemm_w8a16: null operand");
+    GemmParams p{};
+    p.A = (const bf16*)A;
+    p.lda = lda;
+    p.W8 = (const unsigned char*)W8;
+    p.wscale = wscale;
+    p.bias = bias;
+    p.out = out;
+    p.ldo = ldo;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.gate = gate;
+    p.gate_stride = gate_stride;
+    p.gate_table = gate_table;
+    return gemm_launch(p, epilogue, false, (hipStream_t)stream);
+}
+
 int ltx2_gemv_f32(const float* a, int64_t lda, const void* W, const float* bias, float* out, int64_t ldo, int M,
                   int N, int K, int act_in, int act_out, void* stream) {
     LTX2_CHECK_ARG(a && W && out, "gemv: null operand");
@@ -165,6 +185,23 @@ int ltx2_pixnorm_mod_silu(const void* x, void* y, int64_t P, int C, float eps, c
 int ltx2_vae_unpatchify(const void* x, float* video, int T, int H, int W, void* stream) {
     LTX2_CHECK_ARG(x && video, "vae_unpatchify: null operand");
     return vae_unpatchify_launch((const bf16*)x, video, T, H, W, (hipStream_t)stream);
+}
+
+int ltx2_video_chunk_to_uint8(const float* cur, const float* prev, const float* ramp, uint8_t* frames, int Tc, int prev_T, int ov, int H,
+                              int W, int t_dst0, int T_out, void* stream) {
+    LTX2_CHECK_ARG(cur && frames, "video_chunk_to_uint8: null operand");
+    return video_chunk_to_uint8_launch(cur, prev, ramp, frames, Tc, prev_T, ov, H, W, t_dst0, T_out, (hipStream_t)stream);
+}
+
+int ltx2_tile_blend_accumulate(const float* tile, int dt, int dh, int dw, int nt, int nh, int nw, const float* mt, const float* mh,
+                               const float* mw, float* out, float* wsum, int OT, int OH, int OW, int t0, int h0, int w0, void* stream) {
+    LTX2_CHECK_ARG(tile && mt && mh && mw && out && wsum, "tile_blend_accumulate: null operand");
+    return tile_blend_accumulate_launch(tile, dt, dh, dw, nt, nh, nw, mt, mh, mw, out, wsum, OT, OH, OW, t0, h0, w0, (hipStream_t)stream);
+}
+
+int ltx2_tile_blend_finish(float* out, const float* wsum, int64_t plane, void* stream) {
+    LTX2_CHECK_ARG(out && wsum && plane > 0, "tile_blend_finish: bad argument");
+    return tile_blend_finish_launch(out, wsum, (long)plane, (hipStream_t)stream);
 }
 
 int ltx2_video_to_uint8(const float* video, uint8_t* frames, int T, int H, int W, void* stream) {

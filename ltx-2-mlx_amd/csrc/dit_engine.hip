@@ -164,11 +164,25 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
     return off;
 }
 
+// fp8-resident linear weights: the typed `const bf16*` fields of the weight structs then hold the CODES pointer; dense() looks it
+// up here to hand the GEMM (codes, per-row scale) instead of bf16 weights.  Filled while weights are resolved (single thread),
+// read-only afterwards.
+std::unordered_map<const void*, const float*> g_fp8_scale;
+
 const void* find(ltx2_dit* c, const std::string& name, int dtype, long numel) {
     auto it = c->weights.find(name);
     if (it == c->weights.end()) {
         ltx2_set_error("dit: missing weight '%s'", name.c_str());
         return nullptr;
+    }
+    if (dtype == LTX2_DTYPE_BF16 && it->second.dtype == LTX2_DTYPE_FP8_E4M3FN && it->second.n == numel) {
+        auto sc = c->weights.find(name + "_scale");
+        if (sc == c->weights.end() || sc->second.dtype != LTX2_DTYPE_F32) {
+            ltx2_set_error("dit: fp8-resident weight '%s' has no fp32 '%s_scale' vector", name.c_str(), name.c_str());
+            return nullptr;
+        }
+        g_fp8_scale[it->second.p] = (const float*)sc->second.p;
+        return it->second.p;
     }
     if (it->second.dtype != dtype || it->second.n != numel) {
         ltx2_set_error("dit: weight '%s' has dtype %d / numel %ld, expected dtype %d / numel %ld", name.c_str(),
@@ -295,6 +309,14 @@ int dense(const bf16* A, long lda, const bf16* W, const float* bias, void* out, 
     p.A = A;
     p.lda = lda;
     p.W = W;
+    if (!g_fp8_scale.empty()) {
+        auto f8 = g_fp8_scale.find((const void*)W);
+        if (f8 != g_fp8_scale.end()) {      // fp8-resident: codes + per-row scale, expanded inside the GEMM
+            p.W = nullptr;
+            p.W8 = (const unsigned char*)W;
+            p.wscale = f8->second;
+        }
+    }
     p.bias = bias;
     p.out = out;
     p.ldo = ldo;
@@ -767,7 +789,7 @@ void ltx2_dit_destroy(ltx2_dit* c) {
 
 int ltx2_dit_set_weight(ltx2_dit* c, const char* name, const void* ptr, int dtype, int64_t numel) {
     LTX2_CHECK_ARG(c && name && ptr, "dit_set_weight: null argument");
-    LTX2_CHECK_ARG(dtype == LTX2_DTYPE_BF16 || dtype == LTX2_DTYPE_F32, "dit_set_weight: bad dtype %d", dtype);
+    LTX2_CHECK_ARG(dtype == LTX2_DTYPE_BF16 || dtype == LTX2_DTYPE_F32 || dtype == LTX2_DTYPE_FP8_E4M3FN, "dit_set_weight: bad dtype %d", dtype);
     c->weights[name] = Wt{ptr, dtype, (long)numel};
     c->resolved = false;
     return LTX2_OK;

@@ -16,6 +16,8 @@ enum GemmEpilogue {
 struct GemmParams {
     const bf16* A;       // dense: [M][lda];  conv: activations [T][H][W][Cin] (channels-last)
     const bf16* W;       // [N][K]  (K contiguous; conv: K = tap*Cin + c, tap = (kt*3+kh)*3+kw)
+    const unsigned char* W8;  // fp8-resident weights (gemm_v4.hip): e4m3fn codes [N][K] instead of W, with
+    const float* wscale;      //   one dequantisation scale per output column: w = bf16(f32(code) * wscale[n])
     const float* bias;   // [N] or null
     void* out;           // bf16 or f32, [M][ldo]  (D2S: [To][Ho][Wo][Cf])
     const float* gate;   // EPI_RESID_GATE_F32: per-row part  gate[m*gate_stride + n]  (may be null)

@@ -322,7 +322,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ a, 
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream) {
     LTX2_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     LTX2_CHECK_ARG(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
-    LTX2_CHECK_ARG(p.A && p.W && p.out, "gemm: null operand");
+    LTX2_CHECK_ARG(p.A && (p.W || p.W8) && p.out, "gemm: null operand");
+    if (p.W8) {     // fp8-resident weights exist only on the 4-wave asm-loop kernel
+        LTX2_CHECK_ARG(!conv && p.lda % 8 == 0, "gemm: fp8-resident weights are dense-only");
+        return gemm_v4_launch(p, epilogue, stream, 3, 0);
+    }
     LTX2_CHECK_ARG(p.N % 4 == 0 && p.ldo % 4 == 0 && p.ldres % 4 == 0 && p.gate_stride % 4 == 0,
                    "gemm: N, ldo, ldres and gate_stride must be multiples of 4 (vector epilogue)");
     if (conv) {

@@ -36,7 +36,7 @@ typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 #define V4_ASM(LOOP) asm volatile(LOOP : V4_OUT16 V4_INS_DENSE : LTX2_V4_CLOBBERS)
 #define V4_ASM_CONV(LOOP) asm volatile(LOOP : V4_OUT16 V4_INS_CONV : LTX2_V4_CLOBBERS)
 
-template <int LAYOUT, int BM>
+template <int LAYOUT, int BM, bool W8 = false>
 struct V4Geo {
     static constexpr int BN = LAYOUT == 4 ? 128 : 256;
     static constexpr int MB = LAYOUT >= 2 ? 16 : 32;               // MFMA block
@@ -45,9 +45,13 @@ struct V4Geo {
     static constexpr int WN = LAYOUT == 4 ? 128 : (L14 ? 64 : 128);
     static constexpr int RBW = (WM + MB - 1) / MB, CBW = WN / MB;  // blocks per wave (first wave row)
     static constexpr int NKS = MB == 16 ? 2 : 4;
-    static constexpr int NPA = BM / 32, NPW = BN / 32;             // 1-KiB LDS-DMA pieces per wave and K-tile
-    static constexpr int A_STAGE = LAYOUT == 4 ? BM * 128 : 32768, W_BASE = 2 * A_STAGE, W_STAGE = BN * 128;
-    static constexpr int LDS_BYTES = W_BASE + 2 * W_STAGE;
+    static constexpr int WROW = W8 ? 64 : 128;                     // bytes of one weight row per K-tile (fp8 codes / bf16)
+    static constexpr int NPA = BM / 32, NPW = BN * WROW / 4096;    // 1-KiB LDS-DMA pieces per wave and K-tile
+    static constexpr int A_STAGE = LAYOUT == 4 ? BM * 128 : 32768, W_BASE = 2 * A_STAGE, W_STAGE = BN * WROW;
+    static_assert(!W8 || LAYOUT == 3, "fp8-resident weights run on layout 3");
+    static constexpr int LOOP_BYTES = W_BASE + 2 * W_STAGE;
+    static constexpr int EPI_BYTES = (LAYOUT == 3 || LAYOUT == 4) ? 4 * WM * WN * 2 : 0;      // bf16 outputs leave through LDS (per-wave slabs)
+    static constexpr int LDS_BYTES = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
     static_assert(LAYOUT == 4 ? (BM == 448 || BM == 512) : (BM == 224 || BM == 256), "tile rows");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -55,7 +59,8 @@ struct V4Geo {
 template <int EPI, int LAYOUT, int BM, bool CONV, int VAR>
 __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     static_assert(LAYOUT >= 0 && LAYOUT <= 4, "wave layout");
-    using G = V4Geo<LAYOUT, BM>;
+    constexpr bool W8 = VAR == 20;          // fp8-resident weights: p.W8 codes [N][K] + p.wscale[N]
+    using G = V4Geo<LAYOUT, BM, W8>;
     constexpr int TBN = G::BN, NPA = G::NPA, NPW = G::NPW, MB = G::MB, WM = G::WM, WN = G::WN, RBW = G::RBW, CBW = G::CBW, NKS = G::NKS;
     static_assert(!CONV || LAYOUT >= 3, "conv runs on the 16x16x32 layouts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,9 +108,15 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-        const int r = (w * NPW + j) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        voffB[j] = (unsigned)(n0 + r) * (unsigned)(p.K * 2) + chunk * 16;
+        if constexpr (W8) {     // 16 rows x 64 B of codes per piece; 8-byte chunks swizzled with 2*((row>>2)&3) (pairs stay 16-byte units)
+            const int r = (w * NPW + j) * 16 + (lane >> 2);
+            const int c8 = (2 * (lane & 3)) ^ (2 * ((r >> 2) & 3));
+            voffB[j] = (unsigned)(n0 + r) * (unsigned)p.K + c8 * 8;
+        } else {
+            const int r = (w * NPW + j) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            voffB[j] = (unsigned)(n0 + r) * (unsigned)(p.K * 2) + chunk * 16;
+        }
     }
     // ---- fragment read addresses (first block of the wave): row lr, 16-byte chunk (kchunk(ks) + kq) ^ ((row >> 1) & 7) ----
     const int lr = lane & (MB - 1), kq = lane / MB;         // row in block, k-quarter (32x32x16: 0..1, 16x16x32: 0..3)
@@ -114,7 +125,9 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const unsigned c = (unsigned)(((MB == 32 ? 2 : 4) * ks) ^ xbase) << 4;
-        const unsigned a0 = lds0 + (wr * WM + lr) * 128 + c, b0 = lds0 + G::W_BASE + (wc * WN + lr) * 128 + c;
+        const unsigned a0 = lds0 + (wr * WM + lr) * 128 + c;
+        const unsigned b0 = W8 ? lds0 + G::W_BASE + (wc * WN + lr) * 64 + ((unsigned)((4 * ks + kq) ^ (2 * ((lr >> 2) & 3))) << 3)
+                               : lds0 + G::W_BASE + (wc * WN + lr) * 128 + c;
         if constexpr (MB == 16) {       // per-stage bases: [ks + 2 * stage]
             addrA[ks] = a0;
             addrA[ks + 2] = a0 + G::A_STAGE;
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         }
     }
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(W8 ? (void*)p.W8 : (void*)p.W, 0, 0x7fffffff, 0x00020000);
     const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + w * NPA * 1024);
     const unsigned lw = __builtin_amdgcn_readfirstlane(lds0 + G::W_BASE + w * NPW * 1024);
     const unsigned nk = __builtin_amdgcn_readfirstlane(p.K / 64 / (p.splitk > 1 ? p.splitk : 1));
@@ -146,7 +159,19 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (CONV) {
+    if constexpr (W8) {
+        // per-column dequantisation scale of this lane's weight rows (column cb*16 + lr of the wave's 64), as (s, s) pairs
+        u32x8 scl;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const float sv = p.wscale[n0 + wc * WN + cb * MB + lr];
+            scl[2 * cb] = scl[2 * cb + 1] = __builtin_bit_cast(unsigned, sv);
+        }
+        if constexpr (BM == 224)
+            asm volatile(LTX2_V4_L14_M16_RB14_W8 : V4_OUT16 V4_INS_DENSE, LTX2_V4_L14_M16_RB14_W8_SCL(scl) : LTX2_V4_L14_M16_RB14_W8_CLOBBERS);
+        else
+            asm volatile(LTX2_V4_L14_M16_RB16_W8 : V4_OUT16 V4_INS_DENSE, LTX2_V4_L14_M16_RB16_W8_SCL(scl) : LTX2_V4_L14_M16_RB16_W8_CLOBBERS);
+    } else if constexpr (CONV) {
         if constexpr (LAYOUT == 3) {
             if constexpr (BM == 224) V4_ASM_CONV(LTX2_V4_L14_M16_RB14_CONV);
             else V4_ASM_CONV(LTX2_V4_L14_M16_RB16_CONV);
@@ -329,7 +354,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 
 template <int EPI, int LAYOUT, int BM, bool CONV = false, int VAR = 0>
 int launch_v4(const GemmParams& p, hipStream_t stream) {
-    using G = V4Geo<LAYOUT, BM>;
+    using G = V4Geo<LAYOUT, BM, VAR == 20>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -375,8 +400,31 @@ bool gemm_v4_supported(const GemmParams& p, int epilogue, bool conv) {
     return true;
 }
 
+bool gemm_v4_w8_supported(const GemmParams& p, int epilogue) {
+    if (epilogue != EPI_BF16 && epilogue != EPI_GELU_BF16 && epilogue != EPI_F32 && epilogue != EPI_RESID_GATE_F32) return false;
+    if (p.N % 256 != 0 || p.K % 128 != 0 || p.K < 256 || p.M < 1) return false;
+    if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.K >= (1L << 31)) return false;
+    if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || ((uintptr_t)p.W8 & 15)) return false;
+    return true;
+}
+
 // layout: 0..4 (see the file comment); bm: 0 = pick, 224 | 256 (layouts 0-3), 448 | 512 (layout 4)
 int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int layout, int bm) {
+    if (p.W8) {     // fp8-resident weights: layout 3 only
+        LTX2_CHECK_ARG(p.wscale && gemm_v4_w8_supported(p, epilogue), "gemm_v4: fp8-resident weights need N %% 256 == 0, K %% 128 == 0, K >= 256, a dense bf16/gelu/f32/residual epilogue (N=%d K=%d epilogue=%d)", p.N, p.K, epilogue);
+        const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
+#define CASE8(E) \
+    case E:      \
+        return b224 ? launch_v4<E, 3, 224, false, 20>(p, stream) : launch_v4<E, 3, 256, false, 20>(p, stream);
+        switch (epilogue) {
+            CASE8(EPI_BF16)
+            CASE8(EPI_GELU_BF16)
+            CASE8(EPI_F32)
+            CASE8(EPI_RESID_GATE_F32)
+        }
+#undef CASE8
+        return LTX2_E_INVALID;
+    }
     if (layout == 4) {
         LTX2_CHECK_ARG(p.N % 128 == 0, "gemm_v4 layout 4: N %% 128");
         const bool b448 = bm == 448;

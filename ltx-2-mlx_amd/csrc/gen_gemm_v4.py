@@ -33,6 +33,12 @@ Fixed registers (the .hip passes them with physical-register constraints):
 Operands: %[ra] %[rw] buffer resources (SGPR quads), %[nk] K-tiles, %[la] %[lw] LDS byte base of this
 wave's activation / weight DMA pieces in stage 0, %[kb] first K-tile of this block (split-K; 0 otherwise); conv: %[lcpt] log2(K-tiles per tap), %[cptm1] K-tiles per tap - 1.
 
+fp8-resident weights (w8=True, 16x16x32 layouts): the weight operand is e4m3fn codes [N][K] (1 byte each) plus one fp32 scale per
+output column.  The W stage holds 64-byte rows (8-byte chunks XOR-swizzled with 2*((row>>2)&3)); a raw fragment is one
+ds_read_b64 (8 codes) into v[RAW..]; it is expanded in the MFMA slots of the SAME k-step into the 4-register bf16 fragment of
+the other set: bf16(f32(code) * scale) = v_cvt_pk_f32_fp8 (exact) -> v_pk_mul_f32 (scale pair v[SCL + 2 cb : +1]) ->
+v_cvt_pk_bf16_f32 (RNE) -- the arithmetic of the dequantise-at-load kernel, so the GEMM output is bit-identical to it.
+
 Implicit-GEMM conv (conv=True): the activation operand is a PADDED channels-last volume, so tap (kt, kh, kw) of every
 output row is the row's own base address plus ONE wave-uniform byte offset; K-tile X covers channels
 [64 (X mod cpt), +64) of tap X div cpt.  The activation soffset of tile X is v_readlane(v32, X >> lcpt) + ((X & cptm1) << 7)
@@ -46,11 +52,11 @@ S_KW = ("s88", "s89")     # weight K byte offset (conv only; dense: the same reg
 S_T, S_NK1, S_TMP = "s94", "s95", "s96"
 S_TAP, S_C0, S_TAPOFF = "s97", ("s98", "s99"), ("s90", "s91")
 SCRATCH_S = ["s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"]
-VGPR_TOP_MAX = 200
+VGPR_TOP_MAX = 224
 
 
 class Gen:
-    def __init__(self, rbw, cbw, mb=32, npa=8, npw=8, a_stage=32768, w_base=65536, w_stage=32768, conv=False,
+    def __init__(self, rbw, cbw, mb=32, npa=8, npw=8, a_stage=32768, w_base=65536, w_stage=32768, conv=False, w8=False,
                  dma_last=None, dma_ks0=None, reads_every=1, m0_early=False,
                  no_dma=False, no_read=False, no_barrier=False):
         self.rbw, self.cbw, self.mb = rbw, cbw, mb
@@ -59,7 +65,11 @@ class Gen:
         assert w_base >= 2 * a_stage and w_base + 2 * w_stage <= 160 * 1024
         if mb == 32:
             assert a_stage + 8 * 4096 <= 65536 and w_stage + 8 * 4096 <= 65536
-        self.s_kw = S_KW if conv else S_KA
+        self.w8 = w8
+        self.s_kw = S_KW if (conv or w8) else S_KA
+        self.kw_shift = 6 if w8 else 7               # weight K-tile = 64 bytes of codes / 128 bytes of bf16
+        if w8:
+            assert mb == 16 and not conv
         self.nks = 4 if mb == 32 else 2
         self.accsz = 16 if mb == 32 else 4
         self.blk_bytes = mb * 128                 # LDS bytes between consecutive row blocks
@@ -69,7 +79,12 @@ class Gen:
         self.nfrag = rbw + cbw
         self.q_base = P_BASE + 4 * self.nfrag
         self.vgpr_top = self.q_base + 4 * self.nfrag
-        assert self.vgpr_top <= VGPR_TOP_MAX
+        if w8:      # raw code pairs (2 per weight fragment), per-column scale pairs (2 per cb), 8 f32 temporaries
+            self.raw_base = self.vgpr_top
+            self.scl_base = self.raw_base + 2 * cbw
+            self.tmp_base = self.scl_base + 2 * cbw
+            self.vgpr_top = self.tmp_base + 8
+        assert self.vgpr_top <= VGPR_TOP_MAX, self.vgpr_top
         assert rbw * cbw * self.accsz <= 256
         n = self.NPIECE
         if dma_last is None:
@@ -119,7 +134,11 @@ class Gen:
         is_a = idx < self.rbw
         blk = (idx if is_a else idx - self.rbw) * self.blk_bytes
         base = ADDR_A if is_a else ADDR_W
-        if self.mb == 16:         # per-stage base registers
+        if self.w8 and not is_a:  # 8 fp8 codes of (row lr, k-quarter): 64-byte rows, per-stage base registers
+            cb = idx - self.rbw
+            r = self.raw_base + 2 * cb
+            a = f"ds_read_b64 v[{r}:{r + 1}], v{base + ks + 2 * stage} offset:{cb * 16 * 64}"
+        elif self.mb == 16:         # per-stage base registers
             a = f"ds_read_b128 v[{f}:{f + 3}], v{base + ks + 2 * stage} offset:{blk}"
         else:
             a = f"ds_read_b128 v[{f}:{f + 3}], v{base + ks} offset:{stage * (self.a_stage if is_a else self.w_stage) + blk}"
@@ -127,6 +146,22 @@ class Gen:
         if self.no_read and tile_tag != "prologue":
             return None
         return a
+
+    def expand(self, setbase, cb):
+        """12 VALU: raw pair of weight fragment cb -> bf16 fragment (4 VGPRs) of `setbase`."""
+        r, t, s, d = self.raw_base + 2 * cb, self.tmp_base, self.scl_base + 2 * cb, self.frag(setbase, self.rbw + cb)
+        return [f"v_cvt_pk_f32_fp8_e32 v[{t}:{t + 1}], v{r}",
+                f"v_cvt_pk_f32_fp8_sdwa v[{t + 2}:{t + 3}], v{r} src0_sel:WORD_1",
+                f"v_cvt_pk_f32_fp8_e32 v[{t + 4}:{t + 5}], v{r + 1}",
+                f"v_cvt_pk_f32_fp8_sdwa v[{t + 6}:{t + 7}], v{r + 1} src0_sel:WORD_1",
+                f"v_pk_mul_f32 v[{t}:{t + 1}], v[{t}:{t + 1}], v[{s}:{s + 1}]",
+                f"v_pk_mul_f32 v[{t + 2}:{t + 3}], v[{t + 2}:{t + 3}], v[{s}:{s + 1}]",
+                f"v_pk_mul_f32 v[{t + 4}:{t + 5}], v[{t + 4}:{t + 5}], v[{s}:{s + 1}]",
+                f"v_pk_mul_f32 v[{t + 6}:{t + 7}], v[{t + 6}:{t + 7}], v[{s}:{s + 1}]",
+                f"v_cvt_pk_bf16_f32 v{d}, v{t}, v{t + 1}",
+                f"v_cvt_pk_bf16_f32 v{d + 1}, v{t + 2}, v{t + 3}",
+                f"v_cvt_pk_bf16_f32 v{d + 2}, v{t + 4}, v{t + 5}",
+                f"v_cvt_pk_bf16_f32 v{d + 3}, v{t + 6}, v{t + 7}"]
 
     def mfma(self, setbase, rb, cb):
         a = self.acc(rb, cb)
@@ -137,6 +172,8 @@ class Gen:
         return f"{op} a[{a}:{a + self.accsz - 1}], v[{w}:{w + 3}], v[{x}:{x + 3}], a[{a}:{a + self.accsz - 1}]"
 
     def read_order(self):
+        if self.w8:             # raw weight codes first: they are expanded while the activation reads are still landing
+            return list(range(self.rbw, self.nfrag)) + list(range(self.rbw))
         return [self.rbw] + list(range(self.rbw)) + list(range(self.rbw + 1, self.nfrag))     # W0, A0..A(rbw-1), W1..
 
     # one k-step: MFMAs on `cur`, reads of (rstage, rks) into `nxt`, DMA pieces in the given slots
@@ -145,7 +182,27 @@ class Gen:
         reads = self.read_order()
         read_at = {i * self.reads_every: r for i, r in enumerate(reads)}
         dma_at = dict(zip(dma_slots, dma_list))
-        pre_slot = {}           # instructions to place in the slot BEFORE a DMA's own slot (M0 set early: no s_nop needed)
+        valu_at = {}
+        if self.w8 and not (self.no_read and rtag != "prologue"):
+            # after `nwait` activation reads are behind the cbw raw reads, lgkmcnt(nwait) proves the raw codes landed (LGKM
+            # returns in order); then one expansion instruction per MFMA slot (two where the k-step would run out of slots)
+            nwait = min(8, self.rbw)
+            s0 = (self.cbw + nwait - 1) * self.reads_every + 1
+            ops = []
+            for cb in range(self.cbw):
+                ops += self.expand(nxt, cb)
+            room = self.nmf - 1 - s0
+            assert room * 2 >= len(ops), (room, len(ops))
+            k = 0
+            for slot in range(s0, self.nmf - 1):
+                take = 2 if (len(ops) - k) > (self.nmf - 1 - slot) else 1
+                valu_at[slot] = ops[k:k + take]
+                k += take
+                if k >= len(ops):
+                    break
+            assert k >= len(ops)
+            valu_at[s0] = [f"s_waitcnt lgkmcnt({nwait})"] + valu_at[s0]
+            self.trace.append(("w8_expand", (nxt, s0)))
         for i, (rb, cb) in enumerate(order):
             mf = self.mfma(cur, rb, cb)
             pre, ins = ([], None)
@@ -164,6 +221,8 @@ class Gen:
                     self.emit(ins)          # M0 was written one slot earlier
                 if r:
                     self.emit(r)
+                for v in valu_at.get(i, []):
+                    self.emit(v)
                 nxt_dma = dma_at.get(i + 1)
                 if nxt_dma is not None and not (self.no_dma and dtag != "prologue"):
                     self.emit(self.m0_for(nxt_dma, dstage))
@@ -202,6 +261,8 @@ class Gen:
             e(f"s_min_u32 {S_TMP}, {S_TMP}, {S_NK1}")
             e(f"s_add_u32 {S_TMP}, {S_TMP}, %[kb]")      # split-K: this block's first K-tile
             e(f"s_lshl_b32 {S_KA[s]}, {S_TMP}, 7")
+            if self.w8:
+                e(f"s_lshl_b32 {S_KW[s]}, {S_TMP}, 6")
 
     def tile(self, s):
         """K-tile living in stage s.  tags: 'T' this tile, 'T+1', 'T+2'."""
@@ -260,6 +321,9 @@ class Gen:
             e(f"s_min_u32 {S_TMP}, 1, {S_NK1}")
             e(f"s_add_u32 {S_TMP}, {S_TMP}, %[kb]")
             e(f"s_lshl_b32 {S_KA[1]}, {S_TMP}, 7")
+            if self.w8:
+                e(f"s_lshl_b32 {S_KW[0]}, %[kb], 6")
+                e(f"s_lshl_b32 {S_KW[1]}, {S_TMP}, 6")
         # tile 0 -> stage 0 (all pieces), first part of tile 1 -> stage 1
         for stage, pieces in ((0, range(NP)), (1, range(n1))):
             for p in pieces:
@@ -278,6 +342,10 @@ class Gen:
             e(self.read(P_BASE, idx, 0, 0, "prologue"))
         e("s_waitcnt lgkmcnt(0)")
         self.trace.append(("lgkm0", None))
+        if self.w8:
+            for cb in range(self.cbw):
+                for v in self.expand(P_BASE, cb):
+                    e(v)
         e(f"s_mov_b32 {S_T}, 0")
         e("LTX2_V4_LOOP_%=:")
         self.trace.append(("loop", None))
@@ -410,8 +478,13 @@ def variant(name, rbw, cbw, **kw):
     if errs and not abl:
         raise SystemExit(f"{name}: pipeline check failed:\n  " + "\n  ".join(errs[:20]))
     body = "".join(f'    "{ln}\\n"\n' for ln in lines)
-    hdr = f"// {name}: rbw={rbw} cbw={cbw} mb={g.mb} npa={g.npa} npw={g.npw} a_stage={g.a_stage} w_base={g.w_base} w_stage={g.w_stage} conv={g.conv} dma_last={g.dma_last} dma_ks0={g.dma_ks0} reads_every={g.reads_every} vgpr_top={g.vgpr_top}"
-    return hdr + f"\n#define {name} \\\n" + body.replace('\n', ' \\\n').rstrip(' \\\n') + "\n\n"
+    extra = ""
+    if g.w8:        # per-variant clobber list: the scale registers are inputs
+        regs = [i for i in range(33, VGPR_TOP_MAX) if not (g.scl_base <= i < g.scl_base + 2 * g.cbw)]
+        extra = (f"#define {name}_SCL \"{{v[{g.scl_base}:{g.scl_base + 2 * g.cbw - 1}]}}\"\n#define {name}_CLOBBERS \\\n    " + ", ".join(f'"v{i}"' for i in regs) +
+                 ", \\\n    " + ", ".join(f'"{s}"' for s in SCRATCH_S) + ', "scc", "memory"\n\n')
+    hdr = f"// {name}: w8={g.w8} rbw={rbw} cbw={cbw} mb={g.mb} npa={g.npa} npw={g.npw} a_stage={g.a_stage} w_base={g.w_base} w_stage={g.w_stage} conv={g.conv} dma_last={g.dma_last} dma_ks0={g.dma_ks0} reads_every={g.reads_every} vgpr_top={g.vgpr_top}"
+    return hdr + f"\n#define {name} \\\n" + body.replace('\n', ' \\\n').rstrip(' \\\n') + "\n\n" + extra
 
 
 def main():
@@ -443,6 +516,9 @@ def main():
                            dma_last=list(range(0, 54, 3)), dma_ks0=[], m0_early=True, conv=conv))
         out.append(variant("LTX2_V4_L41_M16_RB8" + sfx, 8, 8, mb=16, npa=16, npw=4, a_stage=65536, w_base=131072, w_stage=16384,
                            dma_last=list(range(0, 60, 3)), dma_ks0=[], m0_early=True, conv=conv))
+    # layout 3 with fp8-resident weights: W stage = 256 rows x 64 B
+    out.append(variant("LTX2_V4_L14_M16_RB14_W8", 14, 4, mb=16, npa=7, npw=4, w_stage=16384, dma_last=list(range(0, 44, 4)), dma_ks0=[], m0_early=True, w8=True))
+    out.append(variant("LTX2_V4_L14_M16_RB16_W8", 16, 4, mb=16, npa=8, npw=4, w_stage=16384, dma_last=list(range(3, 50, 4)), dma_ks0=[], m0_early=True, w8=True))
     if "--probe" in sys.argv:
         e4 = list(range(3, 64, 4))
         out.append(variant("LTX2_V4_L14_RB8_NODMA", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, no_dma=True))

@@ -76,3 +76,8 @@ int pixnorm_mod_silu_padded_launch(const bf16* x, bf16* y, int T, int H, int W, 
 int vae_unpatchify_launch(const bf16* x, float* video, int T, int H, int W, hipStream_t stream);
 // video fp32 [3][T][H][W] -> frames uint8 [T][H][W][3] = trunc(clip((v+1)/2,0,1)*255)
 int video_to_uint8_launch(const float* video, unsigned char* frames, int T, int H, int W, hipStream_t stream);
+int video_chunk_to_uint8_launch(const float* cur, const float* prev, const float* ramp, unsigned char* frames, int Tc, int prev_T, int ov,
+                                int H, int W, int t_dst0, int T_out, hipStream_t stream);
+int tile_blend_accumulate_launch(const float* tile, int dt, int dh, int dw, int nt, int nh, int nw, const float* mt, const float* mh,
+                                 const float* mw, float* out, float* wsum, int OT, int OH, int OW, int t0, int h0, int w0, hipStream_t stream);
+int tile_blend_finish_launch(float* out, const float* wsum, long plane, hipStream_t stream);

@@ -639,6 +639,63 @@ __global__ void video_to_uint8_kernel(const float* __restrict__ video, unsigned 
     }
 }
 
+// One temporal chunk of decode_latent -> uint8 frames, cross-faded with the previous chunk on the first `ov` frames
+// (simple_decoder.py:760-798): frame j of `cur` lands on output frame t_dst0 + j; for j < ov the value is
+// prev[prev_T - ov + j] * (1 - ramp[j]) + cur[j] * ramp[j] with torch.linspace's ramp, rounded exactly like the separate torch
+// ops it replaces (no FMA contraction); frames at or beyond T_out are dropped (the final trim).
+__global__ void video_chunk_to_uint8_kernel(const float* __restrict__ cur, const float* __restrict__ prev, const float* __restrict__ ramp,
+                                            unsigned char* __restrict__ frames, int Tc, int prev_T, int ov, int H, int W,
+                                            int t_dst0, int T_out) {
+    const long hw = (long)H * W, plane = (long)Tc * hw, pplane = (long)prev_T * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i / hw);
+        const long px = i - (long)j * hw;
+        const int t = t_dst0 + j;
+        if (t >= T_out) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = cur[c * plane + i];
+            if (prev && j < ov) {
+                const float r = ramp[j];
+                const float a = prev[c * pplane + (long)(prev_T - ov + j) * hw + px];
+                v = __fadd_rn(__fmul_rn(a, __fsub_rn(1.0f, r)), __fmul_rn(v, r));
+            }
+            v = (v + 1.f) * 0.5f;
+            v = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
+            frames[((long)t * hw + px) * 3 + c] = (unsigned char)v;
+        }
+    }
+}
+
+// decode_tiled (tiling.py:380-412): out[c][t0+t][h0+h][w0+w] += tile[c][t][h][w] * m, wsum[...] += m with the separable
+// trapezoid mask m = mt[t] * mh[h] * mw[w], one pass over the tile instead of three torch passes over volume slices.
+__global__ void tile_blend_accumulate_kernel(const float* __restrict__ tile, int dt, int dh, int dw, int nt, int nh, int nw,
+                                             const float* __restrict__ mt, const float* __restrict__ mh, const float* __restrict__ mw,
+                                             float* __restrict__ out, float* __restrict__ wsum, int OT, int OH, int OW, int t0, int h0, int w0) {
+    const long n = (long)nt * nh * nw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % nw);
+        const long r = i / nw;
+        const int h = (int)(r % nh), t = (int)(r / nh);
+        const float m = __fmul_rn(__fmul_rn(mt[t], mh[h]), mw[w]);
+        const long o = ((long)(t0 + t) * OH + (h0 + h)) * OW + (w0 + w);
+        wsum[o] = __fadd_rn(wsum[o], m);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const long oc = (long)c * OT * OH * OW + o;
+            out[oc] = __fadd_rn(out[oc], __fmul_rn(tile[((long)c * dt + t) * dh * dw + (long)h * dw + w], m));
+        }
+    }
+}
+
+__global__ void tile_blend_finish_kernel(float* __restrict__ out, const float* __restrict__ wsum, long plane) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        const float d = fmaxf(wsum[i], 1e-8f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c * plane + i] = __fdiv_rn(out[c * plane + i], d);
+    }
+}
+
 inline int grid_for(long n, int block, int cap = 4096) {
     long g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -863,6 +920,32 @@ int vae_unpatchify_launch(const bf16* x, float* video, int T, int H, int W, hipS
     const long n = (long)3 * T * H * 4 * W * 4;
     hipLaunchKernelGGL(vae_unpatchify_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, video, T, H, W);
     LTX2_CHECK_LAUNCH("vae_unpatchify_kernel");
+    return LTX2_OK;
+}
+
+int video_chunk_to_uint8_launch(const float* cur, const float* prev, const float* ramp, unsigned char* frames, int Tc, int prev_T, int ov,
+                                int H, int W, int t_dst0, int T_out, hipStream_t stream) {
+    LTX2_CHECK_ARG(Tc > 0 && H > 0 && W > 0 && (!prev || (ov >= 1 && ov <= Tc && ov <= prev_T && ramp)), "video_chunk_to_uint8: bad overlap");
+    const long n = (long)Tc * H * W;
+    hipLaunchKernelGGL(video_chunk_to_uint8_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, cur, prev, ramp, frames, Tc, prev_T, ov,
+                       H, W, t_dst0, T_out);
+    LTX2_CHECK_LAUNCH("video_chunk_to_uint8_kernel");
+    return LTX2_OK;
+}
+
+int tile_blend_accumulate_launch(const float* tile, int dt, int dh, int dw, int nt, int nh, int nw, const float* mt, const float* mh,
+                                 const float* mw, float* out, float* wsum, int OT, int OH, int OW, int t0, int h0, int w0, hipStream_t stream) {
+    LTX2_CHECK_ARG(nt <= dt && nh <= dh && nw <= dw && t0 + nt <= OT && h0 + nh <= OH && w0 + nw <= OW, "tile_blend_accumulate: tile outside the volume");
+    const long n = (long)nt * nh * nw;
+    hipLaunchKernelGGL(tile_blend_accumulate_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, tile, dt, dh, dw, nt, nh, nw, mt, mh, mw,
+                       out, wsum, OT, OH, OW, t0, h0, w0);
+    LTX2_CHECK_LAUNCH("tile_blend_accumulate_kernel");
+    return LTX2_OK;
+}
+
+int tile_blend_finish_launch(float* out, const float* wsum, long plane, hipStream_t stream) {
+    hipLaunchKernelGGL(tile_blend_finish_kernel, dim3(grid_for(plane, 256, 16384)), dim3(256), 0, stream, out, wsum, plane);
+    LTX2_CHECK_LAUNCH("tile_blend_finish_kernel");
     return LTX2_OK;
 }
 

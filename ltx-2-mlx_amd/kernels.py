@@ -41,6 +41,23 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_w8a16(a: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = nv.EPI_BF16,
+               out: Optional[torch.Tensor] = None, gate_table: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epilogue(a[M,K] @ dequant(w8)[N,K]^T + bias) with fp8-RESIDENT weights: w8 = float8_e4m3fn codes (uint8 view
+    accepted), wscale fp32 [N]; bit-identical to gemm() on bf16(f32(w8) * wscale[:, None])."""
+    assert a.dtype == BF16 and w8.element_size() == 1 and wscale.dtype == torch.float32 and a.dim() == 2 and w8.dim() == 2
+    a, w8, wscale = _c(a), _c(w8), _c(wscale)
+    M, K = a.shape
+    N = w8.shape[0]
+    assert wscale.numel() == N
+    if out is None:
+        assert epilogue != nv.EPI_RESID_GATE_F32, "RESID_GATE accumulates into `out`; pass it"
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if epilogue == nv.EPI_F32 else BF16)
+    nv.check(nv.lib().ltx2_gemm_w8a16(nv.ptr(a), a.stride(0), nv.ptr(w8), nv.ptr(wscale), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
+                                      epilogue, None, 0, nv.ptr(gate_table), nv.stream()))
+    return out
+
+
 def gemv(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_in: int = 0, act_out: int = 0) -> torch.Tensor:
     assert a.dtype == torch.float32 and w.dtype == BF16
     a, w = _c(a), _c(w)
@@ -278,6 +295,35 @@ def pixnorm_mod_silu(x: torch.Tensor, table: torch.Tensor, te: Optional[torch.Te
     nv.check(nv.lib().ltx2_pixnorm_mod_silu(nv.ptr(x), nv.ptr(y), P, C_, eps, nv.ptr(table), nv.ptr(te), shift_row,
                                             scale_row, nv.stream()))
     return y
+
+
+def video_chunk_to_uint8(cur: torch.Tensor, frames: torch.Tensor, t_dst0: int, prev: Optional[torch.Tensor] = None,
+                         ramp: Optional[torch.Tensor] = None) -> None:
+    """One temporal chunk `cur` fp32 [3,Tc,H,W] -> frames uint8 [T,H,W,3] at frame t_dst0, cross-faded with the tail of the previous
+    chunk `prev` over len(ramp) frames, trimmed at T (reference simple_decoder.py:760-798) -- one pass instead of cat / blend / cat /
+    convert over fp32 volumes."""
+    cur = _c(cur.float())
+    _, Tc, H, W = cur.shape
+    ov = 0 if prev is None else int(ramp.numel())
+    if prev is not None:
+        prev, ramp = _c(prev.float()), _c(ramp.float())
+    nv.check(nv.lib().ltx2_video_chunk_to_uint8(nv.ptr(cur), nv.ptr(prev), nv.ptr(ramp), nv.ptr(frames), Tc, 0 if prev is None else prev.shape[1], ov,
+                                                H, W, int(t_dst0), frames.shape[0], nv.stream()))
+
+
+def tile_blend_accumulate(tile: torch.Tensor, nt: int, nh: int, nw: int, mt: torch.Tensor, mh: torch.Tensor, mw: torch.Tensor,
+                          out: torch.Tensor, wsum: torch.Tensor, t0: int, h0: int, w0: int) -> None:
+    """out[3,OT,OH,OW] += tile[3,dt,dh,dw][:, :nt, :nh, :nw] * (mt x mh x mw); wsum[OT,OH,OW] += mask (reference tiling.py:380-404)."""
+    tile = _c(tile.float())
+    _, dt, dh, dw = tile.shape
+    _, OT, OH, OW = out.shape
+    nv.check(nv.lib().ltx2_tile_blend_accumulate(nv.ptr(tile), dt, dh, dw, nt, nh, nw, nv.ptr(_c(mt.float())), nv.ptr(_c(mh.float())),
+                                                 nv.ptr(_c(mw.float())), nv.ptr(out), nv.ptr(wsum), OT, OH, OW, t0, h0, w0, nv.stream()))
+
+
+def tile_blend_finish(out: torch.Tensor, wsum: torch.Tensor) -> None:
+    """out /= clamp(wsum, 1e-8) in place (reference tiling.py:410-412)."""
+    nv.check(nv.lib().ltx2_tile_blend_finish(nv.ptr(out), nv.ptr(wsum), wsum.numel(), nv.stream()))
 
 
 def video_to_uint8(video: torch.Tensor) -> torch.Tensor:

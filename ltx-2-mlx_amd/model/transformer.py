@@ -15,6 +15,8 @@ from dataclasses import dataclass
 from enum import Enum
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
+import re
+
 import torch
 
 from .. import _native as nv
@@ -38,6 +40,25 @@ class LTXModelType(Enum):
 class LTXRopeType(Enum):
     INTERLEAVED = "interleaved"
     SPLIT = "split"
+
+
+
+class Fp8Weight:
+    """A linear weight kept as float8_e4m3fn codes + the checkpoint's per-tensor `weight_scale` (reference loader/fp8_loader.py:14-51
+    dequantises it at load: f32(code) * scale -> compute dtype).  Passed through load_state_dict it stays fp8 in HBM and the GEMM
+    expands it on the fly with the same arithmetic."""
+
+    def __init__(self, codes: torch.Tensor, scale: float):
+        if codes.element_size() != 1 or codes.dim() != 2:
+            raise ValueError("Fp8Weight: codes must be a 2-D float8_e4m3fn (or uint8 view) tensor")
+        self.codes, self.scale = codes, float(scale)
+
+    @property
+    def shape(self):
+        return self.codes.shape
+
+
+FP8_RESIDENT_KEYS = re.compile(r"^transformer_blocks\.\d+\.(attn1|attn2)\.(to_q|to_k|to_v|to_out\.0)\.weight$|^transformer_blocks\.\d+\.ff\.net\.(0\.proj|2)\.weight$")
 
 
 @dataclass
@@ -219,7 +240,8 @@ class LTXModel:
     def _register(self, name: str, t: torch.Tensor) -> None:
         t = t.contiguous()
         self._w[name] = t
-        dt = nv.DTYPE_BF16 if t.dtype == BF16 else nv.DTYPE_F32
+        # uint8 = float8_e4m3fn codes of an fp8-RESIDENT linear weight (its `<name>_scale` fp32 vector is registered with it)
+        dt = nv.DTYPE_BF16 if t.dtype == BF16 else (nv.DTYPE_FP8_E4M3FN if t.dtype == torch.uint8 else nv.DTYPE_F32)
         nv.check(nv.lib().ltx2_dit_set_weight(self._h, name.encode(), nv.ptr(t), dt, t.numel()))
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
@@ -235,6 +257,9 @@ class LTXModel:
         for k, shp in exp.items():
             if k in sd and tuple(sd[k].shape) != shp:
                 raise ValueError(f"weight {k}: shape {tuple(sd[k].shape)} != expected {shp}")
+        for k, v in sd.items():
+            if isinstance(v, Fp8Weight) and not FP8_RESIDENT_KEYS.match(k):
+                raise ValueError(f"{k}: only the video stream's attention / feed-forward projections can stay fp8-resident")
         ff_key = "transformer_blocks.0.ff.net.0.proj.weight"
         if ff_key in sd and sd[ff_key].shape[0] != 4 * self.inner_dim:
             raise ValueError("FFN must be the ungated Linear(D->4D) (reference feed_forward.py:29-54)")
@@ -246,6 +271,20 @@ class LTXModel:
         def Fv(name):
             return sd[name].to(dev, torch.float32)
 
+        def put_linear(dst, names):
+            """Register the (possibly fused) linear weight `dst` from checkpoint tensors `names`.  Fp8Weight entries (codes +
+            per-tensor scale, loader fp8_resident=True) stay fp8 in HBM: codes concatenated, one scale per output row."""
+            vals = [sd[n] for n in names]
+            if any(isinstance(v, Fp8Weight) for v in vals):
+                if not all(isinstance(v, Fp8Weight) for v in vals):
+                    raise ValueError(f"{dst}: fused projection mixes fp8-resident and dequantised parts")
+                if vals[0].codes.shape[0] % 256 or vals[0].codes.shape[1] % 128 or vals[0].codes.shape[1] < 256:
+                    raise ValueError(f"{dst}: fp8-resident weights need out % 256 == 0 and in % 128 == 0 (got {tuple(vals[0].codes.shape)})")
+                self._register(dst, torch.cat([v.codes.to(dev).view(torch.uint8) for v in vals], 0))
+                self._register(dst + "_scale", torch.cat([torch.full((v.codes.shape[0],), float(v.scale), dtype=torch.float32, device=dev) for v in vals]))
+            else:
+                self._register(dst, torch.cat([v.to(dev, BF16) for v in vals], 0) if len(vals) > 1 else vals[0].to(dev, BF16))
+
         fused = set()
         for i in range(self.num_layers):
             p = f"transformer_blocks.{i}"
@@ -254,23 +293,37 @@ class LTXModel:
                 dst = "to_qkv" if is_self else "to_kv"
                 if any(f"{p}.{name}.{n}.weight" not in sd for n in parts):
                     continue
-                self._register(f"{p}.{name}.{dst}.weight", torch.cat([W(f"{p}.{name}.{n}.weight") for n in parts], 0))
+                put_linear(f"{p}.{name}.{dst}.weight", [f"{p}.{name}.{n}.weight" for n in parts])
                 self._register(f"{p}.{name}.{dst}.bias", torch.cat([Fv(f"{p}.{name}.{n}.bias") for n in parts], 0))
                 fused.update(f"{p}.{name}.{n}" for n in parts)
         for k in exp:
             if k not in sd or k.rsplit(".", 1)[0] in fused:
                 continue
             is_linear_w = k.endswith(".weight") and len(exp[k]) == 2
-            self._register(k, W(k) if is_linear_w else Fv(k))
+            if is_linear_w:
+                put_linear(k, [k])
+            else:
+                self._register(k, Fv(k))
         self._prep_key = None
 
-    def init_random_weights(self, seed: int = 0, std: float = 0.02) -> None:
+    def init_random_weights(self, seed: int = 0, std: float = 0.02, fp8_resident: bool = False) -> None:
         """Synthetic N(0, std) weights generated directly in HBM in the engine's fused layout (bench /
-        smoke; no checkpoints exist in this environment)."""
+        smoke; no checkpoints exist in this environment).  fp8_resident: the video stream's attention / feed-forward
+        projections are quantised to float8_e4m3fn + per-tensor scale and stay fp8 in HBM (BASELINE config 3)."""
         g = torch.Generator(device=self.device).manual_seed(seed)
+        fused_fp8 = re.compile(r"^transformer_blocks\.\d+\.(attn1|attn2)\.(to_qkv|to_q|to_kv|to_out\.0)\.weight$|^transformer_blocks\.\d+\.ff\.net\.(0\.proj|2)\.weight$")
 
         def rw(*shape):
             return (torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32) * std).to(BF16)
+
+        def put_w(name, rows, cols):
+            if fp8_resident and fused_fp8.match(name) and rows % 256 == 0 and cols % 128 == 0 and cols >= 256:
+                w = torch.randn(rows, cols, generator=g, device=self.device, dtype=torch.float32) * std
+                scale = float(w.abs().max() / 448.0)
+                self._register(name, (w / scale).to(torch.float8_e4m3fn).view(torch.uint8))
+                self._register(name + "_scale", torch.full((rows,), scale, dtype=torch.float32, device=self.device))
+            else:
+                self._register(name, rw(rows, cols))
 
         def rf(*shape, scale=std, base=0.0):
             return base + scale * torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32)
@@ -290,11 +343,14 @@ class LTXModel:
                     continue
                 done.add(dst)
                 rows = sum(exp[f"{parent}.{n}.{leaf}"][0] for n in fuse[attn])
-                self._register(dst, rw(rows, shp[1]) if leaf == "weight" else rf(rows))
+                if leaf == "weight":
+                    put_w(dst, rows, shp[1])
+                else:
+                    self._register(dst, rf(rows))
             elif k.endswith("_norm.weight"):
                 self._register(k, rf(*shp, scale=0.0, base=1.0))
             elif leaf == "weight" and len(shp) == 2:
-                self._register(k, rw(*shp))
+                put_w(k, *shp)
             else:
                 self._register(k, rf(*shp))
         self._prep_key = None
@@ -380,9 +436,8 @@ class LTXModel:
             return ts, 1
         if ts.numel() != n:
             raise ValueError(f"timesteps has {ts.numel()} elements; expected 1 or N={n}")
-        lo, hi = torch.aminmax(ts)
-        if float(lo) == float(hi):
-            return ts[:1].contiguous(), 1
+        # per-token timesteps stay per-token: asking the device whether they happen to be equal would be a host sync on
+        # every step (uniform sigma arrives as a 1-element tensor from every pipeline that has no conditioning mask)
         return ts, n
 
     def _sigma(self, m: Modality) -> torch.Tensor:

@@ -306,17 +306,27 @@ def decode_latent(latent: torch.Tensor, decoder: SimpleVideoDecoder, timestep: O
         if len(chunks) == 1:
             video = chunks[0][:, :, :total]
         else:
+            # cross-fade, trim and uint8 conversion fused per chunk (the reference concatenates / blends fp32 volumes, :760-798):
+            # chunk i starts `ov` frames before the end of what precedes it; its first ov frames are blended with that tail
             ov_ref = _latent_t_to_pixel_t(temporal_overlap)
-            video = chunks[0]
+            _, _, _, Hp, Wp = chunks[0].shape
+            frames = torch.empty(total, Hp, Wp, 3, device=chunks[0].device, dtype=torch.uint8)
+            K.video_chunk_to_uint8(chunks[0][0], frames, 0)
+            length = chunks[0].shape[2]
+            prev = chunks[0]
             for cur in chunks[1:]:
-                ov = min(ov_ref, cur.shape[2], video.shape[2])
+                ov = min(ov_ref, cur.shape[2], length)
                 if ov <= 1:
-                    video = torch.cat([video, cur], dim=2)
-                    continue
-                ramp = torch.linspace(0.0, 1.0, ov, device=video.device).reshape(1, 1, ov, 1, 1)
-                blended = video[:, :, -ov:] * (1.0 - ramp) + cur[:, :, :ov] * ramp
-                video = torch.cat([video[:, :, :-ov], blended, cur[:, :, ov:]], dim=2)
-            video = video[:, :, :total]
+                    K.video_chunk_to_uint8(cur[0], frames, length)
+                    length += cur.shape[2]
+                else:
+                    if ov > prev.shape[2]:
+                        raise ValueError("temporal overlap longer than the previous chunk")
+                    ramp = torch.linspace(0.0, 1.0, ov, device=cur.device)
+                    K.video_chunk_to_uint8(cur[0], frames, length - ov, prev=prev[0], ramp=ramp)
+                    length += cur.shape[2] - ov
+                prev = cur
+            return frames
     return K.video_to_uint8(video[0])
 
 
@@ -445,8 +455,10 @@ def decode_tiled(latent: torch.Tensor, decoder_fn: Callable, tiling_config: Tili
     b, c, t, h, w = latent.shape
     out_t, out_h, out_w = (t - 1) * 8 + 1, h * 32, w * 32
     dev = latent.device
-    output = torch.zeros(b, 3, out_t, out_h, out_w, device=dev)
-    weights = torch.zeros(1, 1, out_t, out_h, out_w, device=dev)
+    if b != 1:
+        raise ValueError("batch must be 1")
+    output = torch.zeros(3, out_t, out_h, out_w, device=dev)
+    weights = torch.zeros(out_t, out_h, out_w, device=dev)
     for s in generate_tile_specs(latent.shape, tiling_config):
         tile = decoder_fn(latent[:, :, s.in_t_start:s.in_t_end, s.in_h_start:s.in_h_end, s.in_w_start:s.in_w_end], timestep=timestep)
         _, _, dt, dh, dw = tile.shape
@@ -454,8 +466,7 @@ def decode_tiled(latent: torch.Tensor, decoder_fn: Callable, tiling_config: Tili
         mt = compute_trapezoidal_mask_1d(nt, min(s.ramp_t_left, nt), min(s.ramp_t_right, nt), left_starts_from_0=(s.out_t_start == 0), device=dev)
         mh = compute_trapezoidal_mask_1d(nh, min(s.ramp_h_left, nh), min(s.ramp_h_right, nh), device=dev)
         mw = compute_trapezoidal_mask_1d(nw, min(s.ramp_w_left, nw), min(s.ramp_w_right, nw), device=dev)
-        mask = mt[None, None, :, None, None] * mh[None, None, None, :, None] * mw[None, None, None, None, :]
-        ts, hs, ws = s.out_t_start, s.out_h_start, s.out_w_start
-        output[:, :, ts:ts + nt, hs:hs + nh, ws:ws + nw] += tile[:, :, :nt, :nh, :nw].to(dev) * mask
-        weights[:, :, ts:ts + nt, hs:hs + nh, ws:ws + nw] += mask
-    yield output / torch.clamp(weights, min=1e-8)
+        # output += tile * mask, weights += mask in one pass over the tile (blend-accumulate kernel)
+        K.tile_blend_accumulate(tile[0].to(dev), nt, nh, nw, mt, mh, mw, output, weights, s.out_t_start, s.out_h_start, s.out_w_start)
+    K.tile_blend_finish(output, weights)
+    yield output[None]

@@ -83,13 +83,16 @@ def timesteps_from_mask(denoise_mask: torch.Tensor, sigma: float) -> torch.Tenso
     return denoise_mask * sigma
 
 
-def modality_from_state(state: LatentState, context: torch.Tensor, sigma: float, enabled: bool = True) -> Modality:
+def modality_from_state(state: LatentState, context: torch.Tensor, sigma: float, enabled: bool = True, uniform: bool = False) -> Modality:
+    """uniform=True: the caller KNOWS the denoise mask is all ones (checked once per loop, not per step), so the timesteps are
+    the scalar sigma -- the broadcast AdaLN path, identical arithmetic, N x fewer AdaLN MLP rows."""
     # context_mask is always None (reference pipelines/common.py:223-232)
-    return Modality(enabled=enabled, latent=state.latent, timesteps=timesteps_from_mask(state.denoise_mask, sigma),
+    ts = torch.full((1,), float(sigma), device=state.latent.device) if uniform else timesteps_from_mask(state.denoise_mask, sigma)
+    return Modality(enabled=enabled, latent=state.latent, timesteps=ts,
                     positions=state.positions, context=context, context_mask=None,
                     sigma=torch.tensor([sigma], device=state.latent.device))
 
 
-def audio_modality_from_state(state: LatentState, context: torch.Tensor, sigma: float, enabled: bool = True) -> Modality:
+def audio_modality_from_state(state: LatentState, context: torch.Tensor, sigma: float, enabled: bool = True, uniform: bool = False) -> Modality:
     """Same record for the audio modality (reference pipelines/common.py:235-262)."""
-    return modality_from_state(state, context, sigma, enabled)
+    return modality_from_state(state, context, sigma, enabled, uniform)

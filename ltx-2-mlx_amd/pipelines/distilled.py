@@ -124,9 +124,9 @@ class DistilledPipeline:
             return video_state, audio_state
         step = stepper or self.diffusion_step
         for i in range(n):
-            vm = modality_from_state(video_state, video_context, sig[i])
+            vm = modality_from_state(video_state, video_context, sig[i], uniform=uniform)
             if joint:
-                vx0, ax0 = self.transformer(vm, audio_modality_from_state(audio_state, audio_context, sig[i]))
+                vx0, ax0 = self.transformer(vm, audio_modality_from_state(audio_state, audio_context, sig[i], uniform=uniform))
             else:
                 vx0, ax0 = self.transformer(vm), None
             vx0 = post_process_latent(vx0, video_state.denoise_mask, video_state.clean_latent)

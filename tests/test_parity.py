@@ -71,11 +71,12 @@ def test_dit_per_token_timesteps(dev):
     ref = dit.x0_model(lat, ctx, ts, pos, w, cfg)
     x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=pos.to(dev)))
     assert rel_l2(x0.cpu(), ref) < 2e-2
-    # uniform per-token timesteps take the broadcast path and must agree with the scalar call
+    # uniform per-token timesteps stay on the per-token path (no host sync to find out that they are equal -- the pipelines
+    # pass a 1-element tensor when they KNOW the mask is uniform): same arithmetic through the per-token AdaLN GEMMs
     uni = torch.full((1, N, 1), 0.725)
     a = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=uni.to(dev), positions=pos.to(dev)))
     b = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=torch.tensor([0.725], device=dev), positions=pos.to(dev)))
-    assert torch.equal(a, b)
+    assert rel_l2(a.cpu(), b.cpu()) < 2e-3
     assert rel_l2(a.cpu(), dit.x0_model(lat, ctx, uni, pos, w, cfg)) < 2e-2
 
 

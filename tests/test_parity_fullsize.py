@@ -153,3 +153,66 @@ def test_two_stage_pipeline_against_oracle_loop(dev):
         lat = pipe(ctx.to(dev), None, conf, initial_noise=noise1.to(dev), stage2_noise=noise2.to(dev))
         assert lat.shape == ref.shape == (1, 128, 3, 8, 12)
         assert rel_l2(lat.cpu(), ref) < 4e-2 and pearson(lat.cpu(), ref) > 0.999, graph
+
+
+def test_gemm_w8a16_is_bit_identical_to_dequantise_at_load(dev):
+    """fp8-RESIDENT weights (BASELINE config 3): the GEMM that expands e4m3fn codes x per-row scale on the way to the
+    MFMA gives BIT-IDENTICAL outputs to the bf16 GEMM on weights dequantised at load (reference fp8_loader.py:14-51 arithmetic), on
+    the DiT shapes (N = 3456 tokens; to_out / QKV / FFN-up / FFN-down) and a ragged small-M case, for every epilogue the DiT uses."""
+    import ltx_2_mlx_amd.kernels as K
+    from ltx_2_mlx_amd import _native as nv
+    g = torch.Generator(device=dev).manual_seed(5)
+    for (M, N, Kk) in ((3456, 4096, 4096), (3456, 12288, 4096), (3456, 16384, 4096), (3456, 4096, 16384), (70, 512, 256)):
+        a = torch.randn(M, Kk, generator=g, device=dev).to(torch.bfloat16)
+        w = torch.randn(N, Kk, generator=g, device=dev) / Kk ** 0.5
+        parts = 3 if N % 3 == 0 and N > 256 * 3 else 1              # fused q/k/v: one per-tensor scale per part
+        scale = torch.cat([torch.full((N // parts,), float(w[i * (N // parts):(i + 1) * (N // parts)].abs().max() / 448.0), device=dev) for i in range(parts)])
+        codes = (w / scale[:, None]).to(torch.float8_e4m3fn)
+        wdq = torch.cat([K.dequant_fp8(codes[i * (N // parts):(i + 1) * (N // parts)].view(torch.uint8), float(scale[i * (N // parts)])) for i in range(parts)])
+        assert torch.equal(wdq.float(), (codes.float() * scale[:, None]).to(torch.bfloat16).float())         # the load-time kernel is f32(code)*scale -> bf16
+        bias = torch.randn(N, generator=g, device=dev)
+        for epi in (nv.EPI_BF16, nv.EPI_GELU_BF16, nv.EPI_F32):
+            ref = K.gemm(a, wdq, bias, epilogue=epi)
+            out = K.gemm_w8a16(a, codes.view(torch.uint8), scale, bias, epilogue=epi)
+            assert torch.equal(out, ref), (M, N, Kk, epi)
+        gate = torch.randn(N, generator=g, device=dev)
+        x0 = torch.randn(M, N, generator=g, device=dev)
+        xr, xo = x0.clone(), x0.clone()
+        K.gemm(a, wdq, bias, epilogue=nv.EPI_RESID_GATE_F32, out=xr, gate_table=gate)
+        K.gemm_w8a16(a, codes.view(torch.uint8), scale, bias, epilogue=nv.EPI_RESID_GATE_F32, out=xo, gate_table=gate)
+        assert torch.equal(xo, xr), (M, N, Kk, "resid")
+
+
+def test_fp8_resident_model_matches_dequantised_model(dev, tmp_path):
+    """load_transformer_weights(use_fp8=True, fp8_resident=True): the attention / feed-forward projections stay float8_e4m3fn + scale in
+    HBM; the 2-layer full-width model's x0 is BIT-IDENTICAL to the same checkpoint dequantised at load, and its weights take ~half the bytes."""
+    from safetensors.torch import save_file
+    from oracle import dit
+    from ltx_2_mlx_amd.loader import load_transformer_weights
+    from ltx_2_mlx_amd.model.transformer import LTXModel, Modality, X0Model
+    cfg = dit.DiTConfig(num_layers=2)
+    w = dit_weights_on_gpu(cfg, dev, seed=81)
+    ck = {}
+    for k, v in w.items():
+        full = "model.diffusion_model." + k
+        if k.endswith(".weight") and v.dim() == 2 and "transformer_blocks" in k:
+            scale = float(v.abs().max() / 448.0)
+            ck[full] = (v / scale).to(torch.float8_e4m3fn).cpu()
+            ck[full + "_scale"] = torch.tensor(scale)
+        else:
+            ck[full] = (v.to(torch.bfloat16) if (k.endswith(".weight") and v.dim() == 2) else v).cpu()
+    path = str(tmp_path / "l2_fp8.safetensors")
+    save_file(ck, path)
+    del w, ck
+    lat, ctx, pos = inputs(9, 16, 24, 1024, 3840, seed=82)
+    outs, nbytes = [], []
+    for resident in (False, True):
+        m = LTXModel(num_layers=2, device=dev)
+        load_transformer_weights(m, path, strict=True, use_fp8=True, fp8_resident=resident)
+        nbytes.append(sum(t.numel() * t.element_size() for t in m.weight_tensors().values()))
+        x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=torch.tensor([0.725], device=dev), positions=pos.to(dev)))
+        outs.append(x0.clone())
+        del m
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0], outs[1])
+    assert nbytes[1] < 0.62 * nbytes[0]
