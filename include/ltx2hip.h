@@ -61,6 +61,14 @@ int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                    int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table,
                    const void* res, int64_t ldres, void* stream);
 
+/* Fused QKV projection (attention.py:196-214: to_q / to_k / to_v on the same input): out[M][N] = A @ W^T + bias for the columns
+ * < vt_col0 (Q and K), while the columns >= vt_col0 (V, heads of head_dim) leave as attention's V^T operand vt[H][head_dim][Npad]
+ * with the key order ltx2_vt_transpose produces (rows >= M zero up to Npad) -- written by the GEMM's epilogue on the shapes the
+ * 4-wave kernel takes (M >= 1024, N % 256 == 0, vt_col0 % 256 == 0, K % 128 == 0; *fused = 1), else by a transpose pass after
+ * the GEMM (*fused = 0; the V columns of `out` are then written too).  Bit-identical to ltx2_gemm_bf16 + ltx2_vt_transpose. */
+int ltx2_gemm_qkv_vt(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K,
+                     void* vt, int vt_col0, int Npad, int head_dim, int* fused, void* stream);
+
 /* fp8-RESIDENT weights (reference loader/fp8_loader.py:14-51,54-130 dequantises at load; BASELINE config 3): W8 = float8_e4m3fn
  * codes [N][K], wscale[N] fp32 = the checkpoint's per-tensor `weight_scale` repeated per output row (fused q/k/v carry one
  * value per part).  The kernel expands bf16(f32(code) * wscale[n]) on the way from LDS to the MFMA -- exactly
@@ -132,6 +140,16 @@ int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, in
  * Replaces _compiled_attention_core_no_mask (attention.py:12-34).                             */
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
                     int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream);
+/* The same with a scratch buffer: when ceil(Nq/128) * H exceeds the chip's 2-per-CU workgroup slots (3456 tokens x 32 heads =
+ * 864 units on 512 slots) the launch becomes stream-K -- one persistent workgroup per slot, each with an equal range of
+ * (unit, KV-tile) items; units cut by a range boundary are computed in two pieces and merged in a fixed order (bit-reproducible;
+ * equal to ltx2_flash_attn within fp32 rounding of the merge).  workspace: ltx2_flash_attn_workspace_bytes(head_dim) bytes, its
+ * FIRST 4096 bytes zero before the first launch (every launch leaves them zero); launches sharing it must be stream-ordered.
+ * workspace == NULL is ltx2_flash_attn.                                                                        */
+int64_t ltx2_flash_attn_workspace_bytes(int head_dim);
+int ltx2_flash_attn_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
+                       int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 
 /* Per-head attention gates (V2.3, attention.py:241-249): logits[rows][H] (fp32 scratch, also returned)
  * = x[rows][Dq] @ gate_w[H][Dq]^T + gate_b ; att[:, h*hd:(h+1)*hd] *= 2*sigmoid(logits[:, h]).  H <= 32. */

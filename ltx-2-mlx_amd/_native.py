@@ -46,6 +46,7 @@ SIGNATURES = {
     "ltx2_last_error": (C.c_char_p, []),
     "ltx2_abi_version": (i32, []),
     "ltx2_gemm_bf16": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp, i64, vp]),
+    "ltx2_gemm_qkv_vt": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp]),
     "ltx2_gemm_w8a16": (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
     "ltx2_gemv_f32": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "ltx2_conv3d_fused": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -56,6 +57,8 @@ SIGNATURES = {
     "ltx2_qknorm_rope": (i32, [vp, i64, i32, i32, i32, i32, vp, i32, vp, f32, vp, vp, vp]),
     "ltx2_vt_transpose": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
     "ltx2_flash_attn": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp]),
+    "ltx2_flash_attn_workspace_bytes": (i64, [i32]),
+    "ltx2_flash_attn_ws": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i64, vp]),
     "ltx2_attn_head_gate": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ltx2_rope_tables": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "ltx2_timestep_sinusoid": (i32, [vp, i64, f32, i32, i32, vp, vp, vp]),

@@ -11,7 +11,16 @@ struct AttnParams {
     int Nq, Nkv, Npad, H;
     int head_dim;       // 128 (default when 0) or 64
     float scale_log2e;  // (1/sqrt(d)) * log2(e)
+    // stream-K (attention.hip): scratch for the partial (O, m, l) of units cut by a work-range boundary, attn_sk_workspace_bytes()
+    // bytes, its last 4 KiB (the flags) ZERO before the first launch; null = plain one-workgroup-per-unit grid.  Launches that
+    // share a workspace must be ordered on one stream.  sk_xcd / sk_flags are filled by the launcher.
+    void* sk_ws;
+    long sk_ws_bytes;
+    unsigned* sk_flags;
+    int sk_xcd;
+    int sk_force;       // 1: stream-K whenever there are more units than slots (unit tests); 0: only when the plain grid's last round is badly filled
 };
 
 int attn_launch(const AttnParams& p, hipStream_t stream);
+long attn_sk_workspace_bytes(int head_dim);
 int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream, int head_dim = 128);

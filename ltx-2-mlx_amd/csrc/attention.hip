@@ -17,6 +17,17 @@
 //    that key order inside every 32-key block (done once by vt_transpose_kernel), which makes the
 //    V^T fragment a single conflict-free 16-byte LDS read.
 //  * online softmax in the exp2 domain (scale * log2(e) folded into the scores), fp32 statistics.
+//  * stream-K variant (SK = true, round 2): N = 3456 tokens x 32 heads is 864 (q-tile, head) units on 512 workgroup slots,
+//    1.69 rounds -> the second round runs 69 % full.  The SK kernel launches one persistent workgroup per slot.  Phase A:
+//    every workgroup computes whole units, one per round, all starting at KV tile 0 together (that lockstep is what lets the
+//    workgroups of an XCD share K / V^T tiles through its L2; a first version that cut ALL the work into equal ranges lost
+//    it and was 7-10 % slower per tile).  Phase B: the units left over (fewer than there are workgroups) are cut into EQUAL
+//    contiguous ranges of (unit, KV-tile) items; a unit cut by range boundaries is computed in pieces that are merged with
+//    the usual (m, l, O) rule.  Ranges are walked backwards, so the piece that must WAIT (the tail of a unit) is the last
+//    thing a workgroup does and the pieces it waits for come from LOWER-numbered workgroups that published before their
+//    own tails: no workgroup ever waits on a later-dispatched one, and the merge order is fixed (piece order), so results
+//    stay bit-reproducible.  With H % 8 == 0 the heads are dealt to the XCDs (workgroup b runs on XCD b % 8): a head's
+//    K / V^T is then fetched by ONE L2 instead of all eight.
 #include "attention.h"
 #include <type_traits>
 
@@ -73,7 +84,14 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 
 // K / V^T fragments are read with lds_read16 / lds_wait (common.h): measured here, dropping the K reads alone
 // saved as much time as dropping the 16 QK MFMAs while hipcc scheduled them behind lgkmcnt(0).
+// partial (O, m, l) of a unit's head piece: per workgroup slot, per wave: ND*4 x (64 lanes x 16 B) of O, then 64 x {m, l}
 template <int HD>
+struct SkSlot {
+    static constexpr int WAVE_BYTES = (HD / 32) * 4 * 1024 + 512;
+    static constexpr int BYTES = 4 * WAVE_BYTES;
+};
+
+template <int HD, bool SK>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     using G = Geo<HD>;
     constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NKS = G::NKS, ND = G::ND, NJ = G::NJ;
@@ -84,55 +102,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int head = blockIdx.y;
-    const int q0 = blockIdx.x * QB + wv * 32;
+    const int nt = (p.Nkv + KVB - 1) / KVB, nfull = p.Nkv / KVB;
+    const int nqt = (p.Nq + QB - 1) / QB;
 
-    // ---- Q fragments (B operand): Q[q0 + l31][16*ks + 8*hi .. +8], kept in registers ----
-    bf16x8 qf[NKS];
-    {
-        const int qrow = min(q0 + l31, p.Nq - 1);
-        const bf16* qp = p.Q + (long)qrow * p.ldq + head * HD + 8 * hi;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
-    }
-
-    // ---- staging addresses ----
-    const bf16* k_src[NJ];
-    const bf16* v_src[NJ];
-    unsigned k_off[NJ];                                                // element offset of this lane's K row, next tile to stage
+    // ---- staging addresses (head-independent part) ----
+    unsigned k_row0[NJ], k_col[NJ], v_ofs[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         // one LDS-DMA instruction covers 1 KiB: 4 K rows of 256 B (HD 128) or 8 rows of 128 B (HD 64)
         const int kr = HD == 128 ? (wv * NJ + j) * 4 + (lane >> 4) : (wv * NJ + j) * 8 + (lane >> 3);   // 0..63
         const int kchunk = HD == 128 ? ((lane & 15) ^ (kr & 15)) : ((lane & 7) ^ ((kr >> 1) & 7));
-        k_off[j] = (unsigned)kr * (unsigned)p.ldk;
-        k_src[j] = p.K + head * HD + kchunk * 8;
+        k_row0[j] = (unsigned)kr * (unsigned)p.ldk;
+        k_col[j] = kchunk * 8;
         const int vr = (wv * NJ + j) * 8 + (lane >> 3);                // 0..HD-1
         const int vchunk = (lane & 7) ^ ((vr >> 1) & 7);
-        v_src[j] = p.VT + (long)head * p.vt_head_stride + (long)vr * p.Npad + vchunk * 8;
+        v_ofs[j] = (unsigned)vr * (unsigned)p.Npad + vchunk * 8;
     }
-    // K tiles are staged strictly in order (0, 1, .., nt-1, and once more into the idle buffer), so the row offset
+    // K tiles are staged strictly in order (a, a+1, .., b-1, and once more into the idle buffer), so the row offset
     // advances by a constant; clamping the OFFSET to the last row's equals clamping the row (2 VALU per issue
     // instead of a 64-bit multiply-add chain). The launcher guarantees (Nkv + 2*KVB) * ldk < 2^32.
     const unsigned k_last = (unsigned)(p.Nkv - 1) * (unsigned)p.ldk, k_step = (unsigned)KVB * (unsigned)p.ldk;
-    // piece i of tile t's staging into buffer `buf`: pieces [0, NJ) are K, [NJ, 2 NJ) are V^T. One LDS-DMA issue
-    // costs the wave ~50 cycles (a burst of 8: ~100 each), so the pieces are spread between the QK MFMAs.
-    auto stage_piece = [&](int t, int buf, int i) {
-        const unsigned dst = lds0 + buf * STAGE + wv * (NJ * 1024);
-        if (i < NJ) {
-            glds16(k_src[i] + min(k_off[i], k_last), dst + i * 1024);
-            k_off[i] += k_step;
-        } else {
-            glds16(v_src[i - NJ] + t * KVB, dst + K_TILE + (i - NJ) * 1024);
-        }
-    };
-
-    f32x16 o[ND];
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
 
     // per-lane fragment offsets inside a stage (the swizzle of the staging, applied again on the read)
     const int k_xor = HD == 128 ? (l31 & 15) : ((l31 >> 1) & 7);
@@ -143,137 +132,297 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v_lane[i] = K_TILE + l31 * 128 + (((2 * i + hi) ^ v_xor) << 4);
 
-    const int nt = (p.Nkv + KVB - 1) / KVB;
-#pragma unroll
-    for (int i = 0; i < 2 * NJ; ++i) stage_piece(0, 0, i);
-
-    // One KV tile. MASKED is a compile-time flag: only the ragged last tile carries the key-bound compares (left
-    // in the common body, hipcc if-converts them into ~115 predicated VALU ops on EVERY tile -- SQ_INSTS_VALU
-    // showed 236 non-MFMA VALU per tile against 32 MFMAs).
-    auto tile = [&](const int t, auto masked) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int tn = min(t + 1, nt - 1);          // the tail re-stages the last tile into the idle buffer (branch-free body)
-        const int nbuf = (t + 1) & 1;
-        const unsigned sbase = lds0 + (t & 1) * STAGE;
-
-        // ---- S^T = K . Q^T  (two 32-key blocks); fragment i = b * NKS + ks ----
-        f32x16 s[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
-        u32x4 kf[NK];
-        auto read_k = [&](auto I) {
-            constexpr int i = decltype(I)::value;
-            kf[i] = lds_read16<(i / NKS) * 32 * 2 * HD>(sbase + k_lane[i % NKS]);
-        };
-        static_for<0, DK>(read_k);
-        static_for<0, NK>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            if constexpr (i + DK < NK) read_k(std::integral_constant<int, i + DK>{});
-            lds_wait<(i + DK < NK ? DK : NK - 1 - i)>(kf[i]);
-            s[i / NKS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[i]), qf[i % NKS], s[i / NKS], 0, 0, 0);
-            if constexpr ((i & 1) && i / 2 < 2 * NJ) stage_piece(tn, nbuf, i / 2);
-        });
-        static_for<NK / 2, 2 * NJ>([&](auto I) { stage_piece(tn, nbuf, decltype(I)::value); });
-
-        // ---- mask the ragged tail, running max (raw score domain; the softmax scale * log2(e) is
-        //      folded into one fma in front of v_exp_f32: p = 2^(s*c - m*c)) ----
-        if constexpr (MASKED) {
-            const int kv0 = t * KVB;
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kv = kv0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (kv >= p.Nkv) s[b][r] = -INFINITY;
-                }
+    // ---- this workgroup's work (SK): unit u = head * nqt + q-tile.  Phase A: whole units, one per round, every workgroup
+    //      of the group starting at KV tile 0 together (they share K / V^T tiles through the L2 exactly like the plain grid).
+    //      Phase B: the units_g % wl units left over are cut into equal ranges of (unit, KV-tile) items, walked backwards. ----
+    int j = 0, wl = 1, u_base = 0, slot_stride = 1, slot_off = 0;       // worker j of wl in its group; slot(k) = k * stride + off
+    int full_rounds = 0, rem_base = 0, tot_b = 0, wlb = 1, it_lo = 0, it_hi = 0, ra = 0;
+    if constexpr (SK) {
+        const int w = blockIdx.x;
+        int units_g;
+        if (p.sk_xcd) {                     // heads dealt to the XCDs: group = w % 8 (the XCD workgroup w runs on)
+            j = w >> 3;
+            wl = gridDim.x >> 3;
+            units_g = (p.H >> 3) * nqt;
+            u_base = (w & 7) * units_g;
+            slot_stride = 8;
+            slot_off = w & 7;
+        } else {
+            j = w;
+            wl = gridDim.x;
+            units_g = p.H * nqt;
         }
-        // first V^T fragments go out before the row max and the exponentials, which hide their LDS latency
-        // (and part of the MFMA-result wait below);
-        // fragment i = d * 4 + (2 b + k2)
-        u32x4 vf[NV];
-        auto read_v = [&](auto I) {
-            constexpr int i = decltype(I)::value;
-            vf[i] = lds_read16<(i / 4) * 32 * 128>(sbase + v_lane[i % 4]);
-        };
-        static_for<0, DV>(read_v);
+        full_rounds = units_g / wl;
+        rem_base = full_rounds * wl;
+        tot_b = (units_g - rem_base) * nt;
+        wlb = min(wl, max(1, tot_b / 4));   // no range shorter than 4 KV tiles
+        if (j < wlb) {
+            it_lo = (int)((long)tot_b * j / wlb);
+            it_hi = (int)((long)tot_b * (j + 1) / wlb);
+        }
+    }
+    auto range_lo = [&](int k) { return (int)((long)tot_b * k / wlb); };
 
-        float tmax = -INFINITY;
-        mfma_result_guard(s[0], s[1], tmax);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tmax = max3(tmax, s[0][r], s[1][r]);
-        {   // other lane half: VALU swap, no LDS-queue operation between the counted waits
-            float t_lo, t_hi;
-            half_pair(tmax, t_lo, t_hi);
-            tmax = fmaxf(t_lo, t_hi);
-        }
-        // Deferred rescale: keep the old running max while the tile max exceeds it by at most
-        // RESCALE_THR (in exponent units), so P stays <= 2^THR and the O rescale pass is skipped.
-        // The decision is wave-uniform; when taken, O, l and the new P all move to the new max
-        // before anything is accumulated, so no term is ever at a stale scale.
-        const float c = p.scale_log2e;
-        if (!__all((tmax - m_run) * c <= RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);     // first tile: 2^-inf = 0
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-        }
-        const float mc = m_run * c;
-        // two scores per VALU op where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32); v_exp_f32 is scalar
-        const f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
-        f32x2 psum2 = {0.f, 0.f};
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 sv = {s[b][r], s[b][r + 1]};
-                const f32x2 e = __builtin_elementwise_fma(sv, c2, nmc2);
-                const f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-                psum2 += pv;
-                pf[b][r >> 3][r & 7] = f2bf(pv[0]);
-                pf[b][r >> 3][(r & 7) + 1] = f2bf(pv[1]);
+    bool more = true;
+    bool first_seg = true;
+    while (more) {
+        int head, qt, ta, tb, ub = 0;
+        if constexpr (SK) {
+            int u;
+            if (ra < full_rounds) {
+                u = ra * wl + j;
+                ta = 0;
+                tb = nt;
+                ++ra;
+            } else if (it_hi > it_lo) {
+                ub = (it_hi - 1) / nt;
+                ta = max(it_lo, ub * nt) - ub * nt;
+                tb = it_hi - ub * nt;
+                it_hi = ub * nt + ta;
+                u = rem_base + ub;
+            } else {
+                break;
             }
-        l_run += psum2[0] + psum2[1];
+            more = ra < full_rounds || it_hi > it_lo;
+            const int ug = u_base + u;
+            head = ug / nqt;
+            qt = ug - head * nqt;
+            if (!first_seg) __syncthreads();        // every wave is done reading the previous segment's last tile
+            first_seg = false;
+        } else {
+            head = blockIdx.y;
+            qt = blockIdx.x;
+            ta = 0;
+            tb = nt;
+            more = false;
+        }
+        const int q0 = qt * QB + wv * 32;
 
-        // ---- O^T += V^T . P^T ----
-        static_for<0, NV>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            if constexpr (i + DV < NV) read_v(std::integral_constant<int, i + DV>{});
-            lds_wait<(i + DV < NV ? DV : NV - 1 - i)>(vf[i]);
-            o[i / 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[i]), pf[(i % 4) / 2][i % 2], o[i / 4], 0, 0, 0);
-        });
-    };
+        // ---- Q fragments (B operand): Q[q0 + l31][16*ks + 8*hi .. +8], kept in registers ----
+        bf16x8 qf[NKS];
+        {
+            const int qrow = min(q0 + l31, p.Nq - 1);
+            const bf16* qp = p.Q + (long)qrow * p.ldq + head * HD + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+        }
+        const bf16* k_head = p.K + head * HD;
+        const bf16* v_head = p.VT + (long)head * p.vt_head_stride;
+        unsigned k_off[NJ];                                                // element offset of this lane's K row, next tile to stage
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) k_off[j] = k_row0[j] + (unsigned)ta * k_step;
+        // piece i of tile t's staging into buffer `buf`: pieces [0, NJ) are K, [NJ, 2 NJ) are V^T. One LDS-DMA issue
+        // costs the wave ~50 cycles (a burst of 8: ~100 each), so the pieces are spread between the QK MFMAs.
+        auto stage_piece = [&](int t, int buf, int i) {
+            const unsigned dst = lds0 + buf * STAGE + wv * (NJ * 1024);
+            if (i < NJ) {
+                glds16(k_head + k_col[i] + min(k_off[i], k_last), dst + i * 1024);
+                k_off[i] += k_step;
+            } else {
+                glds16(v_head + v_ofs[i - NJ] + t * KVB, dst + K_TILE + (i - NJ) * 1024);
+            }
+        };
 
-    const int nfull = p.Nkv / KVB;
-    for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
-    if (nfull < nt) tile(nfull, std::true_type{});
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ---- finalize: lane owns query q0+l31, dims d*32 + (r&3) + 8*(r>>2) + 4*hi ----
-    float l_lo, l_hi;
-    half_pair(l_run, l_lo, l_hi);
-    const float l_tot = l_lo + l_hi;
-    const float inv = 1.0f / l_tot;
-    const int qrow = q0 + l31;
-    if (qrow < p.Nq) {
-        bf16* op = p.O + (long)qrow * p.ldo + head * HD + 4 * hi;
+        f32x16 o[ND];
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 v;
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = f2bf(o[d][g * 4 + e] * inv);
-                *(bf16x4*)(op + d * 32 + g * 8) = v;
+        for (int i = 0; i < 2 * NJ; ++i) stage_piece(ta, 0, i);
+
+        // One KV tile. MASKED is a compile-time flag: only the ragged last tile carries the key-bound compares (left
+        // in the common body, hipcc if-converts them into ~115 predicated VALU ops on EVERY tile -- SQ_INSTS_VALU
+        // showed 236 non-MFMA VALU per tile against 32 MFMAs).
+        auto tile = [&](const int t, auto masked) __attribute__((always_inline)) {
+            constexpr bool MASKED = decltype(masked)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int tn = min(t + 1, tb - 1);          // the tail re-stages the last tile into the idle buffer (branch-free body)
+            const int nbuf = (t - ta + 1) & 1;
+            const unsigned sbase = lds0 + ((t - ta) & 1) * STAGE;
+
+            // ---- S^T = K . Q^T  (two 32-key blocks); fragment i = b * NKS + ks ----
+            f32x16 s[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+            u32x4 kf[NK];
+            auto read_k = [&](auto I) {
+                constexpr int i = decltype(I)::value;
+                kf[i] = lds_read16<(i / NKS) * 32 * 2 * HD>(sbase + k_lane[i % NKS]);
+            };
+            static_for<0, DK>(read_k);
+            static_for<0, NK>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if constexpr (i + DK < NK) read_k(std::integral_constant<int, i + DK>{});
+                lds_wait<(i + DK < NK ? DK : NK - 1 - i)>(kf[i]);
+                s[i / NKS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[i]), qf[i % NKS], s[i / NKS], 0, 0, 0);
+                if constexpr ((i & 1) && i / 2 < 2 * NJ) stage_piece(tn, nbuf, i / 2);
+            });
+            static_for<NK / 2, 2 * NJ>([&](auto I) { stage_piece(tn, nbuf, decltype(I)::value); });
+
+            // ---- mask the ragged tail, running max (raw score domain; the softmax scale * log2(e) is
+            //      folded into one fma in front of v_exp_f32: p = 2^(s*c - m*c)) ----
+            if constexpr (MASKED) {
+                const int kv0 = t * KVB;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (kv >= p.Nkv) s[b][r] = -INFINITY;
+                    }
             }
+            // first V^T fragments go out before the row max and the exponentials, which hide their LDS latency
+            // (and part of the MFMA-result wait below);
+            // fragment i = d * 4 + (2 b + k2)
+            u32x4 vf[NV];
+            auto read_v = [&](auto I) {
+                constexpr int i = decltype(I)::value;
+                vf[i] = lds_read16<(i / 4) * 32 * 128>(sbase + v_lane[i % 4]);
+            };
+            static_for<0, DV>(read_v);
+
+            float tmax = -INFINITY;
+            mfma_result_guard(s[0], s[1], tmax);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = max3(tmax, s[0][r], s[1][r]);
+            {   // other lane half: VALU swap, no LDS-queue operation between the counted waits
+                float t_lo, t_hi;
+                half_pair(tmax, t_lo, t_hi);
+                tmax = fmaxf(t_lo, t_hi);
+            }
+            // Deferred rescale: keep the old running max while the tile max exceeds it by at most
+            // RESCALE_THR (in exponent units), so P stays <= 2^THR and the O rescale pass is skipped.
+            // The decision is wave-uniform; when taken, O, l and the new P all move to the new max
+            // before anything is accumulated, so no term is ever at a stale scale.
+            const float c = p.scale_log2e;
+            if (!__all((tmax - m_run) * c <= RESCALE_THR)) {
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);     // first tile: 2^-inf = 0
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            const float mc = m_run * c;
+            // two scores per VALU op where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32); v_exp_f32 is scalar
+            const f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
+            f32x2 psum2 = {0.f, 0.f};
+            bf16x8 pf[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 sv = {s[b][r], s[b][r + 1]};
+                    const f32x2 e = __builtin_elementwise_fma(sv, c2, nmc2);
+                    const f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                    psum2 += pv;
+                    pf[b][r >> 3][r & 7] = f2bf(pv[0]);
+                    pf[b][r >> 3][(r & 7) + 1] = f2bf(pv[1]);
+                }
+            l_run += psum2[0] + psum2[1];
+
+            // ---- O^T += V^T . P^T ----
+            static_for<0, NV>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if constexpr (i + DV < NV) read_v(std::integral_constant<int, i + DV>{});
+                lds_wait<(i + DV < NV ? DV : NV - 1 - i)>(vf[i]);
+                o[i / 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[i]), pf[(i % 4) / 2][i % 2], o[i / 4], 0, 0, 0);
+            });
+        };
+
+        const int t_unmasked_end = min(tb, nfull);
+        for (int t = ta; t < t_unmasked_end; ++t) tile(t, std::false_type{});
+        if (nfull < tb) tile(nfull, std::true_type{});
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        if constexpr (SK) {
+            using SL = SkSlot<HD>;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, 0x7fffffff, 0x00020000);
+            if (tb < nt) {
+                // a piece that does not end its unit (head or middle piece): publish (O, m, l) write-through (sc1: the bytes
+                // leave this XCD's L2), drain, then ONE lane raises the flag.  A workgroup publishes at most once per launch.
+                const int base = blockIdx.x * SL::BYTES + wv * SL::WAVE_BYTES + lane * 16;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {o[d][g * 4], o[d][g * 4 + 1], o[d][g * 4 + 2], o[d][g * 4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, base + (d * 4 + g) * 1024, 0, 16);
+                    }
+                const f32x2 ml = {m_run, l_run};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ml), rs,
+                                                      blockIdx.x * SL::BYTES + wv * SL::WAVE_BYTES + ND * 4 * 1024 + lane * 8, 0, 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            if (ta > 0) {
+                // tail piece: the earlier pieces of this unit were published by the workgroups `first .. j-1` of this group
+                // (all lower-numbered, dispatched earlier; each did so BEFORE its own tail piece).  One lane polls relaxed, one
+                // agent-scope acquire, barrier, then every wave folds its slabs in piece order (fixed -> bit-reproducible).
+                const int X = ub * nt;
+                int first = (int)((long)X * wlb / tot_b);
+                while (range_lo(first + 1) <= X) ++first;
+                while (range_lo(first) > X) --first;
+                if (tid == 0) {
+                    for (int k = first; k < j; ++k)
+                        while (__hip_atomic_load(p.sk_flags + k * slot_stride + slot_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                            __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const float c = p.scale_log2e;
+                for (int k = first; k < j; ++k) {
+                    const int sb = (k * slot_stride + slot_off) * SL::BYTES + wv * SL::WAVE_BYTES;
+                    const f32x2 ml = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, sb + ND * 4 * 1024 + lane * 8, 0, 16));
+                    const float m_new = fmaxf(ml[0], m_run);
+                    const float a1 = __builtin_amdgcn_exp2f((ml[0] - m_new) * c), a2 = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+                    m_run = m_new;
+                    l_run = ml[1] * a1 + l_run * a2;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, sb + lane * 16 + (d * 4 + g) * 1024, 0, 16));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[d][g * 4 + e] = v[e] * a1 + o[d][g * 4 + e] * a2;
+                        }
+                }
+                __syncthreads();            // every wave has its slabs: the flags go back to 0 for the next launch
+                if (tid == 0)
+                    for (int k = first; k < j; ++k)
+                        __hip_atomic_store(p.sk_flags + k * slot_stride + slot_off, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+
+        // ---- finalize: lane owns query q0+l31, dims d*32 + (r&3) + 8*(r>>2) + 4*hi ----
+        float l_lo, l_hi;
+        half_pair(l_run, l_lo, l_hi);
+        const float l_tot = l_lo + l_hi;
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + l31;
+        if (qrow < p.Nq) {
+            bf16* op = p.O + (long)qrow * p.ldo + head * HD + 4 * hi;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = f2bf(o[d][g * 4 + e] * inv);
+                    *(bf16x4*)(op + d * 32 + g * 8) = v;
+                }
+        }
     }
 }
 
@@ -324,22 +473,70 @@ __global__ __launch_bounds__(256) void vt_transpose_kernel(const bf16* __restric
 
 }  // namespace
 
+// Stream-K geometry for a problem: number of persistent workgroups (0 = use the plain grid) and whether the heads are
+// dealt to the XCDs.  Only problems that need MORE than one round of the 2-per-CU slots are worth it.
+static int sk_workers(const AttnParams& p, bool* xcd) {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        slots = 2 * prop.multiProcessorCount;
+    }
+    const int nqt = (p.Nq + QB - 1) / QB;
+    const long units = (long)nqt * p.H;
+    if (units <= slots || slots % 8) return 0;
+    // the plain grid already runs units/slots rounds at rounds/ceil(rounds) efficiency: stream-K pays (a few us of partial
+    // hand-off per workgroup) only when the last round is badly filled -- 864 units on 512 slots: 0.84; 3456 units: 0.96
+    const double rounds = (double)units / slots;
+    if (!p.sk_force && (rounds / (double)((units + slots - 1) / slots) > 0.9 || p.Nkv < 32 * KVB)) return 0;   // short KV (text cross-attention, 16 tiles): measured slower
+    *xcd = p.H % 8 == 0 && (long)(p.H / 8) * nqt >= slots / 8;
+    return slots;
+}
+
+long attn_sk_workspace_bytes(int head_dim) {
+    const long slot = head_dim == 64 ? SkSlot<64>::BYTES : SkSlot<128>::BYTES;
+    return 4096 + 1024L * slot;            // the flags (one 4-KiB page, zero before first use) + up to 1024 workgroup slots
+}
+
 int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.Nq > 0 && p.Nkv > 0 && p.H > 0, "attention: empty problem");
     LTX2_CHECK_ARG(p.head_dim == 0 || p.head_dim == 128 || p.head_dim == 64, "attention: head_dim=%d, only 128 and 64 are implemented", p.head_dim);
     LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
     LTX2_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
     LTX2_CHECK_ARG(p.ldk > 0 && ((long)p.Nkv + 2 * KVB) * p.ldk < (1L << 32), "attention: Nkv * ldk exceeds the 32-bit K row offset");
+    LTX2_CHECK_ARG((long)p.Npad * (p.head_dim == 64 ? 64 : 128) < (1L << 31), "attention: Npad * head_dim exceeds the 32-bit V^T row offset");
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
+    }
+    static const int sk_env = [] {
+        const char* e = getenv("LTX2_ATTN_SK");      // 0: plain grid everywhere (same-box A/B); 2: stream-K without dealing the heads to the XCDs
+        return e ? atoi(e) : 1;
+    }();
+    bool xcd = false;
+    const int workers = (p.sk_ws && sk_env) ? sk_workers(p, &xcd) : 0;
+    if (workers > 0) {
+        LTX2_CHECK_ARG(workers <= 1024 && p.sk_ws_bytes >= attn_sk_workspace_bytes(p.head_dim), "attention: stream-K workspace too small");
+        AttnParams q = p;
+        q.sk_xcd = xcd && sk_env != 2;
+        q.sk_flags = (unsigned*)p.sk_ws;
+        q.sk_ws = (char*)p.sk_ws + 4096;
+        if (p.head_dim == 64)
+            hipLaunchKernelGGL((attn_fwd_kernel<64, true>), dim3(workers), dim3(256), Geo<64>::LDS_BYTES, stream, q);
+        else
+            hipLaunchKernelGGL((attn_fwd_kernel<128, true>), dim3(workers), dim3(256), Geo<128>::LDS_BYTES, stream, q);
+        LTX2_CHECK_LAUNCH("attn_fwd_kernel<SK>");
+        return LTX2_OK;
     }
     dim3 grid((p.Nq + QB - 1) / QB, p.H);
     if (p.head_dim == 64)
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), Geo<64>::LDS_BYTES, stream, p);
+        hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), Geo<64>::LDS_BYTES, stream, p);
     else
-        hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
+        hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
     LTX2_CHECK_LAUNCH("attn_fwd_kernel");
     return LTX2_OK;
 }

@@ -45,6 +45,34 @@ int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
     return gemm_launch(p, epilogue, false, (hipStream_t)stream);
 }
 
+int ltx2_gemm_qkv_vt(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K,
+                     void* vt, int vt_col0, int Npad, int head_dim, int* fused, void* stream) {
+    LTX2_CHECK_ARG(A && W && out && vt, "gemm_qkv_vt: null operand");
+    LTX2_CHECK_ARG(head_dim == 64 || head_dim == 128, "gemm_qkv_vt: head_dim=%d, only 128 and 64 are implemented", head_dim);
+    LTX2_CHECK_ARG(vt_col0 > 0 && vt_col0 < N && (N - vt_col0) % head_dim == 0 && Npad % 64 == 0 && Npad >= M, "gemm_qkv_vt: bad V column range / Npad");
+    GemmParams p{};
+    p.A = (const bf16*)A;
+    p.lda = lda;
+    p.W = (const bf16*)W;
+    p.bias = bias;
+    p.out = out;
+    p.ldo = ldo;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.vt = (bf16*)vt;
+    p.vt_col0 = vt_col0;
+    p.vt_npad = Npad;
+    p.vt_hd = head_dim;
+    p.vt_head_stride = (long)head_dim * Npad;
+    const bool f = gemm_vt_fused(p, EPI_BF16);
+    if (fused) *fused = f ? 1 : 0;
+    if (!f) p.vt = nullptr;
+    int rc = gemm_launch(p, EPI_BF16, false, (hipStream_t)stream);
+    if (rc != LTX2_OK || f) return rc;
+    return vt_transpose_launch((const bf16*)out + vt_col0, ldo, (bf16*)vt, M, Npad, (N - vt_col0) / head_dim, (hipStream_t)stream, head_dim);
+}
+
 int ltx2_gemm_w8a16(const void* A, int64_t lda, const void* W8, const float* wscale, const float* bias, void* out, int64_t ldo, int M,
                     int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table, void* stream) {
     LTX2_CHECK_ARG(A && W8 && wscale && out, "gemm_w8a16: null operand");
@@ -101,9 +129,18 @@ int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const
     return head_gate_launch((bf16*)att, ld, logits, H, rows, H, head_dim, (hipStream_t)stream);
 }
 
+int64_t ltx2_flash_attn_workspace_bytes(int head_dim) { return attn_sk_workspace_bytes(head_dim); }
+
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
                     int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream) {
+    return ltx2_flash_attn_ws(Q, ldq, K, ldk, VT, Npad, out, ldo, Nq, Nkv, H, head_dim, scale, nullptr, 0, stream);
+}
+
+int ltx2_flash_attn_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
+                       int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
     LTX2_CHECK_ARG(Q && K && VT && out, "flash_attn: null operand");
+    LTX2_CHECK_ARG(!workspace || workspace_bytes >= attn_sk_workspace_bytes(head_dim), "flash_attn: workspace smaller than ltx2_flash_attn_workspace_bytes()");
     LTX2_CHECK_ARG(head_dim == 128 || head_dim == 64, "flash_attn: head_dim=%d, only 128 and 64 are implemented", head_dim);
     AttnParams a{};
     a.Q = (const bf16*)Q;
@@ -120,6 +157,9 @@ int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, cons
     a.Npad = Npad;
     a.H = H;
     a.scale_log2e = scale * 1.4426950408889634f;
+    a.sk_ws = workspace;
+    a.sk_ws_bytes = workspace_bytes;
+    a.sk_force = 1;
     return attn_launch(a, (hipStream_t)stream);
 }
 

@@ -93,6 +93,8 @@ struct ltx2_dit {
     long ws_bytes = 0;
     int per_token = 0;
     float* sigmas_dev = nullptr;
+    void* sk_ws = nullptr;             // stream-K attention scratch (attention.h); main-stream launches only
+    long sk_bytes = 0;
     bool prepared = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -120,6 +122,8 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         return p;
     };
     c->sigmas_dev = (float*)take(4L * 64);
+    c->sk_bytes = attn_sk_workspace_bytes(128);
+    c->sk_ws = take(c->sk_bytes);
     for (int k = 0; k < (c->av ? 2 : 1); ++k) {
         Mod& m = c->m[k];
         const long n = k ? Na : N, s = k ? Sa : S;
@@ -303,8 +307,16 @@ int resolve(ltx2_dit* c) {
 
 thread_local ltx2_dit* g_prof_ctx = nullptr;
 
+// vt (optional): where the V third of a fused QKV projection goes as attention's V^T operand; *vt_done says whether the
+// GEMM's epilogue wrote it (else the caller runs vt_transpose_launch on the V columns of `out`).
+struct VtOut {
+    bf16* vt;
+    int col0, npad, hd;
+};
+
 int dense(const bf16* A, long lda, const bf16* W, const float* bias, void* out, long ldo, int M, int N, int K, int epi,
-          hipStream_t st, const float* gate = nullptr, long gate_stride = 0, const float* gate_table = nullptr) {
+          hipStream_t st, const float* gate = nullptr, long gate_stride = 0, const float* gate_table = nullptr,
+          const VtOut* vt = nullptr, bool* vt_done = nullptr) {
     GemmParams p{};
     p.A = A;
     p.lda = lda;
@@ -326,6 +338,15 @@ int dense(const bf16* A, long lda, const bf16* W, const float* bias, void* out, 
     p.gate = gate;
     p.gate_stride = gate_stride;
     p.gate_table = gate_table;
+    if (vt) {
+        p.vt = vt->vt;
+        p.vt_col0 = vt->col0;
+        p.vt_npad = vt->npad;
+        p.vt_hd = vt->hd;
+        p.vt_head_stride = (long)vt->hd * vt->npad;
+        *vt_done = gemm_vt_fused(p, epi);
+        if (!*vt_done) p.vt = nullptr;
+    }
     ltx2_dit* pc = g_prof_ctx;
     const bool prof = pc && (pc->prof_epi == -1 || pc->prof_epi == epi);
     if (prof) {
@@ -372,9 +393,15 @@ int adaln_chain(Mod& m, const AdaW& a, const float* ts, long t_stride, int T, fl
     return LTX2_OK;
 }
 
+// sk: the context's stream-K scratch -- only for launches on the MAIN stream (they are ordered; the audio modality's
+// attention runs beside them on the side stream and keeps the plain grid).
 int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int npad, bf16* out, long ldo, int nq,
-           int nkv, int H, int hd, hipStream_t st) {
+           int nkv, int H, int hd, hipStream_t st, ltx2_dit* sk = nullptr) {
     AttnParams a{};
+    if (sk) {
+        a.sk_ws = sk->sk_ws;
+        a.sk_ws_bytes = sk->sk_bytes;
+    }
     a.Q = q;
     a.ldq = ldq;
     a.K = k;
@@ -445,14 +472,16 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     // self-attention: AdaLN rows (shift, scale, gate) = sst[0:3] + emb[0:3]
     TRY(norm_mod_launch(m.x, D, m.h, D, N, D, eps, 0, w.sst + D, w.sst, emb + D, emb, es, st));
     TRY(gate_logits(c, m, w.self, m.h, D, N, H, st));
-    TRY(dense(m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st));
+    const VtOut vo{m.vt, 2 * D, m.Npad, hd};
+    bool vt_done = false;           // the QKV GEMM's epilogue writes V^T itself where it can (gemm_v4.hip)
+    TRY(dense(m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done));
     {
         const int offs[2] = {0, D};
         const float* wts[2] = {w.self.qn, w.self.kn};
         TRY(qknorm_rope_launch(m.qkv, 3 * D, N, D, hd, 2, offs, wts, eps, m.cosb, m.sinb, st));
     }
-    TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
-    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st));
+    if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
+    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, k == 0 ? c : nullptr));
     TRY(gate_apply(c, m, m.att, N, H, hd, st));
     TRY(dense(m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 2 * D, es, w.sst + 2 * D));
 
@@ -479,7 +508,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
         const float* wts[1] = {w.text.qn};
         TRY(qknorm_rope_launch(m.qkv, D, N, D, hd, 1, offs, wts, eps, nullptr, nullptr, st));
     }
-    TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st));
+    TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st, k == 0 ? c : nullptr));
     TRY(gate_apply(c, m, m.att, N, H, hd, st));
     if (c->v2)
         TRY(dense(m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 8 * D, es, w.sst + 8 * D));
@@ -522,7 +551,7 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st) {
         TRY(qknorm_rope_launch(v.qkv, Da, v.N, Da, hd, 1, offs, wts, eps, v.ccos, v.csin, st));
     }
     TRY(project_kv(a.h, a.N, Da, w.a2v, Da, H, hd, eps, a.ccos, a.csin, a.qkv, a.vt, a.Npad, st));
-    TRY(attend(v.qkv, Da, a.qkv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st));
+    TRY(attend(v.qkv, Da, a.qkv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st, c));
     TRY(gate_apply(c, v, v.att, v.N, H, hd, st));
     TRY(dense(v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, v.cross_gate, 0, tv + 4 * Dv));
     // video -> audio: Q from audio, K/V from video (Dv -> Da)
@@ -833,6 +862,7 @@ int ltx2_dit_prepare(ltx2_dit* c, const float* context, int S, const float* rope
         return LTX2_E_STATE;
     }
     TRY(resolve(c));
+    if (hipMemsetAsync(c->sk_ws, 0, 4096, (hipStream_t)stream) != hipSuccess) return LTX2_E_HIP;   // stream-K flags start at zero
     TRY(prepare_modality(c, 0, context, S, rope_cos, rope_sin, nullptr, nullptr, (hipStream_t)stream));
     c->prepared = true;
     return LTX2_OK;
@@ -849,6 +879,7 @@ int ltx2_dit_prepare_av(ltx2_dit* c, const float* v_context, int S, const float*
         return LTX2_E_STATE;
     }
     TRY(resolve(c));
+    if (hipMemsetAsync(c->sk_ws, 0, 4096, (hipStream_t)stream) != hipSuccess) return LTX2_E_HIP;   // stream-K flags start at zero
     TRY(prepare_modality(c, 0, v_context, S, v_cos, v_sin, v_cross_cos, v_cross_sin, (hipStream_t)stream));
     TRY(prepare_modality(c, 1, a_context, Sa, a_cos, a_sin, a_cross_cos, a_cross_sin, (hipStream_t)stream));
     c->prepared = true;

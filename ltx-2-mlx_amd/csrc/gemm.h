@@ -32,11 +32,21 @@ struct GemmParams {
                          // 2: zero padding in H/W + replicate T (VAE encoder)
     // depth-to-space epilogue: column n = s*Cf + c, s = (a*fh + b)*fw + d
     int ft, fh, fw, Cf, cf_shift, drop_first, d2s_residual, c_d2s;
+    // gemm_v4.hip, EPI_BF16, dense, layout 3: output columns >= vt_col0 (the V third of a fused QKV projection) are written
+    // TRANSPOSED and key-permuted as attention's V^T operand vt[h][vt_hd][vt_npad] (attention.hip, vt_transpose_kernel's
+    // layout: rows >= M zero-filled up to vt_npad) instead of into `out`; null = off.  gemm_v4_vt_supported() says when.
+    bf16* vt;
+    long vt_head_stride;
+    int vt_col0, vt_npad, vt_hd;
+    int v4_full_tiles;   // gemm_v4.hip: 1 = the ragged last row tile runs the full-height K loop (LTX2_V4_SHORT=0, same-box A/B)
     int splitk;          // gemm_v4.hip: K split over this many blocks per tile (fp32 slabs + reduce); 0 / 1 = off
     void* dbg;           // ping-pong kernel: optional device buffer for interval timestamps (debug)      // ping-pong kernel: which wave bit selects the staggered group (tuning knob)
 };
 
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream);
+// p.vt set: will gemm_launch route this problem to the kernel that writes V^T from its epilogue?  (false: clear p.vt and run
+// vt_transpose_launch after the GEMM; gemm_launch rejects a p.vt it cannot honour.)
+bool gemm_vt_fused(const GemmParams& p, int epilogue);
 
 // Skinny path (M <= 16 rows, fp32 activations, bf16 weights): out_f32 = act_out(in_act(a) @ W^T + b)
 // act codes: 0 none, 1 silu, 2 gelu_tanh

@@ -319,8 +319,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ a, 
 
 }  // namespace
 
+bool gemm_vt_fused(const GemmParams& p, int epilogue) {
+    static const bool on = [] {
+        const char* e = getenv("LTX2_VT_FUSE");       // 0: always the separate transpose pass (same-box A/B)
+        return !e || atoi(e) != 0;
+    }();
+    if (!on || !p.vt || p.lda % 8 != 0) return false;
+    if (p.W8) return gemm_v4_vt_supported(p, epilogue, 3);
+    return tile_override() == 0 && v4_layout() == 3 && use_big_tile(p) && gemm_v4_vt_supported(p, epilogue, 3);
+}
+
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream) {
     LTX2_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+    LTX2_CHECK_ARG(!p.vt || (!conv && gemm_vt_fused(p, epilogue)), "gemm: a fused V^T output needs the 4-wave layout-3 kernel (ask gemm_vt_fused first)");
     LTX2_CHECK_ARG(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
     LTX2_CHECK_ARG(p.A && (p.W || p.W8) && p.out, "gemm: null operand");
     if (p.W8) {     // fp8-resident weights exist only on the 4-wave asm-loop kernel

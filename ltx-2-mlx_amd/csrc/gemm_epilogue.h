@@ -181,7 +181,8 @@ int gemm_pp_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t str
 // layout 0: 1x4 waves, 32x32x16 MFMA; 1: 2x2 waves, 32x32x16; 2: 2x2 waves, 16x16x32; 3: 1x4 waves, 16x16x32 (default);
 // 4: BN = 128, 4x1 waves, 16x16x32.  bm: 0 = pick, 224 | 256 (448 | 512 for layout 4).
 bool gemm_v4_supported(const GemmParams& p, int epilogue, bool conv);
-bool gemm_v4_w8_supported(const GemmParams& p, int epilogue);     // p.W8 / p.wscale set: fp8-resident weights
+bool gemm_v4_w8_supported(const GemmParams& p, int epilogue);
+bool gemm_v4_vt_supported(const GemmParams& p, int epilogue, int layout);   // p.vt set: V^T written by the epilogue     // p.W8 / p.wscale set: fp8-resident weights
 int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int layout, int bm);
 // implicit-GEMM conv over a PADDED activation volume (p.A = [T+2][H+2][Wd+2][Cin], padding rule applied by the producer;
 // p.T / p.H / p.Wd = output extent): EPI_BF16 / EPI_ADD_BF16, Cin >= 128, Cout % 128 == 0

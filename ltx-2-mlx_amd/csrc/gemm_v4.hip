@@ -93,9 +93,15 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     u32x16 voffA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u32x8 voffB = {0, 0, 0, 0, 0, 0, 0, 0};
     const int Hp = p.H + 2, Wp = p.Wd + 2;
+    // layout 3, 224-row tiles, dense bf16 weights: the ragged last row tile runs a K loop over only the row blocks that hold real
+    // rows (6 of 14 for 3456 rows, 10 of 14 for 13824) -- fewer DMA pieces per wave, so the wave -> tile-row mapping shrinks with it
+    constexpr bool SHORT_OK = LAYOUT == 3 && BM == 224 && !CONV;
+    const int valid_rows = p.M - m0;
+    const int short_rb = (!SHORT_OK || p.v4_full_tiles) ? 0 : valid_rows <= 96 ? 6 : valid_rows <= 160 ? 10 : 0;      // block-uniform
+    const int npa_rt = short_rb ? short_rb / 2 : NPA;
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
-        const int r = (w * NPA + j) * 8 + (lane >> 3);
+        const int r = (w * npa_rt + j) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         const int m = min(m0 + r, p.M - 1);
         if constexpr (CONV) {       // output position (t, h, w) = padded position of its (0,0,0) tap
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     }
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(W8 ? (void*)p.W8 : (void*)p.W, 0, 0x7fffffff, 0x00020000);
-    const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + w * NPA * 1024);
+    const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + w * npa_rt * 1024);
     const unsigned lw = __builtin_amdgcn_readfirstlane(lds0 + G::W_BASE + w * NPW * 1024);
     const unsigned nk = __builtin_amdgcn_readfirstlane(p.K / 64 / (p.splitk > 1 ? p.splitk : 1));
     const unsigned kb = __builtin_amdgcn_readfirstlane(split * nk);
@@ -167,9 +173,14 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             const float sv = p.wscale[n0 + wc * WN + cb * MB + lr];
             scl[2 * cb] = scl[2 * cb + 1] = __builtin_bit_cast(unsigned, sv);
         }
-        if constexpr (BM == 224)
-            asm volatile(LTX2_V4_L14_M16_RB14_W8 : V4_OUT16 V4_INS_DENSE, LTX2_V4_L14_M16_RB14_W8_SCL(scl) : LTX2_V4_L14_M16_RB14_W8_CLOBBERS);
-        else
+        if constexpr (BM == 224) {
+            if (short_rb == 6)
+                asm volatile(LTX2_V4_L14_M16_RB6_W8 : V4_OUT16 V4_INS_DENSE, LTX2_V4_L14_M16_RB6_W8_SCL(scl) : LTX2_V4_L14_M16_RB6_W8_CLOBBERS);
+            else if (short_rb == 10)
+                asm volatile(LTX2_V4_L14_M16_RB10_W8 : V4_OUT16 V4_INS_DENSE, LTX2_V4_L14_M16_RB10_W8_SCL(scl) : LTX2_V4_L14_M16_RB10_W8_CLOBBERS);
+            else
+                asm volatile(LTX2_V4_L14_M16_RB14_W8 : V4_OUT16 V4_INS_DENSE, LTX2_V4_L14_M16_RB14_W8_SCL(scl) : LTX2_V4_L14_M16_RB14_W8_CLOBBERS);
+        } else
             asm volatile(LTX2_V4_L14_M16_RB16_W8 : V4_OUT16 V4_INS_DENSE, LTX2_V4_L14_M16_RB16_W8_SCL(scl) : LTX2_V4_L14_M16_RB16_W8_CLOBBERS);
     } else if constexpr (CONV) {
         if constexpr (LAYOUT == 3) {
@@ -197,8 +208,11 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             V4_ASM(LTX2_V4_L22_RB4);
         }
     } else if constexpr (LAYOUT == 3) {
-        if constexpr (BM == 224) V4_ASM(LTX2_V4_L14_M16_RB14);
-        else V4_ASM(LTX2_V4_L14_M16_RB16);
+        if constexpr (BM == 224) {
+            if (short_rb == 6) V4_ASM(LTX2_V4_L14_M16_RB6);
+            else if (short_rb == 10) V4_ASM(LTX2_V4_L14_M16_RB10);
+            else V4_ASM(LTX2_V4_L14_M16_RB14);
+        } else V4_ASM(LTX2_V4_L14_M16_RB16);
     } else if constexpr (LAYOUT == 4) {
         if constexpr (BM == 448) V4_ASM(LTX2_V4_L41_M16_RB7);
         else V4_ASM(LTX2_V4_L41_M16_RB8);
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < RBH; ++r) {
                 const int rb = half * RBH + r;
-                if (rb >= RBW || wr * WM + rb * MB >= BM) continue;
+                if (rb >= RBW || wr * WM + rb * MB >= BM || m0 + wr * WM + rb * MB >= p.M) continue;     // (block-uniform)
                 const int row = min(m0 + wr * WM + rb * MB + lr, p.M - 1);        // clamped for the load; the store checks
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb)
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < RBH; ++r) {
                 const int rb = half * RBH + r;
-                if (rb >= RBW || wr * WM + rb * MB >= BM) continue;
+                if (rb >= RBW || wr * WM + rb * MB >= BM || m0 + wr * WM + rb * MB >= p.M) continue;
                 const int row = m0 + wr * WM + rb * MB + lr;
                 const bool ok = row < p.M;
 #pragma unroll
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         char* wl = smem + w * (WM * ROWB);
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
+            if (m0 + wr * WM + rb * MB >= p.M) continue;     // no real row in this block (block-uniform): its slab rows are never read as data
             const int r = rb * MB + lr;
             const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
 #pragma unroll
@@ -323,13 +338,41 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                 *(bf16x4*)(wl + r * ROWB + chunk * 16 + (kq & 1) * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
             }
         }
+        if (LAYOUT == 3 && EPI == EPI_BF16 && !CONV && p.vt && n0 >= p.vt_col0) {
+            // V tile of a fused QKV projection: this wave's 64 columns are 64 dims of ONE head; leave as V^T rows
+            // vt[head][d][.] with attention's key order inside every 32-key block: position 16 ks + 8 hh + 4 g0 + e holds
+            // key 8 (2 ks + g0) + 4 hh + e.  One instruction stores 16 dims x 64 bytes (4 chunks of 8 positions); every chunk is
+            // two runs of 4 consecutive keys gathered from the slab with 2-byte LDS reads.  Keys >= M are zeros (up to Npad).
+            const int cw = n0 + wc * WN - p.vt_col0;
+            const int head = cw / p.vt_hd, d0 = cw - head * p.vt_hd;
+            bf16* vrow = p.vt + (long)head * p.vt_head_stride + (long)(d0 + (lane >> 2)) * p.vt_npad + m0;
+#pragma unroll 1
+            for (int dg = 0; dg < WN / 16; ++dg) {
+                const int c = dg * 16 + (lane >> 2);                     // column of the slab = dim d0 + c
+                const int coff = (c & 7) * 2, cchunk = c >> 3;
 #pragma unroll
-        for (int it = 0; it < WM / RPI; ++it) {
-            const int r = it * RPI + lane / CPR, c = lane % CPR;
-            const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
-            const u32x4 v = *(const u32x4*)(wl + r * ROWB + ((c ^ sw) << 4));
-            const int row = m0 + wr * WM + r;
-            if (row < p.M) *(u32x4*)((bf16*)p.out + (long)row * p.ldo + n0 + wc * WN + c * 8) = v;
+                for (int cg = 0; cg < BM / 32; ++cg) {
+                    const int ch = cg * 4 + (lane & 3);                   // 8-position chunk of the tile's key range
+                    const int kbase = (ch >> 2) * 32 + ((ch >> 1) & 1) * 16 + (ch & 1) * 4;      // first key of the chunk's first run
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = kbase + (e >> 2) * 8 + (e & 3);
+                        const bf16 x = *(const bf16*)(wl + r * ROWB + ((cchunk ^ ((r >> 1) & 7)) << 4) + coff);
+                        v[e] = (m0 + r < p.M) ? x : f2bf(0.f);
+                    }
+                    if (m0 + ch * 8 < p.vt_npad) *(bf16x8*)(vrow + (long)dg * 16 * p.vt_npad + ch * 8) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < WM / RPI; ++it) {
+                const int r = it * RPI + lane / CPR, c = lane % CPR;
+                const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
+                const u32x4 v = *(const u32x4*)(wl + r * ROWB + ((c ^ sw) << 4));
+                const int row = m0 + wr * WM + r;
+                if (row < p.M) *(u32x4*)((bf16*)p.out + (long)row * p.ldo + n0 + wc * WN + c * 8) = v;
+            }
         }
     } else {
 #pragma unroll
@@ -360,7 +403,13 @@ int launch_v4(const GemmParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     }
     const int Mt = (p.M + BM - 1) / BM, Nt = p.N / G::BN;
-    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt * (p.splitk > 1 ? p.splitk : 1)), dim3(256), G::LDS_BYTES, stream, p);
+    static const bool full_tiles = [] {
+        const char* e = getenv("LTX2_V4_SHORT");
+        return e && atoi(e) == 0;
+    }();
+    GemmParams q = p;
+    q.v4_full_tiles = full_tiles;
+    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt * (p.splitk > 1 ? p.splitk : 1)), dim3(256), G::LDS_BYTES, stream, q);
     LTX2_CHECK_LAUNCH("gemm_v4_kernel");
     return LTX2_OK;
 }
@@ -398,6 +447,17 @@ bool gemm_v4_supported(const GemmParams& p, int epilogue, bool conv) {
     if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.K * 2 >= (1L << 31)) return false;     // 32-bit buffer offsets
     if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15)) return false;                                       // 16-byte output rows
     return true;
+}
+
+// Fused V^T output (GemmParams::vt): layout 3, dense, EPI_BF16; V columns start on a tile boundary, a wave's 64 columns stay
+// inside one head, and the row tiles reach vt_npad (the zero padding of the last 64-key block is written by the last tile).
+bool gemm_v4_vt_supported(const GemmParams& p, int epilogue, int layout) {
+    if (epilogue != EPI_BF16 || layout != 3 || !p.vt) return false;
+    if (!(p.W8 ? gemm_v4_w8_supported(p, epilogue) : gemm_v4_supported(p, epilogue, false))) return false;
+    if (p.vt_col0 % 256 != 0 || (p.vt_hd != 64 && p.vt_hd != 128) || (p.N - p.vt_col0) % p.vt_hd != 0) return false;
+    if (p.vt_npad % 64 != 0 || p.vt_npad < p.M) return false;
+    const int bm = v4_prefer_224(p) ? 224 : 256;
+    return (long)((p.M + bm - 1) / bm) * bm >= p.vt_npad;
 }
 
 bool gemm_v4_w8_supported(const GemmParams& p, int epilogue) {

@@ -53,6 +53,7 @@ S_T, S_NK1, S_TMP = "s94", "s95", "s96"
 S_TAP, S_C0, S_TAPOFF = "s97", ("s98", "s99"), ("s90", "s91")
 SCRATCH_S = ["s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"]
 VGPR_TOP_MAX = 224
+MFMA_ORDER = next((a.split('=')[1] for a in sys.argv if a.startswith('--order=')), 'rbsnake')     # cbmajor | snake | rbmajor | rbsnake (measured best: one operand register changes per MFMA)
 
 
 class Gen:
@@ -179,6 +180,12 @@ class Gen:
     # one k-step: MFMAs on `cur`, reads of (rstage, rks) into `nxt`, DMA pieces in the given slots
     def kstep(self, cur, nxt, rstage, rks, rtag, dma_list, dma_slots, dstage, dtag):
         order = [(rb, cb) for cb in range(self.cbw) for rb in range(self.rbw)]
+        if MFMA_ORDER == "snake":         # reverse every other column pass: only one operand register changes between MFMAs
+            order = [(rb if cb % 2 == 0 else self.rbw - 1 - rb, cb) for cb in range(self.cbw) for rb in range(self.rbw)]
+        elif MFMA_ORDER == "rbmajor":     # activation fragment fixed over cbw consecutive MFMAs
+            order = [(rb, cb) for rb in range(self.rbw) for cb in range(self.cbw)]
+        elif MFMA_ORDER == "rbsnake":
+            order = [(rb, cb if rb % 2 == 0 else self.cbw - 1 - cb) for rb in range(self.rbw) for cb in range(self.cbw)]
         reads = self.read_order()
         read_at = {i * self.reads_every: r for i, r in enumerate(reads)}
         dma_at = dict(zip(dma_slots, dma_list))
@@ -192,10 +199,14 @@ class Gen:
             for cb in range(self.cbw):
                 ops += self.expand(nxt, cb)
             room = self.nmf - 1 - s0
-            assert room * 2 >= len(ops), (room, len(ops))
+            assert room >= 8, (room, len(ops))
             k = 0
             for slot in range(s0, self.nmf - 1):
-                take = 2 if (len(ops) - k) > (self.nmf - 1 - slot) else 1
+                left = self.nmf - 1 - slot
+                if room * 2 >= len(ops):
+                    take = 2 if (len(ops) - k) > left else 1
+                else:                                       # short last-row-tile variants: up to 4 per slot, spread evenly
+                    take = -(-(len(ops) - k) // left)
                 valu_at[slot] = ops[k:k + take]
                 k += take
                 if k >= len(ops):
@@ -511,6 +522,12 @@ def main():
         sfx = "_CONV" if conv else ""
         out.append(variant("LTX2_V4_L14_M16_RB14" + sfx, 14, 4, mb=16, npa=7, dma_last=d14, dma_ks0=[], m0_early=True, conv=conv))
         out.append(variant("LTX2_V4_L14_M16_RB16" + sfx, 16, 4, mb=16, npa=8, dma_last=d16, dma_ks0=[], m0_early=True, conv=conv))
+        if not conv:
+            # the ragged LAST row tile of a 224-row grid (3456 rows = 15 tiles + 96 rows; 13824 = 61 + 160): only the row blocks
+            # that hold real rows are staged and multiplied -- the chip runs at its power cap, so MFMAs on clamped duplicate
+            # rows cost real time elsewhere
+            out.append(variant("LTX2_V4_L14_M16_RB6", 6, 4, mb=16, npa=3, dma_last=list(range(1, 23, 2)), dma_ks0=[], m0_early=True))
+            out.append(variant("LTX2_V4_L14_M16_RB10", 10, 4, mb=16, npa=5, dma_last=list(range(1, 40, 3)), dma_ks0=[], m0_early=True))
         # layout 4: BN = 128, 4x1 waves, 16x16x32: 7|8 x 8 blocks per wave (tile 448|512 x 128)
         out.append(variant("LTX2_V4_L41_M16_RB7" + sfx, 7, 8, mb=16, npa=14, npw=4, a_stage=57344, w_base=114688, w_stage=16384,
                            dma_last=list(range(0, 54, 3)), dma_ks0=[], m0_early=True, conv=conv))
@@ -519,6 +536,8 @@ def main():
     # layout 3 with fp8-resident weights: W stage = 256 rows x 64 B
     out.append(variant("LTX2_V4_L14_M16_RB14_W8", 14, 4, mb=16, npa=7, npw=4, w_stage=16384, dma_last=list(range(0, 44, 4)), dma_ks0=[], m0_early=True, w8=True))
     out.append(variant("LTX2_V4_L14_M16_RB16_W8", 16, 4, mb=16, npa=8, npw=4, w_stage=16384, dma_last=list(range(3, 50, 4)), dma_ks0=[], m0_early=True, w8=True))
+    out.append(variant("LTX2_V4_L14_M16_RB6_W8", 6, 4, mb=16, npa=3, npw=4, w_stage=16384, dma_last=list(range(1, 22, 3)), dma_ks0=[], m0_early=True, w8=True))
+    out.append(variant("LTX2_V4_L14_M16_RB10_W8", 10, 4, mb=16, npa=5, npw=4, w_stage=16384, dma_last=list(range(1, 37, 4)), dma_ks0=[], m0_early=True, w8=True))
     if "--probe" in sys.argv:
         e4 = list(range(3, 64, 4))
         out.append(variant("LTX2_V4_L14_RB8_NODMA", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, no_dma=True))

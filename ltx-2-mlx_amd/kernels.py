@@ -41,6 +41,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_qkv_vt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], heads: int, head_dim: int = 128):
+    """Fused QKV projection: returns (qkv [M, 3D] bf16 -- V columns only written on the unfused path --, vt [H, hd, Npad], fused)."""
+    assert a.dtype == BF16 and w.dtype == BF16
+    a, w = _c(a), _c(w)
+    M, K = a.shape
+    N = w.shape[0]
+    D = heads * head_dim
+    assert N == 3 * D
+    npad = (M + 63) // 64 * 64
+    out = torch.empty(M, N, device=a.device, dtype=BF16)
+    vt = torch.empty(heads, head_dim, npad, device=a.device, dtype=BF16)
+    import ctypes
+    fused = ctypes.c_int(0)
+    nv.check(nv.lib().ltx2_gemm_qkv_vt(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
+                                       nv.ptr(vt), 2 * D, npad, head_dim, ctypes.byref(fused), nv.stream()))
+    return out, vt, bool(fused.value)
+
+
 def gemm_w8a16(a: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = nv.EPI_BF16,
                out: Optional[torch.Tensor] = None, gate_table: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ dequant(w8)[N,K]^T + bias) with fp8-RESIDENT weights: w8 = float8_e4m3fn codes (uint8 view
@@ -202,16 +220,25 @@ def vt_transpose(v: torch.Tensor, heads: int, head_dim: int = 128) -> torch.Tens
     return vt
 
 
+def flash_attn_workspace(head_dim: int, device) -> torch.Tensor:
+    """Scratch for the stream-K launch form of flash_attn (flags zeroed here; every launch leaves them zero)."""
+    ws = torch.empty(int(nv.lib().ltx2_flash_attn_workspace_bytes(head_dim)), device=device, dtype=torch.uint8)
+    ws[:4096].zero_()
+    return ws
+
+
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int,
-               scale: Optional[float] = None) -> torch.Tensor:
-    """q [Nq, H*hd], k [Nkv, H*hd] bf16 (row-strided views allowed), vt [H,hd,Npad] from vt_transpose (hd 128 or 64)."""
+               scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [Nq, H*hd], k [Nkv, H*hd] bf16 (row-strided views allowed), vt [H,hd,Npad] from vt_transpose (hd 128 or 64).
+    workspace (flash_attn_workspace): lets grids of more than one round of workgroup slots run stream-K."""
     assert q.dtype == BF16 and k.dtype == BF16 and vt.dtype == BF16 and q.stride(1) == 1 and k.stride(1) == 1
     nq, hd = q.shape[0], vt.shape[1]
     out = torch.empty(nq, heads * hd, device=q.device, dtype=BF16)
     if scale is None:
         scale = 1.0 / math.sqrt(float(hd))
-    nv.check(nv.lib().ltx2_flash_attn(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out),
-                                      out.stride(0), nq, nkv, heads, hd, scale, nv.stream()))
+    nv.check(nv.lib().ltx2_flash_attn_ws(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out),
+                                         out.stride(0), nq, nkv, heads, hd, scale, nv.ptr(workspace),
+                                         workspace.numel() if workspace is not None else 0, nv.stream()))
     return out
 
 

@@ -216,6 +216,52 @@ def test_flash_attn_bit_reproducible(K, dev, heads, Nq, Nkv, hd):
         assert torch.equal(K.flash_attn(qq, kk, vt, heads, Nkv), ref)
 
 
+@pytest.mark.parametrize("heads,Nq,Nkv,hd", [(32, 3456, 3456, 128), (32, 3456, 1024, 128), (32, 3456, 68, 64), (32, 3400, 3401, 128),
+                                              (20, 4000, 999, 128), (32, 13824, 1024, 128), (8, 8300, 130, 64)])
+def test_flash_attn_stream_k(K, dev, heads, Nq, Nkv, hd):
+    """The stream-K launch form (more (q-tile, head) units than workgroup slots): same result as the plain grid within the
+    fp32 rounding of the two-piece merge, against the oracle like the plain form, bit-reproducible, and the flags are back
+    at zero after every launch.  (20 heads: the heads cannot be dealt to the 8 XCDs -> the ungrouped range split.)"""
+    from oracle import dit
+    g = torch.Generator().manual_seed(Nq + Nkv + hd)
+    D = heads * hd
+    q32, k32, v32 = (q(torch.randn(n, D, generator=g)) for n in (Nq, Nkv, Nkv))
+    qq, kk = q32.to(dev, BF), k32.to(dev, BF)
+    vt = K.vt_transpose(v32.to(dev, BF), heads, head_dim=hd)
+    ws = K.flash_attn_workspace(hd, dev)
+    plain = K.flash_attn(qq, kk, vt, heads, Nkv)
+    sk = K.flash_attn(qq, kk, vt, heads, Nkv, workspace=ws).clone()
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+    d = (sk.float() - plain.float()).abs().max().item()
+    assert d <= 2.0 ** -7 * max(1.0, plain.float().abs().max().item()), d          # a bf16 ulp or two of the largest output
+    for _ in range(6):
+        assert torch.equal(K.flash_attn(qq, kk, vt, heads, Nkv, workspace=ws), sk)
+    if Nq * Nkv <= 3456 * 3456:
+        ref = dit.sdpa(q32[None], k32[None], v32[None], heads)[0]
+        assert rel_l2(sk.float().cpu(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("M,heads,hd,Kd,expect_fused", [(3456, 32, 128, 4096, True), (3400, 8, 128, 512, True), (2200, 32, 64, 1024, True), (1100, 16, 64, 1024, False),
+                                                       (3360, 8, 128, 512, False), (68, 32, 64, 2048, False)])
+def test_gemm_qkv_writes_vt(K, dev, M, heads, hd, Kd, expect_fused):
+    """V^T written by the QKV GEMM's epilogue (round 2): bit-identical to GEMM + vt_transpose, including the zero padding of the
+    last 64-key block; Q and K columns untouched by the fusion.  3360 = 15 x 224 rows: the row tiles stop short of Npad = 3392, so
+    the launcher must fall back to the transpose pass (as for grids the small-tile kernel takes: 1100 x 3072, the 68-token audio stream)."""
+    g = torch.Generator().manual_seed(M + hd)
+    D = heads * hd
+    a = torch.randn(M, Kd, generator=g).to(dev, BF)
+    w = (torch.randn(3 * D, Kd, generator=g) / math.sqrt(Kd)).to(dev, BF)
+    b = torch.randn(3 * D, generator=g).to(dev)
+    ref = K.gemm(a, w, b)
+    vt_ref = K.vt_transpose(ref[:, 2 * D:], heads, head_dim=hd)
+    out, vt, fused = K.gemm_qkv_vt(a, w, b, heads, hd)
+    assert fused == expect_fused
+    assert torch.equal(out[:, :2 * D], ref[:, :2 * D])
+    assert vt.shape == vt_ref.shape and torch.equal(vt, vt_ref)
+    for _ in range(3):
+        assert torch.equal(K.gemm_qkv_vt(a, w, b, heads, hd)[1], vt_ref)
+
+
 @pytest.mark.parametrize("M,N,Kd", [(1024, 8192, 3840), (3456, 4096, 4096), (300, 512, 256)])
 def test_gemm_bit_reproducible(K, dev, M, N, Kd):
     """Same for the GEMM tile kernels (128x128 tile with hand-issued fragment reads, 224/256-row ping-pong)."""
