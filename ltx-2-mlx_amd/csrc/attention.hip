@@ -513,12 +513,16 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
     }
+    // The engine's launches take the stream-K form only with LTX2_ATTN_SK=1 (2: without dealing the heads to the XCDs): on the DiT's
+    // self-attention it is 1-4 % faster as a kernel and changes NOTHING in the step (82.18 vs 82.14 ms, same box) -- the socket
+    // sits at its 1400 W cap, and filling idle workgroup slots spends the same energy sooner.  Unit callers that pass a workspace
+    // (sk_force) always get it.
     static const int sk_env = [] {
-        const char* e = getenv("LTX2_ATTN_SK");      // 0: plain grid everywhere (same-box A/B); 2: stream-K without dealing the heads to the XCDs
-        return e ? atoi(e) : 1;
+        const char* e = getenv("LTX2_ATTN_SK");
+        return e ? atoi(e) : 0;
     }();
     bool xcd = false;
-    const int workers = (p.sk_ws && sk_env) ? sk_workers(p, &xcd) : 0;
+    const int workers = (p.sk_ws && (sk_env || p.sk_force)) ? sk_workers(p, &xcd) : 0;
     if (workers > 0) {
         LTX2_CHECK_ARG(workers <= 1024 && p.sk_ws_bytes >= attn_sk_workspace_bytes(p.head_dim), "attention: stream-K workspace too small");
         AttnParams q = p;
