@@ -89,6 +89,17 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
 }
+// two elements per VALU op where the ISA has a packed fp32 form (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32); v_exp_f32 and v_rcp_f32
+// stay scalar.  Same formula as gelu_tanh().
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+    const f32x2 k0 = {0.044715f, 0.044715f}, one = {1.0f, 1.0f}, c = {-2.8853900817779268f * 0.7978845608028654f, -2.8853900817779268f * 0.7978845608028654f};
+    const f32x2 t = __builtin_elementwise_fma(x * x, k0, one);          // 1 + 0.044715 x^2
+    const f32x2 a = (x * c) * t;                                        // -2 u log2(e)
+    const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const f32x2 d = e + one;
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * r;
+}
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -332,7 +332,10 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) {
                 f32x4 v = acc_group(rb, cb, 0) + bias4[cb][0];
-                if (EPI == EPI_GELU_BF16) v = f32x4{gelu_tanh(v[0]), gelu_tanh(v[1]), gelu_tanh(v[2]), gelu_tanh(v[3])};
+                if (EPI == EPI_GELU_BF16) {
+                    const f32x2 g0 = gelu_tanh2(f32x2{v[0], v[1]}), g1 = gelu_tanh2(f32x2{v[2], v[3]});
+                    v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                }
                 if (EPI == EPI_SILU_BF16) v = f32x4{silu_f(v[0]), silu_f(v[1]), silu_f(v[2]), silu_f(v[3])};
                 const int chunk = (cb * 2 + (kq >> 1)) ^ sw;
                 *(bf16x4*)(wl + r * ROWB + chunk * 16 + (kq & 1) * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
