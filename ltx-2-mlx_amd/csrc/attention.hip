@@ -517,13 +517,15 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
     }
-    // The engine's launches take the stream-K form only with LTX2_ATTN_SK=1 (2: without dealing the heads to the XCDs): on the DiT's
-    // self-attention it is 1-4 % faster as a kernel and changes NOTHING in the step (82.18 vs 82.14 ms, same box) -- the socket
-    // sits at its 1400 W cap, and filling idle workgroup slots spends the same energy sooner.  Unit callers that pass a workspace
-    // (sk_force) always get it.
+    // LTX2_ATTN_SK=0: plain grid everywhere (same-box A/B); 2: stream-K without dealing the heads to the XCDs.  On the DiT's
+    // self-attention the stream-K form is 5 % faster as a kernel (208 vs 220 us) and worth 0.45 ms on the 78 ms step -- less than
+    // the slot arithmetic promises (0.84 -> 1.0) because the socket sits at its 1400 W cap: a half-empty last round also runs at a
+    // higher clock.  Progress argument for the in-launch wait: a workgroup only ever waits on LOWER-numbered workgroups of its
+    // group (same XCD when the heads are dealt), each XCD dispatches its workgroups in order, and the lowest-numbered unfinished
+    // workgroup never waits on an unfinished one.
     static const int sk_env = [] {
         const char* e = getenv("LTX2_ATTN_SK");
-        return e ? atoi(e) : 0;
+        return e ? atoi(e) : 1;
     }();
     bool xcd = false;
     const int workers = (p.sk_ws && (sk_env || p.sk_force)) ? sk_workers(p, &xcd) : 0;
