@@ -118,6 +118,8 @@ def lib() -> C.CDLL:
                 "(or `make -C ltx-2-mlx_amd/csrc`). There is no CPU fallback for the hot path.")
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("LTX2HIP_LIB") and not hasattr(l, name):
+                continue                # an OLDER build loaded for a same-box A/B run: entries it lacks just cannot be called
             fn = getattr(l, name)       # AttributeError if the ABI and the header drift apart
             fn.restype = res
             fn.argtypes = args

@@ -93,6 +93,7 @@ struct ltx2_dit {
     long ws_bytes = 0;
     int per_token = 0;
     float* sigmas_dev = nullptr;
+    std::vector<const void*> fp8_keys;  // this context's entries of g_fp8_scale (erased on destroy: the addresses get reused)
     void* sk_ws = nullptr;             // stream-K attention scratch (attention.h); main-stream launches only
     long sk_bytes = 0;
     bool prepared = false;
@@ -186,6 +187,7 @@ const void* find(ltx2_dit* c, const std::string& name, int dtype, long numel) {
             return nullptr;
         }
         g_fp8_scale[it->second.p] = (const float*)sc->second.p;
+        c->fp8_keys.push_back(it->second.p);
         return it->second.p;
     }
     if (it->second.dtype != dtype || it->second.n != numel) {
@@ -813,12 +815,15 @@ void ltx2_dit_destroy(ltx2_dit* c) {
     if (c->exec) (void)hipGraphExecDestroy(c->exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    for (const void* k : c->fp8_keys) g_fp8_scale.erase(k);
     delete c;
 }
 
 int ltx2_dit_set_weight(ltx2_dit* c, const char* name, const void* ptr, int dtype, int64_t numel) {
     LTX2_CHECK_ARG(c && name && ptr, "dit_set_weight: null argument");
     LTX2_CHECK_ARG(dtype == LTX2_DTYPE_BF16 || dtype == LTX2_DTYPE_F32 || dtype == LTX2_DTYPE_FP8_E4M3FN, "dit_set_weight: bad dtype %d", dtype);
+    auto old = c->weights.find(name);
+    if (old != c->weights.end()) g_fp8_scale.erase(old->second.p);      // re-registration: the old buffer may be freed by the caller
     c->weights[name] = Wt{ptr, dtype, (long)numel};
     c->resolved = false;
     return LTX2_OK;
