@@ -389,13 +389,17 @@ class LTXModel:
         n, s = positions.shape[2], context.shape[1]
         dev = self.device
         theta = self.positional_embedding_theta
+        # the cache key names the CALLER's tensors (which _ensure_prepared sees again on the next step), not the device copies
+        # made below; the originals are kept alive in _prep_refs so a data_ptr cannot be recycled under the key
+        key = self._key(context, positions, audio_context, audio_positions)
+        originals = (context, positions, audio_context, audio_positions)
         positions = positions.to(dev)
         cos, sin = K.rope_tables(positions, self.inner_dim, theta, self.positional_embedding_max_pos)
         ctx = context[0].to(dev, torch.float32).contiguous()
         if not self.is_av:
             self._bind(n, s, per_token)
             nv.check(nv.lib().ltx2_dit_prepare(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.stream()))
-            self._prep_refs = (context, positions, cos, sin, ctx)     # keep pointers alive / unaliased
+            self._prep_refs = (originals, positions, cos, sin, ctx)     # keep pointers alive / unaliased
         else:
             if audio_context is None or audio_positions is None:
                 raise ValueError("AudioVideo model: audio context and positions are required")
@@ -411,8 +415,8 @@ class LTXModel:
             nv.check(nv.lib().ltx2_dit_prepare_av(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.ptr(vcc), nv.ptr(vcs),
                                                   nv.ptr(actx), sa, nv.ptr(acos), nv.ptr(asin), nv.ptr(acc), nv.ptr(acs),
                                                   nv.stream()))
-            self._prep_refs = (context, positions, audio_context, audio_positions, cos, sin, ctx, acos, asin, vcc, vcs, acc, acs, actx)
-        self._prep_key = self._key(context, positions, audio_context, audio_positions)
+            self._prep_refs = (originals, positions, audio_positions, cos, sin, ctx, acos, asin, vcc, vcs, acc, acs, actx)
+        self._prep_key = key
 
     @staticmethod
     def _key(context, positions, audio_context=None, audio_positions=None):

@@ -254,6 +254,25 @@ def make_av(dev, v23, layers=2, heads=4, seed=17):
     return cfg, w, wq, m
 
 
+def test_prompt_setup_is_cached_for_host_resident_context(dev):
+    """The per-prompt setup (caption projection, 2 x layers text K/V GEMMs, RoPE tables) must run ONCE per prompt also when the
+    caller keeps context / positions on the host: the cache key names the caller's tensors, not the device copies."""
+    from ltx_2_mlx_amd.model.transformer import Modality, X0Model
+    cfg, w, m = make_dit(dev, heads=2, layers=2, cap=128, seed=3)
+    lat, ctx, pos = inputs(3, 4, 4, 64, 128, seed=4)
+    calls = []
+    real = m.prepare
+    m.prepare = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    outs = []
+    for sg in (1.0, 0.725, 0.421875):
+        mod = Modality(latent=lat.to(dev), context=ctx, context_mask=None, timesteps=torch.tensor([sg]), positions=pos)    # ctx, pos: CPU
+        outs.append(X0Model(m)(mod))
+    assert len(calls) == 1
+    mod = Modality(latent=lat.to(dev), context=ctx.clone(), context_mask=None, timesteps=torch.tensor([1.0]), positions=pos)
+    again = X0Model(m)(mod)
+    assert len(calls) == 2 and torch.equal(again, outs[0])          # a NEW context tensor is a new prompt
+
+
 def to_modality(d, dev):
     from ltx_2_mlx_amd.model.transformer import Modality
     return Modality(latent=d["latent"].to(dev), context=d["context"].to(dev), context_mask=None,
