@@ -379,9 +379,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 while (range_lo(first + 1) <= X) ++first;
                 while (range_lo(first) > X) --first;
                 if (tid == 0) {
-                    for (int k = first; k < j; ++k)
-                        while (__hip_atomic_load(p.sk_flags + k * slot_stride + slot_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                    // bounded: a producer that never publishes (it cannot, see the progress argument at the launcher) must not
+                    // hang the GPU -- after ~0.2 s of polling the piece is dropped and the sticky error word (flags[1023]) is set
+                    for (int k = first; k < j; ++k) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(p.sk_flags + k * slot_stride + slot_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                             __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 20)) {
+                                __hip_atomic_store(p.sk_flags + 1023, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
@@ -490,10 +499,9 @@ static int sk_workers(const AttnParams& p, bool* xcd) {
     const int nqt = (p.Nq + QB - 1) / QB;
     const long units = (long)nqt * p.H;
     if (units <= slots || slots % 8) return 0;
-    // the plain grid already runs units/slots rounds at rounds/ceil(rounds) efficiency: stream-K pays (a few us of partial
-    // hand-off per workgroup) only when the last round is badly filled -- 864 units on 512 slots: 0.84; 3456 units: 0.96
-    const double rounds = (double)units / slots;
-    if (!p.sk_force && (rounds / (double)((units + slots - 1) / slots) > 0.9 || p.Nkv < 32 * KVB)) return 0;   // short KV (text cross-attention, 16 tiles): measured slower
+    // Measured (same box, after the MFMA reorder): 864 units x 54 KV tiles 217 -> 201 us, 3456 units x 216 tiles 2896 -> 2838 us;
+    // short KV (text cross-attention, 16 tiles) 72 -> 74 us: the hand-off costs more than the tail there.
+    if (!p.sk_force && p.Nkv < 32 * KVB) return 0;
     *xcd = p.H % 8 == 0 && (long)(p.H / 8) * nqt >= slots / 8;
     return slots;
 }
@@ -530,7 +538,7 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     bool xcd = false;
     const int workers = (p.sk_ws && (sk_env || p.sk_force)) ? sk_workers(p, &xcd) : 0;
     if (workers > 0) {
-        LTX2_CHECK_ARG(workers <= 1024 && p.sk_ws_bytes >= attn_sk_workspace_bytes(p.head_dim), "attention: stream-K workspace too small");
+        LTX2_CHECK_ARG(workers < 1024 && p.sk_ws_bytes >= attn_sk_workspace_bytes(p.head_dim), "attention: stream-K workspace too small");
         AttnParams q = p;
         q.sk_xcd = xcd && sk_env != 2;
         q.sk_flags = (unsigned*)p.sk_ws;
