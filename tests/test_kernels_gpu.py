@@ -67,6 +67,37 @@ def test_gemm_epilogues(K, dev):
     assert rel_l2(o.float().cpu(), lin + res) < 8e-3
 
 
+@pytest.mark.parametrize("M", [3456, 1216, 1217, 1250, 1280, 1300, 1344])
+def test_gemm_v4_ragged_last_row_tile(K, dev, M):
+    """The 4-wave asm-loop kernel runs a SHORT K loop on the ragged last row tile of a 224-row grid (6 or 10 of 14 row blocks:
+    M mod 224 <= 96 / <= 160) -- every remainder class against an fp32 reference, every epilogue the DiT uses, bf16 and fp8-resident
+    weights (bit-identical to each other), and no write outside the M rows."""
+    from ltx_2_mlx_amd import _native as nv
+    g = torch.Generator(device=dev).manual_seed(M)
+    N, Kd = 8192, 512
+    a = torch.randn(M, Kd, generator=g, device=dev).to(BF)
+    w32 = torch.randn(N, Kd, generator=g, device=dev) / math.sqrt(Kd)
+    scale = torch.full((N,), float(w32.abs().max() / 448.0), device=dev)
+    codes = (w32 / scale[:, None]).to(torch.float8_e4m3fn)
+    w = (codes.float() * scale[:, None]).to(BF)
+    b = torch.randn(N, generator=g, device=dev)
+    lin = a.float() @ w.float().t() + b
+    canary = torch.full((M + 300, N), 7.0, device=dev, dtype=BF)
+    out = K.gemm(a, w, b, out=canary[:M])
+    assert rel_l2(out.float(), lin) < 6e-3 and bool((canary[M:] == 7.0).all())
+    assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_F32), lin) < 2e-3
+    assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_GELU_BF16).float(), F.gelu(lin, approximate="tanh")) < 8e-3
+    gate = torch.randn(N, generator=g, device=dev)
+    x0 = torch.randn(M + 300, N, generator=g, device=dev)
+    x = x0.clone()
+    K.gemm(a, w, b, epilogue=nv.EPI_RESID_GATE_F32, out=x[:M], gate_table=gate)
+    assert rel_l2(x[:M], x0[:M] + gate * lin) < 3e-3 and torch.equal(x[M:], x0[M:])
+    assert torch.equal(K.gemm_w8a16(a, codes.view(torch.uint8), scale, b), out)
+    x8 = x0.clone()
+    K.gemm_w8a16(a, codes.view(torch.uint8), scale, b, epilogue=nv.EPI_RESID_GATE_F32, out=x8[:M], gate_table=gate)
+    assert torch.equal(x8, x)
+
+
 def test_gemm_rejects_bad_k(K, dev):
     a = torch.zeros(8, 72, device=dev, dtype=BF)
     w = torch.zeros(128, 72, device=dev, dtype=BF)
