@@ -263,6 +263,7 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ov = tile_override();
     if (ov == 2) return launch_cfg<CfgBig, EPI, CONV>(p, stream);
     if (ov == 1) return launch_cfg<CfgSmall, EPI, CONV>(p, stream);
+    if (ov == 0 && !CONV && EPI != EPI_D2S_BF16 && gemm_skinny_supported(p, EPI)) return gemm_skinny_launch(p, EPI, stream);      // M <= 128: the audio stream
     if (ov == 0 && !CONV && v4_layout() >= 0 && use_big_tile(p) && gemm_v4_supported(p, EPI, CONV)) return gemm_v4_launch(p, EPI, stream, v4_layout(), 0);
     if (ov == 3 || use_big_tile(p)) return gemm_pp_launch(p, EPI, CONV, stream);
     if (p.N <= 64 && p.M >= 4096 && ov != 7) return launch_cfg<CfgNarrow, EPI, CONV>(p, stream);

@@ -177,6 +177,10 @@ struct ConvIter {
 
 // Launcher of the 256x256 ping-pong kernel (gemm_pp.hip)
 int gemm_pp_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream);
+// Skinny-M kernel (gemm_skinny.hip): M <= 128 rows, weight-streaming-bound, grid cut along N and K cut over the waves.
+bool gemm_skinny_supported(const GemmParams& p, int epilogue);
+int gemm_skinny_launch(const GemmParams& p, int epilogue, hipStream_t stream);
+
 // 4-wave kernel with the generated asm K loop (gemm_v4.hip): dense, N % 256 == 0, K % 128 == 0, K >= 256.
 // layout 0: 1x4 waves, 32x32x16 MFMA; 1: 2x2 waves, 32x32x16; 2: 2x2 waves, 16x16x32; 3: 1x4 waves, 16x16x32 (default);
 // 4: BN = 128, 4x1 waves, 16x16x32.  bm: 0 = pick, 224 | 256 (448 | 512 for layout 4).

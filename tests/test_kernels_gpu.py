@@ -98,6 +98,42 @@ def test_gemm_v4_ragged_last_row_tile(K, dev, M):
     assert torch.equal(x8, x)
 
 
+@pytest.mark.parametrize("M,N,Kd", [(68, 2048, 2048), (68, 6144, 2048), (68, 8192, 2048), (68, 2048, 8192), (68, 2048, 4096), (1, 256, 256), (16, 48, 512),
+                                    (128, 4096, 2048), (37, 8192, 256), (129, 2048, 2048)])
+def test_gemm_skinny_m(K, dev, M, N, Kd):
+    """M <= 128 rows (the 68-token audio stream of the AudioVideo DiT): the weight-streaming kernel (N cut into 16/32-column strips,
+    K cut over the 4 waves) against an fp32 reference for every dense epilogue, no write outside the M rows, bit-reproducible.
+    (129 rows: one past its limit -- the tile kernel takes it.)"""
+    from ltx_2_mlx_amd import _native as nv
+    g = torch.Generator(device=dev).manual_seed(M + N + Kd)
+    a = torch.randn(M, Kd, generator=g, device=dev).to(BF)
+    w = (torch.randn(N, Kd, generator=g, device=dev) / math.sqrt(Kd)).to(BF)
+    b = torch.randn(N, generator=g, device=dev)
+    lin = a.float() @ w.float().t() + b
+    canary = torch.full((M + 40, N), 7.0, device=dev, dtype=BF)
+    out = K.gemm(a, w, b, out=canary[:M])
+    assert rel_l2(out.float(), lin) < 6e-3 and bool((canary[M:] == 7.0).all())
+    for _ in range(3):
+        assert torch.equal(K.gemm(a, w, b), out)
+    assert rel_l2(K.gemm(a, w, None, epilogue=nv.EPI_F32), lin - b) < 2e-3
+    assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_GELU_BF16).float(), F.gelu(lin, approximate="tanh")) < 8e-3
+    assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_SILU_BF16).float(), F.silu(lin)) < 8e-3
+    gate = torch.randn(M, N, generator=g, device=dev)
+    tab = torch.randn(N, generator=g, device=dev)
+    x0 = torch.randn(M + 40, N, generator=g, device=dev)
+    x = x0.clone()
+    K.gemm(a, w, b, epilogue=nv.EPI_RESID_GATE_F32, out=x[:M], gate=gate, gate_table=tab)
+    assert rel_l2(x[:M], x0[:M] + (gate + tab) * lin) < 3e-3 and torch.equal(x[M:], x0[M:])
+    x = x0.clone()
+    K.gemm(a, w, b, epilogue=nv.EPI_RESID_GATE_F32, out=x[:M], gate=gate[:1].contiguous(), gate_table=tab)
+    assert rel_l2(x[:M], x0[:M] + (gate[:1] + tab) * lin) < 3e-3
+    res = torch.randn(M, N, generator=g, device=dev).to(BF)
+    assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_ADD_BF16, res=res).float(), lin + res.float()) < 8e-3
+    # strided activations (a column slice of a wider buffer, as the engine passes them)
+    wide = torch.randn(M, Kd + 64, generator=g, device=dev).to(BF)
+    assert rel_l2(K.gemm(wide[:, 64:], w, b).float(), wide[:, 64:].float() @ w.float().t() + b) < 6e-3
+
+
 def test_gemm_rejects_bad_k(K, dev):
     a = torch.zeros(8, 72, device=dev, dtype=BF)
     w = torch.zeros(128, 72, device=dev, dtype=BF)
