@@ -82,6 +82,16 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 
+// float8_e4m3fn code -> fp32 (OCP e4m3fn: bias 7, no infinities, 0x7f / 0xff = NaN); shared by the load-time dequantiser and
+// the kernels that keep fp8 weights resident, so both produce bf16(f32(code) * scale) from the same arithmetic
+__device__ __forceinline__ float e4m3fn_to_f32(unsigned int b) {
+    const unsigned int sign = (b & 0x80u) << 24, exp = (b >> 3) & 0xfu, man = b & 7u;
+    if ((b & 0x7fu) == 0x7fu) return __uint_as_float(0x7fc00000u | sign);
+    if (exp == 0) return __uint_as_float(__float_as_uint((float)man * 0.001953125f) | sign);     // man * 2^-9
+    return __uint_as_float(sign | ((exp + 120u) << 23) | (man << 20));
+}
+
+
 __device__ __forceinline__ float gelu_tanh(float x) {
     // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2u) == x / (1 + 2^(-2u log2 e)).
     // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of __expf and an IEEE division (a ~10-instruction sequence): the FFN-up

@@ -20,7 +20,9 @@ constexpr int SK_MAXRB = 8;      // row blocks of 16: M <= 128
 
 // NB: 16-column blocks per workgroup strip; NW: waves per workgroup = K slices (8 where the grid alone cannot fill the chip: the
 // loop is a chain of dependent global-load round trips, so halving a wave's K range halves the launch time)
-template <int EPI, int NB, int NW>
+// W8: fp8-resident weights (p.W8 codes + p.wscale per output column): a lane's 8 codes are expanded to bf16(f32(code) * scale) --
+// the load-time dequantiser's arithmetic -- so the result is bit-identical to this kernel on the dequantised weights.
+template <int EPI, int NB, int NW, bool W8>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p) {
     __shared__ f32x4 red[NW - 1][SK_MAXRB][NB][64];      // partials of waves 1.. (wave 0 keeps its own)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -29,9 +31,26 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
     const int n0 = blockIdx.x * (16 * NB);
     const int nrb = (p.M + 15) >> 4;                      // block-uniform
     const int kw = p.K / NW;                              // K range of this wave: [w * kw, (w + 1) * kw), kw % 64 == 0
-    const bf16* wp[NB];
+    const bf16* wp[NB];                                   // W8: byte pointers into the code matrix, kept in the same array
+    float wsc[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) wp[nb] = p.W + (long)(n0 + nb * 16 + c) * p.K + w * kw + 8 * g;
+    for (int nb = 0; nb < NB; ++nb) {
+        const long e = (long)(n0 + nb * 16 + c) * p.K + w * kw + 8 * g;
+        wp[nb] = W8 ? (const bf16*)(p.W8 + e) : p.W + e;
+        wsc[nb] = W8 ? p.wscale[n0 + nb * 16 + c] : 1.f;
+    }
+    // fragment of k-step offset `ko` (elements) of column block nb
+    auto load_w = [&](int nb, int ko) __attribute__((always_inline)) -> bf16x8 {
+        if constexpr (W8) {
+            const u32x2 cw = __builtin_nontemporal_load((const u32x2*)((const unsigned char*)wp[nb] + ko));
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(e4m3fn_to_f32((cw[e >> 2] >> (8 * (e & 3))) & 0xffu) * wsc[nb]);
+            return o;
+        } else {
+            return __builtin_nontemporal_load((const bf16x8*)(wp[nb] + ko));     // streamed once
+        }
+    };
     const bf16* ap[SK_MAXRB];
 #pragma unroll
     for (int rb = 0; rb < SK_MAXRB; ++rb) ap[rb] = p.A + (long)min(rb * 16 + c, p.M - 1) * p.lda + w * kw + 8 * g;
@@ -68,7 +87,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) wf[s * NB + nb] = __builtin_nontemporal_load((const bf16x8*)(wp[nb] + k + 32 * s));     // streamed once
+            for (int nb = 0; nb < NB; ++nb) wf[s * NB + nb] = load_w(nb, k + 32 * s);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) two_ksteps(k + 64 * s2, wf + 2 * NB * s2);
     }
@@ -77,7 +96,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) wf[s * NB + nb] = __builtin_nontemporal_load((const bf16x8*)(wp[nb] + k + 32 * s));
+            for (int nb = 0; nb < NB; ++nb) wf[s * NB + nb] = load_w(nb, k + 32 * s);
         two_ksteps(k, wf);
     }
 
@@ -114,15 +133,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
     }
 }
 
-template <int EPI>
+template <int EPI, bool W8>
 int launch_skinny(const GemmParams& p, hipStream_t stream) {
     // 32-column strips while that still gives every CU a workgroup, else 16-column strips, with K over 8 waves where it divides
     if (p.N % 32 == 0 && p.N / 32 >= 256)
-        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2, 4>), dim3(p.N / 32), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2, 4, W8>), dim3(p.N / 32), dim3(256), 0, stream, p);
     else if (p.K % 512 == 0)
-        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1, 8>), dim3(p.N / 16), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1, 8, W8>), dim3(p.N / 16), dim3(512), 0, stream, p);
     else
-        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1, 4>), dim3(p.N / 16), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1, 4, W8>), dim3(p.N / 16), dim3(256), 0, stream, p);
     LTX2_CHECK_LAUNCH("gemm_skinny_kernel");
     return LTX2_OK;
 }
@@ -130,9 +149,9 @@ int launch_skinny(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 bool gemm_skinny_supported(const GemmParams& p, int epilogue) {
-    if (p.W8 || !p.W || p.M < 1 || p.M > 16 * SK_MAXRB) return false;
+    if (!(p.W || (p.W8 && p.wscale)) || p.M < 1 || p.M > 16 * SK_MAXRB) return false;
     if (p.N % 16 != 0 || p.K % 256 != 0) return false;                   // K/4 per wave in 64-k iterations
-    if (p.lda % 8 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
+    if (p.lda % 8 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.W8 & 7)) return false;
     if (p.ldo % 4 != 0 || ((uintptr_t)p.out & 15)) return false;
     switch (epilogue) {
         case EPI_BF16: case EPI_GELU_BF16: case EPI_SILU_BF16: case EPI_F32: case EPI_RESID_GATE_F32: case EPI_ADD_BF16: return true;
@@ -144,7 +163,7 @@ int gemm_skinny_launch(const GemmParams& p, int epilogue, hipStream_t stream) {
     LTX2_CHECK_ARG(gemm_skinny_supported(p, epilogue), "gemm_skinny: unsupported problem (M=%d N=%d K=%d epilogue=%d)", p.M, p.N, p.K, epilogue);
 #define CASE(E) \
     case E:     \
-        return launch_skinny<E>(p, stream);
+        return p.W8 ? launch_skinny<E, true>(p, stream) : launch_skinny<E, false>(p, stream);
     switch (epilogue) {
         CASE(EPI_BF16)
         CASE(EPI_GELU_BF16)

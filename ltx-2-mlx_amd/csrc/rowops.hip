@@ -453,13 +453,6 @@ __global__ void timestep_sinusoid_kernel(const float* __restrict__ t, long t_str
 }
 
 // fp8 e4m3fn (OCP: bias 7, no inf, 0x7f/0xff = NaN) -> fp32, exact (loader/fp8_loader.py:14-51)
-__device__ __forceinline__ float e4m3fn_to_f32(unsigned int b) {
-    const unsigned int sign = (b & 0x80u) << 24, exp = (b >> 3) & 0xfu, man = b & 7u;
-    if ((b & 0x7fu) == 0x7fu) return __uint_as_float(0x7fc00000u | sign);
-    if (exp == 0) return __uint_as_float(__float_as_uint((float)man * 0.001953125f) | sign);     // man * 2^-9
-    return __uint_as_float(sign | ((exp + 120u) << 23) | (man << 20));
-}
-
 // out_bf16[i] = bf16( f32(fp8[i]) * scale )   (weight_converter.py:391-395: fp8 -> f32 * weight_scale -> target dtype)
 __global__ void dequant_fp8_kernel(const unsigned char* __restrict__ in, float scale, bf16* __restrict__ out, long n) {
     const long stride = (long)gridDim.x * blockDim.x * 8;

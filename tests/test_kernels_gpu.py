@@ -129,6 +129,17 @@ def test_gemm_skinny_m(K, dev, M, N, Kd):
     assert rel_l2(x[:M], x0[:M] + (gate[:1] + tab) * lin) < 3e-3
     res = torch.randn(M, N, generator=g, device=dev).to(BF)
     assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_ADD_BF16, res=res).float(), lin + res.float()) < 8e-3
+    # fp8-resident weights on the same kernel: bit-identical to the bf16 run on the dequantised weights
+    if M <= 128:
+        w32 = torch.randn(N, Kd, generator=g, device=dev) / math.sqrt(Kd)
+        scale = torch.full((N,), float(w32.abs().max() / 448.0), device=dev)
+        codes = (w32 / scale[:, None]).to(torch.float8_e4m3fn)
+        wdq = K.dequant_fp8(codes.view(torch.uint8), float(scale[0]))
+        assert torch.equal(K.gemm_w8a16(a, codes.view(torch.uint8), scale, b), K.gemm(a, wdq, b))
+        xa, xb = x0.clone(), x0.clone()
+        K.gemm_w8a16(a, codes.view(torch.uint8), scale, b, epilogue=nv.EPI_RESID_GATE_F32, out=xa[:M], gate_table=tab)
+        K.gemm(a, wdq, b, epilogue=nv.EPI_RESID_GATE_F32, out=xb[:M], gate_table=tab)
+        assert torch.equal(xa, xb)
     # strided activations (a column slice of a wider buffer, as the engine passes them)
     wide = torch.randn(M, Kd + 64, generator=g, device=dev).to(BF)
     assert rel_l2(K.gemm(wide[:, 64:], w, b).float(), wide[:, 64:].float() @ w.float().t() + b) < 6e-3
