@@ -38,6 +38,7 @@ struct GemmParams {
     bf16* vt;
     long vt_head_stride;
     int vt_col0, vt_npad, vt_hd;
+    int v4_direct_resid; // gemm_v4.hip: 1 = the gated fp32-residual epilogue touches x straight from the accumulator layout (LTX2_V4_RESID_LDS=0, A/B)
     int v4_full_tiles;   // gemm_v4.hip: 1 = the ragged last row tile runs the full-height K loop (LTX2_V4_SHORT=0, same-box A/B)
     int splitk;          // gemm_v4.hip: K split over this many blocks per tile (fp32 slabs + reduce); 0 / 1 = off
     void* dbg;           // ping-pong kernel: optional device buffer for interval timestamps (debug)      // ping-pong kernel: which wave bit selects the staggered group (tuning knob)

@@ -273,7 +273,66 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         }
     };
     constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_SILU_BF16;
+    constexpr bool RESID_LDS_OK = EPI == EPI_RESID_GATE_F32 && LAYOUT == 3 && VAR != 9;
+    const bool resid_lds = RESID_LDS_OK && !(p.gate && p.gate_stride != 0) && !p.v4_direct_resid;      // block-uniform
+    if constexpr (RESID_LDS_OK) {
+      if (resid_lds) {
+        // x += gate * (acc + bias) with a ROW-INVARIANT gate (scalar sigma), through LDS: a lane's accumulator groups are 4 columns
+        // of 16 different rows, so touching x straight from them moves 16 x 64 B per instruction -- half of every 128-byte line,
+        // twice.  Transposed through this wave's share of the dead stage buffers (half a wave tile at a time: rows x 256 B, 16-byte
+        // chunks XOR-swizzled with the row) every global load / store instruction covers 4 whole 256-byte row segments.
+        constexpr int RBH = RBW / 2, ROWB = WN * 4, HALF = RBH * MB;      // row blocks, bytes per slab row, rows per pass
+        static_assert(RBW % 2 == 0 && ROWB == 256 && HALF % 4 == 0 && 4 * HALF * ROWB <= G::LDS_BYTES, "resid epilogue slab");
+        f32x4 g4[CBW];
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+            g4[cb] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (p.gate || p.gate_table) {
+                g4[cb] = gate4[cb][0];
+                if (p.gate) g4[cb] += *(const f32x4*)(p.gate + n0 + wc * WN + cb * MB + 4 * kq);
+            }
+        }
+        char* wl = smem + w * (HALF * ROWB);
+        const int rr = lane >> 4, cc = lane & 15;                            // readback: 4 rows x 16 chunks per instruction
+        float* xg = (float*)p.out + (long)(m0 + rr) * p.ldo + n0 + wc * WN + cc * 4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {          // (unrolled: the accumulator indices must be compile-time constants)
+            __syncthreads();            // first pass: every wave has finished its fragment reads; second: the slab is free again
+            if (m0 + half * HALF >= p.M) break;                              // (block-uniform) ragged last row tile
+#pragma unroll
+            for (int r = 0; r < RBH; ++r) {
+                const int rb = half * RBH + r, row = r * MB + lr;
+                if (m0 + rb * MB >= p.M) continue;
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) {
+                    const f32x4 v = g4[cb] * (acc_group(rb, cb, 0) + bias4[cb][0]);
+                    *(f32x4*)(wl + row * ROWB + (((cb * 4 + kq) ^ (row & 15)) << 4)) = v;
+                }
+            }
+            // 8 row groups of 4 in flight per batch (8 x 16 B per lane), consumed in issue order
+            constexpr int NIT = HALF / 4, BATCH = NIT % 8 == 0 ? 8 : 7;
+            static_assert(NIT % BATCH == 0, "readback batches");
+#pragma unroll 1
+            for (int b0 = 0; b0 < NIT; b0 += BATCH) {
+                f32x4 xv[BATCH];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int row = (b0 + i) * 4 + rr;
+                    const long grow = min((long)m0 + half * HALF + row, (long)p.M - 1) - (m0 + rr);
+                    xv[i] = *(const f32x4*)(xg + grow * p.ldo);
+                }
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int row = (b0 + i) * 4 + rr;
+                    const f32x4 d = *(const f32x4*)(wl + row * ROWB + ((cc ^ (row & 15)) << 4));
+                    if (m0 + half * HALF + row < p.M) *(f32x4*)(xg + ((long)half * HALF + row - rr) * p.ldo) = xv[i] + d;
+                }
+            }
+        }
+      }
+    }
     if constexpr (EPI == EPI_RESID_GATE_F32) {
+      if (!resid_lds) {
         // x += gate * (acc + bias).  The accumulators live in AGPRs and the fragment registers are dead, so the VGPR file
         // is free: the residual tile is read HALF A WAVE TILE AT A TIME with every load in flight at once (32 x 16 B per
         // lane), i.e. the HBM latency is paid twice per tile instead of once per row block (measured: one row block per
@@ -315,6 +374,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                     }
             }
         }
+      }
     } else if constexpr ((LAYOUT == 3 || LAYOUT == 4) && VAR != 9 && BF16_OUT) {
         // bf16 outputs of the row-slab layouts leave through LDS: a lane's accumulator groups are 4 columns of 16 different
         // rows (8-byte stores into 32-byte row segments); transposed through this wave's share of the (now dead) stage
@@ -410,8 +470,13 @@ int launch_v4(const GemmParams& p, hipStream_t stream) {
         const char* e = getenv("LTX2_V4_SHORT");
         return e && atoi(e) == 0;
     }();
+    static const bool direct_resid = [] {
+        const char* e = getenv("LTX2_V4_RESID_LDS");
+        return e && atoi(e) == 0;
+    }();
     GemmParams q = p;
     q.v4_full_tiles = full_tiles;
+    q.v4_direct_resid = direct_resid;
     hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt * (p.splitk > 1 ? p.splitk : 1)), dim3(256), G::LDS_BYTES, stream, q);
     LTX2_CHECK_LAUNCH("gemm_v4_kernel");
     return LTX2_OK;
