@@ -297,8 +297,17 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         float* xg = (float*)p.out + (long)(m0 + rr) * p.ldo + n0 + wc * WN + cc * 4;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {          // (unrolled: the accumulator indices must be compile-time constants)
-            __syncthreads();            // first pass: every wave has finished its fragment reads; second: the slab is free again
             if (m0 + half * HALF >= p.M) break;                              // (block-uniform) ragged last row tile
+            // the residual rows of this half are requested FIRST, all of them (HALF / 4 x 16 B per lane: the fragment registers
+            // are dead, the VGPR file is free), so the HBM round trip runs under the barrier and the slab writes
+            constexpr int NIT = HALF / 4;
+            f32x4 xv[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const long grow = min((long)m0 + half * HALF + i * 4 + rr, (long)p.M - 1) - (m0 + rr);
+                xv[i] = *(const f32x4*)(xg + grow * p.ldo);
+            }
+            __syncthreads();            // first pass: every wave has finished its fragment reads; second: the slab is free again
 #pragma unroll
             for (int r = 0; r < RBH; ++r) {
                 const int rb = half * RBH + r, row = r * MB + lr;
@@ -309,24 +318,12 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                     *(f32x4*)(wl + row * ROWB + (((cb * 4 + kq) ^ (row & 15)) << 4)) = v;
                 }
             }
-            // 8 row groups of 4 in flight per batch (8 x 16 B per lane), consumed in issue order
-            constexpr int NIT = HALF / 4, BATCH = NIT % 8 == 0 ? 8 : 7;
-            static_assert(NIT % BATCH == 0, "readback batches");
-#pragma unroll 1
-            for (int b0 = 0; b0 < NIT; b0 += BATCH) {
-                f32x4 xv[BATCH];
 #pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    const int row = (b0 + i) * 4 + rr;
-                    const long grow = min((long)m0 + half * HALF + row, (long)p.M - 1) - (m0 + rr);
-                    xv[i] = *(const f32x4*)(xg + grow * p.ldo);
-                }
-#pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    const int row = (b0 + i) * 4 + rr;
-                    const f32x4 d = *(const f32x4*)(wl + row * ROWB + ((cc ^ (row & 15)) << 4));
-                    if (m0 + half * HALF + row < p.M) *(f32x4*)(xg + ((long)half * HALF + row - rr) * p.ldo) = xv[i] + d;
-                }
+            for (int i = 0; i < NIT; ++i) {
+                const int row = i * 4 + rr;
+                asm volatile("" : "+v"(xv[i]));       // consume in issue order: counted waits, not vmcnt(0)
+                const f32x4 d = *(const f32x4*)(wl + row * ROWB + ((cc ^ (row & 15)) << 4));
+                if (m0 + half * HALF + row < p.M) *(f32x4*)(xg + ((long)half * HALF + row - rr) * p.ldo) = xv[i] + d;
             }
         }
       }
