@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             }
         }
       }
-    } else if constexpr ((LAYOUT == 3 || LAYOUT == 4) && VAR != 9 && BF16_OUT) {
+    } else if constexpr ((LAYOUT == 3 || LAYOUT == 4) && VAR != 9 && (BF16_OUT || EPI == EPI_ADD_BF16)) {
         // bf16 outputs of the row-slab layouts leave through LDS: a lane's accumulator groups are 4 columns of 16 different
         // rows (8-byte stores into 32-byte row segments); transposed through this wave's share of the (now dead) stage
         // buffers every store instruction writes whole rows: 8 rows x 128 B (layout 3) or 4 rows x 256 B (layout 4).
@@ -381,6 +381,17 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         constexpr int ROWB = WN * 2, CPR = ROWB / 16, RPI = 64 / CPR;          // bytes per row, chunks per row, rows per instruction
         __syncthreads();                                    // every wave has finished its fragment reads
         char* wl = smem + w * (WM * ROWB);
+        if constexpr (EPI == EPI_ADD_BF16) {
+            // out = bf16(acc + bias + res): the residual tile comes in through the same slab with whole-row loads; each lane then
+            // replaces ITS 8 bytes (4 columns of one row) by the sum, rounded once -- bit-identical to adding from global memory
+#pragma unroll
+            for (int it = 0; it < WM / RPI; ++it) {
+                const int r = it * RPI + lane / CPR, c = lane % CPR;
+                const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
+                const int row = min(m0 + wr * WM + r, p.M - 1);
+                *(u32x4*)(wl + r * ROWB + ((c ^ sw) << 4)) = *(const u32x4*)(p.res + (long)row * p.ldres + n0 + wc * WN + c * 8);
+            }
+        }
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
             if (m0 + wr * WM + rb * MB >= p.M) continue;     // no real row in this block (block-uniform): its slab rows are never read as data
@@ -395,7 +406,12 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                 }
                 if (EPI == EPI_SILU_BF16) v = f32x4{silu_f(v[0]), silu_f(v[1]), silu_f(v[2]), silu_f(v[3])};
                 const int chunk = (cb * 2 + (kq >> 1)) ^ sw;
-                *(bf16x4*)(wl + r * ROWB + chunk * 16 + (kq & 1) * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+                bf16x4* slot = (bf16x4*)(wl + r * ROWB + chunk * 16 + (kq & 1) * 8);
+                if constexpr (EPI == EPI_ADD_BF16) {
+                    const bf16x4 rs = *slot;
+                    v += f32x4{bf2f(rs[0]), bf2f(rs[1]), bf2f(rs[2]), bf2f(rs[3])};
+                }
+                *slot = pack_bf16x4(v[0], v[1], v[2], v[3]);
             }
         }
         if (LAYOUT == 3 && EPI == EPI_BF16 && !CONV && p.vt && n0 >= p.vt_col0) {
