@@ -105,23 +105,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int nt = (p.Nkv + KVB - 1) / KVB, nfull = p.Nkv / KVB;
     const int nqt = (p.Nq + QB - 1) / QB;
 
-    // ---- staging addresses (head-independent part) ----
-    unsigned k_row0[NJ], k_col[NJ], v_ofs[NJ];
+    // ---- staging: buffer loads straight to LDS; a piece's address is (per-lane byte offset, fixed for the launch) + (tile byte
+    //      offset, scalar) against a descriptor of this head's K / V^T rows -- no vector ALU work per issue (global_load_lds wants a
+    //      64-bit per-lane pointer: ~4 VALU per piece, 32 per KV tile beside 32 MFMAs).  Rows past Nkv are outside the K
+    //      descriptor's range and read as zeros (the ragged last tile masks them anyway). ----
+    unsigned k_vo[NJ], v_vo[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         // one LDS-DMA instruction covers 1 KiB: 4 K rows of 256 B (HD 128) or 8 rows of 128 B (HD 64)
         const int kr = HD == 128 ? (wv * NJ + j) * 4 + (lane >> 4) : (wv * NJ + j) * 8 + (lane >> 3);   // 0..63
         const int kchunk = HD == 128 ? ((lane & 15) ^ (kr & 15)) : ((lane & 7) ^ ((kr >> 1) & 7));
-        k_row0[j] = (unsigned)kr * (unsigned)p.ldk;
-        k_col[j] = kchunk * 8;
+        k_vo[j] = ((unsigned)kr * (unsigned)p.ldk + kchunk * 8) * 2;
         const int vr = (wv * NJ + j) * 8 + (lane >> 3);                // 0..HD-1
         const int vchunk = (lane & 7) ^ ((vr >> 1) & 7);
-        v_ofs[j] = (unsigned)vr * (unsigned)p.Npad + vchunk * 8;
+        v_vo[j] = ((unsigned)vr * (unsigned)p.Npad + vchunk * 8) * 2;
     }
-    // K tiles are staged strictly in order (a, a+1, .., b-1, and once more into the idle buffer), so the row offset
-    // advances by a constant; clamping the OFFSET to the last row's equals clamping the row (2 VALU per issue
-    // instead of a 64-bit multiply-add chain). The launcher guarantees (Nkv + 2*KVB) * ldk < 2^32.
-    const unsigned k_last = (unsigned)(p.Nkv - 1) * (unsigned)p.ldk, k_step = (unsigned)KVB * (unsigned)p.ldk;
+    const unsigned k_tile_bytes = (unsigned)KVB * (unsigned)p.ldk * 2;
+    const unsigned k_bytes = ((unsigned)(p.Nkv - 1) * (unsigned)p.ldk + HD) * 2, v_bytes = (unsigned)HD * (unsigned)p.Npad * 2;
 
     // per-lane fragment offsets inside a stage (the swizzle of the staging, applied again on the read)
     const int k_xor = HD == 128 ? (l31 & 15) : ((l31 >> 1) & 7);
@@ -206,21 +206,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
         }
-        const bf16* k_head = p.K + head * HD;
-        const bf16* v_head = p.VT + (long)head * p.vt_head_stride;
-        unsigned k_off[NJ];                                                // element offset of this lane's K row, next tile to stage
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) k_off[j] = k_row0[j] + (unsigned)ta * k_step;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.K + head * HD), 0, (int)k_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.VT + (long)head * p.vt_head_stride), 0, (int)v_bytes, 0x00020000);
         // piece i of tile t's staging into buffer `buf`: pieces [0, NJ) are K, [NJ, 2 NJ) are V^T. One LDS-DMA issue
         // costs the wave ~50 cycles (a burst of 8: ~100 each), so the pieces are spread between the QK MFMAs.
         auto stage_piece = [&](int t, int buf, int i) {
-            const unsigned dst = lds0 + buf * STAGE + wv * (NJ * 1024);
-            if (i < NJ) {
-                glds16(k_head + k_col[i] + min(k_off[i], k_last), dst + i * 1024);
-                k_off[i] += k_step;
-            } else {
-                glds16(v_head + v_ofs[i - NJ] + t * KVB, dst + K_TILE + (i - NJ) * 1024);
-            }
+            char* dst = smem + buf * STAGE + wv * (NJ * 1024);
+#if defined(__HIP_DEVICE_COMPILE__)          // (the host pass of hipcc does not know this builtin and silently drops the kernel's stub)
+            if (i < NJ)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(dst + i * 1024), 16, k_vo[i], t * k_tile_bytes, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + K_TILE + (i - NJ) * 1024), 16, v_vo[i - NJ], t * (KVB * 2), 0, 0);
+#else
+            (void)dst; (void)t; (void)i;
+#endif
         };
 
         f32x16 o[ND];
@@ -499,9 +498,10 @@ static int sk_workers(const AttnParams& p, bool* xcd) {
     const int nqt = (p.Nq + QB - 1) / QB;
     const long units = (long)nqt * p.H;
     if (units <= slots || slots % 8) return 0;
-    // Measured (same box, after the MFMA reorder): 864 units x 54 KV tiles 217 -> 201 us, 3456 units x 216 tiles 2896 -> 2838 us;
-    // short KV (text cross-attention, 16 tiles) 72 -> 74 us: the hand-off costs more than the tail there.
-    if (!p.sk_force && p.Nkv < 32 * KVB) return 0;
+    // Measured (same box): 864 units x 54 KV tiles (0.84 of the last round filled) 211 -> 203 us; 3456 units x 216 tiles (0.96)
+    // 2869 -> 2869 us; short KV (text cross-attention, 16 tiles) 72 -> 78 us: the hand-off costs more than the tail there.
+    const double rounds = (double)units / slots;
+    if (!p.sk_force && (rounds / (double)((units + slots - 1) / slots) > 0.9 || p.Nkv < 32 * KVB)) return 0;
     *xcd = p.H % 8 == 0 && (long)(p.H / 8) * nqt >= slots / 8;
     return slots;
 }
@@ -516,8 +516,8 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.head_dim == 0 || p.head_dim == 128 || p.head_dim == 64, "attention: head_dim=%d, only 128 and 64 are implemented", p.head_dim);
     LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
     LTX2_CHECK_ARG(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
-    LTX2_CHECK_ARG(p.ldk > 0 && ((long)p.Nkv + 2 * KVB) * p.ldk < (1L << 32), "attention: Nkv * ldk exceeds the 32-bit K row offset");
-    LTX2_CHECK_ARG((long)p.Npad * (p.head_dim == 64 ? 64 : 128) < (1L << 31), "attention: Npad * head_dim exceeds the 32-bit V^T row offset");
+    LTX2_CHECK_ARG(p.ldk > 0 && ((long)p.Nkv + 2 * KVB) * p.ldk * 2 < (1L << 31), "attention: Nkv * ldk exceeds the 31-bit K byte offset");
+    LTX2_CHECK_ARG((long)p.Npad * (p.head_dim == 64 ? 64 : 128) * 2 < (1L << 31), "attention: Npad * head_dim exceeds the 31-bit V^T byte offset");
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);

@@ -1,0 +1,44 @@
+"""Socket power while ONE kernel runs back to back for a few seconds (rocm-smi polled from a thread): is it at the 1400 W cap?
+usage: python tools/kernel_power.py attn|attn_cross|gemm|gemm_resid|norm"""
+import math, os, re, subprocess, sys, threading, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ltx_2_mlx_amd.kernels as K
+from ltx_2_mlx_amd import _native as nv
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "attn"
+N, D, H = 3456, 4096, 32
+if which.startswith("attn"):
+    nkv = 1024 if which == "attn_cross" else N
+    q = torch.randn(N, D, device=dev).to(torch.bfloat16); k = torch.randn(nkv, D, device=dev).to(torch.bfloat16)
+    vt = K.vt_transpose(torch.randn(nkv, D, device=dev).to(torch.bfloat16), H)
+    ws = K.flash_attn_workspace(128, dev)
+    fn = lambda: K.flash_attn(q, k, vt, H, nkv, workspace=ws if which == "attn" else None)
+    flop = 4.0 * N * nkv * D
+elif which.startswith("gemm"):
+    a = torch.randn(N, D, device=dev).to(torch.bfloat16); w = (torch.randn(4 * D, D, device=dev) / 64).to(torch.bfloat16)
+    out = torch.empty(N, 4 * D, device=dev, dtype=torch.bfloat16)
+    fn = lambda: K.gemm(a, w, None, out=out)
+    flop = 2.0 * N * 4 * D * D
+else:
+    x = torch.randn(N, D, device=dev); t = [0.1 * torch.randn(D, device=dev) for _ in range(4)]
+    fn = lambda: K.adaln_rmsnorm(x, 1e-6, False, *t, 0)
+    flop = 0.0
+samples, stop = [], False
+def poll():
+    while not stop:
+        o = subprocess.run(["rocm-smi", "-d", "0", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True).stdout
+        for l in o.splitlines():
+            if l.startswith("card0"):
+                f = l.split(",")
+                samples.append((float(f[-1]), int(re.sub(r"\D", "", f[6]))))
+th = threading.Thread(target=poll); th.start()
+for _ in range(20): fn()
+torch.cuda.synchronize()
+t0 = time.time(); n = 0
+while time.time() - t0 < 6.0:
+    for _ in range(200): fn()
+    torch.cuda.synchronize(); n += 200
+dt = time.time() - t0
+stop = True; th.join()
+busy = [s for s in samples[len(samples) // 4:]]
+print(f"{which}: {dt / n * 1e6:.1f} us per launch, {flop / (dt / n) / 1e12:.0f} TF/s; socket power mean {sum(s[0] for s in busy) / len(busy):.0f} W (max {max(s[0] for s in busy):.0f}), sclk mean {sum(s[1] for s in busy) / len(busy):.0f} MHz over {len(busy)} samples")
