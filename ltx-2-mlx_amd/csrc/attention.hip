@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int v_xor = (l31 >> 1) & 7;
     unsigned k_lane[NKS], v_lane[4];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) k_lane[ks] = l31 * (2 * HD) + (((2 * ks + hi) ^ k_xor) << 4);
+    for (int ks = 0; ks < NKS; ++ks) k_lane[ks] = lds0 + l31 * (2 * HD) + (((2 * ks + hi) ^ k_xor) << 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v_lane[i] = K_TILE + l31 * 128 + (((2 * i + hi) ^ v_xor) << 4);
+    for (int i = 0; i < 4; ++i) v_lane[i] = lds0 + K_TILE + l31 * 128 + (((2 * i + hi) ^ v_xor) << 4);
 
     // ---- this workgroup's work (SK): unit u = head * nqt + q-tile.  Phase A: whole units, one per round, every workgroup
     //      of the group starting at KV tile 0 together (they share K / V^T tiles through the L2 exactly like the plain grid).
@@ -235,13 +235,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         // One KV tile. MASKED is a compile-time flag: only the ragged last tile carries the key-bound compares (left
         // in the common body, hipcc if-converts them into ~115 predicated VALU ops on EVERY tile -- SQ_INSTS_VALU
         // showed 236 non-MFMA VALU per tile against 32 MFMAs).
-        auto tile = [&](const int t, auto masked) __attribute__((always_inline)) {
+        // PAR: which of the two stage buffers holds tile t -- a template flag, so the buffer's byte offset rides in the ds_read
+        // immediates instead of one v_add per fragment read (12 per tile)
+        auto tile = [&](const int t, auto masked, auto par) __attribute__((always_inline)) {
             constexpr bool MASKED = decltype(masked)::value;
+            constexpr int PAR = decltype(par)::value;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const int tn = min(t + 1, tb - 1);          // the tail re-stages the last tile into the idle buffer (branch-free body)
-            const int nbuf = (t - ta + 1) & 1;
-            const unsigned sbase = lds0 + ((t - ta) & 1) * STAGE;
+            constexpr int nbuf = 1 - PAR;
 
             // ---- S^T = K . Q^T  (two 32-key blocks); fragment i = b * NKS + ks ----
             f32x16 s[2];
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             // (the socket runs at its power cap: operand traffic is time; the GEMM's K loop gained 0.8 % from the same rule)
             auto read_k = [&](auto N) {
                 constexpr int n = decltype(N)::value, i = (n & 1) * NKS + (n >> 1);
-                kf[i] = lds_read16<(i / NKS) * 32 * 2 * HD>(sbase + k_lane[i % NKS]);
+                kf[i] = lds_read16<PAR * STAGE + (i / NKS) * 32 * 2 * HD>(k_lane[i % NKS]);
             };
             static_for<0, DK>(read_k);
             static_for<0, NK>([&](auto N) {
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             // issue order n = ND j + d (fragment i = 4 d + j): the P fragment stays put over ND consecutive MFMAs, the accumulators rotate
             auto read_v = [&](auto N) {
                 constexpr int n = decltype(N)::value, i = (n % ND) * 4 + n / ND;
-                vf[i] = lds_read16<(i / 4) * 32 * 128>(sbase + v_lane[i % 4]);
+                vf[i] = lds_read16<PAR * STAGE + (i / 4) * 32 * 128>(v_lane[i % 4]);
             };
             static_for<0, DV>(read_v);
 
@@ -342,8 +344,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         };
 
         const int t_unmasked_end = min(tb, nfull);
-        for (int t = ta; t < t_unmasked_end; ++t) tile(t, std::false_type{});
-        if (nfull < tb) tile(nfull, std::true_type{});
+        int t = ta;
+        for (; t + 1 < t_unmasked_end; t += 2) {
+            tile(t, std::false_type{}, std::integral_constant<int, 0>{});
+            tile(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
+        }
+        if (t < t_unmasked_end) {
+            tile(t, std::false_type{}, std::integral_constant<int, 0>{});
+            ++t;
+        }
+        if (nfull < tb) {
+            if ((nfull - ta) & 1) tile(nfull, std::true_type{}, std::integral_constant<int, 1>{});
+            else tile(nfull, std::true_type{}, std::integral_constant<int, 0>{});
+        }
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
