@@ -161,6 +161,23 @@ class LTXModel:
         self._bound: Tuple[int, ...] = (0, 0, 0, 0, 0)
         self._prep_key = None
         self._prep_refs = None
+        self._twin: Optional["LTXModel"] = None        # VideoOnly engine over the SAME weight tensors (video-only inference on an AV model)
+        self._ctor = dict(num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim, in_channels=in_channels,
+                          out_channels=out_channels, num_layers=num_layers, cross_attention_dim=cross_attention_dim, norm_eps=norm_eps,
+                          caption_channels=caption_channels, positional_embedding_theta=positional_embedding_theta,
+                          positional_embedding_max_pos=positional_embedding_max_pos, timestep_scale_multiplier=timestep_scale_multiplier,
+                          cross_attention_adaln=cross_attention_adaln, apply_gated_attention=apply_gated_attention, device=device)
+
+    def _video_twin(self) -> "LTXModel":
+        """The video half of this AudioVideo model as a VideoOnly engine: with no audio tokens the reference's blocks run only
+        video self-attention, text cross-attention and the video feed-forward (transformer.py:479-483: run_ax and run_a2v are
+        False for an empty audio stream), which is exactly the VideoOnly program over the video weights.  No weight is copied."""
+        if self._twin is None:
+            t = LTXModel(model_type=LTXModelType.VideoOnly, **self._ctor)
+            for k, v in self._w.items():
+                t._register(k, v)
+            self._twin = t
+        return self._twin
 
     def __del__(self):
         try:
@@ -305,6 +322,7 @@ class LTXModel:
             else:
                 self._register(k, Fv(k))
         self._prep_key = None
+        self._twin = None
 
     def init_random_weights(self, seed: int = 0, std: float = 0.02, fp8_resident: bool = False) -> None:
         """Synthetic N(0, std) weights generated directly in HBM in the engine's fused layout (bench /
@@ -354,6 +372,7 @@ class LTXModel:
             else:
                 self._register(k, rf(*shp))
         self._prep_key = None
+        self._twin = None
 
     def weight_tensors(self) -> Dict[str, torch.Tensor]:
         """Engine-layout device tensors (used by the RCCL weight broadcast)."""
@@ -459,13 +478,15 @@ class LTXModel:
                 raise NotImplementedError("context_mask is None on every live reference path (pipelines/common.py:223-232)")
             if m is not None and m.latent.shape[0] != 1:
                 raise ValueError("batch must be 1")
-        if self.is_av and audio is None:
-            raise NotImplementedError("video-only inference on an AudioVideo model: build a VideoOnly LTXModel from the same weights")
         if not self.is_av and audio is not None:
             raise ValueError("audio modality passed to a VideoOnly model")
 
     def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None, perturbations=None):
         self._check_inputs(video, audio, perturbations)
+        if self.is_av and (audio is None or audio.latent.shape[1] == 0):
+            # video-only inference on an AudioVideo model (model.py:829-840, 866-874): (video velocity, empty audio output)
+            v = self._video_twin()(video, None, perturbations=perturbations)
+            return v, torch.zeros(1, 0, self.AUDIO_OUT_CHANNELS, device=self.device)
         ts, n_ts = self._timesteps(video)
         lat = video.latent[0].to(self.device, torch.float32).contiguous()
         out = torch.empty(lat.shape[0], self.out_channels, device=self.device, dtype=torch.float32)
@@ -551,6 +572,8 @@ class X0Model:
     def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None, perturbations=None):
         out = self.velocity_model(video, audio, perturbations=perturbations)
         if isinstance(out, tuple):
+            if out[1].shape[1] == 0:            # video-only inference on an AudioVideo model: nothing to denoise on the audio side
+                return self._denoise(video, out[0]), out[1]
             return self._denoise(video, out[0]), self._denoise(audio, out[1])
         return self._denoise(video, out)
 

@@ -273,6 +273,34 @@ def test_prompt_setup_is_cached_for_host_resident_context(dev):
     assert len(calls) == 2 and torch.equal(again, outs[0])          # a NEW context tensor is a new prompt
 
 
+@pytest.mark.parametrize("v23", [False, True])
+def test_video_only_inference_on_an_audiovideo_model(dev, v23):
+    """AudioVideo LTXModel called without an audio modality (reference model.py:829-840: an empty audio stream; the blocks then run
+    only the video self-attention / text cross-attention / feed-forward, transformer.py:479-483): the video output equals, bit for
+    bit, a VideoOnly model holding the video half of the same weights, and the audio output is the reference's empty (1, 0, 128)."""
+    from oracle import dit_av
+    from ltx_2_mlx_amd.model.transformer import LTXModel, LTXModelType, Modality, X0Model
+    cfg = dit_av.AVConfig(num_attention_heads=4, attention_head_dim=128, audio_heads=4, audio_head_dim=64, num_layers=2,
+                          caption_channels=None if v23 else 256, cross_attention_adaln=v23, apply_gated_attention=v23)
+    w = dit_av.make_av_weights(cfg, seed=5 + v23)
+    kw = dict(num_attention_heads=4, attention_head_dim=128, num_layers=2, caption_channels=cfg.caption_channels,
+              cross_attention_adaln=v23, apply_gated_attention=v23, device=dev)
+    av = LTXModel(model_type=LTXModelType.AudioVideo, audio_attention_heads=4, **kw)
+    av.load_state_dict(w)
+    vo = LTXModel(model_type=LTXModelType.VideoOnly, **kw)
+    vo.load_state_dict({k: w[k] for k in vo.expected_weight_shapes()})
+    g = torch.Generator().manual_seed(9)
+    s = torch.tensor([0.725])
+    from oracle import loop
+    vid = Modality(latent=torch.randn(1, 3 * 4 * 4, 128, generator=g).to(dev), context=(0.1 * torch.randn(1, 64, cfg.caption_channels or cfg.inner_dim, generator=g)).to(dev),
+                   context_mask=None, timesteps=s.to(dev), positions=loop.video_positions(1, 3, 4, 4, 24.0).to(dev), sigma=s.to(dev))
+    ref = X0Model(vo)(vid)
+    x0v, x0a = X0Model(av)(vid, None)
+    assert torch.equal(x0v, ref) and x0a.shape == (1, 0, 128)
+    vel, aud = av(vid)
+    assert torch.equal(vel, vo(vid)) and aud.shape == (1, 0, 128)
+
+
 def to_modality(d, dev):
     from ltx_2_mlx_amd.model.transformer import Modality
     return Modality(latent=d["latent"].to(dev), context=d["context"].to(dev), context_mask=None,
