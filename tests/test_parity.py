@@ -301,6 +301,31 @@ def test_video_only_inference_on_an_audiovideo_model(dev, v23):
     assert torch.equal(vel, vo(vid)) and aud.shape == (1, 0, 128)
 
 
+def test_video_dit_against_reference_vectors(dev):
+    """The VideoOnly HIP path DIRECTLY against the vectors recorded from the reference's own LTXModel / X0Model
+    (tests/golden/dit_tiny.npz: 2 layers, 2 x 128 heads, scalar and per-token timesteps) -- not only through the oracle."""
+    import numpy as np
+    import os
+    from oracle import dit, loop
+    from ltx_2_mlx_amd.model.transformer import Modality, X0Model
+    cfg, wq, m = make_dit(dev, heads=2, layers=2, cap=64, seed=11)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_tiny.npz"))
+    f, h, wd, S = 3, 4, 4, 16
+    gen = torch.Generator().manual_seed(1234)            # the recording script's draws, in its order (test_oracle_golden.py)
+    lat = torch.randn(1, f * h * wd, 128, generator=gen)
+    ctx = 0.1 * torch.randn(1, S, 64, generator=gen)
+    pos = loop.video_positions(1, f, h, wd, 24.0)
+    ts = torch.tensor([0.725])
+    tsp = (torch.rand(1, f * h * wd, 1, generator=gen) > 0.3).float() * 0.909375
+    for tag, t in (("scalar", ts), ("pertoken", tsp)):
+        mod = Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=t.to(dev), positions=pos.to(dev))
+        vel = m(mod).cpu()
+        x0 = X0Model(m)(mod).cpu()
+        rv, rx = torch.from_numpy(z[f"velocity_{tag}"]), torch.from_numpy(z[f"x0_{tag}"])
+        assert rel_l2(vel, rv) < 3e-2 and pearson(vel, rv) > 0.999, tag
+        assert rel_l2(x0, rx) < 3e-2 and pearson(x0, rx) > 0.999, tag
+
+
 def to_modality(d, dev):
     from ltx_2_mlx_amd.model.transformer import Modality
     return Modality(latent=d["latent"].to(dev), context=d["context"].to(dev), context_mask=None,
