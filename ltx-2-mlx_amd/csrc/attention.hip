@@ -56,9 +56,6 @@ struct Geo {
 #define AT_DV 6
 #endif
 
-__device__ __forceinline__ void glds16(const bf16* g, unsigned lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const void*)g, (lds_ptr_t)(uintptr_t)lds_wave_base, 16, 0, 0);
-}
 
 // v_max3_f32 directly: fmaxf() lowers to llvm.maxnum, which first canonicalises every MFMA output (one extra
 // v_max x,x per score).  The hazard recogniser does not see an asm's operands and an MFMA result has no hardware

@@ -15,14 +15,6 @@
 
 namespace {
 
-__device__ __forceinline__ float block_sum_256(float v, float* red) {
-    v = wave_sum(v);
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
-    if (lane == 0) red[wv] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-}
 
 // two simultaneous block sums over 256 threads
 __device__ __forceinline__ void block_sum2_256(float& a, float& b, float* red) {
