@@ -68,8 +68,9 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, const EpiRow& er
         if (to < 0) return;
         if (p.d2s_residual) {
             const int sp = p.ft * p.fh * p.fw;
+            const bf16* xs = p.res ? p.res : p.A;      // the padded-volume kernel reads its taps from a padded copy: p.res = the plain [M][Cin] input
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bf2f(p.A[(long)row * p.Cin + ((c_idx + e) % p.c_d2s) * sp + s_idx]);
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(xs[(long)row * p.Cin + ((c_idx + e) % p.c_d2s) * sp + s_idx]);
         }
         const long opos = ((long)to * (p.H * p.fh) + (er.h * p.fh + db)) * (p.Wd * p.fw) + (er.w * p.fw + dd);
         *(bf16x4*)((bf16*)p.out + opos * p.Cf + c_idx) = pack_bf16x4(v[0], v[1], v[2], v[3]);

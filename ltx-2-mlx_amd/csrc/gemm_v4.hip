@@ -608,7 +608,8 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
 // the padding rule already applied by the producer (replicate in T with `pad_front` leading frames, reflect in H / W), p.T /
 // p.H / p.Wd = the OUTPUT extent, M = T*H*Wd, K = 9*taps_t*Cin, weights [Cout][taps][Cin].
 bool gemm_v4_conv_supported(const GemmParams& p, int epilogue) {
-    if (epilogue != EPI_BF16 && epilogue != EPI_ADD_BF16) return false;
+    if (epilogue != EPI_BF16 && epilogue != EPI_ADD_BF16 && epilogue != EPI_D2S_BF16) return false;
+    if (epilogue == EPI_D2S_BF16 && (p.N % 256 != 0 || p.Cf < 4 || (p.d2s_residual && !p.res))) return false;      // depth-to-space scatter: layout 3 only; residual from p.res
     if (p.Cin < 128 || (p.Cin & (p.Cin - 1)) || p.N % 128 != 0) return false;          // an even number of K-tiles: 27 * Cin / 64
     if (p.taps_t != 3 && p.taps_t != 1) return false;
     if (p.M < 512) return false;
@@ -641,6 +642,7 @@ int gemm_v4_conv_launch(const GemmParams& p_in, int epilogue, hipStream_t stream
     const long t256 = ((long)(p.M + 255) / 256) * (p.N / 256), t224 = ((long)(p.M + 223) / 224) * (p.N / 256);
     const bool b224 = (t224 + 255) / 256 * 224 < (t256 + 255) / 256 * 256 || t224 < 256;
     const long mn = (long)p.M * p.N;
+    if (epilogue == EPI_D2S_BF16) return b224 ? launch_v4<EPI_D2S_BF16, 3, 224, true>(p, stream) : launch_v4<EPI_D2S_BF16, 3, 256, true>(p, stream);
     const int splits = (splitk_ws && p.ldo == p.N) ? conv_splits(b224 ? t224 : t256, p.K / 64, mn, ws_bytes) : 1;
     if (splits > 1) {
         GemmParams q = p;

@@ -73,6 +73,7 @@ int pixnorm_mod_silu_launch(const bf16* x, bf16* y, long P, int C, float eps, co
 int pixnorm_mod_silu_padded_launch(const bf16* x, bf16* y, int T, int H, int W, int C, float eps, const float* tab, const float* te,
                                    int shift_row, int scale_row, int pad_front, hipStream_t stream);
 // conv_out [T][H][W][48] bf16 -> video fp32 [3][T][4H][4W]  (reference ops.unpatchify packing (c, r_w, r_h))
+int pad_volume_launch(const bf16* x, bf16* y, int T, int H, int W, int C, int pad_front, hipStream_t stream);
 int vae_unpatchify_launch(const bf16* x, float* video, int T, int H, int W, hipStream_t stream);
 // video fp32 [3][T][H][W] -> frames uint8 [T][H][W][3] = trunc(clip((v+1)/2,0,1)*255)
 int video_to_uint8_launch(const float* video, unsigned char* frames, int T, int H, int W, hipStream_t stream);

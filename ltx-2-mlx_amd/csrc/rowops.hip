@@ -865,6 +865,25 @@ int vae_prepare_latent_launch(const float* latent, const float* std, const float
     return LTX2_OK;
 }
 
+// y = x copied into the padded channels-last volume [T+2][H+2][W+2][C] of the implicit-GEMM conv (same padding rule as the padded
+// pixel norm above, no arithmetic): the input of the depth-to-space upsample convs, which no norm precedes
+__global__ __launch_bounds__(256) void pad_volume_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long P, int cshift, int T, int H, int W,
+                                                         int pad_front) {
+    const int Hp = H + 2, Wp = W + 2, C8 = 1 << cshift;            // 16-byte chunks per position
+    const long total = P << cshift;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pos = i >> cshift;
+        const int c = (int)(i & (C8 - 1));
+        const int tp = (int)(pos / ((long)Hp * Wp)), r2 = (int)(pos - (long)tp * Hp * Wp), hp = r2 / Wp, wp = r2 - hp * Wp;
+        const int t = min(max(tp - pad_front, 0), T - 1);
+        int h = hp - 1, w = wp - 1;
+        h = h < 0 ? -h : (h >= H ? 2 * H - 2 - h : h);
+        w = w < 0 ? -w : (w >= W ? 2 * W - 2 - w : w);
+        const long src = ((long)t * H + h) * W + w;
+        *(u32x4*)(y + (pos << (cshift + 3)) + c * 8) = *(const u32x4*)(x + (src << (cshift + 3)) + c * 8);
+    }
+}
+
 static int pixnorm_launch_impl(const bf16* x, bf16* y, long P, int C, float eps, const float* tab, const float* te,
                                int shift_row, int scale_row, bool pad, int T, int H, int W, int pad_front, hipStream_t stream) {
     LTX2_CHECK_ARG(C >= 64 && (C & (C - 1)) == 0 && C <= 1024, "pixnorm: C=%d must be a power of two in [64,1024]", C);
@@ -899,6 +918,16 @@ int pixnorm_mod_silu_padded_launch(const bf16* x, bf16* y, int T, int H, int W, 
                                    int shift_row, int scale_row, int pad_front, hipStream_t stream) {
     LTX2_CHECK_ARG(H >= 2 && W >= 2 && T >= 1 && (pad_front == 1 || pad_front == 2), "pixnorm (padded): reflect padding needs H, W >= 2");
     return pixnorm_launch_impl(x, y, (long)(T + 2) * (H + 2) * (W + 2), C, eps, tab, te, shift_row, scale_row, true, T, H, W, pad_front, stream);
+}
+
+int pad_volume_launch(const bf16* x, bf16* y, int T, int H, int W, int C, int pad_front, hipStream_t stream) {
+    LTX2_CHECK_ARG(H >= 2 && W >= 2 && T >= 1 && (pad_front == 1 || pad_front == 2) && C >= 8 && (C & (C - 1)) == 0, "pad_volume: reflect padding needs H, W >= 2; C a power of two >= 8");
+    int cshift = 0;
+    while ((8 << cshift) < C) ++cshift;
+    const long P = (long)(T + 2) * (H + 2) * (W + 2);
+    hipLaunchKernelGGL(pad_volume_kernel, dim3(grid_for(P << cshift, 256, 16384)), dim3(256), 0, stream, x, y, P, cshift, T, H, W, pad_front);
+    LTX2_CHECK_LAUNCH("pad_volume_kernel");
+    return LTX2_OK;
 }
 
 int vae_unpatchify_launch(const bf16* x, float* video, int T, int H, int W, hipStream_t stream) {

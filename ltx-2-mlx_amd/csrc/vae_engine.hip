@@ -332,7 +332,23 @@ int ltx2_vae_decode(ltx2_vae* c, const float* latent, int T, int H, int W, float
             NEED(w);
             const float* b = W_F32(pre + ".conv.conv.bias", cout);
             NEED(b);
-            TRY(conv(X, w, b, Z, T, H, W, ch, cout, causal, EPI_D2S_BF16, nullptr, ft, fh, fw, cfg.residual[i], st));
+            GemmParams up = conv_params(Y, w, b, Z, T, H, W, ch, cout, causal, X);
+            up.ft = ft;
+            up.fh = fh;
+            up.fw = fw;
+            up.Cf = cout / sp;
+            up.cf_shift = ilog2(up.Cf);
+            up.drop_first = ft > 1 ? 1 : 0;
+            up.d2s_residual = cfg.residual[i];
+            up.c_d2s = ch / sp;
+            if (vae_v4_enabled() && (up.Cf & (up.Cf - 1)) == 0 && (!cfg.residual[i] || (ch % sp == 0 && up.c_d2s > 0)) && gemm_v4_conv_supported(up, EPI_D2S_BF16)) {
+                // the same padded-volume GEMM as the res-block convs: a copy pass writes the padding, the epilogue scatters depth to
+                // space and adds the tiled d2s(x) residual read from the unpadded input
+                TRY(pad_volume_launch(X, Y, T, H, W, ch, causal ? 2 : 1, st));
+                TRY(gemm_v4_conv_launch(up, EPI_D2S_BF16, st));
+            } else {
+                TRY(conv(X, w, b, Z, T, H, W, ch, cout, causal, EPI_D2S_BF16, nullptr, ft, fh, fw, cfg.residual[i], st));
+            }
             bf16* t = X;
             X = Z;
             Z = t;
