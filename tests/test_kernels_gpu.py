@@ -319,6 +319,35 @@ def test_flash_attn_stream_k(K, dev, heads, Nq, Nkv, hd):
         assert rel_l2(sk.float().cpu(), ref) < 1e-2
 
 
+def test_flash_attn_stream_k_beside_a_busy_stream(K, dev):
+    """The stream-K hand-off (workgroups waiting on flags of lower-numbered workgroups) while a second stream keeps GEMMs and row
+    kernels in flight on the same GPU -- the AudioVideo engine's situation: every launch bit-identical, flags and the sticky error
+    word clean afterwards (tools/sk_soak.py is the long form)."""
+    N, D, H = 3456, 4096, 32
+    g = torch.Generator(device=dev).manual_seed(0)
+    qq, kk = (torch.randn(N, D, generator=g, device=dev).to(BF) for _ in range(2))
+    vt = K.vt_transpose(torch.randn(N, D, generator=g, device=dev).to(BF), H)
+    ws = K.flash_attn_workspace(128, dev)
+    ref = K.flash_attn(qq, kk, vt, H, N, workspace=ws).clone()
+    side = torch.cuda.Stream()
+    a = torch.randn(3456, 4096, device=dev).to(BF)
+    w = (torch.randn(4096, 4096, device=dev) / 64).to(BF)
+    x = torch.randn(3456, 4096, device=dev)
+    for i in range(300):
+        with torch.cuda.stream(side):
+            if i % 3 == 0:
+                K.gemm(a, w)
+            elif i % 3 == 1:
+                K.adaln_rmsnorm(x)
+            else:
+                x.mul_(1.0)
+        out = K.flash_attn(qq, kk, vt, H, N, workspace=ws)
+        if i % 25 == 0:
+            assert torch.equal(out, ref), i
+    torch.cuda.synchronize()
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("M,heads,hd,Kd,expect_fused", [(3456, 32, 128, 4096, True), (3400, 8, 128, 512, True), (2200, 32, 64, 1024, True), (1100, 16, 64, 1024, False),
                                                        (3360, 8, 128, 512, False), (68, 32, 64, 2048, False)])
 def test_gemm_qkv_writes_vt(K, dev, M, heads, hd, Kd, expect_fused):
