@@ -381,3 +381,27 @@ def test_generate_video_keeps_the_reference_keyword_surface(tmp_path, capsys):
         generate.generate_video("a prompt", **dict(kw, num_frames=96))
     with pytest.raises(ValueError, match="divisible by 32"):
         generate.generate_video("a prompt", **dict(kw, height=250))
+
+
+def test_gemm_k_loop_generator_checks_its_own_pipeline():
+    """ltx-2-mlx_amd/csrc/gen_gemm_v4.py emits the hand-scheduled K loops AND replays each schedule against the LDS-stage / fragment
+    protocol (read only after the DMA landed + a barrier, DMA only after the last read retired + a barrier, no MFMA on an unretired
+    fragment).  The shipped variants must pass; schedules that break the protocol must be caught -- that is the point of the checker."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ltx-2-mlx_amd", "csrc", "gen_gemm_v4.py")
+    spec = importlib.util.spec_from_file_location("gen_gemm_v4", path)
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    d14 = list(range(0, 56, 4)) + [55]
+    ok = gen.Gen(14, 4, mb=16, npa=7, dma_last=d14, dma_ks0=[], m0_early=True)
+    ok.build()
+    assert gen.check(ok) == []
+    short = gen.Gen(6, 4, mb=16, npa=3, dma_last=list(range(1, 23, 2)), dma_ks0=[], m0_early=True)       # the ragged-last-row-tile loop
+    short.build()
+    assert gen.check(short) == []
+    # the checker must notice a broken protocol: replay the SAME schedule with its barriers, its DMA waits or its fragment waits removed
+    for drop in ("barrier", "vm", "lgkm0"):
+        bad = gen.Gen(14, 4, mb=16, npa=7, dma_last=d14, dma_ks0=[], m0_early=True)
+        bad.build()
+        bad.trace = [e for e in bad.trace if e[0] != drop]
+        assert gen.check(bad), drop
