@@ -363,7 +363,7 @@ def main():
         "step_mfma_roofline_frac": round(alg / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "hipgraph_ms_per_step": graph_ms if not isinstance(graph_ms, float) else round(graph_ms, 3),
         "prompt_setup_ms": round(prep_ms, 1),
-        "rccl_ranks": world, "weight_bytes": w_bytes, "weight_broadcast_s": round(bcast_s, 3),
+        "rccl_ranks": world, "collective_backend": (torch.distributed.get_backend() if world > 1 else None), "weight_bytes": w_bytes, "weight_broadcast_s": round(bcast_s, 3),
         "weight_broadcast_collectives": n_coll,
         "weight_broadcast_gbps": round(w_bytes / bcast_s / 1e9, 1) if world > 1 and bcast_s > 0 else None,
         "roofline": {"kernel": "gemm_v4_kernel<EPI_RESID_GATE_F32, layout 3, 224> (224x256x64 tile, 4 waves, generated asm K loop, "
