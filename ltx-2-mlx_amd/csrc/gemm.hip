@@ -233,6 +233,17 @@ inline bool use_big_tile(const GemmParams& p) {
     return tiles_big >= 160;
 }
 
+// Grids of 128..159 big tiles (the V2.3 text K/V projection: 1024 x 8192 x 4096 = 160 tiles of 224 rows) on the 4-wave kernel: one
+// round of tiles costs K/64 x ~1.27 us whatever the grid, the 128x128 kernel runs the chip at ~0.75 PF/s -- take the 4-wave kernel
+// only where that estimate says so (the a2v query projection, 3456 x 2048 x 4096 = 128 tiles, stays on the small tile: 68 vs ~89 us).
+inline bool v4_wins_medium_grid(const GemmParams& p) {
+    if (p.N < 256 || p.N % 256 != 0 || p.M < 1024) return false;
+    const long t224 = (long)((p.M + 223) / 224) * (p.N / 256);
+    if (t224 < 128 || t224 > 256) return false;
+    const double t_v4 = (p.K / 64) * 1.27e-6 + 8e-6, t_small = 2.0 * p.M * p.N * p.K / 0.75e15 + 10e-6;
+    return t_v4 < t_small;
+}
+
 // LTX2_V4_LAYOUT = 0 | 1 | 2 | 3 selects the wave layout of the 4-wave asm-loop kernel (gemm_v4.hip; default 3), -1 disables it
 inline int v4_layout() {
     static int v = -2;
@@ -264,7 +275,7 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
     if (ov == 2) return launch_cfg<CfgBig, EPI, CONV>(p, stream);
     if (ov == 1) return launch_cfg<CfgSmall, EPI, CONV>(p, stream);
     if (ov == 0 && !CONV && EPI != EPI_D2S_BF16 && gemm_skinny_supported(p, EPI)) return gemm_skinny_launch(p, EPI, stream);      // M <= 128: the audio stream
-    if (ov == 0 && !CONV && v4_layout() >= 0 && use_big_tile(p) && gemm_v4_supported(p, EPI, CONV)) return gemm_v4_launch(p, EPI, stream, v4_layout(), 0);
+    if (ov == 0 && !CONV && v4_layout() >= 0 && (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_supported(p, EPI, CONV)) return gemm_v4_launch(p, EPI, stream, v4_layout(), 0);
     if (ov == 3 || use_big_tile(p)) return gemm_pp_launch(p, EPI, CONV, stream);
     if (p.N <= 64 && p.M >= 4096 && ov != 7) return launch_cfg<CfgNarrow, EPI, CONV>(p, stream);
     return launch_cfg<CfgSmall, EPI, CONV>(p, stream);
@@ -328,7 +339,7 @@ bool gemm_vt_fused(const GemmParams& p, int epilogue) {
     if (!on || !p.vt || p.lda % 8 != 0) return false;
     if (tile_override() == 0 && gemm_skinny_supported(p, epilogue)) return false;      // M <= 128 goes to the skinny kernel
     if (p.W8) return gemm_v4_vt_supported(p, epilogue, 3);
-    return tile_override() == 0 && v4_layout() == 3 && use_big_tile(p) && gemm_v4_vt_supported(p, epilogue, 3);
+    return tile_override() == 0 && v4_layout() == 3 && (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_vt_supported(p, epilogue, 3);
 }
 
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream) {
