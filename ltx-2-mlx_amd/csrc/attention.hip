@@ -507,7 +507,17 @@ static int sk_workers(const AttnParams& p, bool* xcd) {
     }
     const int nqt = (p.Nq + QB - 1) / QB;
     const long units = (long)nqt * p.H;
-    if (units <= slots || slots % 8) return 0;
+    if (slots % 8) return 0;
+    if (units * 4 <= slots && p.Nkv >= 16 * KVB) {
+        // FEW query tiles against a long KV range (video -> audio cross-modal attention: 68 audio queries x 32 heads = 32 units, each
+        // walking 54 KV tiles alone): phase B alone cuts every unit's KV range over several workgroups (>= 4 tiles each), the unit's
+        // last workgroup folds the pieces in order -- the split-KV form of the same hand-off (39 -> ~17 us at 68 x 3456, head_dim 64)
+        const long nt = (p.Nkv + KVB - 1) / KVB;
+        const long w = units * nt / 4;
+        *xcd = false;
+        return (int)(w < slots ? w : slots);
+    }
+    if (units <= slots) return 0;
     // Measured (same box): 864 units x 54 KV tiles (0.84 of the last round filled) 211 -> 203 us; 3456 units x 216 tiles (0.96)
     // 2869 -> 2869 us; short KV (text cross-attention, 16 tiles) 72 -> 78 us: the hand-off costs more than the tail there.
     const double rounds = (double)units / slots;

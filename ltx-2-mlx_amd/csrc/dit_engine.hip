@@ -457,10 +457,13 @@ int gate_apply(ltx2_dit* c, Mod& m, bf16* att, int rows, int H, int hd, hipStrea
 // K (k_norm applied, optional RoPE) and V^T of a text / cross-modal context
 int project_kv(const bf16* ctx, int rows, int Dc, const AttnW& w, int Di, int H, int hd, float eps, const float* cosb,
                const float* sinb, bf16* kv, bf16* vt, int npad, hipStream_t st) {
-    TRY(dense(ctx, Dc, w.kv_w, w.kv_b, kv, 2 * Di, rows, 2 * Di, Dc, EPI_BF16, st));
+    const VtOut vo{vt, Di, npad, hd};
+    bool vt_done = false;           // V^T straight from the K/V GEMM's epilogue where the 4-wave kernel takes the shape
+    TRY(dense(ctx, Dc, w.kv_w, w.kv_b, kv, 2 * Di, rows, 2 * Di, Dc, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done));
     const int offs[1] = {0};
     const float* wts[1] = {w.kn};
     TRY(qknorm_rope_launch(kv, 2 * Di, rows, Di, hd, 1, offs, wts, eps, cosb, sinb, st));
+    if (vt_done) return LTX2_OK;
     return vt_transpose_launch(kv + Di, 2 * Di, vt, rows, npad, H, st, hd);
 }
 
@@ -564,7 +567,7 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st) {
         TRY(qknorm_rope_launch(a.qkv, Da, a.N, Da, hd, 1, offs, wts, eps, a.ccos, a.csin, st));
     }
     TRY(project_kv(v.h2, v.N, Dv, w.v2a, Da, H, hd, eps, v.ccos, v.csin, v.qkv, v.vt, v.Npad, st));
-    TRY(attend(a.qkv, Da, v.qkv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, st));
+    TRY(attend(a.qkv, Da, v.qkv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, st, c));        // few queries, long KV: the split-KV launch form
     TRY(gate_apply(c, a, a.att, a.N, H, hd, st));
     TRY(dense(a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, st, a.cross_gate, 0, ta + 4 * Da));
     return LTX2_OK;

@@ -295,7 +295,8 @@ def test_flash_attn_bit_reproducible(K, dev, heads, Nq, Nkv, hd):
 
 
 @pytest.mark.parametrize("heads,Nq,Nkv,hd", [(32, 3456, 3456, 128), (32, 3456, 1024, 128), (32, 3456, 68, 64), (32, 3400, 3401, 128),
-                                              (20, 4000, 999, 128), (32, 13824, 1024, 128), (8, 8300, 130, 64)])
+                                              (20, 4000, 999, 128), (32, 13824, 1024, 128), (8, 8300, 130, 64),
+                                              (32, 68, 3456, 64), (2, 100, 5000, 128), (3, 37, 1100, 64)])       # few queries, long KV: the split-KV form
 def test_flash_attn_stream_k(K, dev, heads, Nq, Nkv, hd):
     """The stream-K launch form (more (q-tile, head) units than workgroup slots): same result as the plain grid within the
     fp32 rounding of the two-piece merge, against the oracle like the plain form, bit-reproducible, and the flags are back
