@@ -281,8 +281,8 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         // of 16 different rows, so touching x straight from them moves 16 x 64 B per instruction -- half of every 128-byte line,
         // twice.  Transposed through this wave's share of the dead stage buffers (half a wave tile at a time: rows x 256 B, 16-byte
         // chunks XOR-swizzled with the row) every global load / store instruction covers 4 whole 256-byte row segments.
-        constexpr int RBH = RBW / 2, ROWB = WN * 4, HALF = RBH * MB;      // row blocks, bytes per slab row, rows per pass
-        static_assert(RBW % 2 == 0 && ROWB == 256 && HALF % 4 == 0 && 4 * HALF * ROWB <= G::LDS_BYTES, "resid epilogue slab");
+        constexpr int ROWB = WN * 4, PR = 2 * MB, NP = RBW / 2, NIT = PR / 4;   // bytes per slab row, rows / parts / readback steps per part
+        static_assert(RBW % 2 == 0 && ROWB == 256 && 4 * 2 * PR * ROWB <= G::LDS_BYTES, "resid epilogue slab");
         f32x4 g4[CBW];
 #pragma unroll
         for (int cb = 0; cb < CBW; ++cb) {
@@ -292,38 +292,44 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                 if (p.gate) g4[cb] += *(const f32x4*)(p.gate + n0 + wc * WN + cb * MB + 4 * kq);
             }
         }
-        char* wl = smem + w * (HALF * ROWB);
+        // The wave tile leaves in parts of two row blocks (32 rows).  Each wave owns a double-buffered slab of its own, so after
+        // the one barrier that ends the K loop nothing synchronises: slab write of part p, then the residual rows of part p + 2
+        // are requested, then part p is read back row-contiguously, added and stored -- two parts' loads are always in flight.
+        char* wl = smem + w * (2 * PR * ROWB);
         const int rr = lane >> 4, cc = lane & 15;                            // readback: 4 rows x 16 chunks per instruction
         float* xg = (float*)p.out + (long)(m0 + rr) * p.ldo + n0 + wc * WN + cc * 4;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {          // (unrolled: the accumulator indices must be compile-time constants)
-            if (m0 + half * HALF >= p.M) break;                              // (block-uniform) ragged last row tile
-            // the residual rows of this half are requested FIRST, all of them (HALF / 4 x 16 B per lane: the fragment registers
-            // are dead, the VGPR file is free), so the HBM round trip runs under the barrier and the slab writes
-            constexpr int NIT = HALF / 4;
-            f32x4 xv[NIT];
+        const int nparts = min(NP, (p.M - m0 + PR - 1) / PR);                // (block-uniform) ragged last row tile
+        f32x4 xv[3][NIT];
+        auto load_part = [&](int part, f32x4* dst) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
-                const long grow = min((long)m0 + half * HALF + i * 4 + rr, (long)p.M - 1) - (m0 + rr);
-                xv[i] = *(const f32x4*)(xg + grow * p.ldo);
+                const long grow = min((long)m0 + part * PR + i * 4 + rr, (long)p.M - 1) - (m0 + rr);
+                dst[i] = *(const f32x4*)(xg + grow * p.ldo);
             }
-            __syncthreads();            // first pass: every wave has finished its fragment reads; second: the slab is free again
+        };
+        load_part(0, xv[0]);
+        if (nparts > 1) load_part(1, xv[1]);
+        __syncthreads();                // every wave has finished its fragment reads: the stage buffers are free
 #pragma unroll
-            for (int r = 0; r < RBH; ++r) {
-                const int rb = half * RBH + r, row = r * MB + lr;
-                if (m0 + rb * MB >= p.M) continue;
+        for (int part = 0; part < NP; ++part) {         // (unrolled: the accumulator indices must be compile-time constants)
+            if (part >= nparts) break;
+            char* sl = wl + (part & 1) * (PR * ROWB);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int rb = part * 2 + r, row = r * MB + lr;
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb) {
                     const f32x4 v = g4[cb] * (acc_group(rb, cb, 0) + bias4[cb][0]);
-                    *(f32x4*)(wl + row * ROWB + (((cb * 4 + kq) ^ (row & 15)) << 4)) = v;
+                    *(f32x4*)(sl + row * ROWB + (((cb * 4 + kq) ^ (row & 15)) << 4)) = v;
                 }
             }
+            if (part + 2 < nparts) load_part(part + 2, xv[(part + 2) % 3]);
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int row = i * 4 + rr;
-                asm volatile("" : "+v"(xv[i]));       // consume in issue order: counted waits, not vmcnt(0)
-                const f32x4 d = *(const f32x4*)(wl + row * ROWB + ((cc ^ (row & 15)) << 4));
-                if (m0 + half * HALF + row < p.M) *(f32x4*)(xg + ((long)half * HALF + row - rr) * p.ldo) = xv[i] + d;
+                asm volatile("" : "+v"(xv[part % 3][i]));       // consume in issue order: counted waits, not vmcnt(0)
+                const f32x4 d = *(const f32x4*)(sl + row * ROWB + ((cc ^ (row & 15)) << 4));
+                if (m0 + part * PR + row < p.M) *(f32x4*)(xg + ((long)part * PR + row - rr) * p.ldo) = xv[part % 3][i] + d;
             }
         }
       }
