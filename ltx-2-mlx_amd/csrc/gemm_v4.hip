@@ -161,6 +161,29 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         cptm1 = __builtin_amdgcn_readfirstlane((p.Cin >> 6) - 1);
     }
 
+    // bias / gate-table column vectors of this lane (4 consecutive columns per column block).  Layout 3 requests the bias BEFORE the K
+    // loop: 16 VGPRs above the loop's register range carry it across, and that L2 round trip is off the epilogue's start.
+    constexpr int NG = MB == 32 ? 4 : 1;
+    constexpr bool HOIST_COL_VECTORS = LAYOUT == 3 && MB == 16 && BM == 224 && !CONV &&        // (the instantiations with the registers to spare: checked with -Rpass-analysis)
+                                       (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RESID_GATE_F32);
+    f32x4 bias4[CBW][NG];
+    f32x4 gate4[CBW][NG];
+    auto load_bias = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq)
+                bias4[cb][gq] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto load_gate = [&]() __attribute__((always_inline)) {       // (the gated-residual kernel has no room to carry these across the loop too)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq)
+                gate4[cb][gq] = (EPI == EPI_RESID_GATE_F32 && p.gate_table) ? *(const f32x4*)(p.gate_table + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq)
+                                                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    if constexpr (HOIST_COL_VECTORS) load_bias();
     f32x16 acc[16];
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
@@ -242,17 +265,8 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     // ---- epilogue (gemm_epilogue.h): a lane owns ONE row of every row block and 4-column groups of it ----
     // 32x32 block: row lr, groups gq = 0..3 at columns 8 gq + 4 kq (accumulator registers 4 gq .. 4 gq + 3)
     // 16x16 block: row lr, one group at columns 4 kq (accumulator registers 0..3)
-    constexpr int NG = MB == 32 ? 4 : 1;
-    f32x4 bias4[CBW][NG];
-    f32x4 gate4[CBW][NG];
-#pragma unroll
-    for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-        for (int gq = 0; gq < NG; ++gq) {
-            const int col = n0 + wc * WN + cb * MB + 8 * gq + 4 * kq;
-            bias4[cb][gq] = p.bias ? *(const f32x4*)(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-            gate4[cb][gq] = (EPI == EPI_RESID_GATE_F32 && p.gate_table) ? *(const f32x4*)(p.gate_table + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    if constexpr (!HOIST_COL_VECTORS) load_bias();
+    load_gate();
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
