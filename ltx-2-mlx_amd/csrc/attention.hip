@@ -55,6 +55,12 @@ struct Geo {
 #ifndef AT_DV
 #define AT_DV 6
 #endif
+#ifndef AT_MAX2
+#define AT_MAX2 0
+#endif
+#ifndef AT_SFMA
+#define AT_SFMA 1       // scalar-slot fma / add for the exponent argument and the row sum (round 3, same-box A/B: -2.5 % vs the packed forms)
+#endif
 
 
 // v_max3_f32 directly: fmaxf() lowers to llvm.maxnum, which first canonicalises every MFMA output (one extra
@@ -291,8 +297,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
             float tmax = -INFINITY;
             mfma_result_guard(s[0], s[1], tmax);
+#if AT_MAX2
+            {   // two independent v_max3 chains in two asm blocks (the compiler puts a hazard s_nop behind every single-instruction asm)
+                float ta = -INFINITY, tb2 = -INFINITY;
+#define MX4(o) "v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %1, %1, %8, %9\n\t" \
+               "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %1, %1, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max3_f32 %1, %1, %16, %17"
+                asm volatile(MX4(0) : "+v"(ta), "+v"(tb2) : "v"(s[0][0]), "v"(s[1][0]), "v"(s[0][1]), "v"(s[1][1]), "v"(s[0][2]), "v"(s[1][2]), "v"(s[0][3]), "v"(s[1][3]),
+                             "v"(s[0][4]), "v"(s[1][4]), "v"(s[0][5]), "v"(s[1][5]), "v"(s[0][6]), "v"(s[1][6]), "v"(s[0][7]), "v"(s[1][7]));
+                asm volatile(MX4(0) : "+v"(ta), "+v"(tb2) : "v"(s[0][8]), "v"(s[1][8]), "v"(s[0][9]), "v"(s[1][9]), "v"(s[0][10]), "v"(s[1][10]), "v"(s[0][11]), "v"(s[1][11]),
+                             "v"(s[0][12]), "v"(s[1][12]), "v"(s[0][13]), "v"(s[1][13]), "v"(s[0][14]), "v"(s[1][14]), "v"(s[0][15]), "v"(s[1][15]));
+#undef MX4
+                asm volatile("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(ta), "v"(tb2));
+            }
+#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) tmax = max3(tmax, s[0][r], s[1][r]);
+#endif
             {   // other lane half: VALU swap, no LDS-queue operation between the counted waits
                 float t_lo, t_hi;
                 half_pair(tmax, t_lo, t_hi);
@@ -315,9 +335,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             }
             const float mc = m_run * c;
             // two scores per VALU op where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32); v_exp_f32 is scalar
+            bf16x8 pf[2][2];
+#if AT_SFMA
+            // scalar-slot v_fma_f32 / v_add_f32 (packed f32 VALU beside MFMAs costs more than its two scalar halves: MI355X_MICROARCH.md)
+            const float nmc = -mc;
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float e0 = __builtin_fmaf(s[b][r], c, nmc), e1 = __builtin_fmaf(s[b][r + 1], c, nmc);
+                    const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
+                    ps0 += p0;
+                    ps1 += p1;
+                    pf[b][r >> 3][r & 7] = f2bf(p0);
+                    pf[b][r >> 3][(r & 7) + 1] = f2bf(p1);
+                }
+            l_run += ps0 + ps1;
+#else
             const f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
             f32x2 psum2 = {0.f, 0.f};
-            bf16x8 pf[2][2];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -330,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                     pf[b][r >> 3][(r & 7) + 1] = f2bf(pv[1]);
                 }
             l_run += psum2[0] + psum2[1];
+#endif
 
             // ---- O^T += V^T . P^T ----
             static_for<0, NV>([&](auto N) {
