@@ -36,6 +36,12 @@ extern "C" {
 #define LTX2_DTYPE_F32 1
 #define LTX2_DTYPE_FP8_E4M3FN 2   /* ltx2_dit_set_weight: codes of a fp8-resident linear weight; `<name>_scale` (fp32 [out]) must be set too */
 
+/* Version of THIS header's signatures.  ltx2_abi_version() returns the version the library was built with; a caller compares the
+ * two before its first compute call (the Python binding refuses to load a library that reports another version).  History:
+ * 1 = round 1;  2 = round 2 added the `sigma` / `sigma_dev` argument to ltx2_dit_forward / ltx2_dit_denoise_step (in the middle of
+ * the list: an old caller's arguments would shift silently), round 3 added ltx2_dit_health. */
+#define LTX2_ABI_VERSION 2
+
 const char* ltx2_last_error(void);
 int ltx2_abi_version(void);
 
@@ -296,6 +302,12 @@ int ltx2_dit_graph_capture(ltx2_dit* ctx, float* latent, const float* host_sigma
 int ltx2_dit_graph_capture_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps,
                               void* stream);
 int ltx2_dit_graph_launch(ltx2_dit* ctx, void* stream);
+
+/* Health check at a host synchronisation point (per prompt / after a sampling loop): synchronises `stream`, reads the sticky error
+ * word of the stream-K attention hand-off (a consumer that waited ~0.2 s for a partial result gives up instead of hanging the GPU,
+ * ltx2_flash_attn_ws) and, if it is set, resets the flag page and returns LTX2_E_STATE: everything computed since the last check is
+ * invalid.  LTX2_OK otherwise.                                                                                         */
+int ltx2_dit_health(ltx2_dit* ctx, void* stream);
 
 /* Measurement aid: bracket every launch of one GEMM kernel instantiation (epilogue id, or -1 for
  * every GEMM) issued by this thread's ltx2_dit_* calls with HIP events on the launch stream;

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LTX2HIP_LIB: another build of the same library (A/B timing of kernel changes on one GPU box)
 LIB_PATH = os.environ.get("LTX2HIP_LIB") or os.path.join(_HERE, "lib", "libltx2hip.so")
 
+ABI_VERSION = 2         # LTX2_ABI_VERSION of include/ltx2hip.h these signatures were written against
 OK, E_INVALID, E_HIP, E_STATE = 0, -1, -2, -3
 DTYPE_BF16, DTYPE_F32, DTYPE_FP8_E4M3FN = 0, 1, 2
 MODEL_VIDEO_ONLY, MODEL_AUDIO_VIDEO = 0, 1
@@ -89,6 +90,7 @@ SIGNATURES = {
     "ltx2_dit_denoise_step": (i32, [vp, vp, vp, i32, vp, vp, vp, f32, f32, vp, vp]),
     "ltx2_dit_graph_capture": (i32, [vp, vp, C.POINTER(f32), i32, vp]),
     "ltx2_dit_graph_launch": (i32, [vp, vp]),
+    "ltx2_dit_health": (i32, [vp, vp]),
     "ltx2_dit_profile_begin": (i32, [vp, i32]),
     "ltx2_dit_profile_end": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
     "ltx2_vae_create": (i32, [C.POINTER(VaeConfig), C.POINTER(vp)]),
@@ -117,9 +119,17 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C ltx-2-mlx_amd/csrc`). There is no CPU fallback for the hot path.")
         l = C.CDLL(LIB_PATH)
+        l.ltx2_abi_version.restype = i32
+        l.ltx2_abi_version.argtypes = []
+        have = l.ltx2_abi_version()
+        if have != ABI_VERSION:
+            # signatures changed between versions (arguments inserted mid-list): calling through mismatched ones would shift
+            # pointers silently, so a library of another version is refused outright -- also under LTX2HIP_LIB
+            raise NativeLibraryMissing(f"{LIB_PATH} reports ABI version {have}, this binding needs {ABI_VERSION}: rebuild it "
+                                       "(`make -C ltx-2-mlx_amd/csrc`)")
         for name, (res, args) in SIGNATURES.items():
             if os.environ.get("LTX2HIP_LIB") and not hasattr(l, name):
-                continue                # an OLDER build loaded for a same-box A/B run: entries it lacks just cannot be called
+                continue                # an A/B build of the SAME ABI version that predates a newly ADDED entry: it just cannot be called
             fn = getattr(l, name)       # AttributeError if the ABI and the header drift apart
             fn.restype = res
             fn.argtypes = args

@@ -20,7 +20,7 @@ void ltx2_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* ltx2_last_error(void) { return g_err; }
-int ltx2_abi_version(void) { return 1; }
+int ltx2_abi_version(void) { return LTX2_ABI_VERSION; }
 
 int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M,
                    int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table,

@@ -93,7 +93,10 @@ struct ltx2_dit {
     long ws_bytes = 0;
     int per_token = 0;
     float* sigmas_dev = nullptr;
-    std::vector<const void*> fp8_keys;  // this context's entries of g_fp8_scale (erased on destroy: the addresses get reused)
+    // fp8-resident linear weights: the typed `const bf16*` fields of the weight structs then hold the CODES pointer; dense() looks it
+    // up here to hand the GEMM (codes, per-row scale) instead of bf16 weights.  Per context (a second context over the same tensors
+    // -- the video twin of an AudioVideo model -- keeps its own entries); rebuilt whenever the weights are resolved again.
+    std::unordered_map<const void*, const float*> fp8_scale;
     void* sk_ws = nullptr;             // stream-K attention scratch (attention.h); main-stream launches only
     long sk_bytes = 0;
     bool prepared = false;
@@ -169,11 +172,6 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
     return off;
 }
 
-// fp8-resident linear weights: the typed `const bf16*` fields of the weight structs then hold the CODES pointer; dense() looks it
-// up here to hand the GEMM (codes, per-row scale) instead of bf16 weights.  Filled while weights are resolved (single thread),
-// read-only afterwards.
-std::unordered_map<const void*, const float*> g_fp8_scale;
-
 const void* find(ltx2_dit* c, const std::string& name, int dtype, long numel) {
     auto it = c->weights.find(name);
     if (it == c->weights.end()) {
@@ -186,8 +184,7 @@ const void* find(ltx2_dit* c, const std::string& name, int dtype, long numel) {
             ltx2_set_error("dit: fp8-resident weight '%s' has no fp32 '%s_scale' vector", name.c_str(), name.c_str());
             return nullptr;
         }
-        g_fp8_scale[it->second.p] = (const float*)sc->second.p;
-        c->fp8_keys.push_back(it->second.p);
+        c->fp8_scale[it->second.p] = (const float*)sc->second.p;
         return it->second.p;
     }
     if (it->second.dtype != dtype || it->second.n != numel) {
@@ -249,6 +246,7 @@ int resolve_attn(ltx2_dit* c, AttnW& a, const std::string& name, long Dq, long D
 
 int resolve(ltx2_dit* c) {
     if (c->resolved) return LTX2_OK;
+    c->fp8_scale.clear();
     const int nm = c->av ? 2 : 1;
     const int rows = c->v2 ? 9 : 6;
     for (int k = 0; k < nm; ++k) {
@@ -316,16 +314,16 @@ struct VtOut {
     int col0, npad, hd;
 };
 
-int dense(const bf16* A, long lda, const bf16* W, const float* bias, void* out, long ldo, int M, int N, int K, int epi,
+int dense(ltx2_dit* c, const bf16* A, long lda, const bf16* W, const float* bias, void* out, long ldo, int M, int N, int K, int epi,
           hipStream_t st, const float* gate = nullptr, long gate_stride = 0, const float* gate_table = nullptr,
           const VtOut* vt = nullptr, bool* vt_done = nullptr) {
     GemmParams p{};
     p.A = A;
     p.lda = lda;
     p.W = W;
-    if (!g_fp8_scale.empty()) {
-        auto f8 = g_fp8_scale.find((const void*)W);
-        if (f8 != g_fp8_scale.end()) {      // fp8-resident: codes + per-row scale, expanded inside the GEMM
+    if (!c->fp8_scale.empty()) {
+        auto f8 = c->fp8_scale.find((const void*)W);
+        if (f8 != c->fp8_scale.end()) {      // fp8-resident: codes + per-row scale, expanded inside the GEMM
             p.W = nullptr;
             p.W8 = (const unsigned char*)W;
             p.wscale = f8->second;
@@ -375,7 +373,7 @@ __global__ void silu_cast_kernel(const float* __restrict__ in, bf16* __restrict_
 
 // AdaLayerNormSingle over T rows of timesteps (ts[i*t_stride] * mult): emb [T][rows*D] (fp32) and,
 // when e_out != null, the embedded timestep e [T][D] (model.py:113-140).
-int adaln_chain(Mod& m, const AdaW& a, const float* ts, long t_stride, int T, float mult, float* emb, float* e_out,
+int adaln_chain(ltx2_dit* c, Mod& m, const AdaW& a, const float* ts, long t_stride, int T, float mult, float* emb, float* e_out,
                 hipStream_t st) {
     const int D = m.D;
     if (T == 1) {
@@ -386,11 +384,11 @@ int adaln_chain(Mod& m, const AdaW& a, const float* ts, long t_stride, int T, fl
         TRY(gemv_launch(e, D, a.lin_w, a.lin_b, emb, (long)a.rows * D, 1, a.rows * D, D, 1, 0, st));
     } else {
         TRY(timestep_sinusoid_launch(ts, t_stride, 0.f, mult, T, 256, nullptr, m.sin_b, st));
-        TRY(dense(m.sin_b, 256, a.t1_w, a.t1_b, m.e1_b, D, T, D, 256, EPI_SILU_BF16, st));
-        TRY(dense(m.e1_b, D, a.t2_w, a.t2_b, e_out, D, T, D, D, EPI_F32, st));
+        TRY(dense(c, m.sin_b, 256, a.t1_w, a.t1_b, m.e1_b, D, T, D, 256, EPI_SILU_BF16, st));
+        TRY(dense(c, m.e1_b, D, a.t2_w, a.t2_b, e_out, D, T, D, D, EPI_F32, st));
         hipLaunchKernelGGL(silu_cast_kernel, dim3(2048), dim3(256), 0, st, e_out, m.es_b, (long)T * D);
         LTX2_CHECK_LAUNCH("silu_cast_kernel");
-        TRY(dense(m.es_b, D, a.lin_w, a.lin_b, emb, (long)a.rows * D, T, a.rows * D, D, EPI_F32, st));
+        TRY(dense(c, m.es_b, D, a.lin_w, a.lin_b, emb, (long)a.rows * D, T, a.rows * D, D, EPI_F32, st));
     }
     return LTX2_OK;
 }
@@ -455,11 +453,11 @@ int gate_apply(ltx2_dit* c, Mod& m, bf16* att, int rows, int H, int hd, hipStrea
 }
 
 // K (k_norm applied, optional RoPE) and V^T of a text / cross-modal context
-int project_kv(const bf16* ctx, int rows, int Dc, const AttnW& w, int Di, int H, int hd, float eps, const float* cosb,
+int project_kv(ltx2_dit* c, const bf16* ctx, int rows, int Dc, const AttnW& w, int Di, int H, int hd, float eps, const float* cosb,
                const float* sinb, bf16* kv, bf16* vt, int npad, hipStream_t st) {
     const VtOut vo{vt, Di, npad, hd};
     bool vt_done = false;           // V^T straight from the K/V GEMM's epilogue where the 4-wave kernel takes the shape
-    TRY(dense(ctx, Dc, w.kv_w, w.kv_b, kv, 2 * Di, rows, 2 * Di, Dc, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done));
+    TRY(dense(c, ctx, Dc, w.kv_w, w.kv_b, kv, 2 * Di, rows, 2 * Di, Dc, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done));
     const int offs[1] = {0};
     const float* wts[1] = {w.kn};
     TRY(qknorm_rope_launch(kv, 2 * Di, rows, Di, hd, 1, offs, wts, eps, cosb, sinb, st));
@@ -479,7 +477,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     TRY(gate_logits(c, m, w.self, m.h, D, N, H, st));
     const VtOut vo{m.vt, 2 * D, m.Npad, hd};
     bool vt_done = false;           // the QKV GEMM's epilogue writes V^T itself where it can (gemm_v4.hip)
-    TRY(dense(m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done));
+    TRY(dense(c, m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done));
     {
         const int offs[2] = {0, D};
         const float* wts[2] = {w.self.qn, w.self.kn};
@@ -488,7 +486,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
     TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, k == 0 ? c : nullptr));
     TRY(gate_apply(c, m, m.att, N, H, hd, st));
-    TRY(dense(m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 2 * D, es, w.sst + 2 * D));
+    TRY(dense(c, m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 2 * D, es, w.sst + 2 * D));
 
     // text cross-attention: no RoPE, no mask.  V1: plain RMSNorm on x, K/V cached per prompt.
     // V2.3 (transformer.py:427-455): q side modulated by rows (6,7) and gated by row 8; the context
@@ -498,7 +496,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     if (c->v2) {
         TRY(norm_mod_launch(m.x, D, m.h, D, N, D, eps, 0, w.sst + 7 * D, w.sst + 6 * D, emb + 7 * D, emb + 6 * D, es, st));
         TRY(ctx_mod_launch(m.ctx, m.ctxm, m.S, D, w.prompt_sst + D, w.prompt_sst, m.prompt_emb + D, m.prompt_emb, st));
-        TRY(project_kv(m.ctxm, m.S, D, w.text, D, H, hd, eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st));
+        TRY(project_kv(c, m.ctxm, m.S, D, w.text, D, H, hd, eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st));
         kk = m.kv2;
         vt = m.vt2;
     } else {
@@ -507,7 +505,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
         vt = m.vt2 + (long)l * D * m.Spad;
     }
     TRY(gate_logits(c, m, w.text, m.h, D, N, H, st));
-    TRY(dense(m.h, D, w.text.q_w, w.text.q_b, m.qkv, D, N, D, D, EPI_BF16, st));
+    TRY(dense(c, m.h, D, w.text.q_w, w.text.q_b, m.qkv, D, N, D, D, EPI_BF16, st));
     {
         const int offs[1] = {0};
         const float* wts[1] = {w.text.qn};
@@ -516,9 +514,9 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st, k == 0 ? c : nullptr));
     TRY(gate_apply(c, m, m.att, N, H, hd, st));
     if (c->v2)
-        TRY(dense(m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 8 * D, es, w.sst + 8 * D));
+        TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 8 * D, es, w.sst + 8 * D));
     else
-        TRY(dense(m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st));
+        TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st));
     return LTX2_OK;
 }
 
@@ -529,8 +527,8 @@ int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     const int N = m.N, D = m.D;
     const float* emb = m.emb;
     TRY(norm_mod_launch(m.x, D, m.h, D, N, D, c->cfg.norm_eps, 0, w.sst + 4 * D, w.sst + 3 * D, emb + 4 * D, emb + 3 * D, es, st));
-    TRY(dense(m.h, D, w.ff1_w, w.ff1_b, m.ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st));
-    TRY(dense(m.ff, 4 * D, w.ff2_w, w.ff2_b, m.x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, emb + 5 * D, es, w.sst + 5 * D));
+    TRY(dense(c, m.h, D, w.ff1_w, w.ff1_b, m.ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st));
+    TRY(dense(c, m.ff, 4 * D, w.ff2_w, w.ff2_b, m.x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, emb + 5 * D, es, w.sst + 5 * D));
     return LTX2_OK;
 }
 
@@ -550,26 +548,26 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st) {
     const int offs[1] = {0};
     // audio -> video: Q from video (Dv -> Da), K/V from audio
     TRY(gate_logits(c, v, w.a2v, v.h, Dv, v.N, H, st));
-    TRY(dense(v.h, Dv, w.a2v.q_w, w.a2v.q_b, v.qkv, Da, v.N, Da, Dv, EPI_BF16, st));
+    TRY(dense(c, v.h, Dv, w.a2v.q_w, w.a2v.q_b, v.qkv, Da, v.N, Da, Dv, EPI_BF16, st));
     {
         const float* wts[1] = {w.a2v.qn};
         TRY(qknorm_rope_launch(v.qkv, Da, v.N, Da, hd, 1, offs, wts, eps, v.ccos, v.csin, st));
     }
-    TRY(project_kv(a.h, a.N, Da, w.a2v, Da, H, hd, eps, a.ccos, a.csin, a.qkv, a.vt, a.Npad, st));
+    TRY(project_kv(c, a.h, a.N, Da, w.a2v, Da, H, hd, eps, a.ccos, a.csin, a.qkv, a.vt, a.Npad, st));
     TRY(attend(v.qkv, Da, a.qkv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st, c));
     TRY(gate_apply(c, v, v.att, v.N, H, hd, st));
-    TRY(dense(v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, v.cross_gate, 0, tv + 4 * Dv));
+    TRY(dense(c, v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, v.cross_gate, 0, tv + 4 * Dv));
     // video -> audio: Q from audio, K/V from video (Dv -> Da)
     TRY(gate_logits(c, a, w.v2a, a.h2, Da, a.N, H, st));
-    TRY(dense(a.h2, Da, w.v2a.q_w, w.v2a.q_b, a.qkv, Da, a.N, Da, Da, EPI_BF16, st));
+    TRY(dense(c, a.h2, Da, w.v2a.q_w, w.v2a.q_b, a.qkv, Da, a.N, Da, Da, EPI_BF16, st));
     {
         const float* wts[1] = {w.v2a.qn};
         TRY(qknorm_rope_launch(a.qkv, Da, a.N, Da, hd, 1, offs, wts, eps, a.ccos, a.csin, st));
     }
-    TRY(project_kv(v.h2, v.N, Dv, w.v2a, Da, H, hd, eps, v.ccos, v.csin, v.qkv, v.vt, v.Npad, st));
+    TRY(project_kv(c, v.h2, v.N, Dv, w.v2a, Da, H, hd, eps, v.ccos, v.csin, v.qkv, v.vt, v.Npad, st));
     TRY(attend(a.qkv, Da, v.qkv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, st, c));        // few queries, long KV: the split-KV launch form
     TRY(gate_apply(c, a, a.att, a.N, H, hd, st));
-    TRY(dense(a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, st, a.cross_gate, 0, ta + 4 * Da));
+    TRY(dense(c, a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, st, a.cross_gate, 0, ta + 4 * Da));
     return LTX2_OK;
 }
 
@@ -592,19 +590,19 @@ int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = t
         LTX2_CHECK_ARG(in[k].n_ts == 1 || c->per_token, "dit_forward: workspace was not sized for per-token timesteps");
         // patchify_proj (model.py:242) -> fp32 residual stream
         TRY(cast_f32_bf16_launch(in[k].latent, m.lat, (long)m.N * m.Cin, st));
-        TRY(dense(m.lat, m.Cin, w.patch_w, w.patch_b, m.x, m.D, m.N, m.D, m.Cin, EPI_F32, st));
+        TRY(dense(c, m.lat, m.Cin, w.patch_w, w.patch_b, m.x, m.D, m.N, m.D, m.Cin, EPI_F32, st));
         // AdaLN-single (model.py:113-140)
-        TRY(adaln_chain(m, w.ada, in[k].ts, 1, in[k].n_ts, c->cfg.timestep_scale, m.emb, m.e_f, st));
+        TRY(adaln_chain(c, m, w.ada, in[k].ts, 1, in[k].n_ts, c->cfg.timestep_scale, m.emb, m.e_f, st));
         if (in[k].n_ts > 1) {
             es[k] = (long)w.ada.rows * m.D;
             ee[k] = m.D;
         }
         if (c->v2)           // prompt AdaLN from this modality's sigma (model.py:151-161)
-            TRY(adaln_chain(m, w.prompt, in[k].sigma, 0, 1, c->cfg.timestep_scale, m.prompt_emb, nullptr, st));
+            TRY(adaln_chain(c, m, w.prompt, in[k].sigma, 0, 1, c->cfg.timestep_scale, m.prompt_emb, nullptr, st));
         if (c->av) {         // cross-modal AdaLN from the OTHER modality's sigma (model.py:346-364,392-404)
             const float* cs = in[1 - k].sigma;
-            TRY(adaln_chain(m, w.cross_ss, cs, 0, 1, c->cfg.timestep_scale, m.cross_ss, nullptr, st));
-            TRY(adaln_chain(m, w.cross_gate, cs, 0, 1, c->cfg.av_ca_timestep_scale, m.cross_gate, nullptr, st));
+            TRY(adaln_chain(c, m, w.cross_ss, cs, 0, 1, c->cfg.timestep_scale, m.cross_ss, nullptr, st));
+            TRY(adaln_chain(c, m, w.cross_gate, cs, 0, 1, c->cfg.av_ca_timestep_scale, m.cross_gate, nullptr, st));
         }
     }
     // the audio modality's block program runs on the side stream, joined around the cross-modal attention
@@ -629,7 +627,7 @@ int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = t
         Mod& m = c->m[k];
         const ModW& w = c->mw[k];
         TRY(norm_mod_launch(m.x, m.D, m.h, m.D, m.N, m.D, c->cfg.norm_eps, 1, w.sst_out + m.D, w.sst_out, m.e_f, m.e_f, ee[k], st));
-        TRY(dense(m.h, m.D, w.proj_w, w.proj_b, in[k].velocity, m.Cout, m.N, m.Cout, m.D, EPI_F32, st));
+        TRY(dense(c, m.h, m.D, w.proj_w, w.proj_b, in[k].velocity, m.Cout, m.N, m.Cout, m.D, EPI_F32, st));
     }
     return LTX2_OK;
 }
@@ -681,13 +679,13 @@ int prepare_modality(ltx2_dit* c, int k, const float* context, int S, const floa
     TRY(cast_f32_bf16_launch(context, m.ctx_in, (long)S * Cctx, st));
     m.ctx = m.ctx_in;
     if (c->cfg.caption_channels > 0) {   // PixArtAlphaTextProjection (model.py:52-56)
-        TRY(dense(m.ctx_in, Cctx, w.cap1_w, w.cap1_b, m.c1, D, S, D, Cctx, EPI_GELU_BF16, st));
-        TRY(dense(m.c1, D, w.cap2_w, w.cap2_b, m.ctxp, D, S, D, D, EPI_BF16, st));
+        TRY(dense(c, m.ctx_in, Cctx, w.cap1_w, w.cap1_b, m.c1, D, S, D, Cctx, EPI_GELU_BF16, st));
+        TRY(dense(c, m.c1, D, w.cap2_w, w.cap2_b, m.ctxp, D, S, D, D, EPI_BF16, st));
         m.ctx = m.ctxp;
     }
     if (!c->v2)
         for (int l = 0; l < c->cfg.num_layers; ++l)
-            TRY(project_kv(m.ctx, S, D, c->layers[l].m[k].text, D, m.H, m.hd, c->cfg.norm_eps, nullptr, nullptr,
+            TRY(project_kv(c, m.ctx, S, D, c->layers[l].m[k].text, D, m.H, m.hd, c->cfg.norm_eps, nullptr, nullptr,
                            m.kv2 + (long)l * S * 2 * D, m.vt2 + (long)l * D * m.Spad, m.Spad, st));
     return LTX2_OK;
 }
@@ -818,15 +816,12 @@ void ltx2_dit_destroy(ltx2_dit* c) {
     if (c->exec) (void)hipGraphExecDestroy(c->exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
-    for (const void* k : c->fp8_keys) g_fp8_scale.erase(k);
     delete c;
 }
 
 int ltx2_dit_set_weight(ltx2_dit* c, const char* name, const void* ptr, int dtype, int64_t numel) {
     LTX2_CHECK_ARG(c && name && ptr, "dit_set_weight: null argument");
     LTX2_CHECK_ARG(dtype == LTX2_DTYPE_BF16 || dtype == LTX2_DTYPE_F32 || dtype == LTX2_DTYPE_FP8_E4M3FN, "dit_set_weight: bad dtype %d", dtype);
-    auto old = c->weights.find(name);
-    if (old != c->weights.end()) g_fp8_scale.erase(old->second.p);      // re-registration: the old buffer may be freed by the caller
     c->weights[name] = Wt{ptr, dtype, (long)numel};
     c->resolved = false;
     return LTX2_OK;
@@ -990,6 +985,28 @@ int ltx2_dit_profile_end(ltx2_dit* c, double* total_ms, int64_t* launches, doubl
     *total_ms = tot;
     *launches = (int64_t)(c->prof_used / 2);
     *flops = c->prof_flops;
+    return LTX2_OK;
+}
+
+int ltx2_dit_health(ltx2_dit* c, void* stream) {
+    LTX2_CHECK_ARG(c, "dit_health: null context");
+    if (!c->sk_ws) return LTX2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned sticky = 0;
+    if (hipMemcpyAsync(&sticky, (const char*)c->sk_ws + 4 * 1023, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        ltx2_set_error("dit_health: %s", hipGetErrorString(hipGetLastError()));
+        return LTX2_E_HIP;
+    }
+    if (sticky) {
+        // a stream-K consumer gave up waiting for a producer's partial result (attention.hip): that launch's output and possibly
+        // later ones are wrong, and producer flags may be stale -- the whole flag page is reset so the NEXT launch is clean
+        (void)hipMemsetAsync(c->sk_ws, 0, 4096, st);
+        (void)hipStreamSynchronize(st);
+        ltx2_set_error("dit_health: a stream-K attention launch timed out waiting for a partial result since the last check; the results "
+                       "computed since then are invalid (flag page reset)");
+        return LTX2_E_STATE;
+    }
     return LTX2_OK;
 }
 

@@ -162,6 +162,7 @@ class LTXModel:
         self._prep_key = None
         self._prep_refs = None
         self._twin: Optional["LTXModel"] = None        # VideoOnly engine over the SAME weight tensors (video-only inference on an AV model)
+        self._sigma_dev: Dict[float, torch.Tensor] = {}  # device scalars of the step sigmas (no host-to-device copy inside the loop)
         self._ctor = dict(num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim, in_channels=in_channels,
                           out_channels=out_channels, num_layers=num_layers, cross_attention_dim=cross_attention_dim, norm_eps=norm_eps,
                           caption_channels=caption_channels, positional_embedding_theta=positional_embedding_theta,
@@ -451,8 +452,11 @@ class LTXModel:
 
     # ------------------------------------------------------------------ forward
     def _timesteps(self, m: Modality) -> Tuple[torch.Tensor, int]:
-        """-> (fp32 device vector, n_timesteps in {1, N}).  Per-token timesteps that are all equal
-        take the broadcast path (identical arithmetic, N x fewer AdaLN MLP rows)."""
+        """-> (fp32 device vector, n_timesteps in {1, N}).  A 1-element tensor (shape (B,), what every pipeline here passes when no
+        token carries a conditioning mask -- `modality_from_state(..., uniform=True)`) takes the broadcast AdaLN path; N timesteps
+        (shape (B, N) / (B, N, 1), the reference's `denoise_mask * sigma`) ALWAYS take the per-token path, equal or not: identical
+        arithmetic, N x more AdaLN MLP rows -- asking the device whether they happen to be equal would be a host sync per step.  A
+        caller that knows its mask is all ones should pass the scalar form."""
         ts = m.timesteps.to(self.device, torch.float32).reshape(-1).contiguous()
         n = m.latent.shape[1]
         if ts.numel() == 1:
@@ -505,6 +509,21 @@ class LTXModel:
                                               nv.ptr(as_), nv.ptr(out), nv.ptr(aout), nv.stream()))
         return out[None], aout[None]
 
+    def _sigma_scalar(self, sigma: float) -> torch.Tensor:
+        t = self._sigma_dev.get(float(sigma))
+        if t is None:
+            if len(self._sigma_dev) > 256:
+                self._sigma_dev.clear()
+            t = self._sigma_dev[float(sigma)] = torch.tensor([float(sigma)], device=self.device, dtype=torch.float32)
+        return t
+
+    def check_health(self) -> None:
+        """Host sync point (per prompt / after a sampling loop): raises RuntimeError if a stream-K attention launch gave up waiting
+        for a partial result since the last check (ltx2_dit_health; the results since then are invalid)."""
+        nv.check(nv.lib().ltx2_dit_health(self._h, nv.stream()))
+        if self._twin is not None:
+            self._twin.check_health()
+
     # ------------------------------------------------------------------ fused sampling step / graph
     def denoise_step_(self, latent: torch.Tensor, video: Modality, sigma: float, sigma_next: float,
                       denoise_mask: Optional[torch.Tensor] = None, clean_latent: Optional[torch.Tensor] = None,
@@ -516,14 +535,14 @@ class LTXModel:
         assert latent.dtype == torch.float32 and latent.is_contiguous() and latent.dim() == 2
         if not self.is_av:
             self._ensure_prepared(video, per_token=(n_ts != 1))
-            sg = torch.tensor([float(sigma)], device=self.device, dtype=torch.float32) if self.cross_attention_adaln else None
+            sg = self._sigma_scalar(sigma) if self.cross_attention_adaln else None
             nv.check(nv.lib().ltx2_dit_denoise_step(self._h, nv.ptr(latent), nv.ptr(ts), n_ts, nv.ptr(sg), nv.ptr(denoise_mask),
                                                     nv.ptr(clean_latent), float(sigma), float(sigma_next), None, nv.stream()))
             return
         assert audio is not None and audio_latent is not None and audio_latent.dtype == torch.float32 and audio_latent.is_contiguous()
         ats, n_ats = self._timesteps(audio)
         self._ensure_prepared(video, per_token=(n_ts != 1 or n_ats != 1), audio=audio)
-        sg = torch.tensor([float(sigma)], device=self.device, dtype=torch.float32)
+        sg = self._sigma_scalar(sigma)
         nv.check(nv.lib().ltx2_dit_denoise_step_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), nv.ptr(ts), n_ts, nv.ptr(ats), n_ats,
                                                    nv.ptr(sg), nv.ptr(denoise_mask), nv.ptr(clean_latent), nv.ptr(audio_denoise_mask),
                                                    nv.ptr(audio_clean_latent), float(sigma), float(sigma_next), None, None, nv.stream()))

@@ -87,12 +87,67 @@ def modality_from_state(state: LatentState, context: torch.Tensor, sigma: float,
     """uniform=True: the caller KNOWS the denoise mask is all ones (checked once per loop, not per step), so the timesteps are
     the scalar sigma -- the broadcast AdaLN path, identical arithmetic, N x fewer AdaLN MLP rows."""
     # context_mask is always None (reference pipelines/common.py:223-232)
-    ts = torch.full((1,), float(sigma), device=state.latent.device) if uniform else timesteps_from_mask(state.denoise_mask, sigma)
+    sg = torch.full((1,), float(sigma), device=state.latent.device)
+    ts = sg if uniform else timesteps_from_mask(state.denoise_mask, sigma)
     return Modality(enabled=enabled, latent=state.latent, timesteps=ts,
-                    positions=state.positions, context=context, context_mask=None,
-                    sigma=torch.tensor([sigma], device=state.latent.device))
+                    positions=state.positions, context=context, context_mask=None, sigma=sg)
 
 
 def audio_modality_from_state(state: LatentState, context: torch.Tensor, sigma: float, enabled: bool = True, uniform: bool = False) -> Modality:
     """Same record for the audio modality (reference pipelines/common.py:235-262)."""
     return modality_from_state(state, context, sigma, enabled, uniform)
+
+
+def joint_denoise_loop(transformer, is_av_model: bool, video_state: LatentState, audio_state: Optional[LatentState], sigmas,
+                       video_context: torch.Tensor, audio_context: Optional[torch.Tensor], stepper, callback=None,
+                       use_hip_graph: bool = False):
+    """The guidance-free sampling loop every pipeline here shares (reference pipelines/distilled.py:198-271 and the
+    `need_cfg == False` branch of pipelines/one_stage.py:466-568 / :224-330).  Per step and modality:
+    Modality(timesteps = denoise_mask * sigma) -> X0Model -> post_process_latent -> EulerDiffusionStep.
+    Two equivalent executions: (a) API-faithful, one X0Model call + stepper.step per step; (b) hipGraph replay of the fused
+    steps (ltx2_dit_graph_*) when the denoise masks are uniform and no callback needs intermediate states.
+    `transformer` is an X0Model; returns (video_state, audio_state)."""
+    sig = [float(s) for s in sigmas]
+    n = len(sig) - 1
+    model = transformer.velocity_model
+    joint = is_av_model and audio_state is not None
+    if joint and audio_context is None:
+        raise ValueError("AudioVideo model: audio_encoding (the audio text context) is required")
+    if is_av_model and not joint:
+        model = model._video_twin()        # no audio tokens: the video half alone (reference model.py:829-840), same weights
+    states = [video_state] + ([audio_state] if joint else [])
+    uniform = all(bool((st.denoise_mask == 1).all()) for st in states)        # no conditioning tokens
+    if use_hip_graph and callback is None and uniform:
+        lat = video_state.latent[0].float().contiguous()
+        alat = audio_state.latent[0].float().contiguous() if joint else None
+        if joint:
+            model.prepare(video_context, video_state.positions, audio_context=audio_context, audio_positions=audio_state.positions)
+        else:
+            model.prepare(video_context, video_state.positions)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model.capture_denoise_graph(lat, sig, audio_latent=alat)
+            model.replay_denoise_graph()
+        torch.cuda.current_stream().wait_stream(side)
+        model.check_health()            # host sync at the end of the loop: a stream-K hand-off that timed out raises here
+        video_state = video_state.replace(latent=lat[None].to(video_state.latent.dtype))
+        if joint:
+            audio_state = audio_state.replace(latent=alat[None].to(audio_state.latent.dtype))
+        return video_state, audio_state
+    for i in range(n):
+        vm = modality_from_state(video_state, video_context, sig[i], uniform=uniform)
+        if joint:
+            vx0, ax0 = transformer(vm, audio_modality_from_state(audio_state, audio_context, sig[i], uniform=uniform))
+        else:
+            out = transformer(vm)
+            vx0, ax0 = (out[0] if isinstance(out, tuple) else out), None
+        vx0 = post_process_latent(vx0, video_state.denoise_mask, video_state.clean_latent)
+        video_state = video_state.replace(latent=stepper.step(sample=video_state.latent, denoised_sample=vx0, sigmas=sig, step_index=i))
+        if joint:
+            ax0 = post_process_latent(ax0, audio_state.denoise_mask, audio_state.clean_latent)
+            audio_state = audio_state.replace(latent=stepper.step(sample=audio_state.latent, denoised_sample=ax0, sigmas=sig, step_index=i))
+        if callback:
+            callback(i + 1, n)
+    model.check_health()
+    return video_state, audio_state

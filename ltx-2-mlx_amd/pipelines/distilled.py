@@ -22,8 +22,7 @@ from ..model.transformer import LTXModel, LTXModelType, Modality, X0Model
 from ..model.upscaler import SpatialUpscaler, upscale_latent
 from ..model.video_vae import SimpleVideoDecoder, TilingConfig, decode_latent, decode_tiled
 from ..types import AudioLatentShape, LatentState, VideoLatentShape, VideoPixelShape
-from .common import (apply_conditionings, audio_modality_from_state, create_image_conditionings, modality_from_state,
-                     post_process_latent)
+from .common import apply_conditionings, create_image_conditionings, joint_denoise_loop
 
 
 @dataclass
@@ -91,52 +90,9 @@ class DistilledPipeline:
                          video_context: torch.Tensor, audio_context: Optional[torch.Tensor] = None,
                          stepper: Optional[EulerDiffusionStep] = None, callback: Optional[Callable[[int, int], None]] = None,
                          use_hip_graph: bool = False):
-        """Joint audio+video loop (reference pipelines/distilled.py:198-271).  Per step: Modality(mask*sigma) ->
-        X0 -> post_process -> Euler, per modality.  Two equivalent executions: (a) API-faithful, one X0Model call +
-        EulerDiffusionStep per step; (b) hipGraph replay of the fused steps when the denoise masks are uniform
-        and no callback needs intermediate states."""
-        sig = [float(s) for s in sigmas]
-        n = len(sig) - 1
-        model = self.transformer.velocity_model
-        joint = self.is_av_model and audio_state is not None
-        if self.is_av_model and not joint:
-            raise NotImplementedError("video-only inference on an AudioVideo model: build a VideoOnly LTXModel from the same weights")
-        if joint and audio_context is None:
-            raise ValueError("AudioVideo model: audio_encoding (the audio text context) is required")
-        states = [video_state] + ([audio_state] if joint else [])
-        uniform = all(bool((st.denoise_mask == 1).all()) for st in states)        # no conditioning tokens
-        if use_hip_graph and callback is None and uniform:
-            lat = video_state.latent[0].float().contiguous()
-            alat = audio_state.latent[0].float().contiguous() if joint else None
-            if joint:
-                model.prepare(video_context, video_state.positions, audio_context=audio_context, audio_positions=audio_state.positions)
-            else:
-                model.prepare(video_context, video_state.positions)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                model.capture_denoise_graph(lat, sig, audio_latent=alat)
-                model.replay_denoise_graph()
-            torch.cuda.current_stream().wait_stream(side)
-            video_state = video_state.replace(latent=lat[None].to(video_state.latent.dtype))
-            if joint:
-                audio_state = audio_state.replace(latent=alat[None].to(audio_state.latent.dtype))
-            return video_state, audio_state
-        step = stepper or self.diffusion_step
-        for i in range(n):
-            vm = modality_from_state(video_state, video_context, sig[i], uniform=uniform)
-            if joint:
-                vx0, ax0 = self.transformer(vm, audio_modality_from_state(audio_state, audio_context, sig[i], uniform=uniform))
-            else:
-                vx0, ax0 = self.transformer(vm), None
-            vx0 = post_process_latent(vx0, video_state.denoise_mask, video_state.clean_latent)
-            video_state = video_state.replace(latent=step.step(sample=video_state.latent, denoised_sample=vx0, sigmas=sig, step_index=i))
-            if joint:
-                ax0 = post_process_latent(ax0, audio_state.denoise_mask, audio_state.clean_latent)
-                audio_state = audio_state.replace(latent=step.step(sample=audio_state.latent, denoised_sample=ax0, sigmas=sig, step_index=i))
-            if callback:
-                callback(i + 1, n)
-        return video_state, audio_state
+        """Joint audio+video loop (reference pipelines/distilled.py:198-271): see pipelines.common.joint_denoise_loop."""
+        return joint_denoise_loop(self.transformer, self.is_av_model, video_state, audio_state, sigmas, video_context, audio_context,
+                                  stepper or self.diffusion_step, callback, use_hip_graph)
 
     def __call__(self, text_encoding: torch.Tensor, text_mask: Optional[torch.Tensor], config: DistilledConfig,
                  images: Optional[List] = None, callback: Optional[Callable[[str, int, int], None]] = None,

@@ -218,6 +218,29 @@ def av_x0_model(video: dict, audio: dict, w, cfg: AVConfig):
     return den(video, vv), den(audio, av)
 
 
+def video_only_x0_model(video: dict, w, cfg: AVConfig) -> Tensor:
+    """X0Model(LTXModel) with NO audio tokens on the AudioVideo / V2.3 block program (model.py:829-840: video-only inference;
+    transformer.py:479-483: run_ax and run_a2v are False for an empty audio stream, so a block is video self-attention, text
+    cross-attention -- with the prompt AdaLN driven by Modality.sigma, model.py:151-158 -- and the video feed-forward).  This is
+    also what a VideoOnly LTXModel with cross_attention_adaln / apply_gated_attention computes."""
+    vs = video.get("sigma", video["timesteps"])
+    va = prepare_modality(video["latent"], video["context"], video["timesteps"], vs, video["positions"], w, cfg, False, vs)
+    x, eps, H = va["x"], cfg.norm_eps, cfg.num_attention_heads
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}"
+        vt = w[p + ".scale_shift_table"]
+        sh, sc, g = _ada(vt, va["timesteps"], 0, 3)
+        x = x + attention(D.adaln_forward(x, sc, sh, eps), w, p + ".attn1", H, eps, pe=va["pe"]) * g
+        x = x + _text_cross(x, va["context"], w, p + ".attn2", vt, w.get(p + ".prompt_scale_shift_table"), va["timesteps"],
+                            va.get("prompt_timestep"), H, cfg)
+        sh, sc, g = _ada(vt, va["timesteps"], 3, 6)
+        x = x + D.feed_forward(D.adaln_forward(x, sc, sh, eps), w, p + ".ff") * g
+    v = _output(x, va["embedded_timestep"], w, "", cfg.inner_dim, eps)
+    t = video["timesteps"].float()
+    t = t[:, None, None] if t.ndim == 1 else (t[:, :, None] if t.ndim == 2 else t)
+    return video["latent"].float() - t * v
+
+
 def audio_positions(batch: int, num_steps: int, sample_rate: int = 16000, hop_length: int = 160, downsample: int = 4) -> Tensor:
     """AudioPatchifier.get_patch_grid_bounds (components/patchifiers.py:287-347,398-411): causal
     [start, end) seconds per audio latent frame -> [B, 1, T, 2]."""

@@ -120,32 +120,105 @@ def encode_text_features(path: str, weights_path=None, device="cuda", seed: int 
     return out.video_encoding, out.attention_mask.float()
 
 
-def load_transformer(weights_path, num_layers=48, num_heads=32, caption_channels=3840, seed=0, device="cuda", use_fp8=False,
-                     lora_path=None, lora_strength=1.0):
-    """LTXModel(VideoOnly, 32x128, 48 layers, caption 3840) (reference load_transformer :788-835)."""
-    model = LTXModel(num_attention_heads=num_heads, attention_head_dim=128, num_layers=num_layers,
-                     caption_channels=caption_channels, device=device)
-    if weights_path:
-        from ltx_2_mlx_amd.loader import is_fp8_checkpoint, load_transformer_weights
-        from ltx_2_mlx_amd.loader import LoRAConfig
-        load_transformer_weights(model, weights_path, strict=True, use_fp8=use_fp8 or is_fp8_checkpoint(weights_path),
+def _read_checkpoint_config(checkpoint_path: str) -> dict:
+    """The JSON `config` entry of the safetensors metadata (reference scripts/generate.py:142-152); {} when absent / unreadable."""
+    import json
+    try:
+        from safetensors import safe_open
+        with safe_open(checkpoint_path, framework="pt") as f:
+            metadata = f.metadata() or {}
+        return json.loads(metadata.get("config", "{}"))
+    except Exception:
+        return {}
+
+
+def detect_model_version(checkpoint_path: str) -> str:
+    """`model_version` of the safetensors metadata, e.g. "2.3.0"; "" if unknown (reference :224-236)."""
+    try:
+        from safetensors import safe_open
+        with safe_open(checkpoint_path, framework="pt") as f:
+            metadata = f.metadata() or {}
+        return metadata.get("model_version", "")
+    except Exception:
+        return ""
+
+
+def is_v2_model(checkpoint_path: str) -> bool:
+    """LTX-2.3 ("V2") checkpoint? (reference :239-242)"""
+    return detect_model_version(checkpoint_path).startswith("2.3")
+
+
+def get_vae_config(checkpoint_path: str) -> dict:
+    """`config.vae` of the checkpoint metadata: decoder_blocks / decoder_base_channels / timestep_conditioning (reference :245-254)."""
+    return _read_checkpoint_config(checkpoint_path).get("vae", {})
+
+
+def create_vae_decoder(weights_path, device="cuda", seed=0, use_placeholder=False, base_channels_override=None):
+    """SimpleVideoDecoder built from the checkpoint's own architecture record (reference :1255-1273): decoder_blocks,
+    decoder_base_channels (128 when absent), timestep_conditioning (True when absent).  Without a readable checkpoint the
+    default 19B decoder is built and random-initialised (no checkpoints exist on a bare box; the reference would run the
+    uninitialised module)."""
+    have = bool(weights_path) and os.path.exists(weights_path)
+    vae_config = get_vae_config(weights_path) if have else {}
+    decoder_blocks = vae_config.get("decoder_blocks", None)
+    base_channels = vae_config.get("decoder_base_channels", 128) if base_channels_override is None else base_channels_override
+    timestep_cond = vae_config.get("timestep_conditioning", True)
+    if decoder_blocks:
+        print(f"  VAE config: {len(decoder_blocks)} blocks, base_ch={base_channels}, timestep={timestep_cond}")
+    dec = SimpleVideoDecoder(decoder_blocks=decoder_blocks, base_channels=base_channels, timestep_conditioning=timestep_cond, device=device)
+    if have and not use_placeholder:
+        load_vae_decoder_weights(dec, weights_path)
+    else:
+        if weights_path and not have:
+            print(f"  Warning: Weights not found at {weights_path}, using random init")
+        dec.init_random_weights(seed=seed)
+    return dec
+
+
+def _dtype_of(compute_dtype):
+    return torch.bfloat16 if compute_dtype is None else compute_dtype
+
+
+def load_transformer(weights_path, num_layers: int = 48, compute_dtype=None, use_fp8: bool = False, low_memory: bool = False,
+                     fast_mode: bool = False, *, num_heads: int = 32, caption_channels: int = 3840, seed: int = 0, device="cuda",
+                     lora_path=None, lora_strength: float = 1.0, fp8_resident: bool = False):
+    """LTXModel(VideoOnly, 32x128, caption 3840) with checkpoint weights (reference load_transformer :788-835; same leading
+    parameters).  A missing checkpoint file means random init with the reference's warning.  low_memory / fast_mode have
+    no effect here; keyword-only extras are MI355X additions."""
+    model = LTXModel(num_attention_heads=num_heads, attention_head_dim=128, num_layers=num_layers, caption_channels=caption_channels,
+                     compute_dtype=_dtype_of(compute_dtype), device=device)
+    if weights_path and os.path.exists(weights_path):
+        from ltx_2_mlx_amd.loader import LoRAConfig, is_fp8_checkpoint, load_transformer_weights
+        fp8 = use_fp8 or is_fp8_checkpoint(weights_path)
+        load_transformer_weights(model, weights_path, strict=True, use_fp8=fp8, fp8_resident=fp8_resident and fp8,
                                  lora_configs=[LoRAConfig(lora_path, lora_strength)] if lora_path else None)
     elif lora_path:
         raise ValueError("--lora needs --weights (an adapter is fused into checkpoint weights)")
     else:
+        if weights_path:
+            print(f"  Warning: Weights not found at {weights_path}, using random init")
         model.init_random_weights(seed=seed)
     return model
 
 
-def load_av_transformer(weights_path, num_layers=48, num_heads=32, caption_channels=3840, seed=0, device="cuda", use_fp8=False):
-    """AudioVideo LTXModel (video 32x128 + audio 32x64 heads; reference load_av_transformer :838-902)."""
+def load_av_transformer(weights_path, num_layers: int = 48, compute_dtype=None, use_fp8: bool = False, low_memory: bool = False,
+                        caption_channels=3840, cross_attention_adaln: bool = False, apply_gated_attention: bool = False, *,
+                        num_heads: int = 32, seed: int = 0, device="cuda"):
+    """AudioVideo LTXModel (video 32x128 + audio 32x64 heads) with checkpoint weights (reference load_av_transformer :838-902,
+    same parameters): caption_channels = 3840 for LTX-2.0, None for LTX-2.3 (the feature extractor already projects to the
+    transformer widths); cross_attention_adaln / apply_gated_attention = the LTX-2.3 block variant;
+    av_ca_timestep_scale_multiplier = 1000 as the reference passes it."""
     from ltx_2_mlx_amd.model.transformer import LTXModelType
     model = LTXModel(model_type=LTXModelType.AudioVideo, num_attention_heads=num_heads, attention_head_dim=128, num_layers=num_layers,
-                     caption_channels=caption_channels, audio_attention_heads=num_heads, device=device)
-    if weights_path:
+                     caption_channels=caption_channels, audio_attention_heads=num_heads, cross_attention_adaln=cross_attention_adaln,
+                     apply_gated_attention=apply_gated_attention, av_ca_timestep_scale_multiplier=1000,
+                     compute_dtype=_dtype_of(compute_dtype), device=device)
+    if weights_path and os.path.exists(weights_path):
         from ltx_2_mlx_amd.loader import is_fp8_checkpoint, load_av_transformer_weights
         load_av_transformer_weights(model, weights_path, strict=True, use_fp8=use_fp8 or is_fp8_checkpoint(weights_path))
     else:
+        if weights_path:
+            print(f"  Warning: Weights not found at {weights_path}, using random init")
         model.init_random_weights(seed=seed)
     return model
 
@@ -160,9 +233,22 @@ def euler_step_x0(sample, denoised, sigma, sigma_next):
 # the reference can switch without touching its call site.  Options outside the MI355X hot path are accepted at their
 # reference defaults and raise NotImplementedError only when set to something else.
 _OUT_OF_PATH_DEFAULTS = dict(
-    upscale_temporal=False, temporal_upscaler_weights=None, early_layers_only=False, enhance_prompt_flag=False,
+    upscale_temporal=False, early_layers_only=False, enhance_prompt_flag=False,
     cross_attn_scale=1.0, distilled_lora=None, stg_scale=0.0, apg_scale=1.0, control_video=None, save_control=False,
     ge_gamma=0.0, keyframes=None, ic_lora_weights=None, negative_prompt=None)
+# pipelines whose algorithm is not built: "two-stage" is the dev model's CFG stage 1 + distilled-LoRA stage 2 (TwoStageCFGConfig,
+# reference :1276-1431), "ic-lora" / "keyframe-interpolation" condition on control videos / keyframes (:1434-1636)
+_PIPELINES_BUILT = ("text-to-video", "distilled", "one-stage")
+_PIPELINES_KNOWN = _PIPELINES_BUILT + ("two-stage", "ic-lora", "keyframe-interpolation")
+
+
+def _frames_from_video(video):
+    """Pipeline output -> uint8 (T, H, W, 3): decode_latent already returns that; decode_tiled returns float (1, 3, T, H, W) in
+    [-1, 1] (reference :1744-1755 converts it the same way)."""
+    if video.dtype == torch.uint8:
+        return video
+    from ltx_2_mlx_amd import kernels as K
+    return K.video_to_uint8(video[0] if video.dim() == 5 else video)
 
 
 def generate_video(
@@ -230,21 +316,38 @@ def generate_video(
     use_hip_graph: bool = True,
     num_layers: int = 48,
     num_heads: int = 32,
-    vae_base_channels: int = 128,
+    vae_base_channels=None,
     device: str = "cuda",
     text_features_path=None,
     save_mp4: bool = True,
+    two_stage_distilled: bool = False,
+    fp8_resident: bool = False,
+    model_version=None,
 ):
-    """Generate video from a text prompt: distilled denoise loop + VAE decode on MI355X behind the reference's signature."""
-    given = dict(upscale_temporal=upscale_temporal, temporal_upscaler_weights=temporal_upscaler_weights, early_layers_only=early_layers_only,
+    """Generate video from a text prompt: denoise loop + VAE decode on MI355X behind the reference's signature.
+
+    Routing follows the reference (scripts/generate.py:1064-2095): an LTX-2.3 checkpoint (`model_version` 2.3.* in the
+    safetensors metadata) or generate_audio=True runs the AudioVideo transformer through OneStagePipeline (fps 25,
+    LTX2Scheduler over num_steps); everything else the standard video-only loop on the distilled sigma table; the VAE decoder is
+    built from the checkpoint's `config.vae` record; upscale_spatial doubles the denoised latent before decoding (2W x 2H output).
+    pipeline_type "two-stage" / "ic-lora" / "keyframe-interpolation" raise NotImplementedError.
+    MI355X extras: two_stage_distilled=True runs the reference's DistilledPipeline class (8 steps at half resolution, x2
+    upscale, 3 steps; pipelines/distilled.py:274-505), which the reference's own CLI never wires; model_version="2.3" builds
+    the LTX-2.3 architecture without a checkpoint (random init, for tests and benchmarks); fp8_resident keeps fp8 checkpoint
+    weights as codes in HBM; vae_base_channels overrides the checkpoint's decoder_base_channels."""
+    given = dict(upscale_temporal=upscale_temporal, early_layers_only=early_layers_only,
                  enhance_prompt_flag=enhance_prompt_flag and use_gemma, cross_attn_scale=cross_attn_scale, distilled_lora=distilled_lora,
                  stg_scale=stg_scale, apg_scale=apg_scale, control_video=control_video, save_control=save_control, ge_gamma=ge_gamma,
                  keyframes=keyframes, ic_lora_weights=ic_lora_weights, negative_prompt=negative_prompt)
     for k, v in given.items():
         if v != _OUT_OF_PATH_DEFAULTS[k]:
             raise NotImplementedError(f"{k}={v!r} is outside the MI355X hot path (see DESIGN.md); leave it at its default {_OUT_OF_PATH_DEFAULTS[k]!r}")
-    if pipeline_type not in ("text-to-video", "distilled", "one-stage", "two-stage"):
-        raise NotImplementedError(f"pipeline_type={pipeline_type!r} is outside the MI355X hot path (see DESIGN.md)")
+    if pipeline_type not in _PIPELINES_KNOWN:
+        raise ValueError(f"unknown pipeline_type {pipeline_type!r}; the reference knows {_PIPELINES_KNOWN}")
+    if pipeline_type not in _PIPELINES_BUILT:
+        raise NotImplementedError(f"pipeline_type={pipeline_type!r} is outside the MI355X hot path (see DESIGN.md): 'two-stage' is the dev "
+                                  "model's CFG stage 1 + distilled-LoRA stage 2; for the distilled two-stage DistilledPipeline pass "
+                                  "two_stage_distilled=True (--two-stage-distilled)")
     output_dir = os.path.dirname(output_path)
     if output_dir:
         os.makedirs(output_dir, exist_ok=True)          # reference :1000-1003
@@ -262,90 +365,162 @@ def generate_video(
                   f"embedding_path / text_features_path")
             return None
         raise NotImplementedError("Gemma-3 text encoding is outside the hot path: pass embedding_path / text_features_path (or use_gemma=False)")
-    if model_variant == "distilled" and cfg_scale > 1.2 and pipeline_type != "two-stage":
+    if model_variant == "distilled" and cfg_scale > 1.2:
         print(f"  WARNING: Distilled model requires CFG=1.0 (no guidance). You requested {cfg_scale}.\n  Forcing CFG=1.0 (reference :1207-1216).")
-        cfg_scale, guidance_rescale = 1.0, 0.0
+        cfg_scale, guidance_rescale, audio_cfg_scale, rescale_scale = 1.0, 0.0, 1.0, 0.0
     if cfg_scale > 1.0:
-        raise NotImplementedError(f"cfg_scale={cfg_scale}: classifier-free guidance is outside the MI355X hot path (distilled single-pass only)")
+        raise NotImplementedError(f"cfg_scale={cfg_scale}: classifier-free guidance is outside the MI355X hot path (single-pass only)")
     if low_memory or fast_mode:
         print("  low_memory / fast_mode: no effect here (weights and caches stay resident in HBM, the loop is one hipGraph)")
-    num_inference_steps = num_steps
-    pipeline = "distilled" if (pipeline_type in ("distilled", "two-stage") or upscale_spatial) else "text-to-video"
+    have_ckpt = bool(weights_path) and os.path.exists(weights_path)
+    version = model_version if model_version is not None else (detect_model_version(weights_path) if have_ckpt else "")
+    v2 = version.startswith("2.3")                      # reference :1073: V2.3 always uses the AV transformer and the dual text encodings
+    use_av_encoder = generate_audio or v2
     fps, speed = output_fps, output_speed
     torch.manual_seed(seed)
     t_all = time.time()
+    base = os.path.splitext(output_path)[0]
+
     print("[1/5] text encoding")
+    text_audio_encoding = None
     if text_features_path:
-        text_encoding, _ = encode_text_features(text_features_path, weights_path, device, seed)
+        text_encoding, _ = encode_text_features(text_features_path, weights_path if have_ckpt else None, device, seed)
+    elif embedding_path:
+        text_encoding, _ = load_text_embedding(embedding_path, device)
+        z = np.load(embedding_path)
+        if use_av_encoder and "audio_embedding" in z:
+            text_audio_encoding = torch.from_numpy(z["audio_embedding"]).float().to(device)
+            text_audio_encoding = text_audio_encoding[None] if text_audio_encoding.dim() == 2 else text_audio_encoding
+        elif use_av_encoder:
+            print("  WARNING: Pre-computed embeddings don't include audio encoding. Audio quality may be degraded.")
     else:
-        text_encoding, _ = load_text_embedding(embedding_path, device) if embedding_path else create_dummy_text_encoding(prompt, device=device)
+        # dummy encodings (reference :1129-1138).  LTX-2.3 has no caption projection: its contexts arrive at the transformer
+        # widths (4096 video / 2048 audio) -- the reference's 3840-wide dummy would not fit that model at all
+        text_encoding, _ = create_dummy_text_encoding(prompt, embed_dim=num_heads * 128 if v2 else 3840, device=device)
+        if v2:
+            text_audio_encoding, _ = create_dummy_text_encoding(prompt + " (audio)", embed_dim=num_heads * 64, device=device)
+        print("  Using DUMMY encoding (test mode - output will be random)")
+    if use_av_encoder and text_audio_encoding is None:
+        text_audio_encoding = text_encoding             # reference :1080-1081, :1131-1132
+
     print("[2/5] transformer")
-    if generate_audio:
-        if not spatial_upscaler_weights:
-            raise ValueError("--generate-audio runs the joint audio+video DistilledPipeline: it needs --spatial-upscaler-weights")
+    model = None
+    if use_placeholder:
+        print("  Skipping model load (placeholder mode)")
+    elif use_av_encoder:
         if lora_path:
-            raise NotImplementedError("--lora with --generate-audio")
-        model = X0Model(load_av_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device, use_fp8=use_fp8))
+            raise NotImplementedError("--lora with the AudioVideo transformer")
+        model = X0Model(load_av_transformer(weights_path, num_layers=num_layers, use_fp8=use_fp8, low_memory=low_memory,
+                                            caption_channels=None if v2 else text_encoding.shape[-1], cross_attention_adaln=v2,
+                                            apply_gated_attention=v2, num_heads=num_heads, seed=seed, device=device))
     else:
-        model = X0Model(load_transformer(weights_path, num_layers, num_heads, text_encoding.shape[-1], seed, device, use_fp8=use_fp8,
-                                         lora_path=lora_path, lora_strength=lora_strength))
+        model = X0Model(load_transformer(weights_path, num_layers=num_layers, use_fp8=use_fp8, low_memory=low_memory, fast_mode=fast_mode,
+                                         num_heads=num_heads, caption_channels=text_encoding.shape[-1], seed=seed, device=device,
+                                         lora_path=lora_path, lora_strength=lora_strength, fp8_resident=fp8_resident))
     print("[3/5] VAE decoder")
     vae_decoder = None
     if not skip_vae:
-        vae_decoder = SimpleVideoDecoder(base_channels=vae_base_channels, device=device)
-        if weights_path:
-            load_vae_decoder_weights(vae_decoder, weights_path)
+        vae_decoder = create_vae_decoder(weights_path, device, seed + 1, use_placeholder, vae_base_channels)
+    else:
+        print("  VAE decoder skipped by user")
+    toy = vae_base_channels is not None and vae_base_channels != 128        # debug-size VAE: matching debug-size upscaler / encoder
+
+    def make_encoder():
+        enc = SimpleVideoEncoder(device=device)
+        if have_ckpt:
+            load_vae_encoder_weights(enc, weights_path)
         else:
-            vae_decoder.init_random_weights(seed=seed + 1)
-    if spatial_upscaler_weights or pipeline == "distilled":
-        # `--pipeline distilled` + `--spatial-upscaler-weights`: the reference's two-stage DistilledPipeline
-        # (pipelines/distilled.py:274-505; scripts/generate.py:1622-1700): 8 steps at half resolution, x2 latent
-        # upscale, 3 steps at full resolution.  "random" as the path builds a random-weight upscaler (no checkpoint here).
-        if not spatial_upscaler_weights:
-            raise ValueError("--pipeline distilled needs --spatial-upscaler-weights (two-stage pipeline)")
-        if image_path or tiled_vae:
-            raise NotImplementedError("the two-stage pipeline here takes neither --image nor --tiled-vae (single-stage text-to-video does)")
-        if vae_decoder is None:
-            raise ValueError("the two-stage pipeline needs the VAE weights (per-channel statistics): drop --skip-vae")
+            enc.init_random_weights(seed=seed + 2)
+        return enc
+
+    def make_upscaler():
         from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler, load_spatial_upscaler_weights
-        from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline
-        mid = 1024 if vae_base_channels == 128 else 64
-        up = SpatialUpscaler(mid_channels=mid, device=device) if spatial_upscaler_weights != "random" else \
-            SpatialUpscaler(mid_channels=mid, num_blocks_per_stage=4 if mid == 1024 else 1, device=device)
-        if spatial_upscaler_weights == "random":
+        mid = 64 if toy else 1024
+        if spatial_upscaler_weights == "random" or not os.path.exists(str(spatial_upscaler_weights)):
+            if spatial_upscaler_weights != "random":
+                print(f"  Warning: Weights not found at {spatial_upscaler_weights}, using random init")
+            up = SpatialUpscaler(mid_channels=mid, num_blocks_per_stage=4 if mid == 1024 else 1, device=device)
             up.init_random_weights(seed=seed + 2)
         else:
+            up = SpatialUpscaler(mid_channels=mid, device=device)
             load_spatial_upscaler_weights(up, spatial_upscaler_weights)
-        pipe = DistilledPipeline(model, vae_decoder, vae_decoder, spatial_upscaler=up)
-        conf = DistilledConfig(height=height, width=width, num_frames=num_frames, seed=seed, fps=24.0, use_hip_graph=use_hip_graph,
-                               audio_enabled=generate_audio)
-        print("[4/5] two-stage distilled pipeline (8 steps at half resolution, x2 upscale, 3 steps)" + (" with the audio branch" if generate_audio else ""))
-        t0 = time.time()
-        base = os.path.splitext(output_path)[0]
-        if generate_audio:
-            # the audio text context: `audio_embedding` of the --embedding file when present, else the video context
-            actx = text_encoding
-            if embedding_path and "audio_embedding" in np.load(embedding_path):
-                actx = torch.from_numpy(np.load(embedding_path)["audio_embedding"]).float().to(device)
-                actx = actx[None] if actx.dim() == 2 else actx
-            frames, audio_latent = pipe(text_encoding, None, conf, audio_encoding=actx)
-            np.savez(base + "_audio_latent.npz", latent=audio_latent.float().cpu().numpy())     # audio VAE / vocoder are outside this path
-        else:
-            frames = pipe(text_encoding, None, conf)
-        torch.cuda.synchronize()
-        print(f"  two-stage: {(time.time() - t0):.3f} s -> {tuple(frames.shape)}")
+        return up
+
+    def finish(frames, extra=""):
         frames_np = frames.cpu().numpy()
         np.savez_compressed(base + ".npz", frames=frames_np)
         if save_mp4:
             print(f"  video: {save_video(frames_np, output_path, fps=fps, speed=speed)}")
-        print(f"Done in {time.time() - t_all:.1f} s: {base}.npz")
+        print(f"Done in {time.time() - t_all:.1f} s: {base}.npz{extra}")
         return frames
+
+    images = []
+    if image_path and (two_stage_distilled or use_av_encoder):
+        from ltx_2_mlx_amd.pipelines import ImageCondition
+        print(f"  Image conditioning: {image_path} (strength={image_strength})")
+        images = [ImageCondition(image_path=image_path, frame_index=0, strength=image_strength)]
+
+    if two_stage_distilled:
+        # MI355X extra: the reference's DistilledPipeline class (pipelines/distilled.py:274-505): 8 steps at half resolution, x2
+        # latent upscale, 3 steps at full resolution, image conditioning at both resolutions, auto-tiled decode
+        if not spatial_upscaler_weights:
+            raise ValueError("two_stage_distilled needs --spatial-upscaler-weights (two-stage pipeline)")
+        if vae_decoder is None:
+            raise ValueError("the two-stage pipeline needs the VAE weights (per-channel statistics): drop --skip-vae")
+        if model is None:
+            raise ValueError("Two-stage pipeline requires a loaded model (cannot use placeholder mode)")
+        from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline
+        pipe = DistilledPipeline(model, make_encoder() if images else vae_decoder, vae_decoder, spatial_upscaler=make_upscaler())
+        conf = DistilledConfig(height=height, width=width, num_frames=num_frames, seed=seed, fps=24.0, use_hip_graph=use_hip_graph,
+                               audio_enabled=generate_audio, tiling_config=TilingConfig.default() if tiled_vae else None)
+        print("[4/5] two-stage distilled pipeline (8 steps at half resolution, x2 upscale, 3 steps)" + (" with the audio branch" if use_av_encoder else ""))
+        t0 = time.time()
+        out = pipe(text_encoding, None, conf, images=images, audio_encoding=text_audio_encoding)
+        frames, audio_latent = out if generate_audio else (out, None)
+        if audio_latent is not None:
+            np.savez(base + "_audio_latent.npz", latent=audio_latent.float().cpu().numpy())     # audio VAE / vocoder are outside this path
+        frames = _frames_from_video(frames)
+        torch.cuda.synchronize()
+        print(f"  two-stage: {(time.time() - t0):.3f} s -> {tuple(frames.shape)}")
+        return finish(frames)
+
+    if use_av_encoder:
+        # === AUDIO-VIDEO PIPELINE (reference :1638-1776): OneStagePipeline on the AudioVideo transformer; LTX-2.3 always ===
+        print("\n=== Using Audio-Video Pipeline ===")
+        if model is None:
+            print("  AV pipeline requires model - cannot use placeholder mode")
+            return None
+        if vae_decoder is None:
+            raise ValueError("AV pipeline requires VAE decoder")
+        if upscale_spatial:
+            raise NotImplementedError("upscale_spatial with the AudioVideo pipeline (the reference's AV branch returns before its upscalers)")
+        from ltx_2_mlx_amd.pipelines import OneStageCFGConfig, OneStagePipeline
+        av_pipeline = OneStagePipeline(transformer=model, video_encoder=make_encoder() if images else None, video_decoder=vae_decoder)
+        av_config = OneStageCFGConfig(
+            height=height, width=width, num_frames=num_frames, seed=seed,
+            fps=25.0,  # matches the upstream frame_rate for the audio latent shape (reference :1704-1712)
+            num_inference_steps=num_steps, cfg_scale=cfg_scale,
+            audio_cfg_scale=audio_cfg_scale if audio_cfg_scale is not None else (1.0 if model_variant == "distilled" else 7.0),
+            rescale_scale=rescale_scale if rescale_scale is not None else (0.0 if model_variant == "distilled" else 0.7),
+            audio_enabled=generate_audio, use_hip_graph=use_hip_graph, tiling_config=TilingConfig.default() if tiled_vae else None)
+        print(f"[5/5] Running audio-video generation ({num_steps} steps)...")
+        t0 = time.time()
+        video, audio_latent = av_pipeline(positive_encoding=text_encoding, negative_encoding=None, config=av_config, images=images,
+                                          positive_audio_encoding=text_audio_encoding, negative_audio_encoding=None)
+        frames = _frames_from_video(video)
+        torch.cuda.synchronize()
+        print(f"  audio-video pipeline: {(time.time() - t0):.3f} s -> {tuple(frames.shape)}")
+        if audio_latent is not None:
+            np.savez(base + "_audio_latent.npz", latent=audio_latent.float().cpu().numpy())     # audio VAE / vocoder are outside this path
+        return finish(frames)
+
+    # === STANDARD PIPELINE (one-stage, distilled, video-only; reference :1778-2095) ===
     print("[4/5] latent noise")
     lf, lh, lw = (num_frames - 1) // 8 + 1, height // 32, width // 32
     g = torch.Generator(device=device).manual_seed(seed)
     latent = torch.randn(1, 128, lf, lh, lw, generator=g, device=device)
-    sigmas = DISTILLED_SIGMA_VALUES[:num_inference_steps + 1] if model_variant == "distilled" else \
-        [float(s) for s in get_sigma_schedule(num_inference_steps, distilled=False, latent=latent)]
+    sigmas = DISTILLED_SIGMA_VALUES[:num_steps + 1] if model_variant == "distilled" else \
+        [float(s) for s in get_sigma_schedule(num_steps, distilled=False, latent=latent)]
     patchifier = VideoLatentPatchifier(patch_size=1)
     shape = VideoLatentShape(1, 128, lf, lh, lw)
     coords = patchifier.get_patch_grid_bounds(shape, device=device)
@@ -360,18 +535,13 @@ def generate_video(
     elif image_path:
         # image-to-video: encoded image replaces latent frame 0, its tokens keep (1 - strength) of the noise level
         from ltx_2_mlx_amd.conditioning import VideoLatentTools
-        from ltx_2_mlx_amd.components import GaussianNoiser
-        from ltx_2_mlx_amd.pipelines import DistilledPipeline, ImageCondition, apply_conditionings, create_image_conditionings
-        enc = SimpleVideoEncoder(device=device)
-        if weights_path:
-            load_vae_encoder_weights(enc, weights_path)
-        else:
-            enc.init_random_weights(seed=seed + 2)
+        from ltx_2_mlx_amd.components import EulerDiffusionStep, GaussianNoiser
+        from ltx_2_mlx_amd.pipelines import ImageCondition, apply_conditionings, create_image_conditionings, joint_denoise_loop
         tools = VideoLatentTools(patchifier, shape, fps=24.0)
         st = tools.create_initial_state(device=device)
-        st = apply_conditionings(st, create_image_conditionings([ImageCondition(image_path, 0, image_strength)], enc, height, width), tools)
+        st = apply_conditionings(st, create_image_conditionings([ImageCondition(image_path, 0, image_strength)], make_encoder(), height, width), tools)
         st = GaussianNoiser()(st, noise_scale=1.0, noise=tok)
-        st, _ = DistilledPipeline(model, enc, None)._denoise_loop_av(st, None, sigmas, text_encoding, use_hip_graph=use_hip_graph)
+        st, _ = joint_denoise_loop(model, False, st, None, sigmas, text_encoding, None, EulerDiffusionStep(), None, use_hip_graph)
         tok = st.latent
     elif use_hip_graph:
         vm = model.velocity_model
@@ -383,6 +553,7 @@ def generate_video(
             vm.capture_denoise_graph(lat2d, sigmas)
             vm.replay_denoise_graph()
         torch.cuda.current_stream().wait_stream(side)
+        vm.check_health()
         tok = lat2d[None]
     else:
         for i in range(len(sigmas) - 1):
@@ -392,79 +563,140 @@ def generate_video(
     torch.cuda.synchronize()
     print(f"  denoise: {(time.time() - t0):.3f} s")
     latent = patchifier.unpatchify(tok, shape)
-    base = os.path.splitext(output_path)[0]
     np.savez(base + "_latent.npz", latent=latent.float().cpu().numpy())
+    if upscale_spatial and spatial_upscaler_weights:
+        # post-denoise 2x latent upscale (reference :2000-2037): un-normalise with the VAE statistics, upscale, re-normalise;
+        # the decoded video is 2W x 2H
+        from ltx_2_mlx_amd.model.upscaler import upscale_latent
+        print(f"\nApplying 2x spatial upscaling...\n  Input latent: {tuple(latent.shape)}")
+        up = make_upscaler()
+        if vae_decoder is not None:
+            stats = vae_decoder.per_channel_statistics
+            latent = upscale_latent(latent, up, stats.mean_of_means, stats.std_of_means)
+        else:
+            print("  WARNING: No VAE decoder for normalization - output may have wrong range")
+            latent = upscale_latent(latent, up, torch.zeros(128, device=device), torch.ones(128, device=device))
+        print(f"  Upscaled latent: {tuple(latent.shape)}")
+        np.savez(base + "_latent.npz", latent=latent.float().cpu().numpy())
     frames = None
     if vae_decoder is not None:
         t0 = time.time()
         if tiled_vae:
-            video = next(decode_tiled(latent, vae_decoder, TilingConfig.default()))
-            from ltx_2_mlx_amd import kernels as K
-            frames = K.video_to_uint8(video[0])
+            frames = _frames_from_video(next(decode_tiled(latent, vae_decoder, TilingConfig.default())))
         else:
             frames = decode_latent(latent, vae_decoder)
         torch.cuda.synchronize()
         print(f"  decode: {(time.time() - t0):.3f} s -> {tuple(frames.shape)}")
-        frames_np = frames.cpu().numpy()
-        np.savez_compressed(base + ".npz", frames=frames_np)
-        if save_mp4:
-            print(f"  video: {save_video(frames_np, output_path, fps=fps, speed=speed)}")
-    print(f"Done in {time.time() - t_all:.1f} s: {base}.npz")
+        return finish(frames)
+    print(f"Done in {time.time() - t_all:.1f} s: {base}_latent.npz")
     return frames
 
 
-def main():
-    p = argparse.ArgumentParser(description="LTX-2 video generation (MI355X hot path)")
-    p.add_argument("prompt", type=str)
+def build_parser() -> argparse.ArgumentParser:
+    """Every flag of the reference's parser (scripts/generate.py:2364-2641: names, types, defaults, choices;
+    tests/golden/generate_cli_flags.json), plus the MI355X extras at the end."""
+    p = argparse.ArgumentParser(description="Generate video with LTX-2 on MI355X (denoise + VAE-decode hot path)")
+    p.add_argument("prompt", type=str, help="Text prompt for generation")
     p.add_argument("--height", type=int, default=480)
     p.add_argument("--width", type=int, default=704)
     p.add_argument("--frames", type=int, default=97)
     p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--cfg", type=float, default=5.0, help="CFG scale (forced to 1.0 for the distilled model, as the reference does)")
+    p.add_argument("--guidance-rescale", type=float, default=0.7)
+    p.add_argument("--steps-stage1", type=int, default=15)
+    p.add_argument("--steps-stage2", type=int, default=3)
+    p.add_argument("--cfg-stage1", type=float, default=None)
     p.add_argument("--seed", type=int, default=42)
-    p.add_argument("--output", "-o", type=str, default="output.mp4")
-    p.add_argument("--weights", type=str, default=None)
-    p.add_argument("--embedding", type=str, default=None)
-    p.add_argument("--text-features", type=str, default=None, help="npz with Gemma `features` [T,3840] (or `hidden_states` [L,T,3840]) + `attention_mask`: run the text connector on the GPU")
-    p.add_argument("--no-gemma", action="store_true", help="dummy text embeddings (reference default without Gemma weights)")
-    p.add_argument("--gemma-path", type=str, default=None)
-    p.add_argument("--model-variant", choices=["distilled", "dev"], default="distilled")
-    p.add_argument("--pipeline", type=str, default="text-to-video")
-    p.add_argument("--cfg", type=float, default=1.0)
-    p.add_argument("--fp16", action="store_true", help="reference default; here: bf16 operands, fp32 accumulate (a notice is printed)")
-    p.add_argument("--fp32", action="store_true")
-    p.add_argument("--fp8", action="store_true")
-    p.add_argument("--skip-vae", action="store_true")
+    p.add_argument("--fps", type=int, default=24, help="output frame rate; > 24 interpolates")
+    p.add_argument("--speed", type=float, default=1.0, help="playback speed multiplier")
+    p.add_argument("--output", "-o", type=str, default="outputs/output.mp4")
+    p.add_argument("--weights", type=str, default="weights/ltx-2/ltx-2-19b-distilled.safetensors")
     p.add_argument("--placeholder", action="store_true")
-    p.add_argument("--tiled-vae", action="store_true")
+    p.add_argument("--skip-vae", action="store_true")
+    p.add_argument("--embedding", type=str, default=None)
+    p.add_argument("--gemma-path", type=str, default="weights/gemma-3-12b")
+    p.add_argument("--no-gemma", action="store_true", help="dummy text embeddings")
+    p.add_argument("--fp16", action="store_true", default=True, help="reference default; here: bf16 operands, fp32 accumulate (a notice is printed)")
+    p.add_argument("--fp32", "--no-fp16", action="store_true", dest="fp32")
+    p.add_argument("--fp8", action="store_true")
+    p.add_argument("--model-variant", type=str, choices=["distilled", "dev"], default="distilled")
+    p.add_argument("--distilled-lora", type=str, default=None)
+    p.add_argument("--distilled-lora-scale", type=float, default=1.0)
+    p.add_argument("--upscale-spatial", action="store_true")
+    p.add_argument("--spatial-upscaler-weights", type=str, default="weights/ltx-2/ltx-2-spatial-upscaler-x2-1.0.safetensors")
+    p.add_argument("--upscale-temporal", action="store_true")
+    p.add_argument("--temporal-upscaler-weights", type=str, default="weights/ltx-2/ltx-2-temporal-upscaler-x2-1.0.safetensors")
+    p.add_argument("--generate-audio", action="store_true")
     p.add_argument("--low-memory", action="store_true")
     p.add_argument("--fast-mode", action="store_true")
-    p.add_argument("--no-hip-graph", action="store_true", help="MI355X: run the step loop eagerly instead of replaying the captured hipGraph")
     p.add_argument("--image", type=str, default=None)
     p.add_argument("--image-strength", type=float, default=0.95)
     p.add_argument("--lora", type=str, default=None)
     p.add_argument("--lora-strength", type=float, default=1.0)
-    p.add_argument("--generate-audio", action="store_true")
-    p.add_argument("--spatial-upscaler-weights", type=str, default=None)
+    p.add_argument("--stg-scale", type=float, default=0.0)
+    p.add_argument("--stg-mode", type=str, choices=["video", "audio", "both"], default="video")
+    p.add_argument("--apg-scale", type=float, default=1.0)
+    p.add_argument("--apg-eta", type=float, default=1.0)
+    p.add_argument("--apg-norm-threshold", type=float, default=0.0)
+    p.add_argument("--apg-momentum", type=float, default=0.0)
+    p.add_argument("--ge-gamma", type=float, default=0.0)
+    p.add_argument("--control-video", type=str, default=None)
+    p.add_argument("--control-type", type=str, choices=["canny", "raw"], default="raw")
+    p.add_argument("--canny-low", type=int, default=100)
+    p.add_argument("--canny-high", type=int, default=200)
+    p.add_argument("--control-strength", type=float, default=0.95)
+    p.add_argument("--save-control", action="store_true")
+    p.add_argument("--tiled-vae", action="store_true")
+    p.add_argument("--pipeline", type=str, choices=list(_PIPELINES_KNOWN), default="text-to-video")
+    p.add_argument("--keyframe", type=str, action="append", default=None)
+    p.add_argument("--ic-lora-weights", type=str, default=None)
+    p.add_argument("--early-layers-only", action="store_true")
+    p.add_argument("--enhance-prompt", action="store_true")
+    p.add_argument("--cross-attn-scale", type=float, default=1.0)
+    # --- MI355X extras (no counterpart in the reference) ---
+    p.add_argument("--text-features", type=str, default=None, help="npz with Gemma `features` [T,3840] (or `hidden_states` [L,T,3840]) + `attention_mask`: run the text connector on the GPU")
+    p.add_argument("--no-hip-graph", action="store_true", help="run the step loop eagerly instead of replaying the captured hipGraph")
+    p.add_argument("--two-stage-distilled", action="store_true", help="DistilledPipeline: 8 steps at half resolution, x2 latent upscale (--spatial-upscaler-weights), 3 steps")
+    p.add_argument("--fp8-resident", action="store_true", help="keep fp8 checkpoint weights as codes in HBM (bit-identical to dequantising at load)")
+    p.add_argument("--model-version", type=str, default=None, help="force the architecture family (e.g. 2.3) instead of reading the checkpoint metadata")
     p.add_argument("--layers", type=int, default=48, help="debug: number of DiT layers for random-weight runs")
     p.add_argument("--heads", type=int, default=32, help="debug: attention heads (x128) for random-weight runs")
-    p.add_argument("--vae-base-channels", type=int, default=128)
-    p.add_argument("--fps", type=int, default=24, help="output frame rate; > 24 interpolates (reference flag)")
-    p.add_argument("--speed", type=float, default=1.0, help="playback speed multiplier (reference flag)")
+    p.add_argument("--vae-base-channels", type=int, default=None, help="debug: override the checkpoint's decoder_base_channels")
     p.add_argument("--no-video-file", action="store_true", help="keep only the .npz outputs (skip ffmpeg / PNG frames)")
-    a = p.parse_args()
-    if a.pipeline not in ("text-to-video", "distilled", "one-stage", "two-stage"):
-        raise NotImplementedError(f"--pipeline {a.pipeline} is outside the MI355X hot path")
-    if a.model_variant == "dev" and a.cfg != 1.0:
-        raise NotImplementedError("--model-variant dev with --cfg != 1: classifier-free guidance is not built on this path")
-    generate_video(a.prompt, height=a.height, width=a.width, num_frames=a.frames, num_steps=a.steps, seed=a.seed, cfg_scale=a.cfg,
-                   output_path=a.output, weights_path=a.weights, embedding_path=a.embedding, text_features_path=a.text_features,
-                   gemma_path=a.gemma_path or "weights/gemma-3-12b", use_gemma=not a.no_gemma and not (a.embedding or a.text_features) and bool(a.gemma_path),
-                   use_fp16=not a.fp32, model_variant=a.model_variant, skip_vae=a.skip_vae,
-                   use_placeholder=a.placeholder, tiled_vae=a.tiled_vae, use_hip_graph=not a.no_hip_graph, use_fp8=a.fp8,
-                   low_memory=a.low_memory, fast_mode=a.fast_mode, num_layers=a.layers, num_heads=a.heads, vae_base_channels=a.vae_base_channels,
-                   image_path=a.image, image_strength=a.image_strength, lora_path=a.lora, lora_strength=a.lora_strength,
-                   output_fps=a.fps, output_speed=a.speed, save_mp4=not a.no_video_file, generate_audio=a.generate_audio,
-                   spatial_upscaler_weights=a.spatial_upscaler_weights, pipeline_type=a.pipeline)
+    return p
+
+
+def kwargs_from_args(a) -> dict:
+    """argparse namespace -> generate_video keywords, as the reference's main() maps them (:2644-2725), incl. its weight-file
+    auto-selection for --model-variant dev / --fp8."""
+    if a.model_variant == "dev":
+        a.weights = a.weights.replace("distilled", "dev")
+        if a.steps == 7:
+            a.steps = 30
+    if a.fp8 and ".safetensors" in a.weights and "-fp8" not in a.weights:
+        a.weights = a.weights.replace(".safetensors", "-fp8.safetensors")
+    return dict(
+        distilled_lora=a.distilled_lora, distilled_lora_scale=a.distilled_lora_scale, prompt=a.prompt, height=a.height, width=a.width,
+        num_frames=a.frames, num_steps=a.steps, cfg_scale=a.cfg, guidance_rescale=a.guidance_rescale, seed=a.seed, weights_path=a.weights,
+        output_path=a.output, use_placeholder=a.placeholder, skip_vae=a.skip_vae, embedding_path=a.embedding, gemma_path=a.gemma_path,
+        use_gemma=not a.no_gemma, use_fp16=not a.fp32, use_fp8=a.fp8, model_variant=a.model_variant, upscale_spatial=a.upscale_spatial,
+        spatial_upscaler_weights=a.spatial_upscaler_weights, upscale_temporal=a.upscale_temporal,
+        temporal_upscaler_weights=a.temporal_upscaler_weights, generate_audio=a.generate_audio, low_memory=a.low_memory, fast_mode=a.fast_mode,
+        image_path=a.image, image_strength=a.image_strength, lora_path=a.lora, lora_strength=a.lora_strength, tiled_vae=a.tiled_vae,
+        pipeline_type=a.pipeline, early_layers_only=a.early_layers_only, enhance_prompt_flag=a.enhance_prompt, cross_attn_scale=a.cross_attn_scale,
+        steps_stage1=a.steps_stage1, steps_stage2=a.steps_stage2, cfg_stage1=a.cfg_stage1, stg_scale=a.stg_scale, stg_mode=a.stg_mode,
+        apg_scale=a.apg_scale, apg_eta=a.apg_eta, apg_norm_threshold=a.apg_norm_threshold, apg_momentum=a.apg_momentum,
+        control_video=a.control_video, control_type=a.control_type, canny_low=a.canny_low, canny_high=a.canny_high,
+        control_strength=a.control_strength, save_control=a.save_control, ge_gamma=a.ge_gamma, output_fps=a.fps, output_speed=a.speed,
+        keyframes=a.keyframe, ic_lora_weights=a.ic_lora_weights,
+        # MI355X extras
+        text_features_path=a.text_features, use_hip_graph=not a.no_hip_graph, two_stage_distilled=a.two_stage_distilled,
+        fp8_resident=a.fp8_resident, model_version=a.model_version, num_layers=a.layers, num_heads=a.heads,
+        vae_base_channels=a.vae_base_channels, save_mp4=not a.no_video_file)
+
+
+def main(argv=None):
+    generate_video(**kwargs_from_args(build_parser().parse_args(argv)))
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@ def test_generate_cli_plumbing(dev, tmp_path):
     with pytest.raises(ValueError, match="8\\*k \\+ 1"):
         generate.generate_video("x", num_frames=16, **{k: v for k, v in kw.items() if k != "num_frames"})
     with pytest.raises(ValueError, match="spatial-upscaler-weights"):
-        generate.generate_video("x", generate_audio=True, **kw)
+        generate.generate_video("x", two_stage_distilled=True, **kw)
     with pytest.raises(ValueError, match="--lora needs --weights"):
         generate.generate_video("x", lora_path="style.safetensors", **kw)
     # --image: the conditioned latent frame survives the loop at strength 1.0 (image-to-video through the VAE encoder)
@@ -90,16 +90,24 @@ def test_bench_self_launch(dev):
 
 
 def test_generate_cli_two_stage(dev, tmp_path):
-    """`--spatial-upscaler-weights` routes the CLI through the two-stage DistilledPipeline (reference generate.py:1622-1700)."""
+    """`--two-stage-distilled` (MI355X extra) routes through the reference's DistilledPipeline class (pipelines/distilled.py:274-505),
+    which the reference's own CLI never wires; `--pipeline two-stage` (dev-model CFG stage 1) is refused."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import generate
     kw = dict(height=256, width=384, num_frames=17, num_steps=8, seed=3, num_layers=2, num_heads=2, vae_base_channels=64, use_gemma=False)
+    kw["two_stage_distilled"] = True
     f = generate.generate_video("a test prompt", output_path=str(tmp_path / "t.mp4"), spatial_upscaler_weights="random", **kw)
     assert f.shape == (17, 256, 384, 3) and f.dtype == torch.uint8
     with pytest.raises(ValueError, match="per-channel statistics"):
         generate.generate_video("x", spatial_upscaler_weights="random", skip_vae=True, **kw)
-    with pytest.raises(ValueError, match="two-stage"):
-        generate.generate_video("x", pipeline_type="distilled", **kw)
+    with pytest.raises(NotImplementedError, match="two-stage"):
+        generate.generate_video("x", pipeline_type="two-stage", **kw)
+    # --image reaches both stages of the two-stage pipeline (reference pipelines/distilled.py:326-333, 420-428)
+    from PIL import Image
+    Image.fromarray((np.random.RandomState(1).rand(256, 384, 3) * 255).astype(np.uint8)).save(tmp_path / "cond.png")
+    fi = generate.generate_video("a test prompt", output_path=str(tmp_path / "ti.mp4"), spatial_upscaler_weights="random",
+                                 image_path=str(tmp_path / "cond.png"), image_strength=1.0, tiled_vae=True, **kw)
+    assert fi.shape == (17, 256, 384, 3) and fi.dtype == torch.uint8 and (fi.float() - f.float()).abs().mean() > 0.5
     # --generate-audio: AudioVideo transformer, joint audio+video loop in both stages, audio latent saved beside the frames
     fa = generate.generate_video("a test prompt", output_path=str(tmp_path / "av.mp4"), spatial_upscaler_weights="random",
                                  generate_audio=True, **kw)
@@ -122,3 +130,81 @@ def test_generate_video_with_reference_default_kwargs(dev, tmp_path):
     frames = generate.generate_video("a cat walking through tall grass", **kw, num_layers=2, save_mp4=False)
     assert frames.shape == (97, 480, 704, 3) and frames.dtype == torch.uint8
     assert os.path.exists(tmp_path / "gens" / "output_latent.npz")
+
+
+def _ckpt_tensors(dit_w, vae_w):
+    t = {"model.diffusion_model." + k: v.contiguous() for k, v in dit_w.items()}
+    t.update({k: v.contiguous() for k, v in vae_w.items()})
+    return t
+
+
+@pytest.mark.parametrize("family", ["v1", "v23"])
+def test_generate_video_from_checkpoint_metadata(dev, tmp_path, family):
+    """Real (tiny) safetensors checkpoints WITH the reference's metadata records go through generate_video(weights_path=...):
+    `config.vae` (decoder_blocks / decoder_base_channels / timestep_conditioning) builds the VAE decoder, `model_version` 2.3.*
+    selects the AudioVideo transformer with cross_attention_adaln + apply_gated_attention and no caption projection, run through
+    OneStagePipeline (reference scripts/generate.py:142-152, 224-254, 1073-1074, 1158-1164, 1255-1266, 1638-1735).  The decoded
+    frames are checked against the oracle's decode of the saved latent with the metadata's architecture."""
+    import json
+    from safetensors.torch import save_file
+    from oracle import dit, dit_av, vae
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import generate
+    blocks = [["res_x", {"num_layers": 1}], ["compress_all", {"multiplier": 2, "residual": True}], ["res_x", {"num_layers": 2}],
+              ["compress_space", {"multiplier": 1, "residual": False}], ["compress_all", {"multiplier": 2, "residual": True}], ["res_x", {"num_layers": 1}]]
+    vcfg = vae.VAEConfig(decoder_blocks=blocks, base_channels=16, timestep_conditioning=(family == "v1"))
+    vw = vae.make_vae_weights(vcfg, 5)
+    meta = {"config": json.dumps({"vae": {"decoder_blocks": blocks, "decoder_base_channels": 16, "timestep_conditioning": family == "v1"}})}
+    if family == "v1":
+        cfg = dit.DiTConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, caption_channels=3840)
+        tensors = _ckpt_tensors(dit.make_dit_weights(cfg, 6), vw)
+        extra = dict(num_heads=2)
+    else:
+        meta["model_version"] = "2.3.0"
+        cfg = dit_av.AVConfig(num_attention_heads=4, attention_head_dim=128, audio_heads=4, audio_head_dim=64, num_layers=2,
+                              caption_channels=None, cross_attention_adaln=True, apply_gated_attention=True)
+        tensors = _ckpt_tensors(dit_av.make_av_weights(cfg, seed=6), vw)
+        extra = dict(num_heads=4)
+    path = str(tmp_path / f"{family}.safetensors")
+    save_file(tensors, path, metadata=meta)
+    built = []
+    real_model, real_dec = generate.LTXModel, generate.SimpleVideoDecoder
+
+    class SpyModel(real_model):
+        def __init__(self, *a, **k):
+            built.append(("model", k))
+            super().__init__(*a, **k)
+
+    class SpyDec(real_dec):
+        def __init__(self, *a, **k):
+            built.append(("vae", k))
+            super().__init__(*a, **k)
+
+    generate.LTXModel, generate.SimpleVideoDecoder = SpyModel, SpyDec
+    try:
+        frames = generate.generate_video("a test prompt", height=64, width=96, num_frames=9, num_steps=4, seed=3, weights_path=path,
+                                         use_gemma=False, num_layers=2, output_path=str(tmp_path / "o.mp4"), save_mp4=False,
+                                         generate_audio=(family == "v23"), **extra)
+    finally:
+        generate.LTXModel, generate.SimpleVideoDecoder = real_model, real_dec
+    mk = [k for n, k in built if n == "model"][0]
+    vk = [k for n, k in built if n == "vae"][0]
+    assert vk["decoder_blocks"] == blocks and vk["base_channels"] == 16 and vk["timestep_conditioning"] == (family == "v1")
+    if family == "v23":
+        from ltx_2_mlx_amd.model.transformer import LTXModelType
+        assert mk["model_type"] == LTXModelType.AudioVideo and mk["caption_channels"] is None
+        assert mk["cross_attention_adaln"] is True and mk["apply_gated_attention"] is True and mk["av_ca_timestep_scale_multiplier"] == 1000
+        al = np.load(tmp_path / "o_audio_latent.npz")["latent"]
+        assert al.shape == (1, 8, 9, 16) and np.isfinite(al).all()          # 9 frames / 25 fps x 25 latents per second
+    else:
+        assert mk["caption_channels"] == 3840 and "model_type" not in mk
+    # the metadata's decoder doubles time only twice (compress_space in the middle): 2 latent frames -> 5 video frames, not 9
+    assert frames.dtype == torch.uint8 and tuple(frames.shape) == (5, 64, 96, 3)
+    if family == "v1":
+        lat = torch.from_numpy(np.load(tmp_path / "o_latent.npz")["latent"])
+        vwq = {k: (v.to(torch.bfloat16).float() if (v.dim() == 5 or (v.dim() == 2 and "linear" in k)) else v) for k, v in vw.items()}
+        # timestep-conditioned decode draws noise on the GPU; compare the noise-free architecture through a second decoder call instead
+        dec = generate.create_vae_decoder(path, device=str(dev))
+        got = dec(lat.to(dev), timestep=0.05, noise=torch.zeros_like(lat).to(dev)).cpu()
+        ref = vae.decoder_forward(lat, vwq, vcfg, 0.05, noise=torch.zeros_like(lat))
+        assert got.shape == ref.shape and float((got - ref).norm() / ref.norm()) < 4e-2

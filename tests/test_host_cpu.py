@@ -246,7 +246,23 @@ def test_capi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libltx2hip.so does not export {name}"
     assert sorted(nv.exported_symbols()) == declared          # python binding table == header
-    assert nv.lib().ltx2_abi_version() == 1
+    # the header's version macro, the library and the binding agree; a library of another version is refused at load
+    hdr = int(re.search(r"#define LTX2_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "ltx2hip.h")).read()).group(1))
+    assert nv.lib().ltx2_abi_version() == nv.ABI_VERSION == hdr == 2
+
+
+def test_library_of_another_abi_version_is_refused(tmp_path):
+    """ltx2_dit_forward / ltx2_dit_denoise_step gained an argument mid-list; a stale .so (or a caller built against the old
+    header) must fail at load, not shift pointers.  A stub library that reports version 1 is refused by the binding."""
+    import subprocess
+    src = tmp_path / "stub.c"
+    src.write_text("int ltx2_abi_version(void) { return 1; }\nconst char* ltx2_last_error(void) { return \"\"; }\n")
+    so = tmp_path / "libstub.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)])
+    code = ("import sys; sys.path.insert(0, %r)\nfrom ltx_2_mlx_amd import _native as nv\n"
+            "try:\n    nv.lib()\nexcept nv.NativeLibraryMissing as e:\n    print('REFUSED', e)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LTX2HIP_LIB=str(so)))
+    assert "REFUSED" in r.stdout and "ABI version 1" in r.stdout, r.stdout + r.stderr
 
 
 def test_product_does_not_import_oracle():
@@ -405,3 +421,187 @@ def test_gemm_k_loop_generator_checks_its_own_pipeline():
         bad.build()
         bad.trace = [e for e in bad.trace if e[0] != drop]
         assert gen.check(bad), drop
+
+
+def _load_generate():
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import generate
+    return generate
+
+
+def test_cli_accepts_every_reference_flag():
+    """Drop-in boundary: every argument of the reference's parser (scripts/generate.py:2364-2641, pinned in
+    tests/golden/generate_cli_flags.json by tools/pin_generate_cli.py) exists here with the same flag strings, type, default,
+    choices and action, and main()'s mapping onto generate_video keywords is the reference's (:2658-2725): the reference's own
+    expressions are evaluated over a namespace parsed by THIS parser and compared keyword by keyword."""
+    import json
+    gen = _load_generate()
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "generate_cli_flags.json")))
+    assert len(gold["flags"]) == 57
+    parser = gen.build_parser()
+    acts = {}
+    for a in parser._actions:
+        for s in (a.option_strings or [a.dest]):
+            acts[s] = a
+    types = {"int": int, "float": float, "str": str}
+    sample = {int: "3", float: "0.25", str: "x"}
+    argv = ["a prompt"]
+    for f in gold["flags"]:
+        a = acts[f["flags"][0]]
+        for s in f["flags"]:
+            assert acts[s] is a, s
+        if f["flags"] == ["prompt"]:
+            continue
+        action = f.get("action", "store")
+        assert type(a).__name__ == {"store": "_StoreAction", "store_true": "_StoreTrueAction", "append": "_AppendAction"}[action], f
+        if "type" in f:
+            assert a.type is types[f["type"]], f
+        assert a.default == f.get("default", False if action == "store_true" else None), f
+        assert (list(a.choices) if a.choices else None) == f.get("choices"), f
+        if "dest" in f:
+            assert a.dest == f["dest"]
+        # a non-default legal value for every flag
+        if action == "store_true":
+            argv.append(f["flags"][-1])
+        else:
+            val = f["choices"][-1] if "choices" in f else sample[types[f["type"]]]
+            argv += [f["flags"][0], val]
+    args = parser.parse_args(argv)
+    import copy
+    ours = gen.kwargs_from_args(copy.copy(args))
+    # the reference's main() edits args.weights / args.steps first (:2644-2656); replay that on a copy, then its expressions
+    ref_args = copy.copy(args)
+    if ref_args.model_variant == "dev":
+        ref_args.weights = ref_args.weights.replace("distilled", "dev")
+        if ref_args.steps == 7:
+            ref_args.steps = 30
+    if ref_args.fp8 and ".safetensors" in ref_args.weights and "-fp8" not in ref_args.weights:
+        ref_args.weights = ref_args.weights.replace(".safetensors", "-fp8.safetensors")
+    assert len(gold["generate_video_kwargs"]) == 56
+    for k, expr in gold["generate_video_kwargs"].items():
+        assert ours[k] == eval(expr, {"args": ref_args, "getattr": getattr}), (k, expr)
+    # and with no flags at all: the reference's defaults reach generate_video unchanged
+    d = gen.kwargs_from_args(parser.parse_args(["p"]))
+    dref = parser.parse_args(["p"])
+    for k, expr in gold["generate_video_kwargs"].items():
+        assert d[k] == eval(expr, {"args": dref, "getattr": getattr}), k
+    import inspect
+    sig = inspect.signature(gen.generate_video).parameters
+    assert set(ours) <= set(sig), set(ours) - set(sig)
+
+
+def _write_ckpt(path, tensors, config=None, version=None):
+    import json
+    from safetensors.torch import save_file
+    md = {}
+    if config is not None:
+        md["config"] = json.dumps(config)
+    if version is not None:
+        md["model_version"] = version
+    save_file(tensors, str(path), metadata=md or None)
+
+
+def test_checkpoint_metadata_drives_model_construction(tmp_path, monkeypatch):
+    """The reference reads the architecture from the safetensors metadata (scripts/generate.py:142-152, 224-254) and builds the
+    VAE decoder (:1255-1266) and the AudioVideo / LTX-2.3 transformer (:1073-1074, 1158-1164) from it.  Tiny safetensors files WITH
+    metadata (an LTX-2.0-style record and a "2.3.0" one) go through the same helpers here; the constructors are spied on, so this
+    runs without a GPU."""
+    import torch
+    gen = _load_generate()
+    blocks = [["res_x", {"num_layers": 2}], ["compress_all", {"multiplier": 2, "residual": True}], ["res_x", {"num_layers": 1}],
+              ["compress_time", {"multiplier": 1}], ["res_x", {"num_layers": 1}]]
+    v1, v23, bare = tmp_path / "v1.safetensors", tmp_path / "v23.safetensors", tmp_path / "bare.safetensors"
+    t = {"x": torch.zeros(2)}
+    _write_ckpt(v1, t, {"vae": {"decoder_blocks": blocks, "decoder_base_channels": 64, "timestep_conditioning": False}, "vocoder": {}}, "2.0.1")
+    _write_ckpt(v23, t, {"vae": {"decoder_base_channels": 32}}, "2.3.0")
+    _write_ckpt(bare, t)
+    assert gen.detect_model_version(str(v1)) == "2.0.1" and not gen.is_v2_model(str(v1))
+    assert gen.detect_model_version(str(v23)) == "2.3.0" and gen.is_v2_model(str(v23))
+    assert gen.detect_model_version(str(bare)) == "" and not gen.is_v2_model(str(bare))
+    assert gen.detect_model_version(str(tmp_path / "missing.safetensors")) == "" and gen.get_vae_config(str(tmp_path / "missing.safetensors")) == {}
+    assert gen.get_vae_config(str(v1)) == {"decoder_blocks": blocks, "decoder_base_channels": 64, "timestep_conditioning": False}
+    assert gen.get_vae_config(str(bare)) == {} and gen._read_checkpoint_config(str(v23)) == {"vae": {"decoder_base_channels": 32}}
+
+    made = []
+
+    class SpyDecoder:
+        def __init__(self, **kw):
+            made.append(kw)
+
+        def init_random_weights(self, seed=0):
+            made[-1]["random"] = seed
+
+    monkeypatch.setattr(gen, "SimpleVideoDecoder", SpyDecoder)
+    monkeypatch.setattr(gen, "load_vae_decoder_weights", lambda dec, path: made[-1].update(loaded=path))
+    gen.create_vae_decoder(str(v1), device="cpu")
+    assert made[-1] == dict(decoder_blocks=blocks, base_channels=64, timestep_conditioning=False, device="cpu", loaded=str(v1))
+    gen.create_vae_decoder(str(v23), device="cpu")          # absent keys take the reference's defaults (:1258-1260)
+    assert made[-1] == dict(decoder_blocks=None, base_channels=32, timestep_conditioning=True, device="cpu", loaded=str(v23))
+    gen.create_vae_decoder(None, device="cpu", seed=7)
+    assert made[-1] == dict(decoder_blocks=None, base_channels=128, timestep_conditioning=True, device="cpu", random=7)
+    gen.create_vae_decoder(str(v1), device="cpu", base_channels_override=16)
+    assert made[-1]["base_channels"] == 16
+
+    # routing of generate_video: which transformer loader gets which architecture arguments
+    class Routed(Exception):
+        pass
+
+    def spy(name):
+        def f(*a, **k):
+            raise Routed(name, a, k)
+        return f
+
+    monkeypatch.setattr(gen, "load_transformer", spy("video"))
+    monkeypatch.setattr(gen, "load_av_transformer", spy("av"))
+    kw = dict(use_gemma=False, device="cpu", output_path=str(tmp_path / "o.mp4"))
+    with pytest.raises(Routed) as e:
+        gen.generate_video("p", weights_path=str(v1), **kw)
+    assert e.value.args[0] == "video" and e.value.args[2]["caption_channels"] == 3840
+    with pytest.raises(Routed) as e:
+        gen.generate_video("p", weights_path=str(v1), generate_audio=True, **kw)
+    assert e.value.args[0] == "av" and e.value.args[1] == (str(v1),)
+    assert {k: e.value.args[2][k] for k in ("caption_channels", "cross_attention_adaln", "apply_gated_attention")} == \
+        dict(caption_channels=3840, cross_attention_adaln=False, apply_gated_attention=False)
+    with pytest.raises(Routed) as e:                        # LTX-2.3: always the AV transformer, V2 blocks, no caption projection
+        gen.generate_video("p", weights_path=str(v23), **kw)
+    assert e.value.args[0] == "av"
+    assert {k: e.value.args[2][k] for k in ("caption_channels", "cross_attention_adaln", "apply_gated_attention", "num_layers")} == \
+        dict(caption_channels=None, cross_attention_adaln=True, apply_gated_attention=True, num_layers=48)
+    with pytest.raises(Routed) as e:                        # no checkpoint on disk + model_version: the same architecture, random init
+        gen.generate_video("p", weights_path=None, model_version="2.3", **kw)
+    assert e.value.args[0] == "av" and e.value.args[2]["cross_attention_adaln"] is True
+    # pipelines the reference knows but this path does not build are refused by name; unknown names are a ValueError
+    for pt in ("two-stage", "ic-lora", "keyframe-interpolation"):
+        with pytest.raises(NotImplementedError, match=pt):
+            gen.generate_video("p", pipeline_type=pt, **kw)
+    with pytest.raises(ValueError, match="unknown pipeline_type"):
+        gen.generate_video("p", pipeline_type="bogus", **kw)
+    with pytest.raises(NotImplementedError, match="cfg_scale"):
+        gen.generate_video("p", model_variant="dev", **kw)      # dev model: cfg 5.0 stays on -> classifier-free guidance
+
+
+def test_one_stage_config_and_guidance_gate():
+    """OneStageCFGConfig keeps the reference's fields / defaults / validation (pipelines/one_stage.py:52-110); the pipeline runs
+    only its guidance-free branches and says so for everything else."""
+    from ltx_2_mlx_amd.pipelines import OneStageCFGConfig, OneStagePipeline
+    c = OneStageCFGConfig()
+    assert (c.height, c.width, c.num_frames, c.seed, c.fps, c.num_inference_steps) == (480, 704, 97, 42, 24.0, 30)
+    assert (c.cfg_scale, c.audio_cfg_scale, c.rescale_scale, c.audio_enabled, c.use_internal_audio_branch) == (3.0, 7.0, 0.7, False, True)
+    assert (c.audio_vae_channels, c.audio_mel_bins, c.audio_sample_rate, c.audio_hop_length, c.audio_downsample_factor, c.audio_output_sample_rate) == \
+        (8, 16, 16000, 160, 4, 24000)
+    assert c._get_tiling_config() is not None                       # 13 x 15 x 22 = 4290 latent voxels > 4000
+    assert OneStageCFGConfig(height=512, width=768, num_frames=65)._get_tiling_config() is None     # 9 x 16 x 24 = 3456
+    with pytest.raises(ValueError, match="8\\*k \\+ 1"):
+        OneStageCFGConfig(num_frames=96)
+    with pytest.raises(ValueError, match="divisible by 32"):
+        OneStageCFGConfig(height=500)
+    gate = OneStagePipeline._require_no_guidance
+    ok = OneStageCFGConfig(cfg_scale=1.0, audio_cfg_scale=1.0)
+    gate(ok, True, 0.0, None, 0.0, "euler", None, 1.0)
+    gate(OneStageCFGConfig(cfg_scale=1.0), False, 0.0, None, 0.0, "euler", None, 1.0)     # audio scale is irrelevant without the audio branch
+    for bad in (dict(config=OneStageCFGConfig()), dict(config=OneStageCFGConfig(cfg_scale=1.0), joint=True), dict(stg_scale=1.0), dict(ge_gamma=2.0),
+                dict(sampler="heun"), dict(temporal_upscaler=object()), dict(cross_attn_scale=5.0), dict(guider_override=object())):
+        a = dict(config=ok, joint=False, stg_scale=0.0, guider_override=None, ge_gamma=0.0, sampler="euler", temporal_upscaler=None, cross_attn_scale=1.0)
+        a.update(bad)
+        with pytest.raises(NotImplementedError):
+            gate(**a)

@@ -201,6 +201,34 @@ def test_av_dit_matches_reference(v23):
             close(ax0, z[f"{tag}_{tsk}_audio_x0"], rtol=2e-4, atol=2e-5)
 
 
+def av_videoonly_case(v23: bool):
+    """The video-only-inference case of pin_dit_av: the AudioVideo model called without audio, per-token timesteps of an image-
+    conditioned state (token 0 clean, first latent frame at strength 0.95), Modality.sigma set."""
+    cfg, w, cases = av_tiny_case(v23)
+    video = dict(cases["scalar"][0])
+    f, h, wd, sigma = 3, 4, 4, 0.725
+    cmask = torch.ones(1, f * h * wd, 1)
+    cmask[:, :h * wd] = 0.05
+    cmask[:, 0] = 0.0
+    video["timesteps"] = cmask * sigma
+    return cfg, w, video
+
+
+@pytest.mark.parametrize("v23", [False, True])
+def test_video_only_inference_matches_reference(v23):
+    """oracle.dit_av.video_only_x0_model against the reference's X0Model(LTXModel(AudioVideo))(video, None) (model.py:829-840),
+    with timesteps[0] = 0 != sigma: pins that the prompt AdaLN of the V2.3 blocks follows Modality.sigma (model.py:151-158)."""
+    from oracle import dit_av
+    z = g("dit_av_tiny.npz")
+    cfg, w, video = av_videoonly_case(v23)
+    with torch.no_grad():
+        x0 = dit_av.video_only_x0_model(video, w, cfg)
+        close(x0, z[f"{'v23' if v23 else 'v1'}_videoonly_x0"], rtol=2e-4, atol=2e-5)
+        if v23:     # negative control: sigma taken from timesteps[0] (= 0) is NOT what the reference computes
+            wrong = dict(video, sigma=video["timesteps"].reshape(-1)[:1])
+            assert (dit_av.video_only_x0_model(wrong, w, cfg) - torch.from_numpy(z["v23_videoonly_x0"])).abs().max() > 1e-3
+
+
 def test_upscaler_matches_reference():
     """Spatial x2 upscaler oracle against the reference's SpatialUpscaler (tiny: 64 -> 64 channels, 2+2 blocks)."""
     from oracle import upscaler

@@ -822,3 +822,139 @@ def test_dit_full_size_per_token_timesteps(dev):
         ref = dit.x0_model(lat.to(dev), ctx.to(dev), ts.to(dev), pos.to(dev), wg, cfg).cpu()
     assert x0.shape == (1, 3456, 128)
     assert rel_l2(x0.cpu(), ref) < 2e-2 and pearson(x0.cpu(), ref) > 0.999
+
+
+@pytest.mark.parametrize("family", ["video", "av_v1", "av_v23"])
+def test_one_stage_pipeline_against_oracle_loop(dev, family):
+    """OneStagePipeline, guidance-free branch (reference pipelines/one_stage.py:731-1011 with cfg_scale = audio_cfg_scale = 1:
+    LTX2Scheduler.execute(steps) sigmas, fps-25 positions, Gaussian noise at scale 1, one X0 evaluation per step, Euler) against
+    the same sequence written with the oracle's pieces on the same supplied noise; eager per-step API and hipGraph replay agree.
+    `av_v23` is BASELINE config 4's path (LTX-2.3: AudioVideo transformer, prompt AdaLN, gated attention, joint audio+video)."""
+    from oracle import dit, dit_av, loop
+    from ltx_2_mlx_amd.components import AudioPatchifier
+    from ltx_2_mlx_amd.pipelines import OneStageCFGConfig, OneStagePipeline
+    from ltx_2_mlx_amd.types import AudioLatentShape
+    H, W, F, steps, S = 64, 96, 17, 5, 24
+    f, h, wd = 3, 2, 3
+    g = torch.Generator().manual_seed(21)
+    noise = torch.randn(1, f * h * wd, 128, generator=g)
+    vpos = loop.video_positions(1, f, h, wd, 25.0)
+    sig = loop.ltx2_scheduler(steps)
+    kw = dict(height=H, width=W, num_frames=F, seed=1, fps=25.0, num_inference_steps=steps, cfg_scale=1.0, audio_cfg_scale=1.0, rescale_scale=0.0)
+    if family == "video":
+        cfg, wq, m = make_dit(dev, heads=2, layers=2, cap=64, seed=11)
+        ctx = 0.1 * torch.randn(1, S, 64, generator=g)
+        rv = noise.clone()
+        for i in range(steps):
+            s = float(sig[i])
+            rv = loop.euler_step(rv, dit.x0_model(rv, ctx, torch.tensor([s]), vpos, wq, cfg), s, float(sig[i + 1]))
+        pipe = OneStagePipeline(m, None, None)
+        lat, aud = pipe(ctx.to(dev), None, OneStageCFGConfig(**kw), initial_noise=noise.to(dev))
+        assert aud is None and rel_l2(lat.cpu(), loop.unpatchify(rv, f, h, wd)) < 3e-2
+        lat_g, _ = pipe(ctx.to(dev), None, OneStageCFGConfig(use_hip_graph=True, **kw), initial_noise=noise.to(dev))
+        assert rel_l2(lat_g.cpu(), lat.cpu()) < 1e-5
+        with pytest.raises(NotImplementedError, match="cfg_scale"):
+            pipe(ctx.to(dev), ctx.to(dev), OneStageCFGConfig(**dict(kw, cfg_scale=3.0)))
+        return
+    v23 = family == "av_v23"
+    cfg, w, wq, m = make_av(dev, v23, seed=23)
+    Ta = AudioLatentShape.from_duration(1, F / 25.0).frames                  # 17 frames at 25 fps -> 17 audio latents
+    anoise = torch.randn(1, Ta, 128, generator=g)
+    vctx = 0.1 * torch.randn(1, S, cfg.caption_channels or cfg.inner_dim, generator=g)
+    actx = 0.1 * torch.randn(1, S, cfg.caption_channels or cfg.audio_inner_dim, generator=g)
+    apos = dit_av.audio_positions(1, Ta)
+    rv, ra = noise.clone(), anoise.clone()
+    for i in range(steps):
+        s = torch.tensor([float(sig[i])])
+        vx0, ax0 = dit_av.av_x0_model(dict(latent=rv, context=vctx, timesteps=s, sigma=s, positions=vpos),
+                                      dict(latent=ra, context=actx, timesteps=s, sigma=s, positions=apos), wq, cfg)
+        rv, ra = loop.euler_step(rv, vx0, float(sig[i]), float(sig[i + 1])), loop.euler_step(ra, ax0, float(sig[i]), float(sig[i + 1]))
+    pipe = OneStagePipeline(m, None, None)
+    with pytest.raises(ValueError, match="Audio encoding required"):
+        pipe(vctx.to(dev), None, OneStageCFGConfig(**kw))
+    lat, aud = pipe(vctx.to(dev), None, OneStageCFGConfig(audio_enabled=True, **kw), positive_audio_encoding=actx.to(dev),
+                    initial_noise=noise.to(dev), initial_audio_noise=anoise.to(dev))
+    assert rel_l2(lat.cpu(), loop.unpatchify(rv, f, h, wd)) < 3e-2
+    ref_aud = AudioPatchifier(patch_size=1).unpatchify(ra, AudioLatentShape(1, 8, Ta, 16))
+    assert aud.shape == (1, 8, Ta, 16) and rel_l2(aud.cpu(), ref_aud) < 3e-2
+    # silent video from an AV checkpoint (audio_enabled=False): the internal audio branch still runs (use_internal_audio_branch),
+    # only the audio output is dropped; hipGraph replay of the joint loop agrees with the eager per-step API
+    lat_g, aud_g = pipe(vctx.to(dev), None, OneStageCFGConfig(use_hip_graph=True, **kw), positive_audio_encoding=actx.to(dev),
+                        initial_noise=noise.to(dev), initial_audio_noise=anoise.to(dev))
+    assert aud_g is None and rel_l2(lat_g.cpu(), lat.cpu()) < 1e-5
+    # use_internal_audio_branch=False on an AV model: the video half alone (reference model.py:829-840), no audio encoding needed
+    lat_v, _ = pipe(vctx.to(dev), None, OneStageCFGConfig(use_internal_audio_branch=False, **kw), initial_noise=noise.to(dev))
+    assert lat_v.shape == lat.shape and torch.isfinite(lat_v).all() and rel_l2(lat_v.cpu(), lat.cpu()) > 1e-3
+
+
+def test_video_only_v23_conditioned_token0_against_oracle(dev):
+    """VideoOnly LTX-2.3 blocks (cross_attention_adaln + gated attention) under image conditioning: per-token timesteps =
+    denoise_mask * sigma with token 0 (and the whole first latent frame) CONDITIONED, so timesteps[0] = 0 != Modality.sigma.
+    The prompt AdaLN must take Modality.sigma (reference model.py:151-158), not timesteps[0] -- checked against the oracle
+    (oracle/dit_av.py restates that rule), not against another engine configuration."""
+    from oracle import dit_av, loop
+    from ltx_2_mlx_amd.model.transformer import LTXModel, LTXModelType, Modality, X0Model
+    heads = 4
+    cfg = dit_av.AVConfig(num_attention_heads=heads, attention_head_dim=128, audio_heads=heads, audio_head_dim=64, num_layers=2,
+                          caption_channels=None, cross_attention_adaln=True, apply_gated_attention=True)
+    w = dit_av.make_av_weights(cfg, seed=31)
+    wq = {k: (v.to(torch.bfloat16).float() if (k.endswith(".weight") and v.dim() == 2) else v) for k, v in w.items()}
+    vo = LTXModel(model_type=LTXModelType.VideoOnly, num_attention_heads=heads, attention_head_dim=128, num_layers=2, caption_channels=None,
+                  cross_attention_adaln=True, apply_gated_attention=True, device=dev)
+    vo.load_state_dict({k: w[k] for k in vo.expected_weight_shapes()})
+    g = torch.Generator().manual_seed(32)
+    f, h, wd, S, sigma = 3, 4, 5, 40, 0.909375
+    n = f * h * wd
+    mask = torch.ones(1, n, 1)
+    mask[:, :h * wd] = 0.05                                     # first latent frame conditioned at strength 0.95
+    mask[:, 0] = 0.0                                            # token 0 fully clean: timesteps[0] == 0
+    ts = mask * sigma
+    video = dict(latent=torch.randn(1, n, 128, generator=g), context=0.1 * torch.randn(1, S, cfg.inner_dim, generator=g),
+                 timesteps=ts, sigma=torch.tensor([sigma]), positions=loop.video_positions(1, f, h, wd, 24.0))
+    rv = dit_av.video_only_x0_model(video, wq, cfg)
+    mod = Modality(latent=video["latent"].to(dev), context=video["context"].to(dev), context_mask=None, timesteps=ts.to(dev),
+                   positions=video["positions"].to(dev), sigma=video["sigma"].to(dev))
+    x0 = X0Model(vo)(mod).cpu()
+    assert rel_l2(x0, rv) < 2e-2 and pearson(x0, rv) > 0.999
+    # the bug this guards against: prompt AdaLN driven by timesteps[0] (= 0 here) instead of sigma gives a different result
+    wrong = Modality(latent=mod.latent, context=mod.context, context_mask=None, timesteps=mod.timesteps, positions=mod.positions, sigma=torch.zeros(1, device=dev))
+    assert rel_l2(X0Model(vo)(wrong).cpu(), rv) > 5e-3
+
+
+@pytest.mark.parametrize("v23", [False, True])
+def test_video_only_inference_against_reference_vectors(dev, v23):
+    """AudioVideo LTXModel called with video alone, image-conditioned per-token timesteps (token 0 clean) and Modality.sigma: the HIP
+    path DIRECTLY against the vector recorded from the reference's own model (tests/golden/dit_av_tiny.npz, `*_videoonly_x0`)."""
+    import numpy as np
+    import os
+    from test_oracle_golden import av_videoonly_case
+    from ltx_2_mlx_amd.model.transformer import X0Model
+    cfg, w, video = av_videoonly_case(v23)
+    _, _, wq, m = make_av(dev, v23, seed=17 + v23)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_av_tiny.npz"))
+    x0, empty = X0Model(m)(to_modality(video, dev), None)
+    ref = torch.from_numpy(z[f"{'v23' if v23 else 'v1'}_videoonly_x0"])
+    assert empty.shape == (1, 0, 128) and rel_l2(x0.cpu(), ref) < 3e-2 and pearson(x0.cpu(), ref) > 0.999
+
+
+def test_stream_k_timeout_is_reported_at_the_next_health_check(dev):
+    """a stream-K attention consumer that gives up waiting sets a sticky word nobody read.  ltx2_dit_health (LTXModel.
+    check_health, called per sampling loop) reads it at a host sync point, raises, and resets the flag page so the next launch is
+    clean.  The sticky word is planted by hand here (workspace layout: 256 B of sigmas, then the 4-KiB flag page)."""
+    from ltx_2_mlx_amd.model.transformer import Modality, X0Model
+    cfg, wq, m = make_dit(dev, heads=2, layers=1, cap=64, seed=2)
+    lat, ctx, pos = inputs(2, 3, 4, 16, 64, seed=3)
+    mod = Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=torch.tensor([0.5], device=dev), positions=pos.to(dev))
+    a = X0Model(m)(mod)
+    m.check_health()                                           # clean
+    base = (m._ws.data_ptr() + 255) // 256 * 256 - m._ws.data_ptr()
+    flags = m._ws[base + 256: base + 256 + 4096].view(torch.int32)
+    flags[1023] = 1
+    flags[5] = 1                                               # a stale producer flag left behind by the same incident
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="stream-K"):
+        m.check_health()
+    torch.cuda.synchronize()
+    assert int(flags.abs().sum()) == 0                         # page reset
+    m.check_health()
+    assert torch.equal(X0Model(m)(mod), a)

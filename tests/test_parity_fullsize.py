@@ -216,3 +216,55 @@ def test_fp8_resident_model_matches_dequantised_model(dev, tmp_path):
         torch.cuda.empty_cache()
     assert torch.equal(outs[0], outs[1])
     assert nbytes[1] < 0.62 * nbytes[0]
+
+
+def av_weights_on_gpu(cfg, dev, seed):
+    """oracle.dit_av.make_av_weights' recipe drawn on the GPU (the 48-layer AudioVideo model is ~22 G parameters); 2-D linear
+    weights are rounded to bf16 values so oracle and engine see identical numbers."""
+    from oracle import dit_av
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = {}
+    for name, shape in dit_av.av_weight_shapes(cfg).items():
+        t = torch.randn(shape, generator=g, device=dev)
+        if name.endswith("_norm.weight"):
+            t = 1.0 + 0.1 * t
+        elif name.endswith(".bias"):
+            t = 0.02 * t
+        elif "scale_shift_table" in name:
+            t = 0.1 * t
+        else:
+            t = 0.02 * t
+        if name.endswith(".weight") and t.dim() == 2:
+            t = t.to(torch.bfloat16).float()
+        out[name] = t
+    return out
+
+
+def test_av_48_layer_step_v23(dev):
+    """The step bench.py times as `ltx23_audiovideo_ms_per_step` (BASELINE config 4): 48-layer full-width LTX-2.3 AudioVideo model
+    (video 32 x 128 + audio 32 x 64 heads, 9-row AdaLN, prompt AdaLN, per-head gates, cross-modal attention), 3456 video + 68
+    audio tokens, S = 1024, distinct weights per layer: one joint x0 evaluation against the fp32 oracle executed on the GPU."""
+    from oracle import dit_av, loop
+    from test_parity import to_modality
+    from ltx_2_mlx_amd.model.transformer import LTXModel, LTXModelType, X0Model
+    cfg = dit_av.AVConfig(num_attention_heads=32, attention_head_dim=128, audio_heads=32, audio_head_dim=64, num_layers=48,
+                          caption_channels=None, cross_attention_adaln=True, apply_gated_attention=True)
+    w = av_weights_on_gpu(cfg, dev, seed=148)
+    m = LTXModel(model_type=LTXModelType.AudioVideo, num_attention_heads=32, attention_head_dim=128, num_layers=48, caption_channels=None,
+                 cross_attention_adaln=True, apply_gated_attention=True, audio_attention_heads=32, device=dev)
+    m.load_state_dict(w)
+    g = torch.Generator().manual_seed(149)
+    f, h, wd, Ta, S = 9, 16, 24, 68, 1024
+    s = torch.tensor([0.725])
+    video = dict(latent=torch.randn(1, f * h * wd, 128, generator=g), context=0.1 * torch.randn(1, S, cfg.inner_dim, generator=g),
+                 timesteps=s, sigma=s, positions=loop.video_positions(1, f, h, wd, 25.0))
+    audio = dict(latent=torch.randn(1, Ta, 128, generator=g), context=0.1 * torch.randn(1, S, cfg.audio_inner_dim, generator=g),
+                 timesteps=s, sigma=s, positions=dit_av.audio_positions(1, Ta))
+    vx0, ax0 = X0Model(m)(to_modality(video, dev), to_modality(audio, dev))
+    with torch.device(dev), torch.no_grad():
+        rv, ra = dit_av.av_x0_model({k: t.to(dev) for k, t in video.items()}, {k: t.to(dev) for k, t in audio.items()}, w, cfg)
+    assert vx0.shape == (1, 3456, 128) and ax0.shape == (1, 68, 128)
+    assert rel_l2(vx0.cpu(), rv.cpu()) < 3e-2 and pearson(vx0.cpu(), rv.cpu()) > 0.999
+    assert rel_l2(ax0.cpu(), ra.cpu()) < 3e-2 and pearson(ax0.cpu(), ra.cpu()) > 0.999
+    del w, m
+    torch.cuda.empty_cache()

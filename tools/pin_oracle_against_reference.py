@@ -145,6 +145,16 @@ def pin_dit_av():
             out[f"{tag}_{tsk}_audio_velocity"] = tn(av.t)
             out[f"{tag}_{tsk}_video_x0"] = tn(vx0.t)
             out[f"{tag}_{tsk}_audio_x0"] = tn(ax0.t)
+        # video-only inference on the AudioVideo model (model.py:829-840; blocks with an empty audio stream, transformer.py:479-483)
+        # under image conditioning: token 0 and most of the first latent frame are conditioned, so timesteps[0] = 0 != sigma
+        cmask = torch.ones(1, f * h * wd, 1)
+        cmask[:, :h * wd] = 0.05
+        cmask[:, 0] = 0.0
+        video = Modality(latent=A(vlat), context=A(vctx), context_mask=None, timesteps=A(cmask * sigma), positions=A(vpos),
+                         sigma=A(torch.tensor([sigma])))
+        res = X0Model(model)(video, None)
+        vx0 = res[0] if isinstance(res, tuple) else res
+        out[f"{tag}_videoonly_x0"] = tn(vx0.t)
     np.savez_compressed(os.path.join(GOLD, "dit_av_tiny.npz"), **out)
     print("dit_av_tiny.npz", {k: v.shape for k, v in out.items()})
 
@@ -422,6 +432,10 @@ def pin_vae():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "text_connector":
         pin_text_connector()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dit_av":
+        with torch.no_grad():
+            pin_dit_av()
         sys.exit(0)
     with torch.no_grad():
         pin_loop()
