@@ -105,16 +105,85 @@ def cpu_baseline(threads):
     return out
 
 
+def _median_replay_ms(model, side, steps=8, reps=3):
+    """Median over `reps` timed replays of the captured `steps`-step graph (after one untimed replay), ms per step."""
+    model.replay_denoise_graph()
+    side.synchronize()
+    runs = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        model.replay_denoise_graph()
+        side.synchronize()
+        runs.append((time.perf_counter() - t0) / steps * 1e3)
+    return round(statistics.median(runs), 2), [round(r, 2) for r in runs]
+
+
+def _median_s(fn, reps=3):
+    fn()                                                  # warm-up: workspaces, kernel attributes
+    torch.cuda.synchronize()
+    runs = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        runs.append(time.perf_counter() - t0)
+    return statistics.median(runs), runs, out
+
+
+def loader_throughput(dev, layers):
+    """load_transformer_weights on a synthetic safetensors checkpoint of `layers` 19B-width blocks (bf16, the reference's key
+    scheme), written to the box's scratch disk first: file -> pinned staging -> HBM GB/s (loader/weight_converter.py
+    SafetensorsStream).  The second load reads the file from the page cache; both are reported."""
+    import tempfile
+    from safetensors.torch import save_file
+    from ltx_2_mlx_amd.loader import load_transformer_weights
+    from ltx_2_mlx_amd.model.transformer import LTXModel
+    m = LTXModel(num_layers=layers, device=dev)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp in m.expected_weight_shapes().items():
+        big = len(shp) == 2 and shp[0] * shp[1] >= 1 << 20
+        # one random block tiled over the big matrices: host RNG for 19 G parameters would take minutes and says nothing about the loader
+        if big:
+            blk = (0.02 * torch.randn(256, shp[1], generator=g)).to(torch.bfloat16)
+            t = blk.repeat((shp[0] + 255) // 256, 1)[:shp[0]].contiguous()
+        else:
+            t = (0.02 * torch.randn(*shp, generator=g)).to(torch.bfloat16 if len(shp) == 2 else torch.float32)
+        sd["model.diffusion_model." + k] = t
+    d = tempfile.mkdtemp(prefix="ltx2_loader_")
+    path = os.path.join(d, "synthetic.safetensors")
+    t0 = time.perf_counter()
+    save_file(sd, path, metadata={"model_version": "2.0.0"})
+    t_write = time.perf_counter() - t0
+    del sd
+    size = os.path.getsize(path)
+    res = {"file_gb": round(size / 1e9, 2), "layers": layers, "write_s": round(t_write, 1)}
+    try:
+        for tag in ("first_load", "cached_load"):
+            t0 = time.perf_counter()
+            st = load_transformer_weights(m, path, strict=True)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            res[tag] = {"file_to_hbm_gbps": round(st["bytes"] / st["seconds"] / 1e9, 2), "file_to_hbm_s": round(st["seconds"], 2),
+                        "incl_weight_packing_s": round(wall, 2)}
+    finally:
+        os.remove(path)
+        os.rmdir(d)
+    return res
+
+
 def extra_configs(dev, layers):
-    """AudioVideo (LTX-2.3-style) joint step and the two-stage 1536x1024x65 pipeline, random-init weights."""
+    """Secondary BASELINE configurations, random-init weights, every timing the MEDIAN of 3 after a warm-up: config 3 (fp8-resident
+    weights), config 4 (LTX-2.3 AudioVideo joint step), config 5 (two-stage 1536x1024x65: denoise + upscale, whole-volume decode
+    and the TILED decode the pipeline itself takes above 4000 latent voxels)."""
     from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES, AudioPatchifier, VideoLatentPatchifier
     from ltx_2_mlx_amd.conditioning import AudioLatentTools, VideoLatentTools
     from ltx_2_mlx_amd.model.transformer import LTXModel, LTXModelType
     from ltx_2_mlx_amd.model.upscaler import SpatialUpscaler
-    from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder, decode_latent
+    from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder, TilingConfig, decode_latent, decode_tiled
     from ltx_2_mlx_amd.pipelines import DistilledConfig, DistilledPipeline
     from ltx_2_mlx_amd.types import AudioLatentShape, VideoLatentShape
-    res = {}
+    res = {"timing": "median of 3 timed repetitions after one warm-up; the individual runs are listed beside each figure"}
     # --- config 3: the same 19B step with fp8-RESIDENT weights (e4m3fn codes + scale in HBM, expanded inside the GEMM; outputs
     #     bit-identical to dequantising at load -- tests/test_parity_fullsize.py)
     from ltx_2_mlx_amd.conditioning import VideoLatentTools as _VLT
@@ -129,37 +198,27 @@ def extra_configs(dev, layers):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         m.capture_denoise_graph(lat3, DISTILLED_SIGMA_VALUES)
-        m.replay_denoise_graph()
-        side.synchronize()
-        t0 = time.perf_counter()
-        m.replay_denoise_graph()
-        side.synchronize()
-        res["fp8_resident_ms_per_step"] = round((time.perf_counter() - t0) / 8 * 1e3, 2)
+        res["fp8_resident_ms_per_step"], res["fp8_resident_runs"] = _median_replay_ms(m, side)
         res["fp8_resident_weight_gb"] = round(sum(t.numel() * t.element_size() for t in m.weight_tensors().values()) / 1e9, 2)
     torch.cuda.current_stream().wait_stream(side)
     del m
     torch.cuda.empty_cache()
     # --- config 4 shape: 48-layer AudioVideo DiT with 9-row AdaLN, prompt-modulated text K/V, per-head gates
     m = LTXModel(model_type=LTXModelType.AudioVideo, num_layers=layers, caption_channels=None, cross_attention_adaln=True,
-                 apply_gated_attention=True, device=dev)
+                 apply_gated_attention=True, av_ca_timestep_scale_multiplier=1000, device=dev)
     m.init_random_weights(seed=0)
     g = torch.Generator(device=dev).manual_seed(1)
     N, Na, S = 3456, 68, 1024
     vlat, alat = torch.randn(N, 128, generator=g, device=dev), torch.randn(Na, 128, generator=g, device=dev)
     vctx, actx = 0.1 * torch.randn(1, S, 4096, generator=g, device=dev), 0.1 * torch.randn(1, S, 2048, generator=g, device=dev)
-    vpos = VideoLatentTools(VideoLatentPatchifier(1), VideoLatentShape(1, 128, 9, 16, 24), fps=24.0).create_initial_state(device=dev).positions
+    vpos = VideoLatentTools(VideoLatentPatchifier(1), VideoLatentShape(1, 128, 9, 16, 24), fps=25.0).create_initial_state(device=dev).positions
     apos = AudioLatentTools(AudioPatchifier(1), AudioLatentShape(1, 8, Na, 16)).create_initial_state(device=dev).positions
     m.prepare(vctx, vpos, audio_context=actx, audio_positions=apos)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         m.capture_denoise_graph(vlat, DISTILLED_SIGMA_VALUES, audio_latent=alat)
-        m.replay_denoise_graph()
-        side.synchronize()
-        t0 = time.perf_counter()
-        m.replay_denoise_graph()
-        side.synchronize()
-        res["ltx23_audiovideo_ms_per_step"] = round((time.perf_counter() - t0) / 8 * 1e3, 2)
+        res["ltx23_audiovideo_ms_per_step"], res["ltx23_audiovideo_runs"] = _median_replay_ms(m, side)
     torch.cuda.current_stream().wait_stream(side)
     del m
     torch.cuda.empty_cache()
@@ -173,22 +232,27 @@ def extra_configs(dev, layers):
     pipe = DistilledPipeline(m, dec, None, spatial_upscaler=up)
     conf = DistilledConfig(height=1024, width=1536, num_frames=65, seed=0, use_hip_graph=True)
     ctx = 0.1 * torch.randn(1, 1024, 3840, generator=g, device=dev)
-    lat = pipe(ctx, None, conf)                       # warm-up: workspaces, kernel attributes
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    lat = pipe(ctx, None, conf)
-    torch.cuda.synchronize()
-    res["two_stage_1536x1024x65_denoise_upscale_s"] = round(time.perf_counter() - t0, 3)
-    decode_latent(lat, dec)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fr = decode_latent(lat, dec)
-    torch.cuda.synchronize()
-    res["two_stage_1536x1024x65_decode_frames_per_sec"] = round(fr.shape[0] / (time.perf_counter() - t0), 1)
+    med, runs, lat = _median_s(lambda: pipe(ctx, None, conf))
+    res["two_stage_1536x1024x65_denoise_upscale_s"] = round(med, 3)
+    res["two_stage_1536x1024x65_denoise_upscale_runs"] = [round(r, 3) for r in runs]
+    med, runs, fr = _median_s(lambda: decode_latent(lat, dec))
+    res["two_stage_1536x1024x65_decode_frames_per_sec"] = round(fr.shape[0] / med, 1)
+    res["two_stage_1536x1024x65_decode_runs_s"] = [round(r, 3) for r in runs]
+    # the decode the pipeline ITSELF takes at this size (9 x 32 x 48 = 13 824 latent voxels > 4000: DistilledConfig._get_tiling_config
+    # -> decode_tiled with the reference's default tiling, pipelines/distilled.py:217-219)
+    tc = conf._get_tiling_config()
+    assert tc is not None
+    med, runs, vid = _median_s(lambda: next(decode_tiled(lat, dec, tc)))
+    res["two_stage_1536x1024x65_decode_tiled_frames_per_sec"] = round(vid.shape[2] / med, 1)
+    res["two_stage_1536x1024x65_decode_tiled_runs_s"] = [round(r, 3) for r in runs]
+    res["two_stage_decode_note"] = ("`decode_tiled` is what DistilledPipeline runs at this size (reference default tiling: overlapping tiles decode "
+                                    "~3.6x the volume); the whole-volume `decode_latent` figure is the same decoder without tiling")
+    del m, dec, up, pipe
+    torch.cuda.empty_cache()
     return res
 
 
-def socket_power_during(work, seconds: float = 1.5):
+def socket_power_during(work, seconds: float = 1.5, smi_device: int = 0):
     """Poll `rocm-smi --showpower` from a thread while `work()` is called in a loop for `seconds`: {mean_w, max_w, cap_w, samples}, or
     None when rocm-smi is unavailable.  Never inside a timed region."""
     import re
@@ -198,11 +262,11 @@ def socket_power_during(work, seconds: float = 1.5):
     def poll():
         while not stop[0]:
             try:
-                out = subprocess.run(["rocm-smi", "-d", "0", "--showpower", "--csv"], capture_output=True, text=True, timeout=5).stdout
+                out = subprocess.run(["rocm-smi", "-d", str(smi_device), "--showpower", "--csv"], capture_output=True, text=True, timeout=5).stdout
             except Exception:  # noqa: BLE001
                 return
             for line in out.splitlines():
-                if line.startswith("card0"):
+                if line.startswith(f"card{smi_device}"):
                     try:
                         samples.append(float(line.split(",")[-1]))
                     except ValueError:
@@ -219,12 +283,12 @@ def socket_power_during(work, seconds: float = 1.5):
     busy = samples[len(samples) // 3:]        # the reading ramps for about a second after the load starts
     cap = None
     try:
-        out = subprocess.run(["rocm-smi", "-d", "0", "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
+        out = subprocess.run(["rocm-smi", "-d", str(smi_device), "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
         m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", out)
         cap = float(m.group(1)) if m else None
     except Exception:  # noqa: BLE001
         pass
-    return {"mean_w": round(sum(busy) / len(busy), 1), "max_w": max(busy), "cap_w": cap, "samples": len(busy),
+    return {"mean_w": round(sum(busy) / len(busy), 1), "max_w": max(busy), "cap_w": cap, "samples": len(busy), "smi_device": smi_device,
             "how": "rocm-smi --showpower polled during an extra hipGraph replay of the denoise loop, outside the timed regions"}
 
 
@@ -250,6 +314,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (AudioVideo step, two-stage pipeline)")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi socket-power samples taken during an extra graph replay")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (instrumented) pass that times the dominant GEMM")
+    ap.add_argument("--loader-layers", type=int, default=8, help="layers of the synthetic checkpoint the loader-throughput leg writes and loads "
+                    "(8 = 4.3 GB, bounded for the default run; 48 = the full 25.8 GB file)")
+    ap.add_argument("--no-loader", action="store_true", help="skip the checkpoint-loader throughput leg")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args.gpus))
@@ -320,8 +387,10 @@ def main():
     t0 = time.perf_counter()
     run_steps(K)
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0                  # this rank's own K steps (before the closing barrier)
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    n_joined = D.count_ranks(dev)                       # counted through the process group (an RCCL all-reduce on device tensors)
 
     # ---------------- second pass (not part of `value`): HIP events around every launch of the dominant GEMM ----------------
     DOM_EPI = nv.EPI_RESID_GATE_F32     # gemm_v4_kernel<EPI_RESID_GATE_F32, 3, 224>: attn1.to_out, attn2.to_out, ff.net.2
@@ -353,8 +422,9 @@ def main():
             graph_ms = (time.perf_counter() - t0) / (reps * 8) * 1e3
             # socket power while the same graph keeps replaying (rank 0, ~3 s, outside every timed region): the step time on this
             # part is set by the 1400 W cap, so the line carries the evidence
-            if rank == 0 and not args.no_power:
-                power = socket_power_during(lambda: (model.replay_denoise_graph(), side.synchronize()), seconds=3.0)
+            # every rank samples ITS socket while all ranks keep replaying (the node at full load, as in the timed region)
+            if not args.no_power:
+                power = socket_power_during(lambda: (model.replay_denoise_graph(), side.synchronize()), seconds=3.0, smi_device=local)
         torch.cuda.current_stream().wait_stream(side)
     except Exception as e:  # noqa: BLE001
         graph_ms = f"failed: {e}"
@@ -380,16 +450,18 @@ def main():
         vae_ms = vdt * 1e3
         vae_fps = world * 65 / vdt
 
+    per_rank = D.gather_floats([dt_rank / K * 1e3, (power or {}).get("mean_w", -1.0), (power or {}).get("max_w", -1.0)], dev)
     if rank != 0:
         return
     steps_per_s = world * K / dt
     ms_per_step = dt / K * 1e3
     alg = dit_algorithmic_flops(N, S, Dm, L)
     # HBM/fabric traffic of the dominant kernel cannot be collected from inside the process: it comes from the committed
-    # rocprofv3 --pmc passes of THIS kernel version (profiles/r02_pmc_traffic.json names the commit), null if absent.
+    # rocprofv3 --pmc passes of THIS kernel version (the newest profiles/r*_pmc_traffic.json names the commit), null if absent.
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        import glob
+        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
             tj = json.load(f)
             traffic, traffic_src = tj.get("per_launch_avg_bytes"), tj.get("commit")
     except Exception:  # noqa: BLE001
@@ -410,7 +482,11 @@ def main():
         "hipgraph_ms_per_step": graph_ms if not isinstance(graph_ms, float) else round(graph_ms, 3),
         "prompt_setup_ms": round(prep_ms, 1),
         "socket_power": power,
-        "rccl_ranks": world, "collective_backend": (torch.distributed.get_backend() if world > 1 else None), "weight_bytes": w_bytes, "weight_broadcast_s": round(bcast_s, 3),
+        "rccl_ranks": n_joined, "rccl_ranks_how": "all_reduce(sum) of a device-resident 1 over the process group",
+        "per_rank_ms_per_step": {"min": round(min(r[0] for r in per_rank), 3), "max": round(max(r[0] for r in per_rank), 3),
+                                 "all": [round(r[0], 3) for r in per_rank]},
+        "per_rank_socket_power_w": None if args.no_power else {"mean": [r[1] for r in per_rank], "max": [r[2] for r in per_rank]},
+        "collective_backend": (torch.distributed.get_backend() if world > 1 else None), "weight_bytes": w_bytes, "weight_broadcast_s": round(bcast_s, 3),
         "weight_broadcast_collectives": n_coll,
         "weight_broadcast_gbps": round(w_bytes / bcast_s / 1e9, 1) if world > 1 and bcast_s > 0 else None,
         "roofline": {"kernel": "gemm_v4_kernel<EPI_RESID_GATE_F32, layout 3, 224> (224x256x64 tile, 4 waves, generated asm K loop, "
@@ -440,13 +516,24 @@ def main():
             out["extra_configs"] = extra_configs(dev, L)
         except Exception as e:  # noqa: BLE001
             out["extra_configs"] = {"error": str(e)}
+    if world == 1 and not args.no_loader:
+        try:
+            torch.cuda.empty_cache()
+            out["loader"] = loader_throughput(dev, args.loader_layers)
+        except Exception as e:  # noqa: BLE001
+            out["loader"] = {"error": str(e)}
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(min(CPU_THREADS, os.cpu_count() or 1))
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"error": str(e)}
-    print(json.dumps(out))
+    _REAL_STDOUT.write(json.dumps(out) + "\n")
+    _REAL_STDOUT.flush()
 
+
+_REAL_STDOUT = sys.stdout
 
 if __name__ == "__main__":
-    main()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # library progress lines go to stderr: stdout carries exactly ONE JSON line
+        main()

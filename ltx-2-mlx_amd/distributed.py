@@ -105,6 +105,27 @@ def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float
     return float(t.item())
 
 
+def count_ranks(device: Optional[torch.device] = None) -> int:
+    """Number of ranks that actually joined the process group, counted THROUGH it: an all-reduce (sum) of a one on `device`
+    (RCCL when the backend is nccl) -- not a copy of WORLD_SIZE."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def gather_floats(values: Sequence[float], device: Optional[torch.device] = None) -> List[List[float]]:
+    """Every rank's list of floats, on every rank (all_gather of a small tensor): per-rank timings / power for the bench line."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [list(values)]
+    # gloo gathers host tensors only (its all_gather has no device path); RCCL gathers on the device
+    t = torch.tensor(list(values), dtype=torch.float64, device=(device or "cuda") if dist.get_backend() == "nccl" else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.tolist()] for o in out]
+
+
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -152,9 +152,9 @@ def test_generate_video_from_checkpoint_metadata(dev, tmp_path, family):
     import generate
     blocks = [["res_x", {"num_layers": 1}], ["compress_all", {"multiplier": 2, "residual": True}], ["res_x", {"num_layers": 2}],
               ["compress_space", {"multiplier": 1, "residual": False}], ["compress_all", {"multiplier": 2, "residual": True}], ["res_x", {"num_layers": 1}]]
-    vcfg = vae.VAEConfig(decoder_blocks=blocks, base_channels=16, timestep_conditioning=(family == "v1"))
+    vcfg = vae.VAEConfig(decoder_blocks=blocks, base_channels=32, timestep_conditioning=(family == "v1"))
     vw = vae.make_vae_weights(vcfg, 5)
-    meta = {"config": json.dumps({"vae": {"decoder_blocks": blocks, "decoder_base_channels": 16, "timestep_conditioning": family == "v1"}})}
+    meta = {"config": json.dumps({"vae": {"decoder_blocks": blocks, "decoder_base_channels": 32, "timestep_conditioning": family == "v1"}})}
     if family == "v1":
         cfg = dit.DiTConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, caption_channels=3840)
         tensors = _ckpt_tensors(dit.make_dit_weights(cfg, 6), vw)
@@ -189,7 +189,7 @@ def test_generate_video_from_checkpoint_metadata(dev, tmp_path, family):
         generate.LTXModel, generate.SimpleVideoDecoder = real_model, real_dec
     mk = [k for n, k in built if n == "model"][0]
     vk = [k for n, k in built if n == "vae"][0]
-    assert vk["decoder_blocks"] == blocks and vk["base_channels"] == 16 and vk["timestep_conditioning"] == (family == "v1")
+    assert vk["decoder_blocks"] == blocks and vk["base_channels"] == 32 and vk["timestep_conditioning"] == (family == "v1")
     if family == "v23":
         from ltx_2_mlx_amd.model.transformer import LTXModelType
         assert mk["model_type"] == LTXModelType.AudioVideo and mk["caption_channels"] is None

@@ -307,7 +307,7 @@ def test_shard_units():
 _WORKER = r"""
 import os, sys, torch
 sys.path.insert(0, {root!r})
-from ltx_2_mlx_amd.distributed import init_distributed, broadcast_tensors, shard_units, max_over_ranks, barrier
+from ltx_2_mlx_amd.distributed import init_distributed, broadcast_tensors, shard_units, max_over_ranks, barrier, count_ranks, gather_floats
 rank, world, _ = init_distributed("gloo")
 g = torch.Generator().manual_seed(100 + rank)          # different content per rank before the broadcast
 t = {{"a.weight": torch.randn(300, 7, generator=g).to(torch.bfloat16), "b.bias": torch.randn(11, generator=g),
@@ -322,6 +322,8 @@ units = shard_units(5, rank, world)
 assert units == ([0, 2, 4] if rank == 0 else [1, 3])
 m = max_over_ranks(float(rank + 1), device=torch.device("cpu"))
 assert m == 2.0
+assert count_ranks(torch.device("cpu")) == 2          # counted through the process group, not read from WORLD_SIZE
+assert gather_floats([10.0 + rank, -1.0]) == [[10.0, -1.0], [11.0, -1.0]]
 barrier()
 open(os.path.join({out!r}, "ok_%d" % rank), "w").write("OK")
 """
