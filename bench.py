@@ -203,6 +203,19 @@ def extra_configs(dev, layers):
     torch.cuda.current_stream().wait_stream(side)
     del m
     torch.cuda.empty_cache()
+    # --- config 3 as BASELINE names it ("fp8 weights (CDNA4 fp8 MFMA)"): opt-in fp8 COMPUTE -- e4m3fn weights x per-token e4m3fn activations
+    #     on v_mfma_f32_32x32x64_f8f6f4 in the six projections of every block; accuracy against the fp32 oracle: tests/test_parity_fullsize.py
+    m = LTXModel(num_layers=layers, device=dev, fp8_compute=True)
+    m.init_random_weights(seed=0)
+    m.prepare(ctx3, pos3)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.capture_denoise_graph(lat3, DISTILLED_SIGMA_VALUES)
+        res["fp8_compute_ms_per_step"], res["fp8_compute_runs"] = _median_replay_ms(m, side)
+    torch.cuda.current_stream().wait_stream(side)
+    del m
+    torch.cuda.empty_cache()
     # --- config 4 shape: 48-layer AudioVideo DiT with 9-row AdaLN, prompt-modulated text K/V, per-head gates
     m = LTXModel(model_type=LTXModelType.AudioVideo, num_layers=layers, caption_channels=None, cross_attention_adaln=True,
                  apply_gated_attention=True, av_ca_timestep_scale_multiplier=1000, device=dev)

@@ -83,6 +83,22 @@ int ltx2_gemm_qkv_vt(const void* A, int64_t lda, const void* W, const float* bia
 int ltx2_gemm_w8a16(const void* A, int64_t lda, const void* W8, const float* wscale, const float* bias, void* out, int64_t ldo, int M,
                     int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table, void* stream);
 
+/* fp8 COMPUTE (BASELINE config 3, "fp8 weights (CDNA4 fp8 MFMA)"; opt-in, not the parity-exact default): both operands are
+ * float8_e4m3fn codes, the products run on v_mfma_f32_32x32x64_f8f6f4 at twice the bf16 MFMA rate, fp32 accumulation;
+ *   out = epilogue(ascale[m] * wscale[n] * sum_k f32(A8[m][k]) * f32(W8[n][k]) + bias[n]).
+ * ltx2_quantize_rows_fp8 is the quantiser of both sides: scale[r] = max_k |x[r][k]| / 448 (1 for an all-zero row), codes[r][k] =
+ * e4m3fn_rne(x[r][k] * (1 / scale[r])) -- per TOKEN for activations, per OUTPUT CHANNEL for weights quantised at load (an fp8
+ * checkpoint's codes + per-tensor `weight_scale`, reference loader/fp8_loader.py:14-51, are used as they are).
+ * N % 256 == 0, K % 256 == 0, K >= 512, lda % 16 == 0; epilogues BF16 / GELU_BF16 / F32 / RESID_GATE_F32.                    */
+int ltx2_quantize_rows_fp8(const void* x_bf16, int64_t ldx, int rows, int K, void* codes, int64_t ldo, float* scale, void* stream);
+int ltx2_gemm_fp8(const void* A8, int64_t lda, const float* ascale, const void* W8, const float* wscale, const float* bias, void* out,
+                  int64_t ldo, int M, int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table,
+                  void* stream);
+
+/* ltx2_gemm_qkv_vt on the fp8 compute path (same contract: V columns leave as attention's V^T operand). */
+int ltx2_gemm_fp8_qkv_vt(const void* A8, int64_t lda, const float* ascale, const void* W8, const float* wscale, const float* bias, void* out,
+                         int64_t ldo, int M, int N, int K, void* vt, int vt_col0, int Npad, int head_dim, int* fused, void* stream);
+
 /* Skinny fp32-activation path (M <= 16): out_f32 = act_out(act_in(a) @ W^T + bias); act: 0 none,
  * 1 silu, 2 gelu_tanh.  Replaces TimestepEmbedding / AdaLayerNormSingle linears for a scalar
  * sigma (model/transformer/timestep_embedding.py:112-124,187-202) and the VAE TimestepEmbedder
@@ -130,6 +146,12 @@ int ltx2_latent_normalize_nchw(const void* x, const float* mean, const float* st
 int ltx2_adaln_rmsnorm(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int D, float eps,
                        int layer_norm, const float* scale_tab, const float* shift_tab, const float* scale_emb,
                        const float* shift_emb, int64_t emb_stride, void* stream);
+
+/* The same with the fp8 compute path's per-token quantiser fused in: codes[rows][ldq] + scale[rows] = ltx2_quantize_rows_fp8 of the
+ * bf16-rounded outputs, bit for bit; out_bf16 may be NULL (the GEMM that follows reads only the codes).                    */
+int ltx2_adaln_rmsnorm_fp8(const float* x, int64_t ldx, void* out_bf16, int64_t ldo, void* codes, int64_t ldq, float* scale, int rows, int D,
+                           float eps, int layer_norm, const float* scale_tab, const float* shift_tab, const float* scale_emb,
+                           const float* shift_emb, int64_t emb_stride, void* stream);
 
 /* In place on bf16 rows: RMSNorm(weight) over the full inner dim of q (and k), then SPLIT RoPE
  * (cos/sin fp32 [rows][D/2], slot h*hd/2 + j) if cos != NULL.
@@ -302,6 +324,13 @@ int ltx2_dit_graph_capture(ltx2_dit* ctx, float* latent, const float* host_sigma
 int ltx2_dit_graph_capture_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps,
                               void* stream);
 int ltx2_dit_graph_launch(ltx2_dit* ctx, void* stream);
+
+/* Engine options, by name (set before ltx2_dit_bind_workspace; unknown names -> LTX2_E_INVALID):
+ *   "fp8_compute" = 1: every linear of the VIDEO stream whose weight is registered fp8-resident (LTX2_DTYPE_FP8_E4M3FN codes +
+ *   `<name>_scale`) and whose GEMM has M >= 1024 rows runs as ltx2_gemm_fp8 on activations quantised per token
+ *   (ltx2_quantize_rows_fp8).  Default 0: fp8-resident weights are expanded to bf16 inside the GEMM (bit-identical to the
+ *   reference's dequantise-at-load).                                                                                    */
+int ltx2_dit_set_option(ltx2_dit* ctx, const char* name, int value);
 
 /* Health check at a host synchronisation point (per prompt / after a sampling loop): synchronises `stream`, reads the sticky error
  * word of the stream-K attention hand-off (a consumer that waited ~0.2 s for a partial result gives up instead of hanging the GPU,

@@ -49,12 +49,16 @@ SIGNATURES = {
     "ltx2_gemm_bf16": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp, i64, vp]),
     "ltx2_gemm_qkv_vt": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp]),
     "ltx2_gemm_w8a16": (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
+    "ltx2_quantize_rows_fp8": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),
+    "ltx2_gemm_fp8": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
+    "ltx2_gemm_fp8_qkv_vt": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp]),
     "ltx2_gemv_f32": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "ltx2_conv3d_fused": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ltx2_groupnorm_silu": (i32, [vp, vp, vp, i64, i32, i32, f32, vp, vp, vp, i32, vp]),
     "ltx2_s2d_downsample": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ltx2_latent_normalize_nchw": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "ltx2_adaln_rmsnorm": (i32, [vp, i64, vp, i64, i32, i32, f32, i32, vp, vp, vp, vp, i64, vp]),
+    "ltx2_adaln_rmsnorm_fp8": (i32, [vp, i64, vp, i64, vp, i64, vp, i32, i32, f32, i32, vp, vp, vp, vp, i64, vp]),
     "ltx2_qknorm_rope": (i32, [vp, i64, i32, i32, i32, i32, vp, i32, vp, f32, vp, vp, vp]),
     "ltx2_vt_transpose": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
     "ltx2_flash_attn": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp]),
@@ -91,6 +95,7 @@ SIGNATURES = {
     "ltx2_dit_graph_capture": (i32, [vp, vp, C.POINTER(f32), i32, vp]),
     "ltx2_dit_graph_launch": (i32, [vp, vp]),
     "ltx2_dit_health": (i32, [vp, vp]),
+    "ltx2_dit_set_option": (i32, [vp, C.c_char_p, i32]),
     "ltx2_dit_profile_begin": (i32, [vp, i32]),
     "ltx2_dit_profile_end": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
     "ltx2_vae_create": (i32, [C.POINTER(VaeConfig), C.POINTER(vp)]),

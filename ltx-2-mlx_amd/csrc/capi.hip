@@ -45,6 +45,33 @@ int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
     return gemm_launch(p, epilogue, false, (hipStream_t)stream);
 }
 
+int ltx2_quantize_rows_fp8(const void* x, int64_t ldx, int rows, int K, void* codes, int64_t ldo, float* scale, void* stream) {
+    LTX2_CHECK_ARG(x && codes && scale, "quantize_rows_fp8: null argument");
+    return quant_rows_fp8_launch((const bf16*)x, ldx, rows, K, (unsigned char*)codes, ldo, scale, (hipStream_t)stream);
+}
+
+int ltx2_gemm_fp8(const void* A8, int64_t lda, const float* ascale, const void* W8, const float* wscale, const float* bias, void* out,
+                  int64_t ldo, int M, int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table,
+                  void* stream) {
+    LTX2_CHECK_ARG(A8 && ascale && W8 && wscale && out, "gemm_fp8: null operand");
+    GemmParams p{};
+    p.A8 = (const unsigned char*)A8;
+    p.ascale = ascale;
+    p.lda = lda;
+    p.W8 = (const unsigned char*)W8;
+    p.wscale = wscale;
+    p.bias = bias;
+    p.out = out;
+    p.ldo = ldo;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.gate = gate;
+    p.gate_stride = gate_stride;
+    p.gate_table = gate_table;
+    return gemm_launch(p, epilogue, false, (hipStream_t)stream);
+}
+
 int ltx2_gemm_qkv_vt(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K,
                      void* vt, int vt_col0, int Npad, int head_dim, int* fused, void* stream) {
     LTX2_CHECK_ARG(A && W && out && vt, "gemm_qkv_vt: null operand");
@@ -54,6 +81,36 @@ int ltx2_gemm_qkv_vt(const void* A, int64_t lda, const void* W, const float* bia
     p.A = (const bf16*)A;
     p.lda = lda;
     p.W = (const bf16*)W;
+    p.bias = bias;
+    p.out = out;
+    p.ldo = ldo;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.vt = (bf16*)vt;
+    p.vt_col0 = vt_col0;
+    p.vt_npad = Npad;
+    p.vt_hd = head_dim;
+    p.vt_head_stride = (long)head_dim * Npad;
+    const bool f = gemm_vt_fused(p, EPI_BF16);
+    if (fused) *fused = f ? 1 : 0;
+    if (!f) p.vt = nullptr;
+    int rc = gemm_launch(p, EPI_BF16, false, (hipStream_t)stream);
+    if (rc != LTX2_OK || f) return rc;
+    return vt_transpose_launch((const bf16*)out + vt_col0, ldo, (bf16*)vt, M, Npad, (N - vt_col0) / head_dim, (hipStream_t)stream, head_dim);
+}
+
+int ltx2_gemm_fp8_qkv_vt(const void* A8, int64_t lda, const float* ascale, const void* W8, const float* wscale, const float* bias, void* out,
+                         int64_t ldo, int M, int N, int K, void* vt, int vt_col0, int Npad, int head_dim, int* fused, void* stream) {
+    LTX2_CHECK_ARG(A8 && ascale && W8 && wscale && out && vt, "gemm_fp8_qkv_vt: null operand");
+    LTX2_CHECK_ARG(head_dim == 64 || head_dim == 128, "gemm_fp8_qkv_vt: head_dim=%d, only 128 and 64 are implemented", head_dim);
+    LTX2_CHECK_ARG(vt_col0 > 0 && vt_col0 < N && (N - vt_col0) % head_dim == 0 && Npad % 64 == 0 && Npad >= M, "gemm_fp8_qkv_vt: bad V column range / Npad");
+    GemmParams p{};
+    p.A8 = (const unsigned char*)A8;
+    p.ascale = ascale;
+    p.lda = lda;
+    p.W8 = (const unsigned char*)W8;
+    p.wscale = wscale;
     p.bias = bias;
     p.out = out;
     p.ldo = ldo;
@@ -105,6 +162,14 @@ int ltx2_adaln_rmsnorm(const float* x, int64_t ldx, void* out, int64_t ldo, int 
     LTX2_CHECK_ARG(x && out, "adaln_rmsnorm: null operand");
     return norm_mod_launch(x, ldx, (bf16*)out, ldo, rows, D, eps, layer_norm, scale_tab, shift_tab, scale_emb, shift_emb,
                            emb_stride, (hipStream_t)stream);
+}
+
+int ltx2_adaln_rmsnorm_fp8(const float* x, int64_t ldx, void* out_bf16, int64_t ldo, void* codes, int64_t ldq, float* scale, int rows, int D,
+                           float eps, int layer_norm, const float* scale_tab, const float* shift_tab, const float* scale_emb,
+                           const float* shift_emb, int64_t emb_stride, void* stream) {
+    LTX2_CHECK_ARG(x && codes && scale, "adaln_rmsnorm_fp8: null operand");
+    return norm_mod_launch(x, ldx, (bf16*)out_bf16, ldo, rows, D, eps, layer_norm, scale_tab, shift_tab, scale_emb, shift_emb, emb_stride,
+                           (hipStream_t)stream, (unsigned char*)codes, ldq, scale);
 }
 
 int ltx2_qknorm_rope(void* buf, int64_t ld, int rows, int D, int head_dim, int q_off, const float* q_weight,

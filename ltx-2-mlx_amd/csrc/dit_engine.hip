@@ -76,6 +76,8 @@ struct Mod {        // per-modality geometry + workspace
          *sin_b = nullptr, *e1_b = nullptr, *es_b = nullptr, *ctx_in = nullptr, *c1 = nullptr, *ctxp = nullptr,
          *ctxm = nullptr, *kv2 = nullptr, *vt2 = nullptr;
     const bf16* ctx = nullptr;      // projected text context (ctxp or ctx_in)
+    unsigned char* a8 = nullptr;    // fp8 compute: per-token e4m3fn codes of the current GEMM's activation operand [N][<= 4D]
+    float* a8s = nullptr;           //              and their row scales [N]
 };
 
 inline long align_up(long v, long a = 256) { return (v + a - 1) / a * a; }
@@ -97,6 +99,7 @@ struct ltx2_dit {
     // up here to hand the GEMM (codes, per-row scale) instead of bf16 weights.  Per context (a second context over the same tensors
     // -- the video twin of an AudioVideo model -- keeps its own entries); rebuilt whenever the weights are resolved again.
     std::unordered_map<const void*, const float*> fp8_scale;
+    bool fp8_compute = false;          // ltx2_dit_set_option("fp8_compute"): fp8-resident weights x per-token fp8 activations on the fp8 MFMA
     void* sk_ws = nullptr;             // stream-K attention scratch (attention.h); main-stream launches only
     long sk_bytes = 0;
     bool prepared = false;
@@ -143,6 +146,8 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         m.att = (bf16*)take(2L * n * D);
         m.ff = (bf16*)take(2L * n * 4 * D);
         m.glog = (float*)take(c->gated ? 4L * n * m.H : 0);
+        m.a8 = (unsigned char*)take((c->fp8_compute && k == 0) ? n * 4 * D : 0);
+        m.a8s = (float*)take((c->fp8_compute && k == 0) ? 4L * n : 0);
         m.sin_f = (float*)take(4L * 256);
         m.e1_f = (float*)take(4L * D);
         m.aux_e = (float*)take(4L * D);
@@ -314,9 +319,30 @@ struct VtOut {
     int col0, npad, hd;
 };
 
+// fp8 compute (opt-in): would dense() send this GEMM to the fp8 MFMA?  (the video stream's big GEMMs on fp8-resident weights)
+bool f8_route(ltx2_dit* c, const bf16* W, int M, int N, int K, int epi) {
+    if (!c->fp8_compute || !c->m[0].a8 || M < 1024 || M > c->m[0].N || K > 4 * c->m[0].D) return false;
+    auto f8 = c->fp8_scale.find((const void*)W);
+    if (f8 == c->fp8_scale.end()) return false;
+    GemmParams q{};
+    q.A8 = c->m[0].a8;
+    q.ascale = c->m[0].a8s;
+    q.lda = K;
+    q.W8 = (const unsigned char*)W;
+    q.wscale = f8->second;
+    q.out = c->m[0].x;
+    q.ldo = 8;
+    q.M = M;
+    q.N = N;
+    q.K = K;
+    return gemm_v4_f8_supported(q, epi);
+}
+
+// preq: the kernel that produced A already left its per-token e4m3fn codes + scales in m[0].a8 / a8s (norm_mod_launch's q8 output);
+// only valid when f8_route() says yes for this GEMM
 int dense(ltx2_dit* c, const bf16* A, long lda, const bf16* W, const float* bias, void* out, long ldo, int M, int N, int K, int epi,
           hipStream_t st, const float* gate = nullptr, long gate_stride = 0, const float* gate_table = nullptr,
-          const VtOut* vt = nullptr, bool* vt_done = nullptr) {
+          const VtOut* vt = nullptr, bool* vt_done = nullptr, bool preq = false) {
     GemmParams p{};
     p.A = A;
     p.lda = lda;
@@ -338,6 +364,17 @@ int dense(ltx2_dit* c, const bf16* A, long lda, const bf16* W, const float* bias
     p.gate = gate;
     p.gate_stride = gate_stride;
     p.gate_table = gate_table;
+    // fp8 compute (opt-in): the video stream's big GEMMs on fp8-resident weights take per-token-quantised activations and the fp8 MFMA
+    if (p.W8 && f8_route(c, W, M, N, K, epi)) {
+        if (!preq) TRY(quant_rows_fp8_launch(A, lda, M, K, c->m[0].a8, K, c->m[0].a8s, st));
+        p.A8 = c->m[0].a8;
+        p.ascale = c->m[0].a8s;
+        p.lda = K;
+        p.A = nullptr;
+    } else if (preq) {
+        ltx2_set_error("dit: a pre-quantised activation reached a GEMM that does not take the fp8 path");
+        return LTX2_E_STATE;
+    }
     if (vt) {
         p.vt = vt->vt;
         p.vt_col0 = vt->col0;
@@ -473,11 +510,14 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     const float eps = c->cfg.norm_eps;
     const float* emb = m.emb;
     // self-attention: AdaLN rows (shift, scale, gate) = sst[0:3] + emb[0:3]
-    TRY(norm_mod_launch(m.x, D, m.h, D, N, D, eps, 0, w.sst + D, w.sst, emb + D, emb, es, st));
+    // fp8 compute: the norm kernels hand the following GEMM per-token e4m3fn codes directly (and skip the bf16 copy nobody else reads)
+    const bool q1 = k == 0 && f8_route(c, w.self.qkv_w, N, 3 * D, D, EPI_BF16);
+    TRY(norm_mod_launch(m.x, D, (q1 && !c->gated) ? nullptr : m.h, D, N, D, eps, 0, w.sst + D, w.sst, emb + D, emb, es, st, q1 ? m.a8 : nullptr, D,
+                        q1 ? m.a8s : nullptr));
     TRY(gate_logits(c, m, w.self, m.h, D, N, H, st));
     const VtOut vo{m.vt, 2 * D, m.Npad, hd};
     bool vt_done = false;           // the QKV GEMM's epilogue writes V^T itself where it can (gemm_v4.hip)
-    TRY(dense(c, m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done));
+    TRY(dense(c, m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done, q1));
     {
         const int offs[2] = {0, D};
         const float* wts[2] = {w.self.qn, w.self.kn};
@@ -493,19 +533,23 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     // is modulated by the prompt AdaLN (rows shift, scale), so K/V are recomputed every step.
     const bf16* kk;
     const bf16* vt;
+    const bool q2 = k == 0 && f8_route(c, w.text.q_w, N, D, D, EPI_BF16);
+    bf16* h2 = (q2 && !c->gated) ? nullptr : m.h;
+    unsigned char* a8q = q2 ? m.a8 : nullptr;
+    float* a8sq = q2 ? m.a8s : nullptr;
     if (c->v2) {
-        TRY(norm_mod_launch(m.x, D, m.h, D, N, D, eps, 0, w.sst + 7 * D, w.sst + 6 * D, emb + 7 * D, emb + 6 * D, es, st));
+        TRY(norm_mod_launch(m.x, D, h2, D, N, D, eps, 0, w.sst + 7 * D, w.sst + 6 * D, emb + 7 * D, emb + 6 * D, es, st, a8q, D, a8sq));
         TRY(ctx_mod_launch(m.ctx, m.ctxm, m.S, D, w.prompt_sst + D, w.prompt_sst, m.prompt_emb + D, m.prompt_emb, st));
         TRY(project_kv(c, m.ctxm, m.S, D, w.text, D, H, hd, eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st));
         kk = m.kv2;
         vt = m.vt2;
     } else {
-        TRY(norm_mod_launch(m.x, D, m.h, D, N, D, eps, 0, nullptr, nullptr, nullptr, nullptr, 0, st));
+        TRY(norm_mod_launch(m.x, D, h2, D, N, D, eps, 0, nullptr, nullptr, nullptr, nullptr, 0, st, a8q, D, a8sq));
         kk = m.kv2 + (long)l * m.S * 2 * D;
         vt = m.vt2 + (long)l * D * m.Spad;
     }
     TRY(gate_logits(c, m, w.text, m.h, D, N, H, st));
-    TRY(dense(c, m.h, D, w.text.q_w, w.text.q_b, m.qkv, D, N, D, D, EPI_BF16, st));
+    TRY(dense(c, m.h, D, w.text.q_w, w.text.q_b, m.qkv, D, N, D, D, EPI_BF16, st, nullptr, 0, nullptr, nullptr, nullptr, q2));
     {
         const int offs[1] = {0};
         const float* wts[1] = {w.text.qn};
@@ -526,8 +570,10 @@ int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     const BlockW& w = c->layers[l].m[k];
     const int N = m.N, D = m.D;
     const float* emb = m.emb;
-    TRY(norm_mod_launch(m.x, D, m.h, D, N, D, c->cfg.norm_eps, 0, w.sst + 4 * D, w.sst + 3 * D, emb + 4 * D, emb + 3 * D, es, st));
-    TRY(dense(c, m.h, D, w.ff1_w, w.ff1_b, m.ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st));
+    const bool q3 = k == 0 && f8_route(c, w.ff1_w, N, 4 * D, D, EPI_GELU_BF16);
+    TRY(norm_mod_launch(m.x, D, q3 ? nullptr : m.h, D, N, D, c->cfg.norm_eps, 0, w.sst + 4 * D, w.sst + 3 * D, emb + 4 * D, emb + 3 * D, es, st,
+                        q3 ? m.a8 : nullptr, D, q3 ? m.a8s : nullptr));
+    TRY(dense(c, m.h, D, w.ff1_w, w.ff1_b, m.ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st, nullptr, 0, nullptr, nullptr, nullptr, q3));
     TRY(dense(c, m.ff, 4 * D, w.ff2_w, w.ff2_b, m.x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, emb + 5 * D, es, w.sst + 5 * D));
     return LTX2_OK;
 }
@@ -834,6 +880,7 @@ int64_t ltx2_dit_workspace_bytes_av(const ltx2_dit* c, int N, int S, int Na, int
     tmp.av = c->av;
     tmp.v2 = c->v2;
     tmp.gated = c->gated;
+    tmp.fp8_compute = c->fp8_compute;
     tmp.m[0] = c->m[0];
     tmp.m[1] = c->m[1];
     return carve(&tmp, nullptr, N, S, Na, Sa, per_token);
@@ -986,6 +1033,20 @@ int ltx2_dit_profile_end(ltx2_dit* c, double* total_ms, int64_t* launches, doubl
     *launches = (int64_t)(c->prof_used / 2);
     *flops = c->prof_flops;
     return LTX2_OK;
+}
+
+int ltx2_dit_set_option(ltx2_dit* c, const char* name, int value) {
+    LTX2_CHECK_ARG(c && name, "dit_set_option: null argument");
+    if (!strcmp(name, "fp8_compute")) {
+        if (c->ws && (value != 0) != c->fp8_compute) {
+            ltx2_set_error("dit_set_option: fp8_compute must be set before the workspace is bound");
+            return LTX2_E_STATE;
+        }
+        c->fp8_compute = value != 0;
+        return LTX2_OK;
+    }
+    ltx2_set_error("dit_set_option: unknown option '%s'", name);
+    return LTX2_E_INVALID;
 }
 
 int ltx2_dit_health(ltx2_dit* c, void* stream) {

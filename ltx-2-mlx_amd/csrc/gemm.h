@@ -18,6 +18,8 @@ struct GemmParams {
     const bf16* W;       // [N][K]  (K contiguous; conv: K = tap*Cin + c, tap = (kt*3+kh)*3+kw)
     const unsigned char* W8;  // fp8-resident weights (gemm_v4.hip): e4m3fn codes [N][K] instead of W, with
     const float* wscale;      //   one dequantisation scale per output column: w = bf16(f32(code) * wscale[n])
+    const unsigned char* A8;  // fp8 COMPUTE (gemm_v4.hip layout 5): e4m3fn activation codes [M][lda] instead of A, with one scale per
+    const float* ascale;      //   row; needs W8 / wscale too: out = epilogue(ascale[m] * wscale[n] * sum_k a8[m][k] * w8[n][k] + bias)
     const float* bias;   // [N] or null
     void* out;           // bf16 or f32, [M][ldo]  (D2S: [To][Ho][Wo][Cf])
     const float* gate;   // EPI_RESID_GATE_F32: per-row part  gate[m*gate_stride + n]  (may be null)
@@ -48,6 +50,8 @@ int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream
 // p.vt set: will gemm_launch route this problem to the kernel that writes V^T from its epilogue?  (false: clear p.vt and run
 // vt_transpose_launch after the GEMM; gemm_launch rejects a p.vt it cannot honour.)
 bool gemm_vt_fused(const GemmParams& p, int epilogue);
+// fp8 compute (p.A8 / p.ascale / p.W8 / p.wscale set): can the fp8-MFMA kernel (gemm_v4.hip layout 5) take this problem?
+bool gemm_v4_f8_supported(const GemmParams& p, int epilogue);
 
 // Skinny path (M <= 16 rows, fp32 activations, bf16 weights): out_f32 = act_out(in_act(a) @ W^T + b)
 // act codes: 0 none, 1 silu, 2 gelu_tanh

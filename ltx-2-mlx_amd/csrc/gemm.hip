@@ -337,6 +337,7 @@ bool gemm_vt_fused(const GemmParams& p, int epilogue) {
         return !e || atoi(e) != 0;
     }();
     if (!on || !p.vt || p.lda % 8 != 0) return false;
+    if (p.A8) return gemm_v4_vt_supported(p, epilogue, 5);
     if (tile_override() == 0 && gemm_skinny_supported(p, epilogue)) return false;      // M <= 128 goes to the skinny kernel
     if (p.W8) return gemm_v4_vt_supported(p, epilogue, 3);
     return tile_override() == 0 && v4_layout() == 3 && (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_vt_supported(p, epilogue, 3);
@@ -344,8 +345,12 @@ bool gemm_vt_fused(const GemmParams& p, int epilogue) {
 
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream) {
     LTX2_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
-    LTX2_CHECK_ARG(!p.vt || (!conv && gemm_vt_fused(p, epilogue)), "gemm: a fused V^T output needs the 4-wave layout-3 kernel (ask gemm_vt_fused first)");
+    LTX2_CHECK_ARG(!p.vt || (!conv && gemm_vt_fused(p, epilogue)), "gemm: a fused V^T output needs the 4-wave layout-3 / layout-5 kernel (ask gemm_vt_fused first)");
     LTX2_CHECK_ARG(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
+    if (p.A8) {     // fp8 compute: both operands e4m3fn codes + scales, fp8 MFMA (gemm_v4.hip layout 5)
+        LTX2_CHECK_ARG(!conv && p.out, "gemm: fp8 compute is dense-only");
+        return gemm_v4_launch(p, epilogue, stream, 5, 0);
+    }
     LTX2_CHECK_ARG(p.A && (p.W || p.W8) && p.out, "gemm: null operand");
     if (p.W8) {     // fp8-resident weights: the 4-wave asm-loop kernel, or the skinny-M kernel where the bf16 path would take it too
         LTX2_CHECK_ARG(!conv && p.lda % 8 == 0, "gemm: fp8-resident weights are dense-only");

@@ -8,6 +8,9 @@
 //   3  BN 256, 1x4 waves, 16x16x32: 14|16 x 4 blocks of 16 (BM 224|256; balanced for 224 rows) -- the DiT default
 //   4  BN 128, 4x1 waves, 16x16x32: wave w owns rows [BM/4 w, +BM/4) x all 128 columns, 7|8 x 8 blocks (BM 448|512) -- the
 //      VAE decoder's 128-channel convs
+//   5  fp8 COMPUTE (round 3, BASELINE config 3): BOTH operands e4m3fn codes, K-tile = 128 elements (the same 128-byte LDS rows, swizzle
+//      and DMA schedule as 64 bf16), 1x4 waves, v_mfma_f32_32x32x64_f8f6f4 (fp8 x fp8 at twice the bf16 rate): 7|8 x 2 blocks of 32;
+//      the per-row activation scale and the per-column weight scale multiply the accumulators in the epilogue
 // What the measurements on MI355X say: with random operands the chip is POWER-limited -- the 32x32x16
 // K loop issues an MFMA every 34 cycles but the chip clocks at 1.45-1.55 GHz, an MFMA-only loop at 2.0 GHz -- and the
 // 16x16x32 instruction (half the accumulator-register traffic per flop) sustains 12-20 % more on the same shapes.
@@ -39,8 +42,8 @@ typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 template <int LAYOUT, int BM, bool W8 = false>
 struct V4Geo {
     static constexpr int BN = LAYOUT == 4 ? 128 : 256;
-    static constexpr int MB = LAYOUT >= 2 ? 16 : 32;               // MFMA block
-    static constexpr bool L14 = LAYOUT == 0 || LAYOUT == 3;        // 1x4 waves
+    static constexpr int MB = (LAYOUT >= 2 && LAYOUT != 5) ? 16 : 32;               // MFMA block
+    static constexpr bool L14 = LAYOUT == 0 || LAYOUT == 3 || LAYOUT == 5;        // 1x4 waves
     static constexpr int WM = LAYOUT == 4 ? BM / 4 : (L14 ? BM : 128);
     static constexpr int WN = LAYOUT == 4 ? 128 : (L14 ? 64 : 128);
     static constexpr int RBW = (WM + MB - 1) / MB, CBW = WN / MB;  // blocks per wave (first wave row)
@@ -50,7 +53,7 @@ struct V4Geo {
     static constexpr int A_STAGE = LAYOUT == 4 ? BM * 128 : 32768, W_BASE = 2 * A_STAGE, W_STAGE = BN * WROW;
     static_assert(!W8 || LAYOUT == 3, "fp8-resident weights run on layout 3");
     static constexpr int LOOP_BYTES = W_BASE + 2 * W_STAGE;
-    static constexpr int EPI_BYTES = (LAYOUT == 3 || LAYOUT == 4) ? 4 * WM * WN * 2 : 0;      // bf16 outputs leave through LDS (per-wave slabs)
+    static constexpr int EPI_BYTES = (LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5) ? 4 * WM * WN * 2 : 0;      // bf16 outputs leave through LDS (per-wave slabs)
     static constexpr int LDS_BYTES = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
     static_assert(LAYOUT == 4 ? (BM == 448 || BM == 512) : (BM == 224 || BM == 256), "tile rows");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -58,8 +61,9 @@ struct V4Geo {
 
 template <int EPI, int LAYOUT, int BM, bool CONV, int VAR>
 __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
-    static_assert(LAYOUT >= 0 && LAYOUT <= 4, "wave layout");
+    static_assert(LAYOUT >= 0 && LAYOUT <= 5, "wave layout");
     constexpr bool W8 = VAR == 20;          // fp8-resident weights: p.W8 codes [N][K] + p.wscale[N]
+    constexpr bool F8 = LAYOUT == 5;        // fp8 compute: p.A8 codes [M][lda] + p.ascale[M], p.W8 codes [N][K] + p.wscale[N]
     using G = V4Geo<LAYOUT, BM, W8>;
     constexpr int TBN = G::BN, NPA = G::NPA, NPW = G::NPW, MB = G::MB, WM = G::WM, WN = G::WN, RBW = G::RBW, CBW = G::CBW, NKS = G::NKS;
     static_assert(!CONV || LAYOUT >= 3, "conv runs on the 16x16x32 layouts");
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             const int t = m / hw, r2 = m - t * hw, h = r2 / p.Wd, x = r2 - h * p.Wd;
             voffA[j] = (unsigned)((t * Hp + h) * Wp + x) * (unsigned)(p.Cin * 2) + chunk * 16;
         } else {
-            voffA[j] = (unsigned)m * (unsigned)(p.lda * 2) + chunk * 16;
+            voffA[j] = (unsigned)m * (unsigned)(p.lda * (F8 ? 1 : 2)) + chunk * 16;
         }
     }
 #pragma unroll
@@ -121,15 +125,24 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         } else {
             const int r = (w * NPW + j) * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-            voffB[j] = (unsigned)(n0 + r) * (unsigned)(p.K * 2) + chunk * 16;
+            voffB[j] = (unsigned)(n0 + r) * (unsigned)(p.K * (F8 ? 1 : 2)) + chunk * 16;
         }
     }
     // ---- fragment read addresses (first block of the wave): row lr, 16-byte chunk (kchunk(ks) + kq) ^ ((row >> 1) & 7) ----
     const int lr = lane & (MB - 1), kq = lane / MB;         // row in block, k-quarter (32x32x16: 0..1, 16x16x32: 0..3)
     const int xbase = kq ^ ((lr >> 1) & 7);
     u32x4 addrA = {0, 0, 0, 0}, addrB = {0, 0, 0, 0};
+    if constexpr (F8) {
+        // a lane's fragment of a 64-element k-step = 32 bytes = the two chunks (4 ks + 2 kq + j), j = 0, 1, of its row: register [2 ks + j]
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+        for (int q = 0; q < 4; ++q) {
+            const unsigned c = (unsigned)((4 * (q >> 1) + 2 * kq + (q & 1)) ^ ((lr >> 1) & 7)) << 4;
+            addrA[q] = lds0 + (wr * WM + lr) * 128 + c;
+            addrB[q] = lds0 + G::W_BASE + (wc * WN + lr) * 128 + c;
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < (F8 ? 0 : NKS); ++ks) {
         const unsigned c = (unsigned)(((MB == 32 ? 2 : 4) * ks) ^ xbase) << 4;
         const unsigned a0 = lds0 + (wr * WM + lr) * 128 + c;
         const unsigned b0 = W8 ? lds0 + G::W_BASE + (wc * WN + lr) * 64 + ((unsigned)((4 * ks + kq) ^ (2 * ((lr >> 2) & 3))) << 3)
@@ -144,11 +157,11 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             addrB[ks] = b0;
         }
     }
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(W8 ? (void*)p.W8 : (void*)p.W, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(F8 ? (void*)p.A8 : (void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((W8 || F8) ? (void*)p.W8 : (void*)p.W, 0, 0x7fffffff, 0x00020000);
     const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + w * npa_rt * 1024);
     const unsigned lw = __builtin_amdgcn_readfirstlane(lds0 + G::W_BASE + w * NPW * 1024);
-    const unsigned nk = __builtin_amdgcn_readfirstlane(p.K / 64 / (p.splitk > 1 ? p.splitk : 1));
+    const unsigned nk = __builtin_amdgcn_readfirstlane(p.K / (F8 ? 128 : 64) / (p.splitk > 1 ? p.splitk : 1));
     const unsigned kb = __builtin_amdgcn_readfirstlane(split * nk);
     // conv: lane i holds the byte offset of tap i = (a*3 + b)*3 + c (a absent for per-frame 3x3 convs) in the padded volume
     unsigned tapv = 0;
@@ -239,6 +252,14 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     } else if constexpr (LAYOUT == 4) {
         if constexpr (BM == 448) V4_ASM(LTX2_V4_L41_M16_RB7);
         else V4_ASM(LTX2_V4_L41_M16_RB8);
+    } else if constexpr (LAYOUT == 5) {     // VAR 1: the v_mfma_scale_* form with unit block scales (same arithmetic; A/B timing)
+        if constexpr (BM == 224) {
+            if constexpr (VAR == 1) V4_ASM(LTX2_V4_F8_RB7_SC);
+            else V4_ASM(LTX2_V4_F8_RB7);
+        } else {
+            if constexpr (VAR == 1) V4_ASM(LTX2_V4_F8_RB8_SC);
+            else V4_ASM(LTX2_V4_F8_RB8);
+        }
     } else {
         if constexpr (BM == 224) {
             if (wr == 0) V4_ASM(LTX2_V4_L22_M16_RB8_224);
@@ -274,10 +295,25 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             asm volatile("" : "+v"(bias4[cb][gq]));      // retire the loads once, here
             if (EPI == EPI_RESID_GATE_F32) asm volatile("" : "+v"(gate4[cb][gq]));
         }
+    // fp8 compute: sum_k a8 w8 is exact in the fp32 accumulator's terms; the row scale of the activations and the column scale of the
+    // weights come back here, one multiply per output (out = as[m] * ws[n] * acc)
+    float as_row[F8 ? RBW : 1];
+    f32x4 ws4[F8 ? CBW : 1][NG];
+    if constexpr (F8) {
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) as_row[rb] = p.ascale[min(m0 + wr * WM + rb * MB + lr, p.M - 1)];
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) ws4[cb][gq] = *(const f32x4*)(p.wscale + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq);
+    }
     auto acc_group = [&](int rb, int cb, int gq) -> f32x4 {
         // accumulator block index as the generator numbers it: rb * cbw + cb (both wave rows share cbw = CBW)
         const int blk = rb * CBW + cb;
-        if constexpr (MB == 32) {
+        if constexpr (F8) {
+            const f32x16& a = acc[blk];
+            return f32x4{a[4 * gq], a[4 * gq + 1], a[4 * gq + 2], a[4 * gq + 3]} * (ws4[cb][gq] * as_row[rb]);
+        } else if constexpr (MB == 32) {
             const f32x16& a = acc[blk];
             return f32x4{a[4 * gq], a[4 * gq + 1], a[4 * gq + 2], a[4 * gq + 3]};
         } else {
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         }
     };
     constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_SILU_BF16;
-    constexpr bool RESID_LDS_OK = EPI == EPI_RESID_GATE_F32 && LAYOUT == 3 && VAR != 9;
+    constexpr bool RESID_LDS_OK = EPI == EPI_RESID_GATE_F32 && (LAYOUT == 3 || LAYOUT == 5) && VAR != 9;
     const bool resid_lds = RESID_LDS_OK && !(p.gate && p.gate_stride != 0) && !p.v4_direct_resid;      // block-uniform
     if constexpr (RESID_LDS_OK) {
       if (resid_lds) {
@@ -295,17 +331,19 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         // of 16 different rows, so touching x straight from them moves 16 x 64 B per instruction -- half of every 128-byte line,
         // twice.  Transposed through this wave's share of the dead stage buffers (half a wave tile at a time: rows x 256 B, 16-byte
         // chunks XOR-swizzled with the row) every global load / store instruction covers 4 whole 256-byte row segments.
-        constexpr int ROWB = WN * 4, PR = 2 * MB, NP = RBW / 2, NIT = PR / 4;   // bytes per slab row, rows / parts / readback steps per part
-        static_assert(RBW % 2 == 0 && ROWB == 256 && 4 * 2 * PR * ROWB <= G::LDS_BYTES, "resid epilogue slab");
-        f32x4 g4[CBW];
+        constexpr int ROWB = WN * 4, PR = 32, RPP = PR / MB, NP = RBW / RPP, NIT = PR / 4;   // bytes per slab row, rows / row blocks per part, parts, readback steps per part
+        static_assert(RBW % RPP == 0 && ROWB == 256 && 4 * 2 * PR * ROWB <= G::LDS_BYTES, "resid epilogue slab");
+        f32x4 g4[CBW][NG];
 #pragma unroll
-        for (int cb = 0; cb < CBW; ++cb) {
-            g4[cb] = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (p.gate || p.gate_table) {
-                g4[cb] = gate4[cb][0];
-                if (p.gate) g4[cb] += *(const f32x4*)(p.gate + n0 + wc * WN + cb * MB + 4 * kq);
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                g4[cb][gq] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (p.gate || p.gate_table) {
+                    g4[cb][gq] = gate4[cb][gq];
+                    if (p.gate) g4[cb][gq] += *(const f32x4*)(p.gate + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq);
+                }
             }
-        }
         // The wave tile leaves in parts of two row blocks (32 rows).  Each wave owns a double-buffered slab of its own, so after
         // the one barrier that ends the K loop nothing synchronises: slab write of part p, then the residual rows of part p + 2
         // are requested, then part p is read back row-contiguously, added and stored -- two parts' loads are always in flight.
@@ -329,13 +367,16 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             if (part >= nparts) break;
             char* sl = wl + (part & 1) * (PR * ROWB);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int rb = part * 2 + r, row = r * MB + lr;
+            for (int r = 0; r < RPP; ++r) {
+                const int rb = part * RPP + r, row = r * MB + lr;
 #pragma unroll
-                for (int cb = 0; cb < CBW; ++cb) {
-                    const f32x4 v = g4[cb] * (acc_group(rb, cb, 0) + bias4[cb][0]);
-                    *(f32x4*)(sl + row * ROWB + (((cb * 4 + kq) ^ (row & 15)) << 4)) = v;
-                }
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int gq = 0; gq < NG; ++gq) {
+                        const f32x4 v = g4[cb][gq] * (acc_group(rb, cb, gq) + bias4[cb][gq]);
+                        const int chunk = (cb * MB + 8 * gq + 4 * kq) >> 2;          // 16-byte chunk of this lane's 4 columns
+                        *(f32x4*)(sl + row * ROWB + ((chunk ^ (row & 15)) << 4)) = v;
+                    }
             }
             if (part + 2 < nparts) load_part(part + 2, xv[(part + 2) % 3]);
 #pragma unroll
@@ -392,7 +433,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             }
         }
       }
-    } else if constexpr ((LAYOUT == 3 || LAYOUT == 4) && VAR != 9 && (BF16_OUT || EPI == EPI_ADD_BF16)) {
+    } else if constexpr ((LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5) && VAR != 9 && (BF16_OUT || EPI == EPI_ADD_BF16)) {
         // bf16 outputs of the row-slab layouts leave through LDS: a lane's accumulator groups are 4 columns of 16 different
         // rows (8-byte stores into 32-byte row segments); transposed through this wave's share of the (now dead) stage
         // buffers every store instruction writes whole rows: 8 rows x 128 B (layout 3) or 4 rows x 256 B (layout 4).
@@ -418,23 +459,26 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             const int r = rb * MB + lr;
             const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
 #pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) {
-                f32x4 v = acc_group(rb, cb, 0) + bias4[cb][0];
+            for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+              for (int gq = 0; gq < NG; ++gq) {
+                f32x4 v = acc_group(rb, cb, gq) + bias4[cb][gq];
                 if (EPI == EPI_GELU_BF16) {
                     const f32x2 g0 = gelu_tanh2(f32x2{v[0], v[1]}), g1 = gelu_tanh2(f32x2{v[2], v[3]});
                     v = f32x4{g0[0], g0[1], g1[0], g1[1]};
                 }
                 if (EPI == EPI_SILU_BF16) v = f32x4{silu_f(v[0]), silu_f(v[1]), silu_f(v[2]), silu_f(v[3])};
-                const int chunk = (cb * 2 + (kq >> 1)) ^ sw;
-                bf16x4* slot = (bf16x4*)(wl + r * ROWB + chunk * 16 + (kq & 1) * 8);
+                const int byte = (cb * MB + 8 * gq + 4 * kq) * 2;        // this lane's 4 columns inside the slab row
+                const int chunk = (byte >> 4) ^ sw;
+                bf16x4* slot = (bf16x4*)(wl + r * ROWB + chunk * 16 + (byte & 15));
                 if constexpr (EPI == EPI_ADD_BF16) {
                     const bf16x4 rs = *slot;
                     v += f32x4{bf2f(rs[0]), bf2f(rs[1]), bf2f(rs[2]), bf2f(rs[3])};
                 }
                 *slot = pack_bf16x4(v[0], v[1], v[2], v[3]);
-            }
+              }
         }
-        if (LAYOUT == 3 && EPI == EPI_BF16 && !CONV && p.vt && n0 >= p.vt_col0) {
+        if ((LAYOUT == 3 || LAYOUT == 5) && EPI == EPI_BF16 && !CONV && p.vt && n0 >= p.vt_col0) {
             // V tile of a fused QKV projection: this wave's 64 columns are 64 dims of ONE head; leave as V^T rows
             // vt[head][d][.] with attention's key order inside every 32-key block: position 16 ks + 8 hh + 4 g0 + e holds
             // key 8 (2 ks + g0) + 4 hh + e.  One instruction stores 16 dims x 64 bytes (4 chunks of 8 positions); every chunk is
@@ -553,8 +597,8 @@ bool gemm_v4_supported(const GemmParams& p, int epilogue, bool conv) {
 // Fused V^T output (GemmParams::vt): layout 3, dense, EPI_BF16; V columns start on a tile boundary, a wave's 64 columns stay
 // inside one head, and the row tiles reach vt_npad (the zero padding of the last 64-key block is written by the last tile).
 bool gemm_v4_vt_supported(const GemmParams& p, int epilogue, int layout) {
-    if (epilogue != EPI_BF16 || layout != 3 || !p.vt) return false;
-    if (!(p.W8 ? gemm_v4_w8_supported(p, epilogue) : gemm_v4_supported(p, epilogue, false))) return false;
+    if (epilogue != EPI_BF16 || (layout != 3 && layout != 5) || !p.vt) return false;
+    if (!(p.A8 ? gemm_v4_f8_supported(p, epilogue) : p.W8 ? gemm_v4_w8_supported(p, epilogue) : gemm_v4_supported(p, epilogue, false))) return false;
     if (p.vt_col0 % 256 != 0 || (p.vt_hd != 64 && p.vt_hd != 128) || (p.N - p.vt_col0) % p.vt_hd != 0) return false;
     if (p.vt_npad % 64 != 0 || p.vt_npad < p.M) return false;
     const int bm = v4_prefer_224(p) ? 224 : 256;
@@ -569,8 +613,37 @@ bool gemm_v4_w8_supported(const GemmParams& p, int epilogue) {
     return true;
 }
 
+bool gemm_v4_f8_supported(const GemmParams& p, int epilogue) {
+    if (epilogue != EPI_BF16 && epilogue != EPI_GELU_BF16 && epilogue != EPI_F32 && epilogue != EPI_RESID_GATE_F32) return false;
+    if (!p.A8 || !p.ascale || !p.W8 || !p.wscale) return false;
+    if (p.N % 256 != 0 || p.K % 256 != 0 || p.K < 512 || p.M < 1) return false;        // an even number (>= 4) of 128-element K-tiles
+    if ((long)p.M * p.lda >= (1L << 31) || (long)p.N * p.K >= (1L << 31)) return false;
+    if (p.lda % 16 != 0 || p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || ((uintptr_t)p.W8 & 15) || ((uintptr_t)p.A8 & 15)) return false;
+    return true;
+}
+
 // layout: 0..4 (see the file comment); bm: 0 = pick, 224 | 256 (layouts 0-3), 448 | 512 (layout 4)
 int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int layout, int bm) {
+    if (p.A8) {     // fp8 compute: layout 5
+        LTX2_CHECK_ARG(gemm_v4_f8_supported(p, epilogue), "gemm_v4: fp8 compute needs A8 + ascale + W8 + wscale, N %% 256 == 0, K %% 256 == 0, K >= 512, a dense bf16/gelu/f32/residual epilogue (N=%d K=%d epilogue=%d)", p.N, p.K, epilogue);
+        const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
+        static const int sc = [] {
+            const char* e = getenv("LTX2_F8_SCALED");
+            return e ? atoi(e) : 0;
+        }();
+#define CASEF(E)                                                                                                                      \
+    case E:                                                                                                                           \
+        if (sc) return b224 ? launch_v4<E, 5, 224, false, 1>(p, stream) : launch_v4<E, 5, 256, false, 1>(p, stream);                  \
+        return b224 ? launch_v4<E, 5, 224>(p, stream) : launch_v4<E, 5, 256>(p, stream);
+        switch (epilogue) {
+            CASEF(EPI_BF16)
+            CASEF(EPI_GELU_BF16)
+            CASEF(EPI_F32)
+            CASEF(EPI_RESID_GATE_F32)
+        }
+#undef CASEF
+        return LTX2_E_INVALID;
+    }
     if (p.W8) {     // fp8-resident weights: layout 3 only
         LTX2_CHECK_ARG(p.wscale && gemm_v4_w8_supported(p, epilogue), "gemm_v4: fp8-resident weights need N %% 256 == 0, K %% 128 == 0, K >= 256, a dense bf16/gelu/f32/residual epilogue (N=%d K=%d epilogue=%d)", p.N, p.K, epilogue);
         const bool b224 = bm ? bm == 224 : v4_prefer_224(p);

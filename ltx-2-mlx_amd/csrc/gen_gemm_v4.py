@@ -59,7 +59,7 @@ MFMA_ORDER = next((a.split('=')[1] for a in sys.argv if a.startswith('--order=')
 class Gen:
     def __init__(self, rbw, cbw, mb=32, npa=8, npw=8, a_stage=32768, w_base=65536, w_stage=32768, conv=False, w8=False,
                  dma_last=None, dma_ks0=None, reads_every=1, m0_early=False,
-                 no_dma=False, no_read=False, no_barrier=False):
+                 no_dma=False, no_read=False, no_barrier=False, f8=False, f8_scaled=False):
         self.rbw, self.cbw, self.mb = rbw, cbw, mb
         self.npw, self.a_stage, self.w_base, self.w_stage, self.conv = npw, a_stage, w_base, w_stage, conv
         assert npa <= 16 and npw <= 8
@@ -67,19 +67,30 @@ class Gen:
         if mb == 32:
             assert a_stage + 8 * 4096 <= 65536 and w_stage + 8 * 4096 <= 65536
         self.w8 = w8
+        # f8: BOTH operands are e4m3fn codes (1 byte each); a K-tile is 128 elements = the same 128-byte rows as 64 bf16, so the LDS
+        # image, the swizzle and the DMA schedule are the bf16 loop's; the MFMA is v_mfma_f32_32x32x64_f8f6f4 (fp8 x fp8, 2 k-steps of 64
+        # per K-tile) on 8-VGPR fragments = 32 bytes per lane, read as TWO ds_read_b128 (the lane's two adjacent 16-byte chunks)
+        self.f8, self.f8_scaled = f8, f8_scaled
+        if f8:
+            assert mb == 32 and not conv and not w8
+        self.fr = 8 if f8 else 4                  # VGPRs per fragment
+        self.rpf = 2 if f8 else 1                 # ds_read_b128 per fragment
         self.s_kw = S_KW if (conv or w8) else S_KA
         self.kw_shift = 6 if w8 else 7               # weight K-tile = 64 bytes of codes / 128 bytes of bf16
         if w8:
             assert mb == 16 and not conv
-        self.nks = 4 if mb == 32 else 2
+        self.nks = 2 if (mb == 16 or f8) else 4
         self.accsz = 16 if mb == 32 else 4
         self.blk_bytes = mb * 128                 # LDS bytes between consecutive row blocks
         self.npa = npa                            # activation DMA pieces per wave (BM / 32)
         self.NPIECE = npa + npw
         self.nmf = rbw * cbw
         self.nfrag = rbw + cbw
-        self.q_base = P_BASE + 4 * self.nfrag
-        self.vgpr_top = self.q_base + 4 * self.nfrag
+        self.q_base = P_BASE + self.fr * self.nfrag
+        self.vgpr_top = self.q_base + self.fr * self.nfrag
+        if f8 and f8_scaled:                      # one VGPR holding the E8M0 code of 1.0 in every byte (v_mfma_scale_* operands)
+            self.one_reg = self.vgpr_top
+            self.vgpr_top += 1
         if w8:      # raw code pairs (2 per weight fragment), per-column scale pairs (2 per cb), 8 f32 temporaries
             self.raw_base = self.vgpr_top
             self.scl_base = self.raw_base + 2 * cbw
@@ -100,16 +111,16 @@ class Gen:
         assert len(dma_last) + len(dma_ks0) == n, (dma_last, dma_ks0, n)
         self.reads_every = reads_every
         self.m0_early = m0_early
-        assert (self.nfrag - 1) * reads_every < self.nmf
+        assert (self.nfrag * self.rpf - 1) * reads_every < self.nmf * (2 if f8 else 1)
         self.no_dma, self.no_read, self.no_barrier = no_dma, no_read, no_barrier
         self.out = []
         self.trace = []
 
     def emit(self, s):
-        self.out.append(s)
+        self.out.extend(s.split("\n"))
 
     def frag(self, setbase, idx):       # idx < rbw: activation fragment rb ; rbw + cb: weight fragment cb
-        return setbase + 4 * idx
+        return setbase + self.fr * idx
 
     def acc(self, rb, cb):
         return (rb * self.cbw + cb) * self.accsz
@@ -130,8 +141,8 @@ class Gen:
             return [], None
         return [m0], ins
 
-    def read(self, setbase, idx, stage, ks, tile_tag):
-        f = self.frag(setbase, idx)
+    def read(self, setbase, idx, stage, ks, tile_tag, half=0):
+        f = self.frag(setbase, idx) + 4 * half
         is_a = idx < self.rbw
         blk = (idx if is_a else idx - self.rbw) * self.blk_bytes
         base = ADDR_A if is_a else ADDR_W
@@ -139,11 +150,13 @@ class Gen:
             cb = idx - self.rbw
             r = self.raw_base + 2 * cb
             a = f"ds_read_b64 v[{r}:{r + 1}], v{base + ks + 2 * stage} offset:{cb * 16 * 64}"
+        elif self.f8:               # address register [2 ks + half]: chunk (4 ks + 2 k-half-of-the-lane + half) ^ swizzle; stage = immediate
+            a = f"ds_read_b128 v[{f}:{f + 3}], v{base + 2 * ks + half} offset:{stage * (self.a_stage if is_a else self.w_stage) + blk}"
         elif self.mb == 16:         # per-stage base registers
             a = f"ds_read_b128 v[{f}:{f + 3}], v{base + ks + 2 * stage} offset:{blk}"
         else:
             a = f"ds_read_b128 v[{f}:{f + 3}], v{base + ks} offset:{stage * (self.a_stage if is_a else self.w_stage) + blk}"
-        self.trace.append(("read", (setbase, idx, stage, ks, tile_tag)))
+        self.trace.append(("read", (setbase, idx, stage, ks, tile_tag, half)))
         if self.no_read and tile_tag != "prologue":
             return None
         return a
@@ -169,6 +182,11 @@ class Gen:
         w = self.frag(setbase, self.rbw + cb)
         x = self.frag(setbase, rb)
         self.trace.append(("mfma", (setbase, rb, cb)))
+        if self.f8:     # cbsz = blgp = 0: both operands OCP e4m3; the scaled form multiplies by 2^(E8M0 - 127) per 32-element block: 1.0 here
+            if self.f8_scaled:
+                return (f"v_mfma_scale_f32_32x32x64_f8f6f4 a[{a}:{a + 15}], v[{w}:{w + 7}], v[{x}:{x + 7}], a[{a}:{a + 15}], "
+                        f"v{self.one_reg}, v{self.one_reg} op_sel_hi:[0,0,0]")
+            return f"v_mfma_f32_32x32x64_f8f6f4 a[{a}:{a + 15}], v[{w}:{w + 7}], v[{x}:{x + 7}], a[{a}:{a + 15}]"
         op = "v_mfma_f32_32x32x16_bf16" if self.mb == 32 else "v_mfma_f32_16x16x32_bf16"
         return f"{op} a[{a}:{a + self.accsz - 1}], v[{w}:{w + 3}], v[{x}:{x + 3}], a[{a}:{a + self.accsz - 1}]"
 
@@ -186,8 +204,13 @@ class Gen:
             order = [(rb, cb) for rb in range(self.rbw) for cb in range(self.cbw)]
         elif MFMA_ORDER == "rbsnake":
             order = [(rb, cb if rb % 2 == 0 else self.cbw - 1 - cb) for rb in range(self.rbw) for cb in range(self.cbw)]
-        reads = self.read_order()
-        read_at = {i * self.reads_every: r for i, r in enumerate(reads)}
+        reads = [(r, h) for r in self.read_order() for h in range(self.rpf)]
+        if self.f8:         # 2 x nfrag reads over nmf slots: two per slot from the start (an MFMA slot is 64 cycles here)
+            read_at = {}
+            for i, rh in enumerate(reads):
+                read_at.setdefault(i // 2, []).append(rh)
+        else:
+            read_at = {i * self.reads_every: [rh] for i, rh in enumerate(reads)}
         dma_at = dict(zip(dma_slots, dma_list))
         valu_at = {}
         if self.w8 and not (self.no_read and rtag != "prologue"):
@@ -226,7 +249,9 @@ class Gen:
             self.emit(mf)
             r = None
             if i in read_at:
-                r = self.read(nxt, read_at[i], rstage, rks, rtag)
+                rr = [self.read(nxt, idx, rstage, rks, rtag, half) for idx, half in read_at[i]]
+                rr = [x for x in rr if x]
+                r = "\n".join(rr) if rr else None
             if self.m0_early:
                 if ins:
                     self.emit(ins)          # M0 was written one slot earlier
@@ -345,12 +370,15 @@ class Gen:
                 e(ins)
         for r in range(self.rbw * self.cbw * self.accsz):
             e(f"v_accvgpr_write_b32 a{r}, 0")
+        if self.f8 and self.f8_scaled:
+            e(f"v_mov_b32 v{self.one_reg}, 0x7f7f7f7f")
         e(f"s_waitcnt vmcnt({n1})")
         self.trace.append(("vm", n1))
         e("s_barrier")
         self.trace.append(("barrier", None))
         for idx in self.read_order():
-            e(self.read(P_BASE, idx, 0, 0, "prologue"))
+            for half in range(self.rpf):
+                e(self.read(P_BASE, idx, 0, 0, "prologue", half))
         e("s_waitcnt lgkmcnt(0)")
         self.trace.append(("lgkm0", None))
         if self.w8:
@@ -384,7 +412,7 @@ def check(g, iters=3):
     tr = g.trace
     li = [i for i, (k, _) in enumerate(tr) if k == "loop"][0]
     body = tr[li + 1:]
-    NP, nfrag, nks = g.NPIECE, g.nfrag, g.nks
+    NP, nfrag, nks, rpf = g.NPIECE, g.nfrag, g.nks, g.rpf
     ev = list(tr[:li])
     for it in range(iters):
         base = 2 * it
@@ -397,8 +425,8 @@ def check(g, iters=3):
                 piece, stage, tag = pl
                 ev.append((k, (piece, stage, cur + {"T+1": 1, "T+2": 2}[tag])))
             elif k == "read":
-                setb, idx, stage, ks, tag = pl
-                ev.append((k, (setb, idx, stage, ks, cur + {"T": 0, "T+1": 1}[tag])))
+                setb, idx, stage, ks, tag, half = pl
+                ev.append((k, (setb, idx, stage, ks, cur + {"T": 0, "T+1": 1}[tag], half)))
             else:
                 ev.append((k, pl))
     errors = []
@@ -409,6 +437,7 @@ def check(g, iters=3):
     reads_by_tile = {}
     pending_reads = []
     frag = {}
+    halves = {}
     frag_last_use = {}
     n_mfma = 0
     done = {}
@@ -426,7 +455,7 @@ def check(g, iters=3):
                     if rp[0] is None or not any(rp[0] < b < pos for b in barriers):
                         errors.append(f"DMA of tile {tile} piece {piece} at {pos} before reads of tile {prev} retired + barrier")
                         break
-                if len(reads_by_tile.get(prev, [])) != nks * nfrag:
+                if len(reads_by_tile.get(prev, [])) != nks * nfrag * rpf:
                     errors.append(f"DMA of tile {tile} at {pos}: tile {prev} has only {len(reads_by_tile.get(prev, []))} reads issued so far")
             dma_order.append((pos, tile, piece))
             stage_tile[stage] = tile
@@ -438,7 +467,7 @@ def check(g, iters=3):
         elif k == "barrier":
             barriers.append(pos)
         elif k == "read":
-            setb, idx, stage, ks, tile = pl
+            setb, idx, stage, ks, tile, half = pl
             if isinstance(tile, str):
                 tile = 0
             if tile % 2 != stage or stage_tile.get(stage) != tile:
@@ -453,11 +482,17 @@ def check(g, iters=3):
             frag.pop((setb, idx), None)
             rec = [None]
             reads_by_tile.setdefault(tile, []).append((pos, rec))
-            pending_reads.append((setb, idx, tile, ks, rec))
+            pending_reads.append((setb, idx, tile, ks, rec, half))
         elif k == "lgkm0":
-            for setb, idx, tile, ks, rec in pending_reads:
+            for setb, idx, tile, ks, rec, half in pending_reads:
                 rec[0] = pos
-                frag[(setb, idx)] = (tile, ks)
+                got = halves.setdefault((setb, idx), {})
+                if got.get("of") != (tile, ks):
+                    got.clear()
+                    got["of"] = (tile, ks)
+                got[half] = True
+                if all(got.get(h) for h in range(rpf)):       # a fragment is whole once every one of its ds_read_b128 has landed
+                    frag[(setb, idx)] = (tile, ks)
             pending_reads = []
         elif k == "mfma":
             setb, rb, cb = pl
@@ -494,7 +529,7 @@ def variant(name, rbw, cbw, **kw):
         regs = [i for i in range(33, VGPR_TOP_MAX) if not (g.scl_base <= i < g.scl_base + 2 * g.cbw)]
         extra = (f"#define {name}_SCL \"{{v[{g.scl_base}:{g.scl_base + 2 * g.cbw - 1}]}}\"\n#define {name}_CLOBBERS \\\n    " + ", ".join(f'"v{i}"' for i in regs) +
                  ", \\\n    " + ", ".join(f'"{s}"' for s in SCRATCH_S) + ', "scc", "memory"\n\n')
-    hdr = f"// {name}: w8={g.w8} rbw={rbw} cbw={cbw} mb={g.mb} npa={g.npa} npw={g.npw} a_stage={g.a_stage} w_base={g.w_base} w_stage={g.w_stage} conv={g.conv} dma_last={g.dma_last} dma_ks0={g.dma_ks0} reads_every={g.reads_every} vgpr_top={g.vgpr_top}"
+    hdr = f"// {name}: f8={g.f8} w8={g.w8} rbw={rbw} cbw={cbw} mb={g.mb} npa={g.npa} npw={g.npw} a_stage={g.a_stage} w_base={g.w_base} w_stage={g.w_stage} conv={g.conv} dma_last={g.dma_last} dma_ks0={g.dma_ks0} reads_every={g.reads_every} vgpr_top={g.vgpr_top}"
     return hdr + f"\n#define {name} \\\n" + body.replace('\n', ' \\\n').rstrip(' \\\n') + "\n\n" + extra
 
 
@@ -538,6 +573,12 @@ def main():
     out.append(variant("LTX2_V4_L14_M16_RB16_W8", 16, 4, mb=16, npa=8, npw=4, w_stage=16384, dma_last=list(range(3, 50, 4)), dma_ks0=[], m0_early=True, w8=True))
     out.append(variant("LTX2_V4_L14_M16_RB6_W8", 6, 4, mb=16, npa=3, npw=4, w_stage=16384, dma_last=list(range(1, 22, 3)), dma_ks0=[], m0_early=True, w8=True))
     out.append(variant("LTX2_V4_L14_M16_RB10_W8", 10, 4, mb=16, npa=5, npw=4, w_stage=16384, dma_last=list(range(1, 37, 4)), dma_ks0=[], m0_early=True, w8=True))
+    # layout 5: BOTH operands fp8 (e4m3fn codes, K-tile = 128 elements), 1x4 waves, v_mfma_f32_32x32x64_f8f6f4: 7|8 x 2 blocks of 32
+    odd14f = [1, 3, 5, 7, 9, 11, 13]
+    for sc in (False, True):
+        sfx = "_SC" if sc else ""
+        out.append(variant("LTX2_V4_F8_RB7" + sfx, 7, 2, npa=7, dma_last=odd14f, dma_ks0=[0, 2, 4, 6, 8, 10, 12, 13], f8=True, f8_scaled=sc))
+        out.append(variant("LTX2_V4_F8_RB8" + sfx, 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, f8=True, f8_scaled=sc))
     if "--probe" in sys.argv:
         e4 = list(range(3, 64, 4))
         out.append(variant("LTX2_V4_L14_RB8_NODMA", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, no_dma=True))

@@ -9,7 +9,9 @@
 // all four null -> plain normalisation.
 int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int D, float eps, int layer_norm,
                     const float* scale_tab, const float* shift_tab, const float* scale_emb, const float* shift_emb,
-                    long emb_stride, hipStream_t stream);
+                    long emb_stride, hipStream_t stream, unsigned char* q8 = nullptr, long ldq = 0, float* qscale = nullptr);
+// q8 / qscale (fp8 compute path): the row additionally (out may then be null: instead) leaves as per-token e4m3fn codes + scale,
+// quantised from the bf16-ROUNDED outputs exactly as quant_rows_fp8_launch would quantise `out`
 
 // In-place on bf16 rows: for each of nseg segments (q, k) at column offsets seg_off[i] of width D:
 //   y = x * rsqrt(mean(x^2) + eps) * weight_i ;  then (if cos != null) SPLIT RoPE per head:
@@ -40,6 +42,9 @@ int timestep_sinusoid_launch(const float* t, long t_stride, float t_scalar, floa
                              bf16* out_bf16, hipStream_t stream);
 
 int cast_f32_bf16_launch(const float* in, bf16* out, long n, hipStream_t stream);
+// fp8 compute path: per-row e4m3fn quantisation of bf16 rows: scale[r] = max|x[r]| / 448 (1 for a zero row),
+// out[r][k] = e4m3fn_rne(x[r][k] * (1 / scale[r]))
+int quant_rows_fp8_launch(const bf16* x, long ldx, int rows, int K, unsigned char* out, long ldo, float* scale, hipStream_t stream);
 // out_bf16 = bf16(f32(fp8_e4m3fn) * scale): checkpoint weights quantised with a per-tensor weight_scale
 int dequant_fp8_launch(const unsigned char* in, float scale, bf16* out, long n, hipStream_t stream);
 

@@ -31,6 +31,40 @@ __device__ __forceinline__ void block_sum2_256(float& a, float& b, float* red) {
     b = red[4] + red[5] + red[6] + red[7];
 }
 
+// fp8 compute path: the block's row (already rounded to bf16: the values the bf16 path would hand the GEMM) leaves as per-token
+// e4m3fn codes + scale -- ltx2_quantize_rows_fp8's arithmetic on the same bf16 values, so fused and unfused agree bit for bit.
+template <int NV>
+__device__ __forceinline__ void row_to_fp8(const bf16x4 (&o)[NV], int D, float* red, unsigned char* qrow, float* qscale_row) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int d = threadIdx.x * 4 + i * 1024;
+        if (d < D)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(bf2f(o[i][e])));
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    const float inv = 1.0f / scale;
+    if (threadIdx.x == 0) *qscale_row = scale;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int d = threadIdx.x * 4 + i * 1024;
+        if (d >= D) continue;
+        unsigned c = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        c = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(bf2f(o[i][0]) * inv, bf2f(o[i][1]) * inv, (int)c, false);
+        c = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(bf2f(o[i][2]) * inv, bf2f(o[i][3]) * inv, (int)c, true);
+#endif
+        *(unsigned*)(qrow + d) = c;
+    }
+}
+
 // One block per row; the row (D <= 1024*NV fp32) is read ONCE and held in registers.
 template <int NV>
 __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__ x, long ldx, bf16* __restrict__ out,
@@ -38,7 +72,8 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
                                                        const float* __restrict__ scale_tab,
                                                        const float* __restrict__ shift_tab,
                                                        const float* __restrict__ scale_emb,
-                                                       const float* __restrict__ shift_emb, long emb_stride) {
+                                                       const float* __restrict__ shift_emb, long emb_stride,
+                                                       unsigned char* __restrict__ q8, long ldq, float* __restrict__ qscale) {
     __shared__ float red[8];
     const long row = blockIdx.x;
     const float* xr = x + row * ldx;
@@ -58,7 +93,8 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
     const float rstd = rsqrtf(var + eps);
     const float* se = scale_emb ? scale_emb + row * emb_stride : nullptr;
     const float* he = shift_emb ? shift_emb + row * emb_stride : nullptr;
-    bf16* orow = out + row * ldo;
+    bf16* orow = out ? out + row * ldo : nullptr;
+    bf16x4 ov[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int d = threadIdx.x * 4 + i * 1024;
@@ -71,8 +107,10 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf((v[i][e] - mean) * rstd * (1.f + sc[e]) + sh[e]);
-        *(bf16x4*)(orow + d) = o;
+        if (orow) *(bf16x4*)(orow + d) = o;
+        ov[i] = o;
     }
+    if (q8) row_to_fp8<NV>(ov, D, red, q8 + row * ldq, qscale + row);
 }
 
 // Row-invariant modulation (emb_stride == 0: the scalar-sigma case).  A block walks rows blockIdx.x, +gridDim.x, ..
@@ -85,7 +123,8 @@ __global__ __launch_bounds__(256) void norm_mod_shared_kernel(const float* __res
                                                               const float* __restrict__ scale_tab,
                                                               const float* __restrict__ shift_tab,
                                                               const float* __restrict__ scale_emb,
-                                                              const float* __restrict__ shift_emb) {
+                                                              const float* __restrict__ shift_emb,
+                                                              unsigned char* __restrict__ q8, long ldq, float* __restrict__ qscale) {
     __shared__ float red[8];
     f32x4 sc1[NV], sh[NV];
 #pragma unroll
@@ -117,7 +156,8 @@ __global__ __launch_bounds__(256) void norm_mod_shared_kernel(const float* __res
         const float ms = s2 / (float)D;
         const float var = layer_norm ? fmaxf(ms - mean * mean, 0.f) : ms;
         const float rstd = rsqrtf(var + eps);
-        bf16* orow = out + row * ldo;
+        bf16* orow = out ? out + row * ldo : nullptr;
+        bf16x4 ov[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int d = threadIdx.x * 4 + i * 1024;
@@ -125,8 +165,10 @@ __global__ __launch_bounds__(256) void norm_mod_shared_kernel(const float* __res
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = f2bf((v[i][e] - mean) * rstd * sc1[i][e] + sh[i][e]);
-            *(bf16x4*)(orow + d) = o;
+            if (orow) *(bf16x4*)(orow + d) = o;
+            ov[i] = o;
         }
+        if (q8) row_to_fp8<NV>(ov, D, red, q8 + row * ldq, qscale + row);
     }
 }
 
@@ -461,6 +503,52 @@ __global__ void dequant_fp8_kernel(const unsigned char* __restrict__ in, float s
     }
 }
 
+// Per-row e4m3fn quantiser of the fp8 compute path: one workgroup per row.
+//   amax = max_k |x[k]| ; scale = amax / 448 (1 when the row is all zeros) ; inv = 1 / scale (IEEE) ; code[k] = e4m3fn_rne(x[k] * inv)
+// The row stays in registers between the two passes (K <= 16384: 8 x 16 bytes per thread).  v_cvt_pk_fp8_f32 is the OCP conversion
+// (round to nearest even, subnormals kept); |x * inv| <= 448 (1 + 2^-23) never reaches the overflow threshold (464).
+template <int NIT>
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16* __restrict__ x, long ldx, int K, unsigned char* __restrict__ out, long ldo,
+                                                             float* __restrict__ scale_out) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bf16* xr = x + (long)row * ldx;
+    bf16x8 v[NIT];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int k = (i * 256 + tid) * 8;
+        if (k < K) {
+            v[i] = *(const bf16x8*)(xr + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f(v[i][e])));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    const float inv = 1.0f / scale;
+    if (tid == 0) scale_out[row] = scale;
+    unsigned char* orow = out + (long)row * ldo;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int k = (i * 256 + tid) * 8;
+        if (k < K) {
+            u32x2 c = {0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+            c[0] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[i][0]) * inv, bf2f(v[i][1]) * inv, (int)c[0], false);
+            c[0] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[i][2]) * inv, bf2f(v[i][3]) * inv, (int)c[0], true);
+            c[1] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[i][4]) * inv, bf2f(v[i][5]) * inv, (int)c[1], false);
+            c[1] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[i][6]) * inv, bf2f(v[i][7]) * inv, (int)c[1], true);
+#endif
+            *(u32x2*)(orow + k) = c;
+        }
+    }
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -690,8 +778,9 @@ inline int grid_for(long n, int block, int cap = 4096) {
 
 int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int D, float eps, int layer_norm,
                     const float* scale_tab, const float* shift_tab, const float* scale_emb, const float* shift_emb,
-                    long emb_stride, hipStream_t stream) {
+                    long emb_stride, hipStream_t stream, unsigned char* q8, long ldq, float* qscale) {
     LTX2_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "norm_mod: D, ldx, ldo must be multiples of 4");
+    LTX2_CHECK_ARG((out || q8) && (!q8 || (qscale && ldq % 4 == 0)), "norm_mod: no output / fp8 output without a scale vector");
     LTX2_CHECK_ARG(D <= 8192 && emb_stride % 4 == 0, "norm_mod: D=%d exceeds 8192 or emb_stride not a multiple of 4", D);
     const bool shared_mod = emb_stride == 0 && (scale_tab || shift_tab || scale_emb || shift_emb) && rows > 1024;
     if (shared_mod) {
@@ -699,16 +788,16 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
         const int grid = (rows + per_block - 1) / per_block;
         if (D <= 4096)
             hipLaunchKernelGGL((norm_mod_shared_kernel<4>), dim3(grid), dim3(256), 0, stream, x, ldx, out, ldo, rows, D, eps, layer_norm,
-                               scale_tab, shift_tab, scale_emb, shift_emb);
+                               scale_tab, shift_tab, scale_emb, shift_emb, q8, ldq, qscale);
         else
             hipLaunchKernelGGL((norm_mod_shared_kernel<8>), dim3(grid), dim3(256), 0, stream, x, ldx, out, ldo, rows, D, eps, layer_norm,
-                               scale_tab, shift_tab, scale_emb, shift_emb);
+                               scale_tab, shift_tab, scale_emb, shift_emb, q8, ldq, qscale);
     } else if (D <= 4096) {
         hipLaunchKernelGGL((norm_mod_kernel<4>), dim3(rows), dim3(256), 0, stream, x, ldx, out, ldo, D, eps, layer_norm,
-                           scale_tab, shift_tab, scale_emb, shift_emb, emb_stride);
+                           scale_tab, shift_tab, scale_emb, shift_emb, emb_stride, q8, ldq, qscale);
     } else {
         hipLaunchKernelGGL((norm_mod_kernel<8>), dim3(rows), dim3(256), 0, stream, x, ldx, out, ldo, D, eps, layer_norm,
-                           scale_tab, shift_tab, scale_emb, shift_emb, emb_stride);
+                           scale_tab, shift_tab, scale_emb, shift_emb, emb_stride, q8, ldq, qscale);
     }
     LTX2_CHECK_LAUNCH("norm_mod_kernel");
     return LTX2_OK;
@@ -829,6 +918,19 @@ int dequant_fp8_launch(const unsigned char* in, float scale, bf16* out, long n, 
     const long blocks = (n / 8 + 255) / 256;
     hipLaunchKernelGGL(dequant_fp8_kernel, dim3((int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks))), dim3(256), 0, stream, in, scale, out, n);
     LTX2_CHECK_LAUNCH("dequant_fp8_kernel");
+    return LTX2_OK;
+}
+
+int quant_rows_fp8_launch(const bf16* x, long ldx, int rows, int K, unsigned char* out, long ldo, float* scale, hipStream_t stream) {
+    LTX2_CHECK_ARG(rows > 0 && K > 0 && K % 8 == 0 && K <= 16 * 2048 && ldx % 8 == 0 && ldo % 8 == 0, "quant_rows_fp8: rows=%d K=%d (K %% 8 == 0, K <= 32768, 16-byte rows)", rows, K);
+    const int nit = (K + 2047) / 2048;
+    if (nit <= 2)
+        hipLaunchKernelGGL(quant_rows_fp8_kernel<2>, dim3(rows), dim3(256), 0, stream, x, ldx, K, out, ldo, scale);
+    else if (nit <= 8)
+        hipLaunchKernelGGL(quant_rows_fp8_kernel<8>, dim3(rows), dim3(256), 0, stream, x, ldx, K, out, ldo, scale);
+    else
+        hipLaunchKernelGGL(quant_rows_fp8_kernel<16>, dim3(rows), dim3(256), 0, stream, x, ldx, K, out, ldo, scale);
+    LTX2_CHECK_LAUNCH("quant_rows_fp8_kernel");
     return LTX2_OK;
 }
 

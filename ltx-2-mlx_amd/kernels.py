@@ -76,6 +76,58 @@ def gemm_w8a16(a: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: Op
     return out
 
 
+def quantize_rows_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """bf16 [R, K] -> (float8_e4m3fn codes as uint8 [R, K], fp32 scale [R]): scale = max|row| / 448 (1 for a zero row),
+    code = e4m3fn_rne(x * (1 / scale)).  The quantiser of the fp8 compute path (activations per token, weights per output channel)."""
+    assert x.dtype == BF16 and x.dim() == 2
+    x = _c(x)
+    R, K = x.shape
+    codes = torch.empty(R, K, device=x.device, dtype=torch.uint8)
+    scale = torch.empty(R, device=x.device, dtype=torch.float32)
+    nv.check(nv.lib().ltx2_quantize_rows_fp8(nv.ptr(x), x.stride(0), R, K, nv.ptr(codes), K, nv.ptr(scale), nv.stream()))
+    return codes, scale
+
+
+def gemm_fp8(a8: torch.Tensor, ascale: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: Optional[torch.Tensor] = None,
+             epilogue: int = nv.EPI_BF16, out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+             gate_table: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epilogue(ascale[m] * wscale[n] * (f32(a8)[M,K] @ f32(w8)[N,K]^T) + bias) on the fp8 MFMA (a8, w8: float8_e4m3fn codes,
+    uint8 views accepted)."""
+    assert a8.element_size() == 1 and w8.element_size() == 1 and a8.dim() == 2 and w8.dim() == 2
+    assert ascale.dtype == torch.float32 and wscale.dtype == torch.float32
+    a8, w8, ascale, wscale = _c(a8), _c(w8), _c(ascale), _c(wscale)
+    M, K = a8.shape
+    N = w8.shape[0]
+    assert ascale.numel() == M and wscale.numel() == N and w8.shape[1] == K
+    if out is None:
+        assert epilogue != nv.EPI_RESID_GATE_F32, "RESID_GATE accumulates into `out`; pass it"
+        out = torch.empty(M, N, device=a8.device, dtype=torch.float32 if epilogue == nv.EPI_F32 else BF16)
+    gs = 0
+    if gate is not None:
+        gate = _c(gate)
+        gs = 0 if gate.shape[0] == 1 else gate.stride(0)
+    nv.check(nv.lib().ltx2_gemm_fp8(nv.ptr(a8), a8.stride(0), nv.ptr(ascale), nv.ptr(w8), nv.ptr(wscale), nv.ptr(bias), nv.ptr(out), out.stride(0),
+                                    M, N, K, epilogue, nv.ptr(gate), gs, nv.ptr(gate_table), nv.stream()))
+    return out
+
+
+def gemm_fp8_qkv_vt(a8, ascale, w8, wscale, bias, heads: int, head_dim: int = 128):
+    """gemm_qkv_vt on the fp8 compute path -> (qkv [M, 3D] bf16, vt [H, hd, Npad], fused)."""
+    a8, w8, ascale, wscale = _c(a8), _c(w8), _c(ascale), _c(wscale)
+    M, K = a8.shape
+    N = w8.shape[0]
+    D = heads * head_dim
+    assert N == 3 * D
+    npad = (M + 63) // 64 * 64
+    out = torch.empty(M, N, device=a8.device, dtype=BF16)
+    vt = torch.empty(heads, head_dim, npad, device=a8.device, dtype=BF16)
+    import ctypes
+    fused = ctypes.c_int(0)
+    nv.check(nv.lib().ltx2_gemm_fp8_qkv_vt(nv.ptr(a8), a8.stride(0), nv.ptr(ascale), nv.ptr(w8), nv.ptr(wscale), nv.ptr(bias), nv.ptr(out),
+                                           out.stride(0), M, N, K, nv.ptr(vt), 2 * D, npad, head_dim, ctypes.byref(fused), nv.stream()))
+    return out, vt, bool(fused.value)
+
+
 def gemv(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_in: int = 0, act_out: int = 0) -> torch.Tensor:
     assert a.dtype == torch.float32 and w.dtype == BF16
     a, w = _c(a), _c(w)
@@ -199,6 +251,21 @@ def adaln_rmsnorm(x: torch.Tensor, eps: float = 1e-6, layer_norm: bool = False,
     nv.check(nv.lib().ltx2_adaln_rmsnorm(nv.ptr(x), D, nv.ptr(out), D, rows, D, eps, int(layer_norm), nv.ptr(scale_tab),
                                          nv.ptr(shift_tab), nv.ptr(scale_emb), nv.ptr(shift_emb), emb_stride, nv.stream()))
     return out
+
+
+def adaln_rmsnorm_fp8(x: torch.Tensor, eps: float = 1e-6, layer_norm: bool = False, scale_tab: Optional[torch.Tensor] = None,
+                      shift_tab: Optional[torch.Tensor] = None, scale_emb: Optional[torch.Tensor] = None,
+                      shift_emb: Optional[torch.Tensor] = None, emb_stride: int = 0, want_bf16: bool = True):
+    """adaln_rmsnorm with the per-token e4m3fn quantiser fused in -> (bf16 out or None, codes uint8 [rows, D], scale fp32 [rows])."""
+    assert x.dtype == torch.float32 and x.dim() == 2
+    x = _c(x)
+    rows, D = x.shape
+    out = torch.empty(rows, D, device=x.device, dtype=BF16) if want_bf16 else None
+    codes = torch.empty(rows, D, device=x.device, dtype=torch.uint8)
+    scale = torch.empty(rows, device=x.device, dtype=torch.float32)
+    nv.check(nv.lib().ltx2_adaln_rmsnorm_fp8(nv.ptr(x), D, nv.ptr(out), D, nv.ptr(codes), D, nv.ptr(scale), rows, D, eps, int(layer_norm),
+                                             nv.ptr(scale_tab), nv.ptr(shift_tab), nv.ptr(scale_emb), nv.ptr(shift_emb), emb_stride, nv.stream()))
+    return out, codes, scale
 
 
 def qknorm_rope_(buf: torch.Tensor, D: int, head_dim: int, q_off: int, q_weight: torch.Tensor,

@@ -119,7 +119,7 @@ class LTXModel:
                  use_middle_indices_grid: bool = True, rope_type: LTXRopeType = LTXRopeType.SPLIT,
                  compute_dtype: torch.dtype = BF16, low_memory: bool = False, fast_mode: bool = False,
                  cross_attention_adaln: bool = False, apply_gated_attention: bool = False,
-                 device: Union[str, torch.device] = "cuda", audio_attention_heads: Optional[int] = None):
+                 device: Union[str, torch.device] = "cuda", audio_attention_heads: Optional[int] = None, fp8_compute: bool = False):
         if model_type == LTXModelType.AudioOnly:
             raise NotImplementedError("AudioOnly transformer is outside the denoise hot path (DESIGN.md)")
         if rope_type != LTXRopeType.SPLIT or not use_middle_indices_grid:
@@ -156,6 +156,13 @@ class LTXModel:
         h = C.c_void_p()
         nv.check(nv.lib().ltx2_dit_create(C.byref(cfg), C.byref(h)))
         self._h = h
+        # MI355X addition (BASELINE config 3, "fp8 weights (CDNA4 fp8 MFMA)"): opt-in fp8 COMPUTE.  The video stream's attention /
+        # feed-forward projections keep e4m3fn weights (an fp8 checkpoint's codes, or bf16 weights quantised per output channel at
+        # load), their activations are quantised per token inside the step, and the products run on the fp8 MFMA at twice the bf16
+        # rate.  Not the parity-exact default: the reference dequantises fp8 checkpoints at load (loader/fp8_loader.py:54-130).
+        self.fp8_compute = bool(fp8_compute)
+        if self.fp8_compute:
+            nv.check(nv.lib().ltx2_dit_set_option(h, b"fp8_compute", 1))
         self._w: Dict[str, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
         self._bound: Tuple[int, ...] = (0, 0, 0, 0, 0)
@@ -167,7 +174,8 @@ class LTXModel:
                           out_channels=out_channels, num_layers=num_layers, cross_attention_dim=cross_attention_dim, norm_eps=norm_eps,
                           caption_channels=caption_channels, positional_embedding_theta=positional_embedding_theta,
                           positional_embedding_max_pos=positional_embedding_max_pos, timestep_scale_multiplier=timestep_scale_multiplier,
-                          cross_attention_adaln=cross_attention_adaln, apply_gated_attention=apply_gated_attention, device=device)
+                          cross_attention_adaln=cross_attention_adaln, apply_gated_attention=apply_gated_attention, device=device,
+                          fp8_compute=fp8_compute)
 
     def _video_twin(self) -> "LTXModel":
         """The video half of this AudioVideo model as a VideoOnly engine: with no audio tokens the reference's blocks run only
@@ -293,6 +301,13 @@ class LTXModel:
             """Register the (possibly fused) linear weight `dst` from checkpoint tensors `names`.  Fp8Weight entries (codes +
             per-tensor scale, loader fp8_resident=True) stay fp8 in HBM: codes concatenated, one scale per output row."""
             vals = [sd[n] for n in names]
+            if self.fp8_compute and all(FP8_RESIDENT_KEYS.match(n) for n in names) and not any(isinstance(v, Fp8Weight) for v in vals) \
+                    and vals[0].shape[0] % 256 == 0 and vals[0].shape[1] % 256 == 0 and vals[0].shape[1] >= 512:
+                # bf16 checkpoint + fp8 compute: one e4m3fn scale per OUTPUT CHANNEL (ltx2_quantize_rows_fp8, the activations' quantiser)
+                q = [K.quantize_rows_fp8(v.to(dev, BF16)) for v in vals]
+                self._register(dst, torch.cat([c for c, _ in q], 0))
+                self._register(dst + "_scale", torch.cat([s_ for _, s_ in q], 0))
+                return
             if any(isinstance(v, Fp8Weight) for v in vals):
                 if not all(isinstance(v, Fp8Weight) for v in vals):
                     raise ValueError(f"{dst}: fused projection mixes fp8-resident and dequantised parts")
@@ -329,6 +344,7 @@ class LTXModel:
         """Synthetic N(0, std) weights generated directly in HBM in the engine's fused layout (bench /
         smoke; no checkpoints exist in this environment).  fp8_resident: the video stream's attention / feed-forward
         projections are quantised to float8_e4m3fn + per-tensor scale and stay fp8 in HBM (BASELINE config 3)."""
+        fp8_resident = fp8_resident or self.fp8_compute
         g = torch.Generator(device=self.device).manual_seed(seed)
         fused_fp8 = re.compile(r"^transformer_blocks\.\d+\.(attn1|attn2)\.(to_qkv|to_q|to_kv|to_out\.0)\.weight$|^transformer_blocks\.\d+\.ff\.net\.(0\.proj|2)\.weight$")
 

@@ -607,3 +607,101 @@ def test_rope_tables_gpu(K, dev, grid, dim, heads, max_pos):
     r1c, r1s = dit.rope_split_tables(apos, 2048, 32, 10000.0, [20])
     assert (c1.cpu() - r1c[0].permute(1, 0, 2).reshape(c1.shape)).abs().max() < 2e-5
     assert (s1.cpu() - r1s[0].permute(1, 0, 2).reshape(s1.shape)).abs().max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ fp8 compute path (BASELINE config 3)
+def quant_rows_emulated(x_bf16):
+    """CPU emulation of ltx2_quantize_rows_fp8 with torch's IEEE fp32 arithmetic and its float8_e4m3fn cast (RNE, OCP)."""
+    xf = x_bf16.float()
+    amax = xf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    inv = 1.0 / scale
+    return (xf * inv[:, None]).to(torch.float8_e4m3fn).view(torch.uint8), scale
+
+
+def test_fp8_quantiser_is_bit_exact(dev):
+    """The per-row e4m3fn quantiser against its fp32 / float8_e4m3fn emulation on the host, bit for bit: random rows, rows with
+    outliers, tiny values (subnormal codes), an all-zero row, the DiT's K values."""
+    g = torch.Generator().manual_seed(5)
+    for K in (128, 4096, 16384):
+        x = torch.randn(37, K, generator=g)
+        x[3] *= 1e-3
+        x[5, 7] = 300.0
+        x[6] = 0.0
+        x[7] *= 1e4
+        x = x.to(torch.bfloat16)
+        import ltx_2_mlx_amd.kernels as KK
+        codes, scale = KK.quantize_rows_fp8(x.to(dev))
+        rc, rs = quant_rows_emulated(x)
+        assert torch.equal(scale.cpu(), rs), K
+        assert torch.equal(codes.cpu(), rc), (K, int((codes.cpu() != rc).sum()))
+
+
+@pytest.mark.parametrize("M,N,K", [(3456, 1024, 4096), (1100, 512, 512), (256, 256, 16384), (3456, 4096, 1024)])
+def test_gemm_fp8_matches_dequantised_product(dev, M, N, K):
+    """ltx2_gemm_fp8 = ascale[m] wscale[n] sum_k a8 w8 + bias on the fp8 MFMA against the same product of the DEQUANTISED codes in fp64
+    (the codes are exact in fp32, so the only difference is fp32 accumulation order), asymmetric operands, ragged M; every epilogue."""
+    import ltx_2_mlx_amd.kernels as KK
+    from ltx_2_mlx_amd import _native as nv
+    g = torch.Generator().manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g) * (1 + torch.arange(M)[:, None] % 7)).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    a8, asc = KK.quantize_rows_fp8(a)
+    w8, wsc = KK.quantize_rows_fp8(w)
+    ref = (a8.view(torch.float8_e4m3fn).double() @ w8.view(torch.float8_e4m3fn).double().t()) * asc.double()[:, None] * wsc.double()[None, :] + bias.double()
+    out = KK.gemm_fp8(a8, asc, w8, wsc, bias, epilogue=nv.EPI_F32)
+    assert rel_l2(out.cpu(), ref.cpu()) < 5e-5
+    # and the quantised product tracks the bf16 one to fp8 accuracy (3 mantissa bits on both sides)
+    full = a.double() @ w.double().t() + bias.double()
+    assert rel_l2(out.cpu(), full.cpu()) < 6e-2
+    ob = KK.gemm_fp8(a8, asc, w8, wsc, bias, epilogue=nv.EPI_BF16)
+    assert rel_l2(ob.cpu().float(), ref.cpu()) < 4e-3
+    og = KK.gemm_fp8(a8, asc, w8, wsc, bias, epilogue=nv.EPI_GELU_BF16)
+    assert rel_l2(og.cpu().float(), torch.nn.functional.gelu(ref.float(), approximate="tanh").cpu()) < 6e-3
+    x = torch.randn(M, N, generator=g).to(dev)
+    gt = torch.randn(N, generator=g).to(dev)
+    x2 = x.clone()
+    KK.gemm_fp8(a8, asc, w8, wsc, bias, epilogue=nv.EPI_RESID_GATE_F32, out=x2, gate_table=gt)
+    assert rel_l2(x2.cpu(), (x.double() + gt.double()[None] * ref).cpu()) < 5e-5
+    assert torch.equal(KK.gemm_fp8(a8, asc, w8, wsc, bias, epilogue=nv.EPI_F32), out)        # bit-reproducible
+
+
+def test_norm_fp8_fusion_is_bit_identical(dev):
+    """norm_mod with the fused per-token quantiser == norm_mod (bf16) followed by ltx2_quantize_rows_fp8, bit for bit: row-invariant
+    modulation (the grid-stride kernel), per-token modulation and the plain norm (the row-per-block kernel), D = 4096 and 2048."""
+    import ltx_2_mlx_amd.kernels as KK
+    g = torch.Generator().manual_seed(8)
+    for rows, D in ((3456, 4096), (1030, 2048)):
+        x = (torch.randn(rows, D, generator=g) * (1 + 5 * torch.rand(rows, 1, generator=g))).to(dev)
+        tab, emb = (0.1 * torch.randn(2, D, generator=g)).to(dev), (0.1 * torch.randn(2, D, generator=g)).to(dev)
+        embt = (0.1 * torch.randn(rows, 2 * D, generator=g)).to(dev)
+        cases = [dict(scale_tab=tab[1], shift_tab=tab[0], scale_emb=emb[1], shift_emb=emb[0]),                      # row-invariant
+                 dict(scale_tab=tab[1], shift_tab=tab[0], scale_emb=embt[:, D:], shift_emb=embt[:, :D], emb_stride=2 * D),   # per token
+                 dict()]                                                                                           # plain RMS norm
+        for kw in cases:
+            ref = KK.adaln_rmsnorm(x, **kw)
+            rc, rs = KK.quantize_rows_fp8(ref)
+            out, codes, scale = KK.adaln_rmsnorm_fp8(x, **kw)
+            assert torch.equal(out, ref) and torch.equal(codes, rc) and torch.equal(scale, rs)
+            _, codes2, scale2 = KK.adaln_rmsnorm_fp8(x, want_bf16=False, **kw)
+            assert torch.equal(codes2, rc) and torch.equal(scale2, rs)
+
+
+def test_gemm_fp8_fused_vt_matches_transpose_pass(dev):
+    """The fp8 QKV projection writes attention's V^T operand from its epilogue like the bf16 kernel does: identical to the same GEMM
+    followed by ltx2_vt_transpose."""
+    import ltx_2_mlx_amd.kernels as KK
+    from ltx_2_mlx_amd import _native as nv
+    g = torch.Generator().manual_seed(9)
+    M, H, hd = 3456, 8, 128
+    D = H * hd
+    a = torch.randn(M, D, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(torch.bfloat16).to(dev)
+    b = torch.randn(3 * D, generator=g).to(dev)
+    a8, asc = KK.quantize_rows_fp8(a)
+    w8, wsc = KK.quantize_rows_fp8(w)
+    full = KK.gemm_fp8(a8, asc, w8, wsc, b, epilogue=nv.EPI_BF16)
+    vt_ref = KK.vt_transpose(full[:, 2 * D:], H, head_dim=hd)
+    out, vt, fused = KK.gemm_fp8_qkv_vt(a8, asc, w8, wsc, b, H, hd)
+    assert fused and torch.equal(out[:, :2 * D], full[:, :2 * D]) and torch.equal(vt, vt_ref)

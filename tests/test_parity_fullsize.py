@@ -15,6 +15,9 @@ from test_parity import inputs, make_dit, make_vae, pearson
 
 pytestmark = pytest.mark.gpu
 
+# accuracy contract of the opt-in fp8-compute mode against the fp32 oracle (48-layer full-width x0)
+FP8_COMPUTE_REL_L2, FP8_COMPUTE_PEARSON = 0.10, 0.995       # measured: 0.045-0.073 / 0.9974-0.9990
+
 
 def dit_weights_on_gpu(cfg, dev, seed):
     """oracle.dit.make_dit_weights' recipe with the tensors drawn on the GPU (19 G parameters are minutes of host RNG);
@@ -47,6 +50,7 @@ def test_dit_48_layer_step(dev):
     m = LTXModel(num_layers=48, device=dev)
     m.load_state_dict(w)
     lat, ctx, pos = inputs(9, 16, 24, 1024, 3840, seed=49)
+    refs = {}
     for sigma in (1.0, 0.421875):
         ts = torch.tensor([sigma])
         with torch.device(dev), torch.no_grad():
@@ -54,7 +58,23 @@ def test_dit_48_layer_step(dev):
         x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=pos.to(dev)))
         assert x0.shape == (1, 3456, 128)
         assert rel_l2(x0.cpu(), ref) < 3e-2 and pearson(x0.cpu(), ref) > 0.999, sigma
-    del w, m
+        refs[sigma] = ref
+    # BASELINE config 3 as an opt-in fp8-COMPUTE step (fp8 MFMA, e4m3fn weights per output channel + per-token e4m3fn activations in the
+    # six projections of every block): same weights, same inputs, against the same fp32 oracle.  Tolerance of THIS mode (stated in
+    # DESIGN.md): it must stay far above the reference's own acceptance bar against upstream (Pearson >= 0.95, reference
+    # tests/test_parity.py:38).
+    del m
+    torch.cuda.empty_cache()
+    m8 = LTXModel(num_layers=48, device=dev, fp8_compute=True)
+    m8.load_state_dict(w)
+    assert m8.weight_tensors()["transformer_blocks.0.ff.net.2.weight"].dtype == torch.uint8
+    for sigma, ref in refs.items():
+        ts = torch.tensor([sigma])
+        x8 = X0Model(m8)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=pos.to(dev)))
+        e, r = rel_l2(x8.cpu(), ref), pearson(x8.cpu(), ref)
+        print(f"fp8 compute, 48 layers, sigma {sigma}: rel-L2 {e:.4f}, Pearson {r:.5f}")
+        assert e < FP8_COMPUTE_REL_L2 and r > FP8_COMPUTE_PEARSON, (sigma, e, r)
+    del w, m8
     torch.cuda.empty_cache()
 
 
