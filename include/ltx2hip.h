@@ -83,6 +83,22 @@ int ltx2_gemm_qkv_vt(const void* A, int64_t lda, const void* W, const float* bia
 int ltx2_gemm_w8a16(const void* A, int64_t lda, const void* W8, const float* wscale, const float* bias, void* out, int64_t ldo, int M,
                     int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table, void* stream);
 
+/* Which kernel ltx2_gemm_bf16 / ltx2_gemm_w8a16 / ltx2_gemm_fp8 (weights = 0 / 1 / 2) would run for a dense M x N x K problem with
+ * this epilogue -- host logic only, nothing is launched, no GPU needed.  Returns LTX2_ROUTE_* (negative: unsupported), OR-ed with
+ * 0x100 when has_vt != 0 and the fused-QKV V^T output (ltx2_gemm_qkv_vt with N = 3 * inner_dim) would come from the GEMM's own epilogue.
+ * The dispatch is a parity surface: tests pin the route of every GEMM the models issue.                                  */
+#define LTX2_ROUTE_SKINNY 0     /* gemm_skinny.hip: M <= 128 rows, weight streaming                         */
+#define LTX2_ROUTE_V4_224 1     /* gemm_v4.hip, generated asm K loop, 224 x 256 tiles                       */
+#define LTX2_ROUTE_V4_256 2     /*                                    256 x 256 tiles                       */
+#define LTX2_ROUTE_V4_W8_224 3  /* ... fp8-resident weights expanded to bf16 in the loop                     */
+#define LTX2_ROUTE_V4_W8_256 4
+#define LTX2_ROUTE_V4_F8_224 5  /* ... fp8 compute (v_mfma_f32_32x32x64_f8f6f4)                             */
+#define LTX2_ROUTE_V4_F8_256 6
+#define LTX2_ROUTE_PP 7         /* gemm_pp.hip: 256 x 256 ping-pong                                         */
+#define LTX2_ROUTE_SMALL 8      /* gemm.hip: 128 x 128                                                      */
+#define LTX2_ROUTE_NARROW 9     /* gemm.hip: 128 x 64 (N <= 64)                                             */
+int ltx2_gemm_route(int M, int N, int K, int epilogue, int weights, int has_vt);
+
 /* fp8 COMPUTE (BASELINE config 3, "fp8 weights (CDNA4 fp8 MFMA)"; opt-in, not the parity-exact default): both operands are
  * float8_e4m3fn codes, the products run on v_mfma_f32_32x32x64_f8f6f4 at twice the bf16 MFMA rate, fp32 accumulation;
  *   out = epilogue(ascale[m] * wscale[n] * sum_k f32(A8[m][k]) * f32(W8[n][k]) + bias[n]).

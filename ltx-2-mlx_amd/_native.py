@@ -21,6 +21,7 @@ OK, E_INVALID, E_HIP, E_STATE = 0, -1, -2, -3
 DTYPE_BF16, DTYPE_F32, DTYPE_FP8_E4M3FN = 0, 1, 2
 MODEL_VIDEO_ONLY, MODEL_AUDIO_VIDEO = 0, 1
 EPI_BF16, EPI_GELU_BF16, EPI_SILU_BF16, EPI_F32, EPI_RESID_GATE_F32, EPI_ADD_BF16 = range(6)
+ROUTE_SKINNY, ROUTE_V4_224, ROUTE_V4_256, ROUTE_V4_W8_224, ROUTE_V4_W8_256, ROUTE_V4_F8_224, ROUTE_V4_F8_256, ROUTE_PP, ROUTE_SMALL, ROUTE_NARROW = range(10)
 VAE_RES, VAE_UPSAMPLE = 0, 1
 VAE_MAX_BLOCKS = 16
 
@@ -49,6 +50,7 @@ SIGNATURES = {
     "ltx2_gemm_bf16": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp, i64, vp]),
     "ltx2_gemm_qkv_vt": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp]),
     "ltx2_gemm_w8a16": (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
+    "ltx2_gemm_route": (i32, [i32, i32, i32, i32, i32, i32]),
     "ltx2_quantize_rows_fp8": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),
     "ltx2_gemm_fp8": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
     "ltx2_gemm_fp8_qkv_vt": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp]),

@@ -583,22 +583,17 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
     }
-    // LTX2_ATTN_SK=0: plain grid everywhere (same-box A/B); 2: stream-K without dealing the heads to the XCDs.  On the DiT's
-    // self-attention the stream-K form is 5 % faster as a kernel (208 vs 220 us) and worth 0.45 ms on the 78 ms step -- less than
-    // the slot arithmetic promises (0.84 -> 1.0) because the socket sits at its 1400 W cap: a half-empty last round also runs at a
+    // On the DiT's self-attention the stream-K form is 5 % faster as a kernel (208 vs 220 us in round 2) and worth 0.45 ms on the step -- less
+    // than the slot arithmetic promises (0.84 -> 1.0) because the socket sits at its 1400 W cap: a half-empty last round also runs at a
     // higher clock.  Progress argument for the in-launch wait: a workgroup only ever waits on LOWER-numbered workgroups of its
     // group (same XCD when the heads are dealt), each XCD dispatches its workgroups in order, and the lowest-numbered unfinished
     // workgroup never waits on an unfinished one.
-    static const int sk_env = [] {
-        const char* e = getenv("LTX2_ATTN_SK");
-        return e ? atoi(e) : 1;
-    }();
     bool xcd = false;
-    const int workers = (p.sk_ws && (sk_env || p.sk_force)) ? sk_workers(p, &xcd) : 0;
+    const int workers = p.sk_ws ? sk_workers(p, &xcd) : 0;
     if (workers > 0) {
         LTX2_CHECK_ARG(workers < 1024 && p.sk_ws_bytes >= attn_sk_workspace_bytes(p.head_dim), "attention: stream-K workspace too small");
         AttnParams q = p;
-        q.sk_xcd = xcd && sk_env != 2;
+        q.sk_xcd = xcd;
         q.sk_flags = (unsigned*)p.sk_ws;
         q.sk_ws = (char*)p.sk_ws + 4096;
         if (p.head_dim == 64)

@@ -45,6 +45,37 @@ int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
     return gemm_launch(p, epilogue, false, (hipStream_t)stream);
 }
 
+int ltx2_gemm_route(int M, int N, int K, int epilogue, int weights, int has_vt) {
+    // host logic only: addresses are never dereferenced (16-byte aligned dummies satisfy the alignment checks)
+    static const long dummy[2] = {0, 0};
+    GemmParams p{};
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.lda = K;
+    p.ldo = N;
+    p.out = (void*)dummy;
+    if (weights == 2) {
+        p.A8 = (const unsigned char*)dummy;
+        p.ascale = (const float*)dummy;
+    } else {
+        p.A = (const bf16*)dummy;
+    }
+    if (weights >= 1) {
+        p.W8 = (const unsigned char*)dummy;
+        p.wscale = (const float*)dummy;
+    } else {
+        p.W = (const bf16*)dummy;
+    }
+    const int r = gemm_route(p, epilogue, false);
+    if (!has_vt || r < 0) return r;
+    p.vt = (bf16*)dummy;
+    p.vt_col0 = 2 * (N / 3);
+    p.vt_hd = (N / 3) % 128 == 0 ? 128 : 64;
+    p.vt_npad = (M + 63) / 64 * 64;
+    return r | (gemm_vt_fused(p, epilogue) ? 0x100 : 0);
+}
+
 int ltx2_quantize_rows_fp8(const void* x, int64_t ldx, int rows, int K, void* codes, int64_t ldo, float* scale, void* stream) {
     LTX2_CHECK_ARG(x && codes && scale, "quantize_rows_fp8: null argument");
     return quant_rows_fp8_launch((const bf16*)x, ldx, rows, K, (unsigned char*)codes, ldo, scale, (hipStream_t)stream);

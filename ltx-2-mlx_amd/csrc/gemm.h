@@ -40,13 +40,27 @@ struct GemmParams {
     bf16* vt;
     long vt_head_stride;
     int vt_col0, vt_npad, vt_hd;
-    int v4_direct_resid; // gemm_v4.hip: 1 = the gated fp32-residual epilogue touches x straight from the accumulator layout (LTX2_V4_RESID_LDS=0, A/B)
-    int v4_full_tiles;   // gemm_v4.hip: 1 = the ragged last row tile runs the full-height K loop (LTX2_V4_SHORT=0, same-box A/B)
     int splitk;          // gemm_v4.hip: K split over this many blocks per tile (fp32 slabs + reduce); 0 / 1 = off
     void* dbg;           // ping-pong kernel: optional device buffer for interval timestamps (debug)      // ping-pong kernel: which wave bit selects the staggered group (tuning knob)
 };
 
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream);
+// Which kernel gemm_launch hands this problem to (host logic only, nothing is launched): the dispatch is a parity surface, so
+// tests/test_host_cpu.py enumerates every GEMM the three models issue and pins its route.
+enum GemmRoute {
+    ROUTE_INVALID = -1,
+    ROUTE_SKINNY = 0,      // gemm_skinny.hip: M <= 128 rows (the audio stream), weight-streaming
+    ROUTE_V4_224 = 1,      // gemm_v4.hip layout 3, 224-row tiles (the DiT's big GEMMs)
+    ROUTE_V4_256 = 2,      // gemm_v4.hip layout 3, 256-row tiles
+    ROUTE_V4_W8_224 = 3,   // ... with fp8-resident weights expanded in the loop
+    ROUTE_V4_W8_256 = 4,
+    ROUTE_V4_F8_224 = 5,   // gemm_v4.hip layout 5: fp8 compute
+    ROUTE_V4_F8_256 = 6,
+    ROUTE_PP = 7,          // gemm_pp.hip: 256x256 ping-pong (big grids the asm-loop kernel does not take; convs of the upscaler / encoder)
+    ROUTE_SMALL = 8,       // gemm.hip 128x128
+    ROUTE_NARROW = 9       // gemm.hip 128x64 (N <= 64)
+};
+int gemm_route(const GemmParams& p, int epilogue, bool conv);
 // p.vt set: will gemm_launch route this problem to the kernel that writes V^T from its epilogue?  (false: clear p.vt and run
 // vt_transpose_launch after the GEMM; gemm_launch rejects a p.vt it cannot honour.)
 bool gemm_vt_fused(const GemmParams& p, int epilogue);

@@ -244,41 +244,40 @@ inline bool v4_wins_medium_grid(const GemmParams& p) {
     return t_v4 < t_small;
 }
 
-// LTX2_V4_LAYOUT = 0 | 1 | 2 | 3 selects the wave layout of the 4-wave asm-loop kernel (gemm_v4.hip; default 3), -1 disables it
-inline int v4_layout() {
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("LTX2_V4_LAYOUT");
-        v = e ? atoi(e) : 3;
-        if (v < -1 || v > 3) v = 3;
-    }
-    return v;
+// 224-row tiles when they need fewer CU-rounds of work than 256-row tiles (gemm_v4.hip makes the same choice)
+inline bool prefer_224(const GemmParams& p) {
+    const long nt = p.N / 256, cus = 256;
+    const long t256 = ((long)(p.M + 255) / 256) * nt, t224 = ((long)(p.M + 223) / 224) * nt;
+    return (t224 + cus - 1) / cus * 224 < (t256 + cus - 1) / cus * 256;
 }
 
-// 0 = heuristic, 1 = force 128x128, 2 = force plain 256x256, 3 = force ping-pong 256x256 (A/B testing)
-inline int tile_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LTX2_GEMM_TILE");
-        v = 0;
-        if (e && !strcmp(e, "small")) v = 1;
-        if (e && !strcmp(e, "big")) v = 2;
-        if (e && !strcmp(e, "pp")) v = 3;
-        if (e && !strcmp(e, "nonarrow")) v = 7;
+// The whole dispatch, as data: gemm_launch follows it, ltx2_gemm_route reports it (round 3: the LTX2_GEMM_TILE / LTX2_V4_LAYOUT /
+// LTX2_PP_BM / LTX2_VT_FUSE overrides are gone -- same-box A/B runs load a second build through LTX2HIP_LIB instead).
+template <bool CONV>
+int route_of(const GemmParams& p, int epi) {
+    if (p.A8) return gemm_v4_f8_supported(p, epi) ? (prefer_224(p) ? ROUTE_V4_F8_224 : ROUTE_V4_F8_256) : ROUTE_INVALID;
+    if (p.W8) {
+        if (CONV) return ROUTE_INVALID;
+        if (gemm_skinny_supported(p, epi)) return ROUTE_SKINNY;
+        return gemm_v4_w8_supported(p, epi) ? (prefer_224(p) ? ROUTE_V4_W8_224 : ROUTE_V4_W8_256) : ROUTE_INVALID;
     }
-    return v;
+    if (!CONV && epi != EPI_D2S_BF16 && gemm_skinny_supported(p, epi)) return ROUTE_SKINNY;      // M <= 128: the audio stream
+    if (!CONV && (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_supported(p, epi, CONV)) return prefer_224(p) ? ROUTE_V4_224 : ROUTE_V4_256;
+    if (use_big_tile(p)) return ROUTE_PP;
+    if (p.N <= 64 && p.M >= 4096) return ROUTE_NARROW;
+    return ROUTE_SMALL;
 }
 
 template <int EPI, bool CONV>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-    const int ov = tile_override();
-    if (ov == 2) return launch_cfg<CfgBig, EPI, CONV>(p, stream);
-    if (ov == 1) return launch_cfg<CfgSmall, EPI, CONV>(p, stream);
-    if (ov == 0 && !CONV && EPI != EPI_D2S_BF16 && gemm_skinny_supported(p, EPI)) return gemm_skinny_launch(p, EPI, stream);      // M <= 128: the audio stream
-    if (ov == 0 && !CONV && v4_layout() >= 0 && (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_supported(p, EPI, CONV)) return gemm_v4_launch(p, EPI, stream, v4_layout(), 0);
-    if (ov == 3 || use_big_tile(p)) return gemm_pp_launch(p, EPI, CONV, stream);
-    if (p.N <= 64 && p.M >= 4096 && ov != 7) return launch_cfg<CfgNarrow, EPI, CONV>(p, stream);
-    return launch_cfg<CfgSmall, EPI, CONV>(p, stream);
+    switch (route_of<CONV>(p, EPI)) {
+        case ROUTE_SKINNY: return gemm_skinny_launch(p, EPI, stream);
+        case ROUTE_V4_224: return gemm_v4_launch(p, EPI, stream, 3, 224);
+        case ROUTE_V4_256: return gemm_v4_launch(p, EPI, stream, 3, 256);
+        case ROUTE_PP: return gemm_pp_launch(p, EPI, CONV, stream);
+        case ROUTE_NARROW: return launch_cfg<CfgNarrow, EPI, CONV>(p, stream);
+        default: return launch_cfg<CfgSmall, EPI, CONV>(p, stream);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,16 +331,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ a, 
 }  // namespace
 
 bool gemm_vt_fused(const GemmParams& p, int epilogue) {
-    static const bool on = [] {
-        const char* e = getenv("LTX2_VT_FUSE");       // 0: always the separate transpose pass (same-box A/B)
-        return !e || atoi(e) != 0;
-    }();
-    if (!on || !p.vt || p.lda % 8 != 0) return false;
+    if (!p.vt || p.lda % 8 != 0) return false;
     if (p.A8) return gemm_v4_vt_supported(p, epilogue, 5);
-    if (tile_override() == 0 && gemm_skinny_supported(p, epilogue)) return false;      // M <= 128 goes to the skinny kernel
+    if (gemm_skinny_supported(p, epilogue)) return false;      // M <= 128 goes to the skinny kernel
     if (p.W8) return gemm_v4_vt_supported(p, epilogue, 3);
-    return tile_override() == 0 && v4_layout() == 3 && (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_vt_supported(p, epilogue, 3);
+    return (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_vt_supported(p, epilogue, 3);
 }
+
+int gemm_route(const GemmParams& p, int epilogue, bool conv) { return conv ? route_of<true>(p, epilogue) : route_of<false>(p, epilogue); }
 
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream) {
     LTX2_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
@@ -354,7 +351,7 @@ int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream
     LTX2_CHECK_ARG(p.A && (p.W || p.W8) && p.out, "gemm: null operand");
     if (p.W8) {     // fp8-resident weights: the 4-wave asm-loop kernel, or the skinny-M kernel where the bf16 path would take it too
         LTX2_CHECK_ARG(!conv && p.lda % 8 == 0, "gemm: fp8-resident weights are dense-only");
-        if (tile_override() == 0 && gemm_skinny_supported(p, epilogue)) return gemm_skinny_launch(p, epilogue, stream);
+        if (gemm_skinny_supported(p, epilogue)) return gemm_skinny_launch(p, epilogue, stream);
         return gemm_v4_launch(p, epilogue, stream, 3, 0);
     }
     LTX2_CHECK_ARG(p.N % 4 == 0 && p.ldo % 4 == 0 && p.ldres % 4 == 0 && p.gate_stride % 4 == 0,

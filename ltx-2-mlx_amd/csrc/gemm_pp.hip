@@ -437,13 +437,6 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
 
 // 224-row tiles when they need fewer CU-rounds of work than 256-row tiles (dense GEMMs only).
 bool prefer_224(const GemmParams& p) {
-    static int ov = -1;     // LTX2_PP_BM=256|224 forces one variant (tuning / tests)
-    if (ov < 0) {
-        const char* e = getenv("LTX2_PP_BM");
-        ov = e ? atoi(e) : 0;
-    }
-    if (ov == 224) return true;
-    if (ov == 256) return false;
     const long nt = (p.N + TBN - 1) / TBN, cus = 256;
     const long t256 = ((long)(p.M + 255) / 256) * nt, t224 = ((long)(p.M + 223) / 224) * nt;
     const long cost256 = (t256 + cus - 1) / cus * 256, cost224 = (t224 + cus - 1) / cus * 224;
@@ -454,11 +447,6 @@ bool prefer_224(const GemmParams& p) {
 
 int gemm_pp_launch(const GemmParams& p_in, int epilogue, bool conv, hipStream_t stream) {
     GemmParams p = p_in;
-    {
-        static const char* d = getenv("LTX2_PP_DBG");      // read once: this launcher sits on the denoise hot path
-        static void* dbg = d ? (void*)strtoull(d, nullptr, 0) : nullptr;
-        p.dbg = dbg;
-    }
     const bool b224 = !conv && prefer_224(p);
 #define CASE(E)                                                                            \
     case E:                                                                                \

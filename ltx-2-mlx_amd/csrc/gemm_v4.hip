@@ -1,10 +1,7 @@
 // 4-wave bf16 MFMA GEMM / implicit-GEMM conv3d for gfx950 with a hand-scheduled K loop: one wave per SIMD, accumulators in
 // AGPRs.  The whole K loop is ONE asm block generated and order-checked by gen_gemm_v4.py (gemm_v4_loop.inc): hipcc schedules
 // nothing in it.  Wave layouts (template LAYOUT), tile BM x BN x 64:
-//   0  BN 256, 1x4 waves, v_mfma_f32_32x32x16_bf16: wave w owns columns [64w, 64w+64) and all 7|8 row blocks
-//   1  BN 256, 2x2 waves, 32x32x16: wave (wr, wc) owns a 128 x 128 quadrant (with 224-row tiles the second wave row owns
-//      96 rows and runs a shorter program with the same barriers)
-//   2  BN 256, 2x2 waves, v_mfma_f32_16x16x32_bf16: 8 x 8 blocks of 16 (6 x 8 for the second wave row of a 224-row tile)
+//   (0-2: round 2's 1x4 / 2x2 layouts on 32x32x16 and 2x2 on 16x16x32 -- deleted in round 3, they lost every same-box comparison)
 //   3  BN 256, 1x4 waves, 16x16x32: 14|16 x 4 blocks of 16 (BM 224|256; balanced for 224 rows) -- the DiT default
 //   4  BN 128, 4x1 waves, 16x16x32: wave w owns rows [BM/4 w, +BM/4) x all 128 columns, 7|8 x 8 blocks (BM 448|512) -- the
 //      VAE decoder's 128-channel convs
@@ -42,10 +39,11 @@ typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 template <int LAYOUT, int BM, bool W8 = false>
 struct V4Geo {
     static constexpr int BN = LAYOUT == 4 ? 128 : 256;
-    static constexpr int MB = (LAYOUT >= 2 && LAYOUT != 5) ? 16 : 32;               // MFMA block
-    static constexpr bool L14 = LAYOUT == 0 || LAYOUT == 3 || LAYOUT == 5;        // 1x4 waves
-    static constexpr int WM = LAYOUT == 4 ? BM / 4 : (L14 ? BM : 128);
-    static constexpr int WN = LAYOUT == 4 ? 128 : (L14 ? 64 : 128);
+    static_assert(LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5, "wave layout");
+    static constexpr int MB = LAYOUT == 5 ? 32 : 16;               // MFMA block
+    static constexpr bool L14 = LAYOUT != 4;                       // 1x4 waves (layout 4: 4x1)
+    static constexpr int WM = LAYOUT == 4 ? BM / 4 : BM;
+    static constexpr int WN = LAYOUT == 4 ? 128 : 64;
     static constexpr int RBW = (WM + MB - 1) / MB, CBW = WN / MB;  // blocks per wave (first wave row)
     static constexpr int NKS = MB == 16 ? 2 : 4;
     static constexpr int WROW = W8 ? 64 : 128;                     // bytes of one weight row per K-tile (fp8 codes / bf16)
@@ -61,18 +59,17 @@ struct V4Geo {
 
 template <int EPI, int LAYOUT, int BM, bool CONV, int VAR>
 __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
-    static_assert(LAYOUT >= 0 && LAYOUT <= 5, "wave layout");
     constexpr bool W8 = VAR == 20;          // fp8-resident weights: p.W8 codes [N][K] + p.wscale[N]
     constexpr bool F8 = LAYOUT == 5;        // fp8 compute: p.A8 codes [M][lda] + p.ascale[M], p.W8 codes [N][K] + p.wscale[N]
     using G = V4Geo<LAYOUT, BM, W8>;
     constexpr int TBN = G::BN, NPA = G::NPA, NPW = G::NPW, MB = G::MB, WM = G::WM, WN = G::WN, RBW = G::RBW, CBW = G::CBW, NKS = G::NKS;
-    static_assert(!CONV || LAYOUT >= 3, "conv runs on the 16x16x32 layouts");
+    static_assert(!CONV || LAYOUT != 5, "conv runs on the 16x16x32 layouts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = LAYOUT == 4 ? w : (G::L14 ? 0 : (w >> 1)), wc = LAYOUT == 4 ? 0 : (G::L14 ? w : (w & 1));
+    const int wr = LAYOUT == 4 ? w : 0, wc = LAYOUT == 4 ? 0 : w;
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_k0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -101,7 +98,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     // rows (6 of 14 for 3456 rows, 10 of 14 for 13824) -- fewer DMA pieces per wave, so the wave -> tile-row mapping shrinks with it
     constexpr bool SHORT_OK = LAYOUT == 3 && BM == 224 && !CONV;
     const int valid_rows = p.M - m0;
-    const int short_rb = (!SHORT_OK || p.v4_full_tiles) ? 0 : valid_rows <= 96 ? 6 : valid_rows <= 160 ? 10 : 0;      // block-uniform
+    const int short_rb = !SHORT_OK ? 0 : valid_rows <= 96 ? 6 : valid_rows <= 160 ? 10 : 0;      // block-uniform
     const int npa_rt = short_rb ? short_rb / 2 : NPA;
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
@@ -226,52 +223,25 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             if constexpr (BM == 448) V4_ASM_CONV(LTX2_V4_L41_M16_RB7_CONV);
             else V4_ASM_CONV(LTX2_V4_L41_M16_RB8_CONV);
         }
-    } else if constexpr (LAYOUT == 0) {
-        if constexpr (BM == 224) V4_ASM(LTX2_V4_L14_RB7);
-        else {
-#ifdef LTX2_V4_PROBE
-            if constexpr (VAR == 1) V4_ASM(LTX2_V4_L14_RB8_NODMA);
-            else if constexpr (VAR == 2) V4_ASM(LTX2_V4_L14_RB8_NOREAD);
-            else
-#endif
-                V4_ASM(LTX2_V4_L14_RB8);
-        }
-    } else if constexpr (LAYOUT == 1) {
-        if constexpr (BM == 224) {
-            if (wr == 0) V4_ASM(LTX2_V4_L22_RB4_224);
-            else V4_ASM(LTX2_V4_L22_RB3_224);
-        } else {
-            V4_ASM(LTX2_V4_L22_RB4);
-        }
     } else if constexpr (LAYOUT == 3) {
         if constexpr (BM == 224) {
             if (short_rb == 6) V4_ASM(LTX2_V4_L14_M16_RB6);
             else if (short_rb == 10) V4_ASM(LTX2_V4_L14_M16_RB10);
             else V4_ASM(LTX2_V4_L14_M16_RB14);
-        } else V4_ASM(LTX2_V4_L14_M16_RB16);
+        } else {
+#ifdef LTX2_V4_PROBE
+            if constexpr (VAR == 1) V4_ASM(LTX2_V4_L14_M16_RB16_NODMA);
+            else if constexpr (VAR == 2) V4_ASM(LTX2_V4_L14_M16_RB16_NOREAD);
+            else
+#endif
+                V4_ASM(LTX2_V4_L14_M16_RB16);
+        }
     } else if constexpr (LAYOUT == 4) {
         if constexpr (BM == 448) V4_ASM(LTX2_V4_L41_M16_RB7);
         else V4_ASM(LTX2_V4_L41_M16_RB8);
-    } else if constexpr (LAYOUT == 5) {     // VAR 1: the v_mfma_scale_* form with unit block scales (same arithmetic; A/B timing)
-        if constexpr (BM == 224) {
-            if constexpr (VAR == 1) V4_ASM(LTX2_V4_F8_RB7_SC);
-            else V4_ASM(LTX2_V4_F8_RB7);
-        } else {
-            if constexpr (VAR == 1) V4_ASM(LTX2_V4_F8_RB8_SC);
-            else V4_ASM(LTX2_V4_F8_RB8);
-        }
-    } else {
-        if constexpr (BM == 224) {
-            if (wr == 0) V4_ASM(LTX2_V4_L22_M16_RB8_224);
-            else V4_ASM(LTX2_V4_L22_M16_RB6_224);
-        } else {
-#ifdef LTX2_V4_PROBE
-            if constexpr (VAR == 1) V4_ASM(LTX2_V4_M16_NODMA);
-            else if constexpr (VAR == 2) V4_ASM(LTX2_V4_M16_NOREAD);
-            else
-#endif
-                V4_ASM(LTX2_V4_L22_M16_RB8);
-        }
+    } else {                                // layout 5: fp8 x fp8
+        if constexpr (BM == 224) V4_ASM(LTX2_V4_F8_RB7);
+        else V4_ASM(LTX2_V4_F8_RB8);
     }
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
@@ -324,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     };
     constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_SILU_BF16;
     constexpr bool RESID_LDS_OK = EPI == EPI_RESID_GATE_F32 && (LAYOUT == 3 || LAYOUT == 5) && VAR != 9;
-    const bool resid_lds = RESID_LDS_OK && !(p.gate && p.gate_stride != 0) && !p.v4_direct_resid;      // block-uniform
+    const bool resid_lds = RESID_LDS_OK && !(p.gate && p.gate_stride != 0);      // block-uniform
     if constexpr (RESID_LDS_OK) {
       if (resid_lds) {
         // x += gate * (acc + bias) with a ROW-INVARIANT gate (scalar sigma), through LDS: a lane's accumulator groups are 4 columns
@@ -543,18 +513,7 @@ int launch_v4(const GemmParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     }
     const int Mt = (p.M + BM - 1) / BM, Nt = p.N / G::BN;
-    static const bool full_tiles = [] {
-        const char* e = getenv("LTX2_V4_SHORT");
-        return e && atoi(e) == 0;
-    }();
-    static const bool direct_resid = [] {
-        const char* e = getenv("LTX2_V4_RESID_LDS");
-        return e && atoi(e) == 0;
-    }();
-    GemmParams q = p;
-    q.v4_full_tiles = full_tiles;
-    q.v4_direct_resid = direct_resid;
-    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt * (p.splitk > 1 ? p.splitk : 1)), dim3(256), G::LDS_BYTES, stream, q);
+    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt * (p.splitk > 1 ? p.splitk : 1)), dim3(256), G::LDS_BYTES, stream, p);
     LTX2_CHECK_LAUNCH("gemm_v4_kernel");
     return LTX2_OK;
 }
@@ -622,18 +581,13 @@ bool gemm_v4_f8_supported(const GemmParams& p, int epilogue) {
     return true;
 }
 
-// layout: 0..4 (see the file comment); bm: 0 = pick, 224 | 256 (layouts 0-3), 448 | 512 (layout 4)
+// layout: 3 | 4 | 5 (see the file comment); bm: 0 = pick, 224 | 256 (layouts 3, 5), 448 | 512 (layout 4)
 int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int layout, int bm) {
     if (p.A8) {     // fp8 compute: layout 5
         LTX2_CHECK_ARG(gemm_v4_f8_supported(p, epilogue), "gemm_v4: fp8 compute needs A8 + ascale + W8 + wscale, N %% 256 == 0, K %% 256 == 0, K >= 512, a dense bf16/gelu/f32/residual epilogue (N=%d K=%d epilogue=%d)", p.N, p.K, epilogue);
         const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
-        static const int sc = [] {
-            const char* e = getenv("LTX2_F8_SCALED");
-            return e ? atoi(e) : 0;
-        }();
-#define CASEF(E)                                                                                                                      \
-    case E:                                                                                                                           \
-        if (sc) return b224 ? launch_v4<E, 5, 224, false, 1>(p, stream) : launch_v4<E, 5, 256, false, 1>(p, stream);                  \
+#define CASEF(E) \
+    case E:      \
         return b224 ? launch_v4<E, 5, 224>(p, stream) : launch_v4<E, 5, 256>(p, stream);
         switch (epilogue) {
             CASEF(EPI_BF16)
@@ -675,13 +629,10 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
 #undef CASE4
     }
     const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
-#define CASE_L(E, L) return b224 ? launch_v4<E, L, 224>(p, stream) : launch_v4<E, L, 256>(p, stream);
-#define CASE(E)                           \
-    case E:                               \
-        if (layout == 0) { CASE_L(E, 0) } \
-        if (layout == 1) { CASE_L(E, 1) } \
-        if (layout == 3) { CASE_L(E, 3) } \
-        CASE_L(E, 2)
+    LTX2_CHECK_ARG(layout == 3, "gemm_v4: wave layout %d (3 = bf16 dense, 4 = 128-column convs, 5 = fp8 compute)", layout);
+#define CASE(E) \
+    case E:     \
+        return b224 ? launch_v4<E, 3, 224>(p, stream) : launch_v4<E, 3, 256>(p, stream);
     switch (epilogue) {
         CASE(EPI_BF16)
         CASE(EPI_GELU_BF16)
@@ -694,7 +645,6 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
             return LTX2_E_INVALID;
     }
 #undef CASE
-#undef CASE_L
 }
 
 // Implicit-GEMM 3x3x3 (or per-frame 3x3) conv over a PADDED channels-last activation volume: p.A = [T+2][H+2][Wd+2][Cin] with
@@ -756,10 +706,10 @@ int gemm_v4_conv_launch(const GemmParams& p_in, int epilogue, hipStream_t stream
 }
 
 #ifdef LTX2_V4_PROBE
-// ablations of the 256-row kernels: var 1 = no DMA in the loop, 2 = no fragment reads; layout 3: var 9 = direct (untransposed) epilogue
+// ablations of the 256-row DiT kernel: var 1 = no DMA in the loop, 2 = no fragment reads, 9 = direct (untransposed) epilogue
 int gemm_v4_probe_launch(const GemmParams& p, int layout, int var, hipStream_t stream) {
-    if (layout == 0) return var == 1 ? launch_v4<EPI_BF16, 0, 256, false, 1>(p, stream) : launch_v4<EPI_BF16, 0, 256, false, 2>(p, stream);
-    if (layout == 3) return launch_v4<EPI_BF16, 3, 224, false, 9>(p, stream);
-    return var == 1 ? launch_v4<EPI_BF16, 2, 256, false, 1>(p, stream) : launch_v4<EPI_BF16, 2, 256, false, 2>(p, stream);
+    (void)layout;
+    if (var == 9) return launch_v4<EPI_BF16, 3, 224, false, 9>(p, stream);
+    return var == 1 ? launch_v4<EPI_BF16, 3, 256, false, 1>(p, stream) : launch_v4<EPI_BF16, 3, 256, false, 2>(p, stream);
 }
 #endif

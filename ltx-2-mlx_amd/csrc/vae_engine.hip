@@ -81,15 +81,7 @@ Plan plan_sizes(const ltx2_vae_config& cfg, int T, int H, int W) {
     return Plan{mx, T, H, W, (int)ch};
 }
 
-// LTX2_VAE_V4=0 keeps every conv on the tap-iterator kernels (A/B testing)
-bool vae_v4_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LTX2_VAE_V4");
-        v = e ? atoi(e) : 1;
-    }
-    return v != 0;
-}
+bool vae_v4_enabled() { return true; }     // (round 2's LTX2_VAE_V4=0 switch back to the tap-iterator kernels is gone)
 
 GemmParams conv_params(const bf16* x, const bf16* w, const float* b, void* out, int T, int H, int W, int Cin, int Cout, int causal,
                        const bf16* res) {

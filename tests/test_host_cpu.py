@@ -607,3 +607,51 @@ def test_one_stage_config_and_guidance_gate():
         a.update(bad)
         with pytest.raises(NotImplementedError):
             gate(**a)
+
+
+def test_gemm_dispatch_routes_of_every_model_gemm():
+    """every dispatch branch is a parity surface.  The route of EVERY dense GEMM the three models issue at the BASELINE
+    geometry (19B VideoOnly at 768x512x65 and at the two-stage 1536x1024x65 size, AudioVideo 19B-style and LTX-2.3) is pinned, for bf16
+    weights, fp8-resident weights and the fp8 compute mode -- so kernel work cannot silently strand a shape on a slow path.  Host logic
+    only (ltx2_gemm_route launches nothing)."""
+    from ltx_2_mlx_amd import _native as nv
+    L = nv.lib()
+    R = {k: getattr(nv, k) for k in dir(nv) if k.startswith("ROUTE_")}
+    name = {v: k for k, v in R.items()}
+    BF, GELU, F32, RES = nv.EPI_BF16, nv.EPI_GELU_BF16, nv.EPI_F32, nv.EPI_RESID_GATE_F32
+
+    def route(M, N, K, epi, weights=0, vt=0):
+        r = L.ltx2_gemm_route(M, N, K, epi, weights, vt)
+        return (name.get(r & 0xff, r), bool(r & 0x100)) if r >= 0 else ("INVALID", False)
+
+    D, Da, S, cap = 4096, 2048, 1024, 3840
+    for N in (3456, 13824):                          # 768x512x65 and the stage-2 grid of 1536x1024x65
+        layer = [("attn1.to_qkv", N, 3 * D, D, BF, 1), ("attn1.to_out", N, D, D, RES, 0), ("attn2.to_q", N, D, D, BF, 0),
+                 ("attn2.to_out", N, D, D, RES, 0), ("ff.net.0", N, 4 * D, D, GELU, 0), ("ff.net.2", N, D, 4 * D, RES, 0)]
+        for nm, M, Nn, K, epi, vt in layer:
+            # 224-row tiles wherever they need fewer CU-rounds than 256-row tiles: everywhere but the 13824 x 16384 grid (a tie -> 256)
+            t = "256" if (N == 13824 and Nn == 4 * D) else "224"
+            assert route(M, Nn, K, epi, 0, vt) == ("ROUTE_V4_" + t, bool(vt)), (nm, N)
+            assert route(M, Nn, K, epi, 1, vt) == ("ROUTE_V4_W8_" + t, bool(vt)), (nm, N)       # fp8-resident weights
+            assert route(M, Nn, K, epi, 2, vt) == ("ROUTE_V4_F8_" + t, bool(vt)), (nm, N)       # fp8 compute
+        assert route(N, D, 128, F32)[0] == "ROUTE_PP"                    # patchify_proj: K = 128 is below the asm loop's minimum
+        assert route(N, 128, D, F32)[0] == "ROUTE_SMALL"                 # proj_out: 128 output channels
+        assert route(N, D, 256, nv.EPI_SILU_BF16)[0] == "ROUTE_V4_224"   # per-token AdaLN MLP (image conditioning)
+        assert route(N, 6 * D, D, F32)[0] == ("ROUTE_V4_224" if N == 3456 else "ROUTE_V4_256")
+    # per-prompt setup (S = 1024 text tokens): caption projection on the 128x128 tile, the fused text K/V projection on the asm-loop kernel
+    assert route(S, D, cap, GELU)[0] == "ROUTE_SMALL" and route(S, D, D, BF)[0] == "ROUTE_SMALL"
+    assert route(S, 2 * D, D, BF)[0] == "ROUTE_V4_224" and route(S, 2 * D, D, BF, 1)[0] == "ROUTE_V4_W8_224"
+    # AudioVideo: the 68-token audio stream streams its weights (skinny kernel); cross-modal projections of the video tokens
+    Na = 68
+    for nm, M, Nn, K, epi in [("audio qkv", Na, 3 * Da, Da, BF), ("audio to_out", Na, Da, Da, RES), ("audio ff1", Na, 4 * Da, Da, GELU),
+                              ("audio ff2", Na, Da, 4 * Da, RES), ("a2v kv", Na, 2 * Da, Da, BF), ("v2a q", Na, Da, Da, BF), ("v2a to_out", Na, Da, Da, RES)]:
+        assert route(M, Nn, K, epi)[0] == "ROUTE_SKINNY", nm
+    assert route(3456, Da, D, BF)[0] == "ROUTE_SMALL"                    # a2v query projection: 128 big tiles lose to the small tile (68 vs ~89 us)
+    assert route(3456, 2 * Da, D, BF)[0] == "ROUTE_V4_224"               # v2a K/V from the video tokens
+    assert route(3456, D, Da, RES)[0] == "ROUTE_V4_224"                  # a2v to_out
+    assert route(S, 2 * Da, Da, BF)[0] == "ROUTE_SMALL"                  # audio text K/V (LTX-2.3: per step)
+    # unsupported fp8 problems are refused, not rerouted
+    assert route(3456, 4096, 384, BF, 2)[0] == "INVALID" and route(3456, 200, 4096, BF, 1)[0] == "INVALID"
+    import re
+    src = "".join(open(os.path.join(ROOT, "ltx-2-mlx_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "ltx-2-mlx_amd", "csrc")) if f.endswith((".hip", ".h")))
+    assert set(re.findall(r'getenv\("(\w+)"\)', src)) == set(), "tuning switches belong in A/B builds (tools/ab_build.py + LTX2HIP_LIB), not in the product"
