@@ -13,8 +13,10 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LTX2HIP_LIB: another build of the same library (A/B timing of kernel changes on one GPU box)
+# LTX2HIP_LIB / LTX2HIP_LIB_F16: another build of the same library (A/B timing of kernel changes on one GPU box)
 LIB_PATH = os.environ.get("LTX2HIP_LIB") or os.path.join(_HERE, "lib", "libltx2hip.so")
+# the same sources compiled with -DLTX2_F16: IEEE-half activations / weights (the reference's default compute dtype)
+LIB_PATH_F16 = os.environ.get("LTX2HIP_LIB_F16") or os.path.join(_HERE, "lib", "libltx2hip_f16.so")
 
 ABI_VERSION = 2         # LTX2_ABI_VERSION of include/ltx2hip.h these signatures were written against
 OK, E_INVALID, E_HIP, E_STATE = 0, -1, -2, -3
@@ -110,42 +112,49 @@ SIGNATURES = {
     "ltx2_vae_out_frames": (i32, [vp, i32]),
 }
 
-_lib: Optional[C.CDLL] = None
+_libs: dict = {}
 
 
 class NativeLibraryMissing(RuntimeError):
     pass
 
 
-def lib() -> C.CDLL:
-    """Load libltx2hip.so (once).  Fails loudly if it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(dtype: Optional[torch.dtype] = None) -> C.CDLL:
+    """Load the library build for `dtype` (once): bfloat16 (default / None) -> libltx2hip.so, float16 -> libltx2hip_f16.so.  Both export
+    the same C ABI; dtype code DTYPE_BF16 means "the build's 16-bit type".  Fails loudly if it has not been built."""
+    key = torch.float16 if dtype == torch.float16 else torch.bfloat16
+    if dtype not in (None, torch.float16, torch.bfloat16):
+        raise ValueError(f"no library build for compute dtype {dtype} (bfloat16 and float16 exist)")
+    if key not in _libs:
+        path = LIB_PATH_F16 if key == torch.float16 else LIB_PATH
+        env = "LTX2HIP_LIB_F16" if key == torch.float16 else "LTX2HIP_LIB"
+        if not os.path.exists(path):
             raise NativeLibraryMissing(
-                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C ltx-2-mlx_amd/csrc`). There is no CPU fallback for the hot path.")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         l.ltx2_abi_version.restype = i32
         l.ltx2_abi_version.argtypes = []
         have = l.ltx2_abi_version()
         if have != ABI_VERSION:
             # signatures changed between versions (arguments inserted mid-list): calling through mismatched ones would shift
             # pointers silently, so a library of another version is refused outright -- also under LTX2HIP_LIB
-            raise NativeLibraryMissing(f"{LIB_PATH} reports ABI version {have}, this binding needs {ABI_VERSION}: rebuild it "
+            raise NativeLibraryMissing(f"{path} reports ABI version {have}, this binding needs {ABI_VERSION}: rebuild it "
                                        "(`make -C ltx-2-mlx_amd/csrc`)")
         for name, (res, args) in SIGNATURES.items():
-            if os.environ.get("LTX2HIP_LIB") and not hasattr(l, name):
+            if os.environ.get(env) and not hasattr(l, name):
                 continue                # an A/B build of the SAME ABI version that predates a newly ADDED entry: it just cannot be called
             fn = getattr(l, name)       # AttributeError if the ABI and the header drift apart
             fn.restype = res
             fn.argtypes = args
-        _lib = l
-    return _lib
+        _libs[key] = l
+    return _libs[key]
 
 
 def last_error() -> str:
-    return lib().ltx2_last_error().decode("utf-8", "replace")
+    # every loaded build keeps its own thread-local message; the one that just failed is the non-empty one
+    msgs = [l.ltx2_last_error().decode("utf-8", "replace") for l in _libs.values()]
+    return " | ".join(m for m in msgs if m) or "unknown error"
 
 
 def check(rc: int) -> None:

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 constexpr int n = decltype(N)::value, i = (n & 1) * NKS + (n >> 1);
                 if constexpr (n + DK < NK) read_k(std::integral_constant<int, n + DK>{});
                 lds_wait<(n + DK < NK ? DK : NK - 1 - n)>(kf[i]);
-                s[i / NKS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[i]), qf[i % NKS], s[i / NKS], 0, 0, 0);
+                s[i / NKS] = LTX2_MFMA_32x32x16(as_bf16x8(kf[i]), qf[i % NKS], s[i / NKS], 0, 0, 0);
                 if constexpr ((n & 1) && n / 2 < 2 * NJ) stage_piece(tn, nbuf, n / 2);
             });
             static_for<NK / 2, 2 * NJ>([&](auto I) { stage_piece(tn, nbuf, decltype(I)::value); });
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 constexpr int n = decltype(N)::value, i = (n % ND) * 4 + n / ND;
                 if constexpr (n + DV < NV) read_v(std::integral_constant<int, n + DV>{});
                 lds_wait<(n + DV < NV ? DV : NV - 1 - n)>(vf[i]);
-                o[i / 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[i]), pf[(i % 4) / 2][i % 2], o[i / 4], 0, 0, 0);
+                o[i / 4] = LTX2_MFMA_32x32x16(as_bf16x8(vf[i]), pf[(i % 4) / 2][i % 2], o[i / 4], 0, 0, 0);
             });
         };
 

@@ -4,10 +4,24 @@
 #include <stdint.h>
 #include <type_traits>
 
+// `bf16` names the 16-bit activation / weight element type of THIS build of the library: bfloat16 in libltx2hip.so (the default), IEEE
+// half in libltx2hip_f16.so (the same sources compiled with -DLTX2_F16: the reference's default compute dtype is float16,
+// scripts/generate.py:1006).  Accumulation, the residual stream, statistics and tables are fp32 in both.  The C ABI is the same; dtype
+// code LTX2_DTYPE_BF16 means "this build's 16-bit type".
+#ifdef LTX2_F16
+typedef _Float16 bf16;
+#define LTX2_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define LTX2_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define LTX2_DT "f16"
+#else
 typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define LTX2_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define LTX2_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define LTX2_DT "bf16"
+#endif
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

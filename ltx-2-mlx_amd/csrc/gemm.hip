@@ -168,7 +168,7 @@ __global__ __launch_bounds__(CFG::NT, 2) void gemm_kernel(const GemmParams p) {
                 constexpr int m = decltype(MI)::value, i = m / TN, j = m % TN;
                 if constexpr (i == 0) lds_wait<younger + R - 1 - pos_b(j)>(fb[s][j]);
                 if constexpr (j == 0) lds_wait<younger + R - 1 - pos_a(i)>(fa[s][i]);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fb[s][j]), as_bf16x8(fa[s][i]), acc[i][j], 0, 0, 0);   // C^T orientation
+                acc[i][j] = LTX2_MFMA_32x32x16(as_bf16x8(fb[s][j]), as_bf16x8(fa[s][i]), acc[i][j], 0, 0, 0);   // C^T orientation
             });
         });
     }

@@ -172,9 +172,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 // issuing one global_load_lds costs 60-150 cycles, which hides in the shadow of the 32-cycle
 // matrix-pipe occupancy of the neighbouring MFMAs instead of stretching an L interval.
 #define PP_MFMA(QA, I, QB, KS) \
-    acc[QA][I][QB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[QB][KS], af[I][KS], acc[QA][I][QB], 0, 0, 0)
+    acc[QA][I][QB] = LTX2_MFMA_32x32x16(bfr[QB][KS], af[I][KS], acc[QA][I][QB], 0, 0, 0)
 #define PP_MFMA2(QB, KS) \
-    acc[1][0][QB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[QB][KS], af[0][KS], acc[1][0][QB], 0, 0, 0)
+    acc[1][0][QB] = LTX2_MFMA_32x32x16(bfr[QB][KS], af[0][KS], acc[1][0][QB], 0, 0, 0)
 #define PP_PIN_IN() asm volatile("" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]), "+v"(bfr[0][3]))
 #define PP_PIN_OUT(QA) asm volatile("" : "+v"(acc[QA][0][0]), "+v"(acc[QA][1][0]), "+v"(acc[QA][0][1]), "+v"(acc[QA][1][1]))
 #define PP_PIN_OUT_B() asm volatile("" : "+v"(acc[0][1][0]), "+v"(acc[0][1][1]), "+v"(acc[1][0][0]), "+v"(acc[1][0][1]))

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
                 if (rb < nrb) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
-                        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s * NB + nb], af[s][rb], acc[rb][nb], 0, 0, 0);
+                        acc[rb][nb] = LTX2_MFMA_16x16x32(wf[s * NB + nb], af[s][rb], acc[rb][nb], 0, 0, 0);
                 }
     };
     int k = 0;

@@ -172,10 +172,10 @@ class Gen:
                 f"v_pk_mul_f32 v[{t + 2}:{t + 3}], v[{t + 2}:{t + 3}], v[{s}:{s + 1}]",
                 f"v_pk_mul_f32 v[{t + 4}:{t + 5}], v[{t + 4}:{t + 5}], v[{s}:{s + 1}]",
                 f"v_pk_mul_f32 v[{t + 6}:{t + 7}], v[{t + 6}:{t + 7}], v[{s}:{s + 1}]",
-                f"v_cvt_pk_bf16_f32 v{d}, v{t}, v{t + 1}",
-                f"v_cvt_pk_bf16_f32 v{d + 1}, v{t + 2}, v{t + 3}",
-                f"v_cvt_pk_bf16_f32 v{d + 2}, v{t + 4}, v{t + 5}",
-                f"v_cvt_pk_bf16_f32 v{d + 3}, v{t + 6}, v{t + 7}"]
+                f'v_cvt_pk_" LTX2_DT "_f32 v{d}, v{t}, v{t + 1}',
+                f'v_cvt_pk_" LTX2_DT "_f32 v{d + 1}, v{t + 2}, v{t + 3}',
+                f'v_cvt_pk_" LTX2_DT "_f32 v{d + 2}, v{t + 4}, v{t + 5}',
+                f'v_cvt_pk_" LTX2_DT "_f32 v{d + 3}, v{t + 6}, v{t + 7}']
 
     def mfma(self, setbase, rb, cb):
         a = self.acc(rb, cb)
@@ -187,7 +187,7 @@ class Gen:
                 return (f"v_mfma_scale_f32_32x32x64_f8f6f4 a[{a}:{a + 15}], v[{w}:{w + 7}], v[{x}:{x + 7}], a[{a}:{a + 15}], "
                         f"v{self.one_reg}, v{self.one_reg} op_sel_hi:[0,0,0]")
             return f"v_mfma_f32_32x32x64_f8f6f4 a[{a}:{a + 15}], v[{w}:{w + 7}], v[{x}:{x + 7}], a[{a}:{a + 15}]"
-        op = "v_mfma_f32_32x32x16_bf16" if self.mb == 32 else "v_mfma_f32_16x16x32_bf16"
+        op = 'v_mfma_f32_32x32x16_" LTX2_DT "' if self.mb == 32 else 'v_mfma_f32_16x16x32_" LTX2_DT "'     # bf16 | f16: the build's operand type
         return f"{op} a[{a}:{a + self.accsz - 1}], v[{w}:{w + 3}], v[{x}:{x + 3}], a[{a}:{a + self.accsz - 1}]"
 
     def read_order(self):

@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16* __restrict
         const bf16x8 a = *(const bf16x8*)(xp + k);
         const bf16x8 b0 = *(const bf16x8*)(w0 + k);
         const bf16x8 b1 = *(const bf16x8*)(w1 + k);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc1, 0, 0, 0);
+        acc0 = LTX2_MFMA_16x16x32(a, b0, acc0, 0, 0, 0);
+        acc1 = LTX2_MFMA_16x16x32(a, b1, acc1, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -13,6 +13,16 @@ import torch
 from . import _native as nv
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+ACT16 = (BF16, F16)         # the 16-bit activation / weight type: bfloat16 (libltx2hip.so) or IEEE half (libltx2hip_f16.so, -DLTX2_F16)
+
+
+def _L(*tensors, dtype=None):
+    """The library build for these tensors' 16-bit type (the first bf16 / f16 tensor decides; `dtype` when there is none)."""
+    for t in tensors:
+        if t is not None and t.dtype in ACT16:
+            return nv.lib(t.dtype)
+    return nv.lib(dtype)
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -23,19 +33,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
          gate_table: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w bf16; bias/gate fp32."""
-    assert a.dtype == BF16 and w.dtype == BF16 and a.dim() == 2 and w.dim() == 2
+    assert a.dtype in ACT16 and w.dtype == a.dtype and a.dim() == 2 and w.dim() == 2
     a, w = _c(a), _c(w)
     M, K = a.shape
     N = w.shape[0]
     if out is None:
-        odt = torch.float32 if epilogue in (nv.EPI_F32, nv.EPI_RESID_GATE_F32) else BF16
+        odt = torch.float32 if epilogue in (nv.EPI_F32, nv.EPI_RESID_GATE_F32) else a.dtype
         assert epilogue != nv.EPI_RESID_GATE_F32, "RESID_GATE accumulates into `out`; pass it"
         out = torch.empty(M, N, device=a.device, dtype=odt)
     gs = 0
     if gate is not None:
         gate = _c(gate)
         gs = 0 if gate.shape[0] == 1 else gate.stride(0)
-    nv.check(nv.lib().ltx2_gemm_bf16(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
+    nv.check(_L(a).ltx2_gemm_bf16(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
                                      epilogue, nv.ptr(gate), gs, nv.ptr(gate_table), nv.ptr(res),
                                      res.stride(0) if res is not None else 0, nv.stream()))
     return out
@@ -43,18 +53,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 
 def gemm_qkv_vt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], heads: int, head_dim: int = 128):
     """Fused QKV projection: returns (qkv [M, 3D] bf16 -- V columns only written on the unfused path --, vt [H, hd, Npad], fused)."""
-    assert a.dtype == BF16 and w.dtype == BF16
+    assert a.dtype in ACT16 and w.dtype == a.dtype
     a, w = _c(a), _c(w)
     M, K = a.shape
     N = w.shape[0]
     D = heads * head_dim
     assert N == 3 * D
     npad = (M + 63) // 64 * 64
-    out = torch.empty(M, N, device=a.device, dtype=BF16)
-    vt = torch.empty(heads, head_dim, npad, device=a.device, dtype=BF16)
+    out = torch.empty(M, N, device=a.device, dtype=a.dtype)
+    vt = torch.empty(heads, head_dim, npad, device=a.device, dtype=a.dtype)
     import ctypes
     fused = ctypes.c_int(0)
-    nv.check(nv.lib().ltx2_gemm_qkv_vt(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
+    nv.check(_L(a).ltx2_gemm_qkv_vt(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
                                        nv.ptr(vt), 2 * D, npad, head_dim, ctypes.byref(fused), nv.stream()))
     return out, vt, bool(fused.value)
 
@@ -63,15 +73,15 @@ def gemm_w8a16(a: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: Op
                out: Optional[torch.Tensor] = None, gate_table: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ dequant(w8)[N,K]^T + bias) with fp8-RESIDENT weights: w8 = float8_e4m3fn codes (uint8 view
     accepted), wscale fp32 [N]; bit-identical to gemm() on bf16(f32(w8) * wscale[:, None])."""
-    assert a.dtype == BF16 and w8.element_size() == 1 and wscale.dtype == torch.float32 and a.dim() == 2 and w8.dim() == 2
+    assert a.dtype in ACT16 and w8.element_size() == 1 and wscale.dtype == torch.float32 and a.dim() == 2 and w8.dim() == 2
     a, w8, wscale = _c(a), _c(w8), _c(wscale)
     M, K = a.shape
     N = w8.shape[0]
     assert wscale.numel() == N
     if out is None:
         assert epilogue != nv.EPI_RESID_GATE_F32, "RESID_GATE accumulates into `out`; pass it"
-        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if epilogue == nv.EPI_F32 else BF16)
-    nv.check(nv.lib().ltx2_gemm_w8a16(nv.ptr(a), a.stride(0), nv.ptr(w8), nv.ptr(wscale), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if epilogue == nv.EPI_F32 else a.dtype)
+    nv.check(_L(a).ltx2_gemm_w8a16(nv.ptr(a), a.stride(0), nv.ptr(w8), nv.ptr(wscale), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
                                       epilogue, None, 0, nv.ptr(gate_table), nv.stream()))
     return out
 
@@ -79,12 +89,12 @@ def gemm_w8a16(a: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: Op
 def quantize_rows_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """bf16 [R, K] -> (float8_e4m3fn codes as uint8 [R, K], fp32 scale [R]): scale = max|row| / 448 (1 for a zero row),
     code = e4m3fn_rne(x * (1 / scale)).  The quantiser of the fp8 compute path (activations per token, weights per output channel)."""
-    assert x.dtype == BF16 and x.dim() == 2
+    assert x.dtype in ACT16 and x.dim() == 2
     x = _c(x)
     R, K = x.shape
     codes = torch.empty(R, K, device=x.device, dtype=torch.uint8)
     scale = torch.empty(R, device=x.device, dtype=torch.float32)
-    nv.check(nv.lib().ltx2_quantize_rows_fp8(nv.ptr(x), x.stride(0), R, K, nv.ptr(codes), K, nv.ptr(scale), nv.stream()))
+    nv.check(_L(x).ltx2_quantize_rows_fp8(nv.ptr(x), x.stride(0), R, K, nv.ptr(codes), K, nv.ptr(scale), nv.stream()))
     return codes, scale
 
 
@@ -129,17 +139,17 @@ def gemm_fp8_qkv_vt(a8, ascale, w8, wscale, bias, heads: int, head_dim: int = 12
 
 
 def gemv(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_in: int = 0, act_out: int = 0) -> torch.Tensor:
-    assert a.dtype == torch.float32 and w.dtype == BF16
+    assert a.dtype == torch.float32 and w.dtype in ACT16
     a, w = _c(a), _c(w)
     M, K = a.shape
     N = w.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    nv.check(nv.lib().ltx2_gemv_f32(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), N, M, N, K, act_in,
+    nv.check(_L(w).ltx2_gemv_f32(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), N, M, N, K, act_in,
                                     act_out, nv.stream()))
     return out
 
 
-def conv_weight_to_engine(w: torch.Tensor, d2s_stride: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+def conv_weight_to_engine(w: torch.Tensor, d2s_stride: Optional[Tuple[int, int, int]] = None, dtype: torch.dtype = BF16) -> torch.Tensor:
     """PyTorch conv3d weight (Cout, Cin, 3, 3, 3) -> engine layout bf16 [Cout][27][Cin]
     (tap = (kt*3+kh)*3+kw).  For depth-to-space convs the output rows are permuted from
     ch = c*sp + s to n' = s*Cf + c so one contiguous channel run lands on one output voxel."""
@@ -149,7 +159,7 @@ def conv_weight_to_engine(w: torch.Tensor, d2s_stride: Optional[Tuple[int, int, 
         sp = d2s_stride[0] * d2s_stride[1] * d2s_stride[2]
         cf = cout // sp
         e = e.reshape(cf, sp, 27, cin).permute(1, 0, 2, 3).reshape(cout, 27, cin)
-    return e.to(BF16).contiguous()
+    return e.to(dtype).contiguous()
 
 
 def conv_bias_to_engine(b: torch.Tensor, d2s_stride: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
@@ -165,7 +175,7 @@ def conv3d(x: torch.Tensor, w_engine: torch.Tensor, bias: Optional[torch.Tensor]
     """x bf16 [T,H,W,Cin] channels-last; w_engine [Cout][27 or 9][Cin] from conv_weight_to_engine /
     conv2d_weight_to_engine (9 taps = per-frame 3x3 conv).  pad_zero: 0 reflect H/W + replicate T (VAE decoder),
     1 / True zero padding in T/H/W (spatial upscaler), 2 zero padding in H/W + replicate T (VAE encoder)."""
-    assert x.dtype == BF16 and x.dim() == 4 and w_engine.dtype == BF16
+    assert x.dtype in ACT16 and x.dim() == 4 and w_engine.dtype == x.dtype
     x = _c(x)
     T, H, W, Cin = x.shape
     Cout = w_engine.shape[0]
@@ -173,16 +183,16 @@ def conv3d(x: torch.Tensor, w_engine: torch.Tensor, bias: Optional[torch.Tensor]
     ft, fh, fw = stride
     if mode == 2:
         sp = ft * fh * fw
-        out = torch.empty(T * ft - (1 if ft > 1 else 0), H * fh, W * fw, Cout // sp, device=x.device, dtype=BF16)
+        out = torch.empty(T * ft - (1 if ft > 1 else 0), H * fh, W * fw, Cout // sp, device=x.device, dtype=x.dtype)
     else:
-        out = torch.empty(T, H, W, Cout, device=x.device, dtype=BF16)
-    nv.check(nv.lib().ltx2_conv3d_fused(nv.ptr(x), nv.ptr(w_engine), nv.ptr(bias), nv.ptr(out), T, H, W, Cin, Cout,
+        out = torch.empty(T, H, W, Cout, device=x.device, dtype=x.dtype)
+    nv.check(_L(x).ltx2_conv3d_fused(nv.ptr(x), nv.ptr(w_engine), nv.ptr(bias), nv.ptr(out), T, H, W, Cin, Cout,
                                         int(causal), mode, nv.ptr(res), ft, fh, fw, int(residual), int(pad_zero), kt,
                                         nv.stream()))
     return out
 
 
-def conv2d_weight_to_engine(w: torch.Tensor, pixel_shuffle: int = 0) -> torch.Tensor:
+def conv2d_weight_to_engine(w: torch.Tensor, pixel_shuffle: int = 0, dtype: torch.dtype = BF16) -> torch.Tensor:
     """PyTorch conv2d weight (Cout, Cin, 3, 3) -> engine layout bf16 [Cout][9][Cin] (tap = kh*3+kw).  With
     pixel_shuffle = r the output rows are permuted from ch = c*r*r + s (PyTorch pixel_shuffle packing
     (C, r_h, r_w)) to n' = s*Cf + c for the depth-to-space epilogue."""
@@ -191,51 +201,51 @@ def conv2d_weight_to_engine(w: torch.Tensor, pixel_shuffle: int = 0) -> torch.Te
     if pixel_shuffle:
         sp = pixel_shuffle * pixel_shuffle
         e = e.reshape(cout // sp, sp, 9, cin).permute(1, 0, 2, 3).reshape(cout, 9, cin)
-    return e.to(BF16).contiguous()
+    return e.to(dtype).contiguous()
 
 
 def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-5,
                    res: Optional[torch.Tensor] = None, act: bool = True) -> torch.Tensor:
     """y = [silu](GroupNorm(x over (C/groups, T, H, W)) * gamma + beta + res) on channels-last bf16 [..., C]."""
-    assert x.dtype == BF16 and x.is_contiguous()
+    assert x.dtype in ACT16 and x.is_contiguous()
     C = x.shape[-1]
     P = x.numel() // C
     y = torch.empty_like(x)
     sums = torch.empty(2 * groups * (1 + (P + 15) // 16), device=x.device, dtype=torch.float32)
-    nv.check(nv.lib().ltx2_groupnorm_silu(nv.ptr(x), nv.ptr(res), nv.ptr(y), P, C, groups, eps, nv.ptr(_c(gamma.float())),
+    nv.check(_L(x).ltx2_groupnorm_silu(nv.ptr(x), nv.ptr(res), nv.ptr(y), P, C, groups, eps, nv.ptr(_c(gamma.float())),
                                           nv.ptr(_c(beta.float())), nv.ptr(sums), int(act), nv.stream()))
     return y
 
 
 def s2d_downsample(y: torch.Tensor, x: torch.Tensor, stride: Tuple[int, int, int]) -> torch.Tensor:
     """space_to_depth(y) + group_mean(space_to_depth(x)) on channels-last bf16 [T,H,W,C] (VAE encoder downsample)."""
-    assert y.dtype == BF16 and x.dtype == BF16 and y.shape[:3] == x.shape[:3]
+    assert y.dtype in ACT16 and x.dtype == y.dtype and y.shape[:3] == x.shape[:3]
     y, x = _c(y), _c(x)
     T, H, W, Cc = y.shape
     st, sh, sw = stride
-    out = torch.empty(T // st, H // sh, W // sw, Cc * st * sh * sw, device=y.device, dtype=BF16)
-    nv.check(nv.lib().ltx2_s2d_downsample(nv.ptr(y), nv.ptr(x), nv.ptr(out), T, H, W, Cc, x.shape[3], st, sh, sw, nv.stream()))
+    out = torch.empty(T // st, H // sh, W // sw, Cc * st * sh * sw, device=y.device, dtype=y.dtype)
+    nv.check(_L(y).ltx2_s2d_downsample(nv.ptr(y), nv.ptr(x), nv.ptr(out), T, H, W, Cc, x.shape[3], st, sh, sw, nv.stream()))
     return out
 
 
-def latent_unnormalize_nhwc(latent: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+def latent_unnormalize_nhwc(latent: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, dtype: torch.dtype = BF16) -> torch.Tensor:
     """latent fp32 [C,T,H,W] -> bf16 [T,H,W,C] = latent * std[c] + mean[c]  (PerChannelStatistics.un_normalize,
     video_vae/ops.py:158-171; same kernel as the VAE decoder's input stage)."""
     assert latent.dtype == torch.float32 and latent.dim() == 4
     latent = _c(latent)
     C, T, H, W = latent.shape
-    out = torch.empty(T, H, W, C, device=latent.device, dtype=BF16)
-    nv.check(nv.lib().ltx2_vae_prepare_latent(nv.ptr(latent), nv.ptr(_c(std.float())), nv.ptr(_c(mean.float())), None, 0.0,
+    out = torch.empty(T, H, W, C, device=latent.device, dtype=dtype)
+    nv.check(nv.lib(dtype).ltx2_vae_prepare_latent(nv.ptr(latent), nv.ptr(_c(std.float())), nv.ptr(_c(mean.float())), None, 0.0,
                                               nv.ptr(out), C, T * H * W, nv.stream()))
     return out
 
 
 def latent_normalize_nchw(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
     """x bf16 [T,H,W,C] -> fp32 [C,T,H,W] = (x - mean[c]) / std[c]."""
-    assert x.dtype == BF16 and x.dim() == 4 and x.is_contiguous()
+    assert x.dtype in ACT16 and x.dim() == 4 and x.is_contiguous()
     T, H, W, C = x.shape
     out = torch.empty(C, T, H, W, device=x.device, dtype=torch.float32)
-    nv.check(nv.lib().ltx2_latent_normalize_nchw(nv.ptr(x), nv.ptr(_c(mean.float())), nv.ptr(_c(std.float())), nv.ptr(out), C,
+    nv.check(_L(x).ltx2_latent_normalize_nchw(nv.ptr(x), nv.ptr(_c(mean.float())), nv.ptr(_c(std.float())), nv.ptr(out), C,
                                                  T * H * W, nv.stream()))
     return out
 
@@ -243,12 +253,12 @@ def latent_normalize_nchw(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor
 def adaln_rmsnorm(x: torch.Tensor, eps: float = 1e-6, layer_norm: bool = False,
                   scale_tab: Optional[torch.Tensor] = None, shift_tab: Optional[torch.Tensor] = None,
                   scale_emb: Optional[torch.Tensor] = None, shift_emb: Optional[torch.Tensor] = None,
-                  emb_stride: int = 0) -> torch.Tensor:
+                  emb_stride: int = 0, dtype: torch.dtype = BF16) -> torch.Tensor:
     assert x.dtype == torch.float32 and x.dim() == 2
     x = _c(x)
     rows, D = x.shape
-    out = torch.empty(rows, D, device=x.device, dtype=BF16)
-    nv.check(nv.lib().ltx2_adaln_rmsnorm(nv.ptr(x), D, nv.ptr(out), D, rows, D, eps, int(layer_norm), nv.ptr(scale_tab),
+    out = torch.empty(rows, D, device=x.device, dtype=dtype)
+    nv.check(nv.lib(dtype).ltx2_adaln_rmsnorm(nv.ptr(x), D, nv.ptr(out), D, rows, D, eps, int(layer_norm), nv.ptr(scale_tab),
                                          nv.ptr(shift_tab), nv.ptr(scale_emb), nv.ptr(shift_emb), emb_stride, nv.stream()))
     return out
 
@@ -271,19 +281,19 @@ def adaln_rmsnorm_fp8(x: torch.Tensor, eps: float = 1e-6, layer_norm: bool = Fal
 def qknorm_rope_(buf: torch.Tensor, D: int, head_dim: int, q_off: int, q_weight: torch.Tensor,
                  k_off: int = 0, k_weight: Optional[torch.Tensor] = None, eps: float = 1e-6,
                  cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None) -> torch.Tensor:
-    assert buf.dtype == BF16 and buf.dim() == 2 and buf.is_contiguous()
-    nv.check(nv.lib().ltx2_qknorm_rope(nv.ptr(buf), buf.stride(0), buf.shape[0], D, head_dim, q_off, nv.ptr(q_weight),
+    assert buf.dtype in ACT16 and buf.dim() == 2 and buf.is_contiguous()
+    nv.check(_L(buf).ltx2_qknorm_rope(nv.ptr(buf), buf.stride(0), buf.shape[0], D, head_dim, q_off, nv.ptr(q_weight),
                                        k_off, nv.ptr(k_weight), eps, nv.ptr(cos), nv.ptr(sin), nv.stream()))
     return buf
 
 
 def vt_transpose(v: torch.Tensor, heads: int, head_dim: int = 128) -> torch.Tensor:
     """v bf16 [Nkv, >= heads*head_dim] (a strided column view is fine) -> VT [H,head_dim,Npad]."""
-    assert v.dtype == BF16 and v.dim() == 2 and v.stride(1) == 1
+    assert v.dtype in ACT16 and v.dim() == 2 and v.stride(1) == 1
     nkv = v.shape[0]
     npad = (nkv + 63) // 64 * 64
-    vt = torch.empty(heads, head_dim, npad, device=v.device, dtype=BF16)
-    nv.check(nv.lib().ltx2_vt_transpose(nv.ptr(v), v.stride(0), nv.ptr(vt), nkv, npad, heads, head_dim, nv.stream()))
+    vt = torch.empty(heads, head_dim, npad, device=v.device, dtype=v.dtype)
+    nv.check(_L(v).ltx2_vt_transpose(nv.ptr(v), v.stride(0), nv.ptr(vt), nkv, npad, heads, head_dim, nv.stream()))
     return vt
 
 
@@ -298,12 +308,12 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n
                scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [Nq, H*hd], k [Nkv, H*hd] bf16 (row-strided views allowed), vt [H,hd,Npad] from vt_transpose (hd 128 or 64).
     workspace (flash_attn_workspace): lets grids of more than one round of workgroup slots run stream-K."""
-    assert q.dtype == BF16 and k.dtype == BF16 and vt.dtype == BF16 and q.stride(1) == 1 and k.stride(1) == 1
+    assert q.dtype in ACT16 and k.dtype == q.dtype and vt.dtype == q.dtype and q.stride(1) == 1 and k.stride(1) == 1
     nq, hd = q.shape[0], vt.shape[1]
-    out = torch.empty(nq, heads * hd, device=q.device, dtype=BF16)
+    out = torch.empty(nq, heads * hd, device=q.device, dtype=q.dtype)
     if scale is None:
         scale = 1.0 / math.sqrt(float(hd))
-    nv.check(nv.lib().ltx2_flash_attn_ws(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out),
+    nv.check(_L(q).ltx2_flash_attn_ws(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out),
                                          out.stride(0), nq, nkv, heads, hd, scale, nv.ptr(workspace),
                                          workspace.numel() if workspace is not None else 0, nv.stream()))
     return out
@@ -311,10 +321,10 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n
 
 def attn_head_gate_(att: torch.Tensor, x: torch.Tensor, gate_w: torch.Tensor, gate_b: torch.Tensor, heads: int) -> torch.Tensor:
     """In place: att [rows, H*hd] bf16 *= 2*sigmoid(x @ gate_w^T + gate_b) per head; returns the fp32 logits."""
-    assert att.dtype == BF16 and x.dtype == BF16 and gate_w.dtype == BF16 and att.is_contiguous() and x.stride(1) == 1
+    assert att.dtype in ACT16 and x.dtype == att.dtype and gate_w.dtype == att.dtype and att.is_contiguous() and x.stride(1) == 1
     rows, hd = att.shape[0], att.shape[1] // heads
     logits = torch.empty(rows, heads, device=att.device, dtype=torch.float32)
-    nv.check(nv.lib().ltx2_attn_head_gate(nv.ptr(att), att.stride(0), nv.ptr(x), x.stride(0), nv.ptr(_c(gate_w)), nv.ptr(_c(gate_b.float())),
+    nv.check(_L(att).ltx2_attn_head_gate(nv.ptr(att), att.stride(0), nv.ptr(x), x.stride(0), nv.ptr(_c(gate_w)), nv.ptr(_c(gate_b.float())),
                                           nv.ptr(logits), rows, x.shape[1], heads, hd, nv.stream()))
     return logits
 
@@ -342,19 +352,19 @@ def timestep_sinusoid(t: torch.Tensor, mult: float, dim: int = 256) -> torch.Ten
     return out
 
 
-def dequant_fp8(w: torch.Tensor, scale: float) -> torch.Tensor:
+def dequant_fp8(w: torch.Tensor, scale: float, dtype: torch.dtype = BF16) -> torch.Tensor:
     """fp8 e4m3fn weight (device tensor, torch.float8_e4m3fn or its uint8 view) * scale -> bf16."""
     raw = w.view(torch.uint8) if w.dtype != torch.uint8 else w
     raw = _c(raw)
-    out = torch.empty(raw.shape, device=raw.device, dtype=BF16)
-    nv.check(nv.lib().ltx2_dequant_fp8_e4m3fn(nv.ptr(raw), float(scale), nv.ptr(out), raw.numel(), nv.stream()))
+    out = torch.empty(raw.shape, device=raw.device, dtype=dtype)
+    nv.check(nv.lib(dtype).ltx2_dequant_fp8_e4m3fn(nv.ptr(raw), float(scale), nv.ptr(out), raw.numel(), nv.stream()))
     return out
 
 
-def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+def cast_bf16(x: torch.Tensor, dtype: torch.dtype = BF16) -> torch.Tensor:
     x = _c(x.float())
-    out = torch.empty(x.shape, device=x.device, dtype=BF16)
-    nv.check(nv.lib().ltx2_cast_f32_bf16(nv.ptr(x), nv.ptr(out), x.numel(), nv.stream()))
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    nv.check(nv.lib(dtype).ltx2_cast_f32_bf16(nv.ptr(x), nv.ptr(out), x.numel(), nv.stream()))
     return out
 
 
@@ -381,12 +391,12 @@ def euler_step(x: torch.Tensor, x0: torch.Tensor, sigma: float, sigma_next: floa
 
 def pixnorm_mod_silu(x: torch.Tensor, table: torch.Tensor, te: Optional[torch.Tensor], shift_row: int, scale_row: int,
                      eps: float = 1e-6) -> torch.Tensor:
-    assert x.dtype == BF16
+    assert x.dtype in ACT16
     x = _c(x)
     C_ = x.shape[-1]
     P = x.numel() // C_
     y = torch.empty_like(x)
-    nv.check(nv.lib().ltx2_pixnorm_mod_silu(nv.ptr(x), nv.ptr(y), P, C_, eps, nv.ptr(table), nv.ptr(te), shift_row,
+    nv.check(_L(x).ltx2_pixnorm_mod_silu(nv.ptr(x), nv.ptr(y), P, C_, eps, nv.ptr(table), nv.ptr(te), shift_row,
                                             scale_row, nv.stream()))
     return y
 

@@ -201,10 +201,10 @@ def load_transformer_weights(model, weights_path: str, strict: bool = False, use
                     sd[key] = Fp8Weight(t.view(torch.uint8), scales[full])
                     n_res += 1
                 else:
-                    sd[key] = K.dequant_fp8(t.view(torch.uint8), scales[full])
+                    sd[key] = K.dequant_fp8(t.view(torch.uint8), scales[full], dtype=model.compute_dtype)
                 n_fp8 += 1
             elif t.dtype == torch.float8_e4m3fn:          # fp8 without a scale (weight_converter.py:399-401)
-                sd[key] = K.dequant_fp8(t.view(torch.uint8), 1.0)
+                sd[key] = K.dequant_fp8(t.view(torch.uint8), 1.0, dtype=model.compute_dtype)
                 n_fp8 += 1
             else:
                 sd[key] = t

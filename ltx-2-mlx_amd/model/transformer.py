@@ -124,8 +124,9 @@ class LTXModel:
             raise NotImplementedError("AudioOnly transformer is outside the denoise hot path (DESIGN.md)")
         if rope_type != LTXRopeType.SPLIT or not use_middle_indices_grid:
             raise NotImplementedError("the DiT uses SPLIT RoPE with middle-of-bounds positions (model.py:455,453)")
-        if compute_dtype not in (BF16,):
-            raise NotImplementedError("compute dtype is bf16 (fp32 accumulate / residual stream)")
+        if compute_dtype not in (BF16, torch.float16):
+            raise NotImplementedError("compute dtype is bfloat16 or float16 operands (fp32 accumulate / residual stream); fp32 operands are not built")
+        self._L = nv.lib(compute_dtype)        # bfloat16 -> libltx2hip.so, float16 (the reference's default) -> libltx2hip_f16.so
         self.model_type = model_type
         self.is_av = model_type == LTXModelType.AudioVideo
         self.num_attention_heads = num_attention_heads
@@ -154,7 +155,7 @@ class LTXModel:
                            self.AUDIO_IN_CHANNELS, self.AUDIO_OUT_CHANNELS, int(cross_attention_adaln),
                            int(apply_gated_attention), float(av_ca_timestep_scale_multiplier))
         h = C.c_void_p()
-        nv.check(nv.lib().ltx2_dit_create(C.byref(cfg), C.byref(h)))
+        nv.check(self._L.ltx2_dit_create(C.byref(cfg), C.byref(h)))
         self._h = h
         # MI355X addition (BASELINE config 3, "fp8 weights (CDNA4 fp8 MFMA)"): opt-in fp8 COMPUTE.  The video stream's attention /
         # feed-forward projections keep e4m3fn weights (an fp8 checkpoint's codes, or bf16 weights quantised per output channel at
@@ -162,7 +163,7 @@ class LTXModel:
         # rate.  Not the parity-exact default: the reference dequantises fp8 checkpoints at load (loader/fp8_loader.py:54-130).
         self.fp8_compute = bool(fp8_compute)
         if self.fp8_compute:
-            nv.check(nv.lib().ltx2_dit_set_option(h, b"fp8_compute", 1))
+            nv.check(self._L.ltx2_dit_set_option(h, b"fp8_compute", 1))
         self._w: Dict[str, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
         self._bound: Tuple[int, ...] = (0, 0, 0, 0, 0)
@@ -175,7 +176,7 @@ class LTXModel:
                           caption_channels=caption_channels, positional_embedding_theta=positional_embedding_theta,
                           positional_embedding_max_pos=positional_embedding_max_pos, timestep_scale_multiplier=timestep_scale_multiplier,
                           cross_attention_adaln=cross_attention_adaln, apply_gated_attention=apply_gated_attention, device=device,
-                          fp8_compute=fp8_compute)
+                          fp8_compute=fp8_compute, compute_dtype=compute_dtype)
 
     def _video_twin(self) -> "LTXModel":
         """The video half of this AudioVideo model as a VideoOnly engine: with no audio tokens the reference's blocks run only
@@ -191,7 +192,7 @@ class LTXModel:
     def __del__(self):
         try:
             if getattr(self, "_h", None):
-                nv.lib().ltx2_dit_destroy(self._h)
+                self._L.ltx2_dit_destroy(self._h)
                 self._h = None
         except Exception:
             pass
@@ -267,8 +268,10 @@ class LTXModel:
         t = t.contiguous()
         self._w[name] = t
         # uint8 = float8_e4m3fn codes of an fp8-RESIDENT linear weight (its `<name>_scale` fp32 vector is registered with it)
-        dt = nv.DTYPE_BF16 if t.dtype == BF16 else (nv.DTYPE_FP8_E4M3FN if t.dtype == torch.uint8 else nv.DTYPE_F32)
-        nv.check(nv.lib().ltx2_dit_set_weight(self._h, name.encode(), nv.ptr(t), dt, t.numel()))
+        dt = nv.DTYPE_BF16 if t.dtype == self.compute_dtype else (nv.DTYPE_FP8_E4M3FN if t.dtype == torch.uint8 else nv.DTYPE_F32)
+        if t.dtype in (BF16, torch.float16) and t.dtype != self.compute_dtype:
+            raise ValueError(f"{name}: {t.dtype} weight registered with a {self.compute_dtype} model")
+        nv.check(self._L.ltx2_dit_set_weight(self._h, name.encode(), nv.ptr(t), dt, t.numel()))
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
         """Consume checkpoint-keyed tensors (any float dtype, any device).  Linear weights stay
@@ -292,7 +295,7 @@ class LTXModel:
         dev = self.device
 
         def W(name):
-            return sd[name].to(dev, BF16)
+            return sd[name].to(dev, self.compute_dtype)
 
         def Fv(name):
             return sd[name].to(dev, torch.float32)
@@ -304,7 +307,7 @@ class LTXModel:
             if self.fp8_compute and all(FP8_RESIDENT_KEYS.match(n) for n in names) and not any(isinstance(v, Fp8Weight) for v in vals) \
                     and vals[0].shape[0] % 256 == 0 and vals[0].shape[1] % 256 == 0 and vals[0].shape[1] >= 512:
                 # bf16 checkpoint + fp8 compute: one e4m3fn scale per OUTPUT CHANNEL (ltx2_quantize_rows_fp8, the activations' quantiser)
-                q = [K.quantize_rows_fp8(v.to(dev, BF16)) for v in vals]
+                q = [K.quantize_rows_fp8(v.to(dev, self.compute_dtype)) for v in vals]
                 self._register(dst, torch.cat([c for c, _ in q], 0))
                 self._register(dst + "_scale", torch.cat([s_ for _, s_ in q], 0))
                 return
@@ -316,7 +319,7 @@ class LTXModel:
                 self._register(dst, torch.cat([v.codes.to(dev).view(torch.uint8) for v in vals], 0))
                 self._register(dst + "_scale", torch.cat([torch.full((v.codes.shape[0],), float(v.scale), dtype=torch.float32, device=dev) for v in vals]))
             else:
-                self._register(dst, torch.cat([v.to(dev, BF16) for v in vals], 0) if len(vals) > 1 else vals[0].to(dev, BF16))
+                self._register(dst, torch.cat([v.to(dev, self.compute_dtype) for v in vals], 0) if len(vals) > 1 else vals[0].to(dev, self.compute_dtype))
 
         fused = set()
         for i in range(self.num_layers):
@@ -349,7 +352,7 @@ class LTXModel:
         fused_fp8 = re.compile(r"^transformer_blocks\.\d+\.(attn1|attn2)\.(to_qkv|to_q|to_kv|to_out\.0)\.weight$|^transformer_blocks\.\d+\.ff\.net\.(0\.proj|2)\.weight$")
 
         def rw(*shape):
-            return (torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32) * std).to(BF16)
+            return (torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32) * std).to(self.compute_dtype)
 
         def put_w(name, rows, cols):
             if fp8_resident and fused_fp8.match(name) and rows % 256 == 0 and cols % 128 == 0 and cols >= 256:
@@ -400,7 +403,7 @@ class LTXModel:
         want = (n, s, na, sa, int(per_token))
         if self._bound[:4] == want[:4] and self._bound[4] >= want[4] and self._ws is not None:
             return
-        L = nv.lib()
+        L = self._L
         nbytes = (L.ltx2_dit_workspace_bytes_av(self._h, n, s, na, sa, int(per_token)) if self.is_av else
                   L.ltx2_dit_workspace_bytes(self._h, n, s, int(per_token)))
         if nbytes <= 0:
@@ -434,7 +437,7 @@ class LTXModel:
         ctx = context[0].to(dev, torch.float32).contiguous()
         if not self.is_av:
             self._bind(n, s, per_token)
-            nv.check(nv.lib().ltx2_dit_prepare(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.stream()))
+            nv.check(self._L.ltx2_dit_prepare(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.stream()))
             self._prep_refs = (originals, positions, cos, sin, ctx)     # keep pointers alive / unaliased
         else:
             if audio_context is None or audio_positions is None:
@@ -448,7 +451,7 @@ class LTXModel:
             vcc, vcs = K.rope_tables(positions[:, 0:1], da, theta, mp)
             acc, acs = K.rope_tables(audio_positions[:, 0:1], da, theta, mp)
             actx = audio_context[0].to(dev, torch.float32).contiguous()
-            nv.check(nv.lib().ltx2_dit_prepare_av(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.ptr(vcc), nv.ptr(vcs),
+            nv.check(self._L.ltx2_dit_prepare_av(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.ptr(vcc), nv.ptr(vcs),
                                                   nv.ptr(actx), sa, nv.ptr(acos), nv.ptr(asin), nv.ptr(acc), nv.ptr(acs),
                                                   nv.stream()))
             self._prep_refs = (originals, positions, audio_positions, cos, sin, ctx, acos, asin, vcc, vcs, acc, acs, actx)
@@ -514,14 +517,14 @@ class LTXModel:
             self._ensure_prepared(video, per_token=(n_ts != 1))
             # prompt AdaLN (V2.3) takes Modality.sigma, not timesteps[0]: with image conditioning timesteps = mask * sigma
             sg = self._sigma(video) if self.cross_attention_adaln else None
-            nv.check(nv.lib().ltx2_dit_forward(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(sg), nv.ptr(out), nv.stream()))
+            nv.check(self._L.ltx2_dit_forward(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(sg), nv.ptr(out), nv.stream()))
             return out[None]
         ats, n_ats = self._timesteps(audio)
         self._ensure_prepared(video, per_token=(n_ts != 1 or n_ats != 1), audio=audio)
         alat = audio.latent[0].to(self.device, torch.float32).contiguous()
         aout = torch.empty(alat.shape[0], self.AUDIO_OUT_CHANNELS, device=self.device, dtype=torch.float32)
         vs, as_ = self._sigma(video), self._sigma(audio)
-        nv.check(nv.lib().ltx2_dit_forward_av(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(vs), nv.ptr(alat), nv.ptr(ats), n_ats,
+        nv.check(self._L.ltx2_dit_forward_av(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(vs), nv.ptr(alat), nv.ptr(ats), n_ats,
                                               nv.ptr(as_), nv.ptr(out), nv.ptr(aout), nv.stream()))
         return out[None], aout[None]
 
@@ -536,7 +539,7 @@ class LTXModel:
     def check_health(self) -> None:
         """Host sync point (per prompt / after a sampling loop): raises RuntimeError if a stream-K attention launch gave up waiting
         for a partial result since the last check (ltx2_dit_health; the results since then are invalid)."""
-        nv.check(nv.lib().ltx2_dit_health(self._h, nv.stream()))
+        nv.check(self._L.ltx2_dit_health(self._h, nv.stream()))
         if self._twin is not None:
             self._twin.check_health()
 
@@ -552,14 +555,14 @@ class LTXModel:
         if not self.is_av:
             self._ensure_prepared(video, per_token=(n_ts != 1))
             sg = self._sigma_scalar(sigma) if self.cross_attention_adaln else None
-            nv.check(nv.lib().ltx2_dit_denoise_step(self._h, nv.ptr(latent), nv.ptr(ts), n_ts, nv.ptr(sg), nv.ptr(denoise_mask),
+            nv.check(self._L.ltx2_dit_denoise_step(self._h, nv.ptr(latent), nv.ptr(ts), n_ts, nv.ptr(sg), nv.ptr(denoise_mask),
                                                     nv.ptr(clean_latent), float(sigma), float(sigma_next), None, nv.stream()))
             return
         assert audio is not None and audio_latent is not None and audio_latent.dtype == torch.float32 and audio_latent.is_contiguous()
         ats, n_ats = self._timesteps(audio)
         self._ensure_prepared(video, per_token=(n_ts != 1 or n_ats != 1), audio=audio)
         sg = self._sigma_scalar(sigma)
-        nv.check(nv.lib().ltx2_dit_denoise_step_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), nv.ptr(ts), n_ts, nv.ptr(ats), n_ats,
+        nv.check(self._L.ltx2_dit_denoise_step_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), nv.ptr(ts), n_ts, nv.ptr(ats), n_ats,
                                                    nv.ptr(sg), nv.ptr(denoise_mask), nv.ptr(clean_latent), nv.ptr(audio_denoise_mask),
                                                    nv.ptr(audio_clean_latent), float(sigma), float(sigma_next), None, None, nv.stream()))
 
@@ -573,22 +576,22 @@ class LTXModel:
             raise RuntimeError("graph capture needs a non-default stream: use `with torch.cuda.stream(torch.cuda.Stream()):`")
         if self.is_av:
             assert audio_latent is not None
-            nv.check(nv.lib().ltx2_dit_graph_capture_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), arr, len(sigmas) - 1, st.cuda_stream))
+            nv.check(self._L.ltx2_dit_graph_capture_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), arr, len(sigmas) - 1, st.cuda_stream))
         else:
-            nv.check(nv.lib().ltx2_dit_graph_capture(self._h, nv.ptr(latent), arr, len(sigmas) - 1, st.cuda_stream))
+            nv.check(self._L.ltx2_dit_graph_capture(self._h, nv.ptr(latent), arr, len(sigmas) - 1, st.cuda_stream))
 
     def replay_denoise_graph(self) -> None:
-        nv.check(nv.lib().ltx2_dit_graph_launch(self._h, nv.stream()))
+        nv.check(self._L.ltx2_dit_graph_launch(self._h, nv.stream()))
 
     # ------------------------------------------------------------------ measurement
     def profile_begin(self, epilogue: int = -1) -> None:
         """HIP-event bracket every launch of one GEMM kernel instantiation (or all, -1)."""
-        nv.check(nv.lib().ltx2_dit_profile_begin(self._h, epilogue))
+        nv.check(self._L.ltx2_dit_profile_begin(self._h, epilogue))
 
     def profile_end(self) -> Tuple[float, int, float]:
         """-> (summed kernel ms, launches, 2*M*N*K flops) since profile_begin."""
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
-        nv.check(nv.lib().ltx2_dit_profile_end(self._h, C.byref(ms), C.byref(n), C.byref(fl)))
+        nv.check(self._L.ltx2_dit_profile_end(self._h, C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
 
 

@@ -38,7 +38,10 @@ class SimpleVideoDecoder:
 
     def __init__(self, decoder_blocks: Optional[List] = None, base_channels: int = 128, timestep_conditioning: bool = True,
                  compute_dtype: torch.dtype = BF16, device: Union[str, torch.device] = "cuda"):
+        if compute_dtype not in (BF16, torch.float16):
+            raise NotImplementedError("VAE compute dtype is bfloat16 or float16 (fp32 accumulation)")
         self.compute_dtype = compute_dtype
+        self._L = nv.lib(compute_dtype)
         self.timestep_conditioning = timestep_conditioning
         self.base_channels = base_channels
         self.decode_noise_scale = 0.025
@@ -71,7 +74,7 @@ class SimpleVideoDecoder:
     def __del__(self):
         try:
             if getattr(self, "_h", None):
-                nv.lib().ltx2_vae_destroy(self._h)
+                self._L.ltx2_vae_destroy(self._h)
                 self._h = None
         except Exception:
             pass
@@ -103,12 +106,12 @@ class SimpleVideoDecoder:
     def _register(self, name: str, t: torch.Tensor) -> None:
         t = t.contiguous()
         self._w[name] = t
-        dt = nv.DTYPE_BF16 if t.dtype == BF16 else nv.DTYPE_F32
-        nv.check(nv.lib().ltx2_vae_set_weight(self._h, name.encode(), nv.ptr(t), dt, t.numel()))
+        dt = nv.DTYPE_BF16 if t.dtype == self.compute_dtype else nv.DTYPE_F32
+        nv.check(self._L.ltx2_vae_set_weight(self._h, name.encode(), nv.ptr(t), dt, t.numel()))
 
     def _create(self) -> None:
         if self._h is not None:
-            nv.lib().ltx2_vae_destroy(self._h)
+            self._L.ltx2_vae_destroy(self._h)
         cfg = nv.VaeConfig()
         cfg.n_blocks = len(self.plan)
         for i, (kind, p, ch) in enumerate(self.plan):
@@ -124,7 +127,7 @@ class SimpleVideoDecoder:
         cfg.timestep_conditioning = int(self.timestep_conditioning)
         cfg.decode_noise_scale = self.decode_noise_scale
         h = C.c_void_p()
-        nv.check(nv.lib().ltx2_vae_create(C.byref(cfg), C.byref(h)))
+        nv.check(self._L.ltx2_vae_create(C.byref(cfg), C.byref(h)))
         self._h = h
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
@@ -144,7 +147,7 @@ class SimpleVideoDecoder:
             t = sd[k].to(dev, torch.float32)
             base = k.rsplit(".", 1)[0]
             if t.dim() == 5:
-                self._register(k, K.conv_weight_to_engine(t, d2s.get(base)))
+                self._register(k, K.conv_weight_to_engine(t, d2s.get(base), dtype=self.compute_dtype))
             elif k.endswith(".bias") and base in d2s:
                 self._register(k, K.conv_bias_to_engine(t, d2s[base]))
             else:
@@ -153,11 +156,11 @@ class SimpleVideoDecoder:
         if self.timestep_conditioning:
             if "vae.decoder.timestep_scale_multiplier" in sd:
                 self.timestep_scale_multiplier = float(sd["vae.decoder.timestep_scale_multiplier"])
-            nv.check(nv.lib().ltx2_vae_set_timestep_multiplier(self._h, self.timestep_scale_multiplier))
+            nv.check(self._L.ltx2_vae_set_timestep_multiplier(self._h, self.timestep_scale_multiplier))
             for k, t in sd.items():
                 if ".time_embedder.timestep_embedder." in k or ".last_time_embedder.timestep_embedder." in k:
                     t = t.to(dev, torch.float32)
-                    self._register(k, t.to(BF16) if k.endswith(".weight") else t)
+                    self._register(k, t.to(self.compute_dtype) if k.endswith(".weight") else t)
 
     @property
     def per_channel_statistics(self) -> "PerChannelStatistics":
@@ -174,11 +177,11 @@ class SimpleVideoDecoder:
             return torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * scale
 
         def conv(name, co, ci):
-            self._register(name + ".weight", rn(co, 27, ci, scale=1.0 / math.sqrt(27 * ci)).to(BF16))
+            self._register(name + ".weight", rn(co, 27, ci, scale=1.0 / math.sqrt(27 * ci)).to(self.compute_dtype))
             self._register(name + ".bias", rn(co, scale=0.02))
 
         def lin(name, o, i):
-            self._register(name + ".weight", rn(o, i, scale=1.0 / math.sqrt(i)).to(BF16))
+            self._register(name + ".weight", rn(o, i, scale=1.0 / math.sqrt(i)).to(self.compute_dtype))
             self._register(name + ".bias", rn(o, scale=0.02))
 
         self._register("vae.per_channel_statistics.mean-of-means", torch.zeros(self.latent_channels, device=dev))
@@ -201,11 +204,11 @@ class SimpleVideoDecoder:
         if self.timestep_conditioning:
             lin("vae.decoder.last_time_embedder.timestep_embedder.linear_1", 256, 256)
             lin("vae.decoder.last_time_embedder.timestep_embedder.linear_2", 2 * self.final_channels, 256)
-            nv.check(nv.lib().ltx2_vae_set_timestep_multiplier(self._h, self.timestep_scale_multiplier))
+            nv.check(self._L.ltx2_vae_set_timestep_multiplier(self._h, self.timestep_scale_multiplier))
 
     # ------------------------------------------------------------------ decode
     def _bind(self, t: int, h: int, w: int) -> None:
-        need = nv.lib().ltx2_vae_workspace_bytes(self._h, t, h, w)
+        need = self._L.ltx2_vae_workspace_bytes(self._h, t, h, w)
         if need <= 0:
             raise ValueError(f"bad latent grid {t}x{h}x{w}")
         if self._ws is None or self._ws_bytes < need:
@@ -213,10 +216,10 @@ class SimpleVideoDecoder:
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
             self._ws_bytes = need
             base = (self._ws.data_ptr() + 255) // 256 * 256
-            nv.check(nv.lib().ltx2_vae_bind_workspace(self._h, base, need))
+            nv.check(self._L.ltx2_vae_bind_workspace(self._h, base, need))
 
     def out_frames(self, t: int) -> int:
-        return nv.lib().ltx2_vae_out_frames(self._h, t)
+        return self._L.ltx2_vae_out_frames(self._h, t)
 
     def __call__(self, latent: torch.Tensor, timestep: Optional[float] = 0.05, show_progress: bool = True,
                  causal: bool = False, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -242,7 +245,7 @@ class SimpleVideoDecoder:
                 sh *= p["stride"][1]
                 sw *= p["stride"][2]
         video = torch.empty(3, tp, h * sh * 4, w * sw * 4, device=self.device, dtype=torch.float32)
-        nv.check(nv.lib().ltx2_vae_decode(self._h, nv.ptr(lat), t, h, w, float(timestep) if tcond else -1.0, nv.ptr(nz),
+        nv.check(self._L.ltx2_vae_decode(self._h, nv.ptr(lat), t, h, w, float(timestep) if tcond else -1.0, nv.ptr(nz),
                                           int(causal), nv.ptr(video), nv.stream()))
         return video[None]
 

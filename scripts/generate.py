@@ -153,7 +153,7 @@ def get_vae_config(checkpoint_path: str) -> dict:
     return _read_checkpoint_config(checkpoint_path).get("vae", {})
 
 
-def create_vae_decoder(weights_path, device="cuda", seed=0, use_placeholder=False, base_channels_override=None):
+def create_vae_decoder(weights_path, device="cuda", seed=0, use_placeholder=False, base_channels_override=None, compute_dtype=None):
     """SimpleVideoDecoder built from the checkpoint's own architecture record (reference :1255-1273): decoder_blocks,
     decoder_base_channels (128 when absent), timestep_conditioning (True when absent).  Without a readable checkpoint the
     default 19B decoder is built and random-initialised (no checkpoints exist on a bare box; the reference would run the
@@ -165,7 +165,8 @@ def create_vae_decoder(weights_path, device="cuda", seed=0, use_placeholder=Fals
     timestep_cond = vae_config.get("timestep_conditioning", True)
     if decoder_blocks:
         print(f"  VAE config: {len(decoder_blocks)} blocks, base_ch={base_channels}, timestep={timestep_cond}")
-    dec = SimpleVideoDecoder(decoder_blocks=decoder_blocks, base_channels=base_channels, timestep_conditioning=timestep_cond, device=device)
+    dec = SimpleVideoDecoder(decoder_blocks=decoder_blocks, base_channels=base_channels, timestep_conditioning=timestep_cond, device=device,
+                             **({} if compute_dtype is None else {"compute_dtype": compute_dtype}))
     if have and not use_placeholder:
         load_vae_decoder_weights(dec, weights_path)
     else:
@@ -323,6 +324,7 @@ def generate_video(
     two_stage_distilled: bool = False,
     fp8_resident: bool = False,
     model_version=None,
+    compute_dtype=None,
 ):
     """Generate video from a text prompt: denoise loop + VAE decode on MI355X behind the reference's signature.
 
@@ -334,7 +336,8 @@ def generate_video(
     MI355X extras: two_stage_distilled=True runs the reference's DistilledPipeline class (8 steps at half resolution, x2
     upscale, 3 steps; pipelines/distilled.py:274-505), which the reference's own CLI never wires; model_version="2.3" builds
     the LTX-2.3 architecture without a checkpoint (random init, for tests and benchmarks); fp8_resident keeps fp8 checkpoint
-    weights as codes in HBM; vae_base_channels overrides the checkpoint's decoder_base_channels."""
+    weights as codes in HBM; vae_base_channels overrides the checkpoint's decoder_base_channels; compute_dtype="bfloat16" runs the
+    bfloat16 build instead of the reference's float16 default (use_fp16=True)."""
     given = dict(upscale_temporal=upscale_temporal, early_layers_only=early_layers_only,
                  enhance_prompt_flag=enhance_prompt_flag and use_gemma, cross_attn_scale=cross_attn_scale, distilled_lora=distilled_lora,
                  stg_scale=stg_scale, apg_scale=apg_scale, control_video=control_video, save_control=save_control, ge_gamma=ge_gamma,
@@ -355,10 +358,17 @@ def generate_video(
         raise ValueError(f"num_frames must be 8*k + 1, got {num_frames}")
     if height % 32 != 0 or width % 32 != 0:
         raise ValueError(f"Resolution ({height}x{width}) must be divisible by 32")
-    if not use_fp16:
-        raise NotImplementedError("use_fp16=False (fp32 compute): the MI355X path computes in bf16 with fp32 accumulation and an fp32 residual stream")
-    print("Compute dtype: bf16 operands / fp32 accumulate / fp32 residual stream (use_fp16=True selects the reduced-precision path; "
-          "fp16 operands are not built)", file=sys.stderr)
+    # use_fp16=True (the reference's default, :1006): float16 operands on libltx2hip_f16.so; compute_dtype="bfloat16" (MI355X extra,
+    # --bf16) selects the bfloat16 build the headline benchmark runs.  Accumulation and the residual stream are fp32 in both.
+    if compute_dtype is None:
+        if not use_fp16:
+            raise NotImplementedError("use_fp16=False (fp32 compute): the MI355X path computes with float16 or bfloat16 operands, fp32 accumulation and an "
+                                      "fp32 residual stream")
+        compute_dtype = "float16"
+    if compute_dtype not in ("float16", "bfloat16"):
+        raise ValueError(f"compute_dtype={compute_dtype!r}: float16 or bfloat16")
+    cdt = torch.float16 if compute_dtype == "float16" else torch.bfloat16
+    print(f"Compute dtype: {compute_dtype} operands / fp32 accumulate / fp32 residual stream")
     if use_gemma and not (embedding_path or text_features_path):
         if not os.path.exists(gemma_path):              # the reference prints this and returns (:1085-1092)
             print(f"\n  ERROR: Gemma weights not found at {gemma_path}\n  Use use_gemma=False (--no-gemma) for dummy embeddings, or pass "
@@ -410,17 +420,17 @@ def generate_video(
     elif use_av_encoder:
         if lora_path:
             raise NotImplementedError("--lora with the AudioVideo transformer")
-        model = X0Model(load_av_transformer(weights_path, num_layers=num_layers, use_fp8=use_fp8, low_memory=low_memory,
+        model = X0Model(load_av_transformer(weights_path, num_layers=num_layers, compute_dtype=cdt, use_fp8=use_fp8, low_memory=low_memory,
                                             caption_channels=None if v2 else text_encoding.shape[-1], cross_attention_adaln=v2,
                                             apply_gated_attention=v2, num_heads=num_heads, seed=seed, device=device))
     else:
-        model = X0Model(load_transformer(weights_path, num_layers=num_layers, use_fp8=use_fp8, low_memory=low_memory, fast_mode=fast_mode,
+        model = X0Model(load_transformer(weights_path, num_layers=num_layers, compute_dtype=cdt, use_fp8=use_fp8, low_memory=low_memory, fast_mode=fast_mode,
                                          num_heads=num_heads, caption_channels=text_encoding.shape[-1], seed=seed, device=device,
                                          lora_path=lora_path, lora_strength=lora_strength, fp8_resident=fp8_resident))
     print("[3/5] VAE decoder")
     vae_decoder = None
     if not skip_vae:
-        vae_decoder = create_vae_decoder(weights_path, device, seed + 1, use_placeholder, vae_base_channels)
+        vae_decoder = create_vae_decoder(weights_path, device, seed + 1, use_placeholder, vae_base_channels, compute_dtype=cdt)
     else:
         print("  VAE decoder skipped by user")
     toy = vae_base_channels is not None and vae_base_channels != 128        # debug-size VAE: matching debug-size upscaler / encoder
@@ -658,6 +668,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--no-hip-graph", action="store_true", help="run the step loop eagerly instead of replaying the captured hipGraph")
     p.add_argument("--two-stage-distilled", action="store_true", help="DistilledPipeline: 8 steps at half resolution, x2 latent upscale (--spatial-upscaler-weights), 3 steps")
     p.add_argument("--fp8-resident", action="store_true", help="keep fp8 checkpoint weights as codes in HBM (bit-identical to dequantising at load)")
+    p.add_argument("--bf16", action="store_true", help="bfloat16 operands instead of the reference's float16 default (both: fp32 accumulate / residual stream)")
     p.add_argument("--model-version", type=str, default=None, help="force the architecture family (e.g. 2.3) instead of reading the checkpoint metadata")
     p.add_argument("--layers", type=int, default=48, help="debug: number of DiT layers for random-weight runs")
     p.add_argument("--heads", type=int, default=32, help="debug: attention heads (x128) for random-weight runs")
@@ -691,7 +702,7 @@ def kwargs_from_args(a) -> dict:
         keyframes=a.keyframe, ic_lora_weights=a.ic_lora_weights,
         # MI355X extras
         text_features_path=a.text_features, use_hip_graph=not a.no_hip_graph, two_stage_distilled=a.two_stage_distilled,
-        fp8_resident=a.fp8_resident, model_version=a.model_version, num_layers=a.layers, num_heads=a.heads,
+        fp8_resident=a.fp8_resident, model_version=a.model_version, compute_dtype="bfloat16" if a.bf16 else None, num_layers=a.layers, num_heads=a.heads,
         vae_base_channels=a.vae_base_channels, save_mp4=not a.no_video_file)
 
 
