@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_$TAG
-rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_$TAG -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-extra --no-cpu-baseline --no-vae --no-graph --no-kernel-pass "$@" > "$OUT/bench_stdout.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_$TAG -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-extra --no-cpu-baseline --no-loader --no-vae --no-graph --no-kernel-pass "$@" > "$OUT/bench_stdout.log" 2>&1
 f=$(find /tmp/rp_$TAG -name "*kernel_trace.csv" | head -1)
 python - "$f" > "$OUT/layer_trace.txt" <<'PY'
 import csv, sys, re, collections

@@ -6,7 +6,7 @@
 TAG=${1:-pmc_bench}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-graph"
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-loader --no-graph"
 PASSES=${2:-"A B C"}
 i=0
 for PMC in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
