@@ -535,7 +535,7 @@ def main():
             out["loader"] = loader_throughput(dev, args.loader_layers)
         except Exception as e:  # noqa: BLE001
             out["loader"] = {"error": str(e)}
-    if not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:        # the CPU leg is reported at N = 1 only (rank 0's host cores)
         try:
             out["cpu_baseline"] = cpu_baseline(min(CPU_THREADS, os.cpu_count() or 1))
         except Exception as e:  # noqa: BLE001

@@ -71,8 +71,8 @@ def test_bench_two_rank_rehearsal(dev):
 
 def test_bench_self_launch(dev):
     """`python bench.py --gpus 2 ...` as a PLAIN process (the form the driver uses for --gpus 1): with no launcher environment
-    it re-launches itself under torch.distributed.run; rank 0 prints the one JSON line, cpu_baseline included (both ranks on
-    this box's single GPU over gloo)."""
+    it re-launches itself under torch.distributed.run; rank 0 prints the one JSON line (both ranks on this box's single GPU over
+    gloo); the CPU leg belongs to the N = 1 line only."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -84,9 +84,24 @@ def test_bench_self_launch(dev):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
+    assert "cpu_baseline" not in out and out["per_rank_ms_per_step"]["max"] >= out["per_rank_ms_per_step"]["min"] > 0 and len(out["per_rank_ms_per_step"]["all"]) == 2
+    assert out["roofline"]["launches"] > 0 and out["roofline"]["frac"] is not None
+
+
+def test_bench_single_gpu_line(dev):
+    """The N = 1 line: one JSON object on stdout and nothing else, with the `roofline` and `cpu_baseline` objects the contract names
+    (2 layers so the test stays short)."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "1", "--layers", "2", "--no-vae", "--no-extra",
+                        "--no-loader", "--no-power"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), r.stdout[-2000:]
+    out = json.loads(lines[0])
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["plumbing_config_8_steps_s"] > 0 and cb["vae_decode_frames_per_sec"] > 0
-    assert out["roofline"]["launches"] > 0 and out["roofline"]["frac"] is not None
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["roofline"]["frac"] is not None and out["roofline"]["traffic"] is not None
 
 
 def test_generate_cli_two_stage(dev, tmp_path):
