@@ -83,6 +83,23 @@ int ltx2_gemm_qkv_vt(const void* A, int64_t lda, const void* W, const float* bia
 int ltx2_gemm_w8a16(const void* A, int64_t lda, const void* W8, const float* wscale, const float* bias, void* out, int64_t ldo, int M,
                     int N, int K, int epilogue, const float* gate, int64_t gate_stride, const float* gate_table, void* stream);
 
+/* Text cross-attention with q_norm folded in (attention.py:231-237 applied as arithmetic instead of a pass over q; round 3).
+ * ltx2_gemm_bf16_rowss: out = A @ W^T + bias (bf16) and, where the 4-wave kernel takes the shape (*written = 1), rowss[m][N / 64] = the
+ * sums of squares of out's ROUNDED values over each 64-column strip of row m; *written = 0: plain GEMM, rowss untouched.
+ * ltx2_flash_attn_rowscale: ltx2_flash_attn with a per-query-row scale: row q uses scale * rsqrt(sum_j q_ss[q][j] / q_norm_dim + q_eps),
+ * i.e. softmax((rms_norm(Q) K'^T) * scale) V for K' carrying q_norm.weight * k_norm.weight -- identical to normalising Q first up to the
+ * rounding of the normalised Q to 16 bits (which this form does not do).  head_dim 128, q_ss_ld % 4 == 0.                      */
+int ltx2_gemm_bf16_rowss(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K, float* rowss,
+                         int* written, void* stream);
+int ltx2_flash_attn_rowscale(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
+                             int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, void* stream);
+
+/* flash attention with a key mask (attention.py:38-70 with the additive mask model.py:163-201 builds from a boolean (B, S) context
+ * mask): mask fp32 [Nkv], non-zero = the key may be attended; a masked key takes no weight unless every key is masked (then the
+ * row averages V over all keys, as the reference's -finfo.max bias does).  words: scratch of Npad / 8 bytes on the device.        */
+int ltx2_flash_attn_keymask(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo,
+                            int Nq, int Nkv, int H, int head_dim, float scale, const float* mask, void* words, void* stream);
+
 /* Which kernel ltx2_gemm_bf16 / ltx2_gemm_w8a16 / ltx2_gemm_fp8 (weights = 0 / 1 / 2) would run for a dense M x N x K problem with
  * this epilogue -- host logic only, nothing is launched, no GPU needed.  Returns LTX2_ROUTE_* (negative: unsupported), OR-ed with
  * 0x100 when has_vt != 0 and the fused-QKV V^T output (ltx2_gemm_qkv_vt with N = 3 * inner_dim) would come from the GEMM's own epilogue.
@@ -340,6 +357,12 @@ int ltx2_dit_graph_capture(ltx2_dit* ctx, float* latent, const float* host_sigma
 int ltx2_dit_graph_capture_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps,
                               void* stream);
 int ltx2_dit_graph_launch(ltx2_dit* ctx, void* stream);
+
+/* Text-context key mask of one modality (0 = video, 1 = audio): Modality.context_mask as the reference's boolean (B, S) mask
+ * (model.py:163-201 turns it into the additive -finfo.max mask of attention.py:38-70): mask fp32 [S] on the device, non-zero = the key may
+ * be attended; NULL clears it.  Applies to the text cross-attention of every block until changed; call after binding the workspace
+ * (binding clears it).  Every pipeline of the reference passes context_mask = None (pipelines/common.py:223-232).                  */
+int ltx2_dit_set_context_mask(ltx2_dit* ctx, int modality, const float* mask, int S, void* stream);
 
 /* Engine options, by name (set before ltx2_dit_bind_workspace; unknown names -> LTX2_E_INVALID):
  *   "fp8_compute" = 1: every linear of the VIDEO stream whose weight is registered fp8-resident (LTX2_DTYPE_FP8_E4M3FN codes +

@@ -52,6 +52,9 @@ SIGNATURES = {
     "ltx2_gemm_bf16": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp, i64, vp]),
     "ltx2_gemm_qkv_vt": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp]),
     "ltx2_gemm_w8a16": (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
+    "ltx2_gemm_bf16_rowss": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, C.POINTER(i32), vp]),
+    "ltx2_flash_attn_keymask": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "ltx2_flash_attn_rowscale": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, i32, f32, vp]),
     "ltx2_gemm_route": (i32, [i32, i32, i32, i32, i32, i32]),
     "ltx2_quantize_rows_fp8": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),
     "ltx2_gemm_fp8": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
@@ -99,6 +102,7 @@ SIGNATURES = {
     "ltx2_dit_graph_capture": (i32, [vp, vp, C.POINTER(f32), i32, vp]),
     "ltx2_dit_graph_launch": (i32, [vp, vp]),
     "ltx2_dit_health": (i32, [vp, vp]),
+    "ltx2_dit_set_context_mask": (i32, [vp, i32, vp, i32, vp]),
     "ltx2_dit_set_option": (i32, [vp, C.c_char_p, i32]),
     "ltx2_dit_profile_begin": (i32, [vp, i32]),
     "ltx2_dit_profile_end": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),

@@ -18,6 +18,17 @@ struct AttnParams {
     long sk_ws_bytes;
     unsigned* sk_flags;
     int sk_xcd;
+    // Per-query-row softmax scale (text cross-attention with q_norm folded in, round 3): q_ss[q * q_ss_ld + j], j < q_ss_ld, are partial sums
+    // of the row's squared norm over the FULL inner dim q_norm_dim; row q then uses scale_log2e * rsqrt(sum / q_norm_dim + q_eps) -- the
+    // RMS normalisation of q as a positive per-row factor on its scores (the row maximum is taken on the raw scores: order-preserving).
+    // null = one scale for every row.  Plain grid only.
+    const float* q_ss;
+    int q_ss_ld, q_norm_dim;
+    float q_eps;
+    // Key mask (reference attention.py:38-70 with the boolean (B, S) context mask of model.py:163-201): bit i of kmask[t] = key 64 t + i may be
+    // attended; a masked key's score is replaced by -1e30 (the reference ADDS -3.4e38 to it: the same softmax, including the uniform
+    // result over the masked keys of a row whose keys are all masked).  null = no mask.  Plain grid only.
+    const unsigned long long* kmask;
     int sk_force;       // 1: stream-K whenever there are more units than slots (unit tests); 0: only when the plain grid's last round is badly filled
 };
 

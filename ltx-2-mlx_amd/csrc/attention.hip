@@ -94,8 +94,14 @@ struct SkSlot {
     static constexpr int BYTES = 4 * WAVE_BYTES;
 };
 
-template <int HD, bool SK>
+// score of a masked key: far below any real score and small enough that (score - max) * scale stays finite for any row scale
+// (the reference adds -3.4e38 to the score, attention.py:38-70: the same softmax, also for a row whose keys are all masked -> uniform)
+#define AT_KEY_MASKED (-1.0e30f)
+
+template <int HD, bool SK, bool QS = false, bool KM = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+    static_assert(!(SK && KM), "the key mask runs on the plain grid");
+    static_assert(!KM || AT_SFMA, "the key mask's exponent form lives in the scalar-fma softmax");
     using G = Geo<HD>;
     constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NKS = G::NKS, ND = G::ND, NJ = G::NJ;
     constexpr int NK = 2 * NKS, NV = 4 * ND;        // K / V^T fragment reads (= MFMAs) per wave per tile
@@ -231,6 +237,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
+        // softmax scale of this lane's query row (exp2 domain): uniform, or with the row's RMS factor folded in (QS)
+        float c = p.scale_log2e;
+        if constexpr (QS) {
+            // the two lanes of a row (hi = 0 / 1) add one half of its partial sums each; the loads of a half are independent
+            const int half = p.q_ss_ld >> 1;
+            const float* sp = p.q_ss + (long)min(q0 + l31, p.Nq - 1) * p.q_ss_ld + hi * half;
+            float ss = 0.f;
+#pragma unroll 8
+            for (int jj = 0; jj < half; jj += 4) {
+                const f32x4 t = *(const f32x4*)(sp + jj);
+                ss += (t[0] + t[1]) + (t[2] + t[3]);
+            }
+            ss += __shfl_xor(ss, 32);
+            c *= rsqrtf(ss / (float)p.q_norm_dim + p.q_eps);
+        }
 
 #pragma unroll
         for (int i = 0; i < 2 * NJ; ++i) stage_piece(ta, 0, i);
@@ -276,12 +297,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             //      folded into one fma in front of v_exp_f32: p = 2^(s*c - m*c)) ----
             if constexpr (MASKED) {
                 const int kv0 = t * KVB;
+                unsigned long long km = ~0ull;
+                if constexpr (KM) km = p.kmask[t];
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int kv = kv0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (kv >= p.Nkv) s[b][r] = -INFINITY;
+                        const int kl = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (kv0 + kl >= p.Nkv) s[b][r] = -INFINITY;
+                        else if (KM && !((km >> kl) & 1ull)) s[b][r] = AT_KEY_MASKED;
                     }
             }
             // first V^T fragments go out before the row max and the exponentials, which hide their LDS latency
@@ -322,7 +346,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             // RESCALE_THR (in exponent units), so P stays <= 2^THR and the O rescale pass is skipped.
             // The decision is wave-uniform; when taken, O, l and the new P all move to the new max
             // before anything is accumulated, so no term is ever at a stale scale.
-            const float c = p.scale_log2e;
             if (!__all((tmax - m_run) * c <= RESCALE_THR)) {
                 const float m_new = fmaxf(m_run, tmax);
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);     // first tile: 2^-inf = 0
@@ -344,7 +367,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float e0 = __builtin_fmaf(s[b][r], c, nmc), e1 = __builtin_fmaf(s[b][r + 1], c, nmc);
+                    // KM: (s - m) c, exact 0 for a masked key of a row whose every key so far is masked (s = m = AT_KEY_MASKED: the fma
+                    // form would leave the rounding error of m c, ~1e22, in the exponent)
+                    const float e0 = KM ? (s[b][r] - m_run) * c : __builtin_fmaf(s[b][r], c, nmc);
+                    const float e1 = KM ? (s[b][r + 1] - m_run) * c : __builtin_fmaf(s[b][r + 1], c, nmc);
                     const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
                     ps0 += p0;
                     ps1 += p1;
@@ -378,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             });
         };
 
-        const int t_unmasked_end = min(tb, nfull);
+        const int t_unmasked_end = KM ? ta : min(tb, nfull);       // with a key mask EVERY tile takes the masked body
         int t = ta;
         for (; t + 1 < t_unmasked_end; t += 2) {
             tile(t, std::false_type{}, std::integral_constant<int, 0>{});
@@ -388,7 +414,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             tile(t, std::false_type{}, std::integral_constant<int, 0>{});
             ++t;
         }
-        if (nfull < tb) {
+        if constexpr (KM) {
+            for (; t < tb; ++t) {
+                if ((t - ta) & 1) tile(t, std::true_type{}, std::integral_constant<int, 1>{});
+                else tile(t, std::true_type{}, std::integral_constant<int, 0>{});
+            }
+        } else if (nfull < tb) {
             if ((nfull - ta) & 1) tile(nfull, std::true_type{}, std::integral_constant<int, 1>{});
             else tile(nfull, std::true_type{}, std::integral_constant<int, 0>{});
         }
@@ -441,7 +472,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
-                const float c = p.scale_log2e;
                 for (int k = first; k < j; ++k) {
                     const int sb = (k * slot_stride + slot_off) * SL::BYTES + wv * SL::WAVE_BYTES;
                     const f32x2 ml = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, sb + ND * 4 * 1024 + lane * 8, 0, 16));
@@ -589,14 +619,21 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     // group (same XCD when the heads are dealt), each XCD dispatches its workgroups in order, and the lowest-numbered unfinished
     // workgroup never waits on an unfinished one.
     bool xcd = false;
-    const int workers = p.sk_ws ? sk_workers(p, &xcd) : 0;
+    if (p.q_ss)
+        LTX2_CHECK_ARG(p.head_dim != 64 && p.q_ss_ld > 0 && p.q_ss_ld % 8 == 0 && p.q_norm_dim > 0, "attention: the per-row scale form needs head_dim 128 and q_ss_ld %% 8 == 0");
+    const int workers = (p.sk_ws && !p.kmask) ? sk_workers(p, &xcd) : 0;
     if (workers > 0) {
         LTX2_CHECK_ARG(workers < 1024 && p.sk_ws_bytes >= attn_sk_workspace_bytes(p.head_dim), "attention: stream-K workspace too small");
         AttnParams q = p;
         q.sk_xcd = xcd;
         q.sk_flags = (unsigned*)p.sk_ws;
         q.sk_ws = (char*)p.sk_ws + 4096;
-        if (p.head_dim == 64)
+        if (p.q_ss) {
+            static PerDeviceOnce sq_once;
+            if (sq_once.first())
+                (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
+            hipLaunchKernelGGL((attn_fwd_kernel<128, true, true>), dim3(workers), dim3(256), Geo<128>::LDS_BYTES, stream, q);
+        } else if (p.head_dim == 64)
             hipLaunchKernelGGL((attn_fwd_kernel<64, true>), dim3(workers), dim3(256), Geo<64>::LDS_BYTES, stream, q);
         else
             hipLaunchKernelGGL((attn_fwd_kernel<128, true>), dim3(workers), dim3(256), Geo<128>::LDS_BYTES, stream, q);
@@ -604,6 +641,30 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
         return LTX2_OK;
     }
     dim3 grid((p.Nq + QB - 1) / QB, p.H);
+    if (p.kmask) {      // masked text cross-attention: plain grid, every tile on the masked body
+        static PerDeviceOnce km_once;
+        if (km_once.first()) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
+        }
+        if (p.head_dim == 64)
+            hipLaunchKernelGGL((attn_fwd_kernel<64, false, false, true>), grid, dim3(256), Geo<64>::LDS_BYTES, stream, p);
+        else if (p.q_ss)
+            hipLaunchKernelGGL((attn_fwd_kernel<128, false, true, true>), grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
+        else
+            hipLaunchKernelGGL((attn_fwd_kernel<128, false, false, true>), grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
+        LTX2_CHECK_LAUNCH("attn_fwd_kernel<KM>");
+        return LTX2_OK;
+    }
+    if (p.q_ss) {
+        static PerDeviceOnce qs_once;
+        if (qs_once.first())
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
+        hipLaunchKernelGGL((attn_fwd_kernel<128, false, true>), grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
+        LTX2_CHECK_LAUNCH("attn_fwd_kernel<QS>");
+        return LTX2_OK;
+    }
     if (p.head_dim == 64)
         hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), Geo<64>::LDS_BYTES, stream, p);
     else

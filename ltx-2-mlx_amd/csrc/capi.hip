@@ -45,6 +45,73 @@ int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
     return gemm_launch(p, epilogue, false, (hipStream_t)stream);
 }
 
+int ltx2_gemm_bf16_rowss(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K, float* rowss,
+                         int* written, void* stream) {
+    LTX2_CHECK_ARG(A && W && out && rowss && written, "gemm_bf16_rowss: null argument");
+    GemmParams p{};
+    p.A = (const bf16*)A;
+    p.lda = lda;
+    p.W = (const bf16*)W;
+    p.bias = bias;
+    p.out = out;
+    p.ldo = ldo;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    *written = gemm_rowss_supported(p, EPI_BF16) ? 1 : 0;
+    if (*written) p.rowss = rowss;
+    return gemm_launch(p, EPI_BF16, false, (hipStream_t)stream);
+}
+
+int ltx2_flash_attn_rowscale(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
+                             int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, void* stream) {
+    LTX2_CHECK_ARG(Q && K && VT && out && q_ss, "flash_attn_rowscale: null operand");
+    LTX2_CHECK_ARG(head_dim == 128, "flash_attn_rowscale: head_dim=%d, only 128 is implemented", head_dim);
+    AttnParams a{};
+    a.Q = (const bf16*)Q;
+    a.ldq = ldq;
+    a.K = (const bf16*)K;
+    a.ldk = ldk;
+    a.VT = (const bf16*)VT;
+    a.vt_head_stride = (long)head_dim * Npad;
+    a.head_dim = head_dim;
+    a.O = (bf16*)out;
+    a.ldo = ldo;
+    a.Nq = Nq;
+    a.Nkv = Nkv;
+    a.Npad = Npad;
+    a.H = H;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.q_ss = q_ss;
+    a.q_ss_ld = q_ss_ld;
+    a.q_norm_dim = q_norm_dim;
+    a.q_eps = q_eps;
+    return attn_launch(a, (hipStream_t)stream);
+}
+
+int ltx2_flash_attn_keymask(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
+                            int H, int head_dim, float scale, const float* mask, void* words, void* stream) {
+    LTX2_CHECK_ARG(Q && K && VT && out && mask && words, "flash_attn_keymask: null operand");
+    if (const int rc = keymask_words_launch(mask, Nkv, (unsigned long long*)words, Npad / 64, (hipStream_t)stream)) return rc;
+    AttnParams a{};
+    a.Q = (const bf16*)Q;
+    a.ldq = ldq;
+    a.K = (const bf16*)K;
+    a.ldk = ldk;
+    a.VT = (const bf16*)VT;
+    a.vt_head_stride = (long)head_dim * Npad;
+    a.head_dim = head_dim;
+    a.O = (bf16*)out;
+    a.ldo = ldo;
+    a.Nq = Nq;
+    a.Nkv = Nkv;
+    a.Npad = Npad;
+    a.H = H;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.kmask = (const unsigned long long*)words;
+    return attn_launch(a, (hipStream_t)stream);
+}
+
 int ltx2_gemm_route(int M, int N, int K, int epilogue, int weights, int has_vt) {
     // host logic only: addresses are never dereferenced (16-byte aligned dummies satisfy the alignment checks)
     static const long dummy[2] = {0, 0};

@@ -76,6 +76,11 @@ struct Mod {        // per-modality geometry + workspace
          *sin_b = nullptr, *e1_b = nullptr, *es_b = nullptr, *ctx_in = nullptr, *c1 = nullptr, *ctxp = nullptr,
          *ctxm = nullptr, *kv2 = nullptr, *vt2 = nullptr;
     const bf16* ctx = nullptr;      // projected text context (ctxp or ctx_in)
+    unsigned long long* kmask = nullptr;   // text cross-attention key mask as 64-bit words (Modality.context_mask); used when has_kmask
+    bool has_kmask = false;
+    float* qss = nullptr;           // text cross-attention with q_norm folded in: partial row sums of squares of the projected queries [N][D/64]
+    float* knq = nullptr;           //   and k_norm.weight * q_norm.weight per layer [L][D] (the per-dim q weight moves onto the cached keys)
+    bool qfold = false;             //   decided per prepare: the query projection runs on a kernel that writes the partial sums
     unsigned char* a8 = nullptr;    // fp8 compute: per-token e4m3fn codes of the current GEMM's activation operand [N][<= 4D]
     float* a8s = nullptr;           //              and their row scales [N]
 };
@@ -146,6 +151,9 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         m.att = (bf16*)take(2L * n * D);
         m.ff = (bf16*)take(2L * n * 4 * D);
         m.glog = (float*)take(c->gated ? 4L * n * m.H : 0);
+        m.kmask = (unsigned long long*)take(8L * (spad / 64));
+        m.qss = (float*)take(4L * n * (D / 64));
+        m.knq = (float*)take(4L * L * D);
         m.a8 = (unsigned char*)take((c->fp8_compute && k == 0) ? n * 4 * D : 0);
         m.a8s = (float*)take((c->fp8_compute && k == 0) ? 4L * n : 0);
         m.sin_f = (float*)take(4L * 256);
@@ -338,11 +346,45 @@ bool f8_route(ltx2_dit* c, const bf16* W, int M, int N, int K, int epi) {
     return gemm_v4_f8_supported(q, epi);
 }
 
+// q_norm folded into the text cross-attention (round 3, VERDICT r2 #4c): possible when the query projection runs on a kernel whose
+// epilogue writes the row partial sums of squares (the 4-wave kernel's bf16 epilogue: M >= 1024, D % 512 == 0: the attention kernel halves the D / 64 partials between two lanes)
+bool text_qfold_ok(ltx2_dit* c, int k) {
+    const Mod& m = c->m[k];
+    if (m.D % 512 != 0 || m.hd != 128) return false;
+    const bf16* W = c->layers[0].m[k].text.q_w;
+    GemmParams q{};
+    q.M = m.N;
+    q.N = m.D;
+    q.K = m.D;
+    q.lda = m.D;
+    q.ldo = m.D;
+    q.out = m.x;
+    if (k == 0 && f8_route(c, W, m.N, m.D, m.D, EPI_BF16)) {
+        q.A8 = m.a8;
+        q.ascale = m.a8s;
+    } else {
+        q.A = m.h;
+    }
+    auto f8 = c->fp8_scale.find((const void*)W);
+    if (f8 != c->fp8_scale.end()) {
+        q.W8 = (const unsigned char*)W;
+        q.wscale = f8->second;
+    } else {
+        q.W = W;
+    }
+    return gemm_rowss_supported(q, EPI_BF16);
+}
+
+__global__ void vec_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+
 // preq: the kernel that produced A already left its per-token e4m3fn codes + scales in m[0].a8 / a8s (norm_mod_launch's q8 output);
 // only valid when f8_route() says yes for this GEMM
 int dense(ltx2_dit* c, const bf16* A, long lda, const bf16* W, const float* bias, void* out, long ldo, int M, int N, int K, int epi,
           hipStream_t st, const float* gate = nullptr, long gate_stride = 0, const float* gate_table = nullptr,
-          const VtOut* vt = nullptr, bool* vt_done = nullptr, bool preq = false) {
+          const VtOut* vt = nullptr, bool* vt_done = nullptr, bool preq = false, float* rowss = nullptr) {
     GemmParams p{};
     p.A = A;
     p.lda = lda;
@@ -364,6 +406,7 @@ int dense(ltx2_dit* c, const bf16* A, long lda, const bf16* W, const float* bias
     p.gate = gate;
     p.gate_stride = gate_stride;
     p.gate_table = gate_table;
+    p.rowss = rowss;
     // fp8 compute (opt-in): the video stream's big GEMMs on fp8-resident weights take per-token-quantised activations and the fp8 MFMA
     if (p.W8 && f8_route(c, W, M, N, K, epi)) {
         if (!preq) TRY(quant_rows_fp8_launch(A, lda, M, K, c->m[0].a8, K, c->m[0].a8s, st));
@@ -433,8 +476,16 @@ int adaln_chain(ltx2_dit* c, Mod& m, const AdaW& a, const float* ts, long t_stri
 // sk: the context's stream-K scratch -- only for launches on the MAIN stream (they are ordered; the audio modality's
 // attention runs beside them on the side stream and keeps the plain grid).
 int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int npad, bf16* out, long ldo, int nq,
-           int nkv, int H, int hd, hipStream_t st, ltx2_dit* sk = nullptr) {
+           int nkv, int H, int hd, hipStream_t st, ltx2_dit* sk = nullptr, const float* q_ss = nullptr, float q_eps = 0.f,
+           const unsigned long long* kmask = nullptr) {
     AttnParams a{};
+    a.kmask = kmask;
+    if (q_ss) {         // q_norm as a per-row softmax scale from the projection's partial sums (text cross-attention)
+        a.q_ss = q_ss;
+        a.q_ss_ld = H * hd / 64;
+        a.q_norm_dim = H * hd;
+        a.q_eps = q_eps;
+    }
     if (sk) {
         a.sk_ws = sk->sk_ws;
         a.sk_ws_bytes = sk->sk_bytes;
@@ -491,12 +542,12 @@ int gate_apply(ltx2_dit* c, Mod& m, bf16* att, int rows, int H, int hd, hipStrea
 
 // K (k_norm applied, optional RoPE) and V^T of a text / cross-modal context
 int project_kv(ltx2_dit* c, const bf16* ctx, int rows, int Dc, const AttnW& w, int Di, int H, int hd, float eps, const float* cosb,
-               const float* sinb, bf16* kv, bf16* vt, int npad, hipStream_t st) {
+               const float* sinb, bf16* kv, bf16* vt, int npad, hipStream_t st, const float* k_weight = nullptr) {
     const VtOut vo{vt, Di, npad, hd};
     bool vt_done = false;           // V^T straight from the K/V GEMM's epilogue where the 4-wave kernel takes the shape
     TRY(dense(c, ctx, Dc, w.kv_w, w.kv_b, kv, 2 * Di, rows, 2 * Di, Dc, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done));
     const int offs[1] = {0};
-    const float* wts[1] = {w.kn};
+    const float* wts[1] = {k_weight ? k_weight : w.kn};
     TRY(qknorm_rope_launch(kv, 2 * Di, rows, Di, hd, 1, offs, wts, eps, cosb, sinb, st));
     if (vt_done) return LTX2_OK;
     return vt_transpose_launch(kv + Di, 2 * Di, vt, rows, npad, H, st, hd);
@@ -540,7 +591,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     if (c->v2) {
         TRY(norm_mod_launch(m.x, D, h2, D, N, D, eps, 0, w.sst + 7 * D, w.sst + 6 * D, emb + 7 * D, emb + 6 * D, es, st, a8q, D, a8sq));
         TRY(ctx_mod_launch(m.ctx, m.ctxm, m.S, D, w.prompt_sst + D, w.prompt_sst, m.prompt_emb + D, m.prompt_emb, st));
-        TRY(project_kv(c, m.ctxm, m.S, D, w.text, D, H, hd, eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st));
+        TRY(project_kv(c, m.ctxm, m.S, D, w.text, D, H, hd, eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st, m.qfold ? m.knq + (long)l * D : nullptr));
         kk = m.kv2;
         vt = m.vt2;
     } else {
@@ -549,13 +600,16 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
         vt = m.vt2 + (long)l * D * m.Spad;
     }
     TRY(gate_logits(c, m, w.text, m.h, D, N, H, st));
-    TRY(dense(c, m.h, D, w.text.q_w, w.text.q_b, m.qkv, D, N, D, D, EPI_BF16, st, nullptr, 0, nullptr, nullptr, nullptr, q2));
-    {
+    // q_norm folded (m.qfold): the projection's epilogue leaves the partial sums of squares of its rows; q_norm.weight already sits on the keys
+    // (k_norm.weight * q_norm.weight, prepare) and the row's RMS factor becomes its softmax scale -- no pass over q between GEMM and attention
+    TRY(dense(c, m.h, D, w.text.q_w, w.text.q_b, m.qkv, D, N, D, D, EPI_BF16, st, nullptr, 0, nullptr, nullptr, nullptr, q2, m.qfold ? m.qss : nullptr));
+    if (!m.qfold) {
         const int offs[1] = {0};
         const float* wts[1] = {w.text.qn};
         TRY(qknorm_rope_launch(m.qkv, D, N, D, hd, 1, offs, wts, eps, nullptr, nullptr, st));
     }
-    TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st, k == 0 ? c : nullptr));
+    TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st, k == 0 ? c : nullptr, m.qfold ? m.qss : nullptr, eps,
+               m.has_kmask ? m.kmask : nullptr));
     TRY(gate_apply(c, m, m.att, N, H, hd, st));
     if (c->v2)
         TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 8 * D, es, w.sst + 8 * D));
@@ -729,10 +783,16 @@ int prepare_modality(ltx2_dit* c, int k, const float* context, int S, const floa
         TRY(dense(c, m.c1, D, w.cap2_w, w.cap2_b, m.ctxp, D, S, D, D, EPI_BF16, st));
         m.ctx = m.ctxp;
     }
+    m.qfold = text_qfold_ok(c, k);
+    if (m.qfold)
+        for (int l = 0; l < c->cfg.num_layers; ++l) {
+            const AttnW& tw = c->layers[l].m[k].text;
+            hipLaunchKernelGGL(vec_mul_kernel, dim3((D + 255) / 256), dim3(256), 0, st, tw.kn, tw.qn, m.knq + (long)l * D, D);
+        }
     if (!c->v2)
         for (int l = 0; l < c->cfg.num_layers; ++l)
             TRY(project_kv(c, m.ctx, S, D, c->layers[l].m[k].text, D, m.H, m.hd, c->cfg.norm_eps, nullptr, nullptr,
-                           m.kv2 + (long)l * S * 2 * D, m.vt2 + (long)l * D * m.Spad, m.Spad, st));
+                           m.kv2 + (long)l * S * 2 * D, m.vt2 + (long)l * D * m.Spad, m.Spad, st, m.qfold ? m.knq + (long)l * D : nullptr));
     return LTX2_OK;
 }
 
@@ -806,6 +866,7 @@ int bind(ltx2_dit* c, void* ptr, int64_t bytes, int N, int S, int Na, int Sa, in
     }
     c->per_token = per_token;
     c->prepared = false;
+    c->m[0].has_kmask = c->m[1].has_kmask = false;
     return LTX2_OK;
 }
 
@@ -1032,6 +1093,23 @@ int ltx2_dit_profile_end(ltx2_dit* c, double* total_ms, int64_t* launches, doubl
     *total_ms = tot;
     *launches = (int64_t)(c->prof_used / 2);
     *flops = c->prof_flops;
+    return LTX2_OK;
+}
+
+int ltx2_dit_set_context_mask(ltx2_dit* c, int modality, const float* mask, int S, void* stream) {
+    LTX2_CHECK_ARG(c && (modality == 0 || (modality == 1 && c->av)), "dit_set_context_mask: bad context / modality");
+    Mod& m = c->m[modality];
+    if (!c->ws) {
+        ltx2_set_error("dit_set_context_mask: no workspace bound");
+        return LTX2_E_STATE;
+    }
+    if (!mask) {
+        m.has_kmask = false;
+        return LTX2_OK;
+    }
+    LTX2_CHECK_ARG(S == m.S, "dit_set_context_mask: S=%d differs from the bound workspace S=%d", S, m.S);
+    TRY(keymask_words_launch(mask, S, m.kmask, m.Spad / 64, (hipStream_t)stream));
+    m.has_kmask = true;
     return LTX2_OK;
 }
 

@@ -40,6 +40,10 @@ struct GemmParams {
     bf16* vt;
     long vt_head_stride;
     int vt_col0, vt_npad, vt_hd;
+    // gemm_v4.hip, EPI_BF16, dense, layouts 3 / 5: rowss[m * (N / 64) + n / 64] = sum over the 64-column strip of out[m][n]^2 (of the
+    // ROUNDED outputs): the partial sums of a row's squared norm, for a consumer that folds an RMS normalisation of `out` into its own
+    // arithmetic (text cross-attention: q_norm as a per-row softmax scale).  null = off.  gemm_rowss_supported() says when.
+    float* rowss;
     int splitk;          // gemm_v4.hip: K split over this many blocks per tile (fp32 slabs + reduce); 0 / 1 = off
     void* dbg;           // ping-pong kernel: optional device buffer for interval timestamps (debug)      // ping-pong kernel: which wave bit selects the staggered group (tuning knob)
 };
@@ -64,6 +68,8 @@ int gemm_route(const GemmParams& p, int epilogue, bool conv);
 // p.vt set: will gemm_launch route this problem to the kernel that writes V^T from its epilogue?  (false: clear p.vt and run
 // vt_transpose_launch after the GEMM; gemm_launch rejects a p.vt it cannot honour.)
 bool gemm_vt_fused(const GemmParams& p, int epilogue);
+// p.rowss set: will gemm_launch route this problem to a kernel that writes the row partial sums?  (false: the caller must not set it)
+bool gemm_rowss_supported(const GemmParams& p, int epilogue);
 // fp8 compute (p.A8 / p.ascale / p.W8 / p.wscale set): can the fp8-MFMA kernel (gemm_v4.hip layout 5) take this problem?
 bool gemm_v4_f8_supported(const GemmParams& p, int epilogue);
 

@@ -338,12 +338,19 @@ bool gemm_vt_fused(const GemmParams& p, int epilogue) {
     return (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_vt_supported(p, epilogue, 3);
 }
 
+bool gemm_rowss_supported(const GemmParams& p, int epilogue) {
+    if (epilogue != EPI_BF16 || p.vt || p.N % 64 != 0) return false;
+    const int r = route_of<false>(p, epilogue);
+    return r == ROUTE_V4_224 || r == ROUTE_V4_256 || r == ROUTE_V4_W8_224 || r == ROUTE_V4_W8_256 || r == ROUTE_V4_F8_224 || r == ROUTE_V4_F8_256;
+}
+
 int gemm_route(const GemmParams& p, int epilogue, bool conv) { return conv ? route_of<true>(p, epilogue) : route_of<false>(p, epilogue); }
 
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream) {
     LTX2_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     LTX2_CHECK_ARG(!p.vt || (!conv && gemm_vt_fused(p, epilogue)), "gemm: a fused V^T output needs the 4-wave layout-3 / layout-5 kernel (ask gemm_vt_fused first)");
     LTX2_CHECK_ARG(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
+    LTX2_CHECK_ARG(!p.rowss || (!conv && gemm_rowss_supported(p, epilogue)), "gemm: row partial sums need the 4-wave kernel's bf16 epilogue (ask gemm_rowss_supported first)");
     if (p.A8) {     // fp8 compute: both operands e4m3fn codes + scales, fp8 MFMA (gemm_v4.hip layout 5)
         LTX2_CHECK_ARG(!conv && p.out, "gemm: fp8 compute is dense-only");
         return gemm_v4_launch(p, epilogue, stream, 5, 0);

@@ -482,6 +482,18 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                 const u32x4 v = *(const u32x4*)(wl + r * ROWB + ((c ^ sw) << 4));
                 const int row = m0 + wr * WM + r;
                 if (row < p.M) *(u32x4*)((bf16*)p.out + (long)row * p.ldo + n0 + wc * WN + c * 8) = v;
+                if constexpr (EPI == EPI_BF16 && !CONV && (LAYOUT == 3 || LAYOUT == 5)) {
+                    if (p.rowss) {      // (block-uniform) squared norm of this wave's 64-column strip of the row, from the ROUNDED values
+                        const bf16x8 h = as_bf16x8(v);
+                        float ss = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ss += bf2f(h[e]) * bf2f(h[e]);
+                        ss += __shfl_xor(ss, 1);
+                        ss += __shfl_xor(ss, 2);
+                        ss += __shfl_xor(ss, 4);
+                        if (c == 0 && row < p.M) p.rowss[(long)row * (p.N / 64) + (n0 + wc * WN) / 64] = ss;
+                    }
+                }
             }
         }
     } else {

@@ -42,6 +42,8 @@ int timestep_sinusoid_launch(const float* t, long t_stride, float t_scalar, floa
                              bf16* out_bf16, hipStream_t stream);
 
 int cast_f32_bf16_launch(const float* in, bf16* out, long n, hipStream_t stream);
+// key mask fp32 [S] (non-zero = may be attended) -> 64-bit words, bit i of word t = key 64 t + i (attention.h: AttnParams::kmask)
+int keymask_words_launch(const float* mask, int S, unsigned long long* words, int nwords, hipStream_t stream);
 // fp8 compute path: per-row e4m3fn quantisation of bf16 rows: scale[r] = max|x[r]| / 448 (1 for a zero row),
 // out[r][k] = e4m3fn_rne(x[r][k] * (1 / scale[r]))
 int quant_rows_fp8_launch(const bf16* x, long ldx, int rows, int K, unsigned char* out, long ldo, float* scale, hipStream_t stream);

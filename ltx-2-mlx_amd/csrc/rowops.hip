@@ -549,6 +549,15 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16* __restr
     }
 }
 
+// key mask fp32 [S] (non-zero = attend) -> one 64-bit word per 64 keys (bit i of word t = key 64 t + i); keys >= S read as masked
+__global__ void keymask_words_kernel(const float* __restrict__ mask, int S, unsigned long long* __restrict__ words, int nwords) {
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= nwords) return;
+    const int k = w * 64 + lane;
+    const unsigned long long b = __ballot(k < S && mask[k] != 0.f);
+    if (lane == 0) words[w] = b;
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -931,6 +940,13 @@ int quant_rows_fp8_launch(const bf16* x, long ldx, int rows, int K, unsigned cha
     else
         hipLaunchKernelGGL(quant_rows_fp8_kernel<16>, dim3(rows), dim3(256), 0, stream, x, ldx, K, out, ldo, scale);
     LTX2_CHECK_LAUNCH("quant_rows_fp8_kernel");
+    return LTX2_OK;
+}
+
+int keymask_words_launch(const float* mask, int S, unsigned long long* words, int nwords, hipStream_t stream) {
+    LTX2_CHECK_ARG(mask && words && S > 0 && nwords * 64 >= S, "keymask_words: bad argument");
+    hipLaunchKernelGGL(keymask_words_kernel, dim3((nwords + 3) / 4), dim3(256), 0, stream, mask, S, words, nwords);
+    LTX2_CHECK_LAUNCH("keymask_words_kernel");
     return LTX2_OK;
 }
 

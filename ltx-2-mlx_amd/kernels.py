@@ -69,6 +69,51 @@ def gemm_qkv_vt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     return out, vt, bool(fused.value)
 
 
+def gemm_rowss(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """out = a @ w^T + bias (16-bit) plus the row partial sums of squares of out over 64-column strips -> (out, rowss [M, N/64] fp32 or None
+    when the shape does not run on the kernel that writes them)."""
+    assert a.dtype in ACT16 and w.dtype == a.dtype
+    a, w = _c(a), _c(w)
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=a.device, dtype=a.dtype)
+    rowss = torch.zeros(M, max(N // 64, 1), device=a.device, dtype=torch.float32)
+    import ctypes
+    written = ctypes.c_int(0)
+    nv.check(_L(a).ltx2_gemm_bf16_rowss(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K, nv.ptr(rowss),
+                                        ctypes.byref(written), nv.stream()))
+    return out, (rowss if written.value else None)
+
+
+def flash_attn_rowscale(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, q_ss: torch.Tensor, eps: float = 1e-6,
+                        scale: Optional[float] = None) -> torch.Tensor:
+    """flash_attn with q's RMS normalisation over its FULL width folded in as a per-row softmax scale (q_ss: partial sums of squares [Nq, P])."""
+    assert q.dtype in ACT16 and q_ss.dtype == torch.float32 and q_ss.is_contiguous()
+    nq, hd = q.shape[0], vt.shape[1]
+    out = torch.empty(nq, heads * hd, device=q.device, dtype=q.dtype)
+    if scale is None:
+        scale = 1.0 / math.sqrt(float(hd))
+    nv.check(_L(q).ltx2_flash_attn_rowscale(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out), out.stride(0), nq, nkv,
+                                            heads, hd, scale, nv.ptr(q_ss), q_ss.shape[1], heads * hd, eps, nv.stream()))
+    return out
+
+
+def flash_attn_keymask(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, mask: torch.Tensor,
+                       scale: Optional[float] = None) -> torch.Tensor:
+    """flash_attn with a key mask: mask [Nkv] bool / 0-1 (True = attend) -- the boolean context mask of the reference's text
+    cross-attention (model.py:163-201, attention.py:38-70)."""
+    assert q.dtype in ACT16 and mask.numel() == nkv
+    nq, hd = q.shape[0], vt.shape[1]
+    out = torch.empty(nq, heads * hd, device=q.device, dtype=q.dtype)
+    f = (mask.reshape(-1).to(q.device) != 0).to(torch.float32).contiguous()
+    words = torch.empty(vt.shape[2] // 64, device=q.device, dtype=torch.int64)
+    if scale is None:
+        scale = 1.0 / math.sqrt(float(hd))
+    nv.check(_L(q).ltx2_flash_attn_keymask(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out), out.stride(0), nq, nkv,
+                                           heads, hd, scale, nv.ptr(f), nv.ptr(words), nv.stream()))
+    return out
+
+
 def gemm_w8a16(a: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = nv.EPI_BF16,
                out: Optional[torch.Tensor] = None, gate_table: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ dequant(w8)[N,K]^T + bias) with fp8-RESIDENT weights: w8 = float8_e4m3fn codes (uint8 view

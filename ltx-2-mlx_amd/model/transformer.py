@@ -66,7 +66,7 @@ class Modality:
     """Input record (reference model.py:59-69)."""
     latent: torch.Tensor                  # (B, T, C) patchified latents
     context: torch.Tensor                 # (B, S, C_ctx) text context
-    context_mask: Optional[torch.Tensor]  # None on every live path (pipelines/common.py:223-232)
+    context_mask: Optional[torch.Tensor]  # boolean / 0-1 integer key mask (B, S), True = attend; None on every live path (pipelines/common.py:223-232)
     timesteps: torch.Tensor               # (B,) or (B, T) / (B, T, 1)
     positions: torch.Tensor               # (B, 3, T, 2) [start, end) in (seconds, px, px)
     enabled: bool = True
@@ -168,6 +168,7 @@ class LTXModel:
         self._ws: Optional[torch.Tensor] = None
         self._bound: Tuple[int, ...] = (0, 0, 0, 0, 0)
         self._prep_key = None
+        self._mask_refs = {}
         self._prep_refs = None
         self._twin: Optional["LTXModel"] = None        # VideoOnly engine over the SAME weight tensors (video-only inference on an AV model)
         self._sigma_dev: Dict[float, torch.Tensor] = {}  # device scalars of the step sigmas (no host-to-device copy inside the loop)
@@ -417,6 +418,7 @@ class LTXModel:
             nv.check(L.ltx2_dit_bind_workspace(self._h, base, nbytes, n, s, int(per_token)))
         self._bound = want
         self._prep_key = None
+        self._mask_refs = {}            # binding clears the engine's context masks
 
     def prepare(self, context: torch.Tensor, positions: torch.Tensor, per_token: bool = False,
                 audio_context: Optional[torch.Tensor] = None, audio_positions: Optional[torch.Tensor] = None) -> None:
@@ -498,7 +500,12 @@ class LTXModel:
             raise NotImplementedError("STG perturbations are outside the distilled hot path (cfg forced to 1)")
         for m in (video, audio):
             if m is not None and m.context_mask is not None:
-                raise NotImplementedError("context_mask is None on every live reference path (pipelines/common.py:223-232)")
+                cm = m.context_mask
+                if cm.dtype.is_floating_point:
+                    # model.py:186-187 hands a float mask to the attention as an ADDITIVE bias of any shape; no reference path builds one
+                    raise NotImplementedError("float (additive) context_mask: pass the boolean (B, S) key mask instead")
+                if cm.dim() != 2 or cm.shape[0] != 1 or cm.shape[1] != m.context.shape[1]:
+                    raise ValueError(f"context_mask must be (1, S={m.context.shape[1]}); got {tuple(cm.shape)}")
             if m is not None and m.latent.shape[0] != 1:
                 raise ValueError("batch must be 1")
         if not self.is_av and audio is not None:
@@ -515,18 +522,35 @@ class LTXModel:
         out = torch.empty(lat.shape[0], self.out_channels, device=self.device, dtype=torch.float32)
         if not self.is_av:
             self._ensure_prepared(video, per_token=(n_ts != 1))
+            self._apply_context_masks(video)
             # prompt AdaLN (V2.3) takes Modality.sigma, not timesteps[0]: with image conditioning timesteps = mask * sigma
             sg = self._sigma(video) if self.cross_attention_adaln else None
             nv.check(self._L.ltx2_dit_forward(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(sg), nv.ptr(out), nv.stream()))
             return out[None]
         ats, n_ats = self._timesteps(audio)
         self._ensure_prepared(video, per_token=(n_ts != 1 or n_ats != 1), audio=audio)
+        self._apply_context_masks(video, audio)
         alat = audio.latent[0].to(self.device, torch.float32).contiguous()
         aout = torch.empty(alat.shape[0], self.AUDIO_OUT_CHANNELS, device=self.device, dtype=torch.float32)
         vs, as_ = self._sigma(video), self._sigma(audio)
         nv.check(self._L.ltx2_dit_forward_av(self._h, nv.ptr(lat), nv.ptr(ts), n_ts, nv.ptr(vs), nv.ptr(alat), nv.ptr(ats), n_ats,
                                               nv.ptr(as_), nv.ptr(out), nv.ptr(aout), nv.stream()))
         return out[None], aout[None]
+
+    def _apply_context_masks(self, video: Modality, audio: Optional[Modality] = None) -> None:
+        """Modality.context_mask -> the engine's text cross-attention key mask (ltx2_dit_set_context_mask; model.py:163-201 +
+        attention.py:38-70).  After _ensure_prepared: binding a workspace clears the engine's masks."""
+        for k, m in enumerate((video, audio)):
+            if m is None:
+                continue
+            if m.context_mask is None:
+                if self._mask_refs.get(k) is not None:
+                    nv.check(self._L.ltx2_dit_set_context_mask(self._h, k, None, 0, nv.stream()))
+                    self._mask_refs[k] = None
+                continue
+            f = (m.context_mask[0].to(self.device) != 0).to(torch.float32).contiguous()
+            nv.check(self._L.ltx2_dit_set_context_mask(self._h, k, nv.ptr(f), f.numel(), nv.stream()))
+            self._mask_refs[k] = f
 
     def _sigma_scalar(self, sigma: float) -> torch.Tensor:
         t = self._sigma_dev.get(float(sigma))
@@ -554,6 +578,7 @@ class LTXModel:
         assert latent.dtype == torch.float32 and latent.is_contiguous() and latent.dim() == 2
         if not self.is_av:
             self._ensure_prepared(video, per_token=(n_ts != 1))
+            self._apply_context_masks(video)
             sg = self._sigma_scalar(sigma) if self.cross_attention_adaln else None
             nv.check(self._L.ltx2_dit_denoise_step(self._h, nv.ptr(latent), nv.ptr(ts), n_ts, nv.ptr(sg), nv.ptr(denoise_mask),
                                                     nv.ptr(clean_latent), float(sigma), float(sigma_next), None, nv.stream()))
@@ -561,6 +586,7 @@ class LTXModel:
         assert audio is not None and audio_latent is not None and audio_latent.dtype == torch.float32 and audio_latent.is_contiguous()
         ats, n_ats = self._timesteps(audio)
         self._ensure_prepared(video, per_token=(n_ts != 1 or n_ats != 1), audio=audio)
+        self._apply_context_masks(video, audio)
         sg = self._sigma_scalar(sigma)
         nv.check(self._L.ltx2_dit_denoise_step_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), nv.ptr(ts), n_ts, nv.ptr(ats), n_ats,
                                                    nv.ptr(sg), nv.ptr(denoise_mask), nv.ptr(clean_latent), nv.ptr(audio_denoise_mask),

@@ -135,8 +135,19 @@ def apply_split_rope(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------
 # Attention  (attention.py:12-34,203-253)
 # ---------------------------------------------------------------------------
-def sdpa(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
-    """_compiled_attention_core_no_mask: softmax(q k^T / sqrt(d)) v per head (attention.py:21-34)."""
+def prepare_attention_mask(context_mask: Optional[Tensor]) -> Optional[Tensor]:
+    """LTXModel._prepare_attention_mask (model.py:163-201) for fp32 compute: a boolean / integer key mask (B, S) becomes the additive
+    mask (1 - m) * -3.40e38 of shape (B, 1, 1, S); a float mask is taken as it is (already additive)."""
+    if context_mask is None:
+        return None
+    if context_mask.dtype in (torch.float16, torch.float32, torch.bfloat16, torch.float64):
+        return context_mask
+    m = (1 - context_mask.float()) * -3.40e38
+    return m.reshape(context_mask.shape[0], 1, 1, context_mask.shape[-1])
+
+
+def sdpa(q: Tensor, k: Tensor, v: Tensor, heads: int, mask: Optional[Tensor] = None) -> Tensor:
+    """_compiled_attention_core_no_mask / _with_mask: softmax(q k^T / sqrt(d) + mask) v per head (attention.py:21-34, 38-70)."""
     b, tq, hd = q.shape
     tk = k.shape[1]
     d = hd // heads
@@ -144,6 +155,12 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
     kh = k.reshape(b, tk, heads, d).transpose(1, 2)
     vh = v.reshape(b, tk, heads, d).transpose(1, 2)
     s = torch.matmul(qh, kh.transpose(-1, -2)) * (1.0 / math.sqrt(d))
+    if mask is not None:
+        if mask.ndim == 2:
+            mask = mask[None, None]
+        elif mask.ndim == 3:
+            mask = mask[:, None]
+        s = s + mask.to(s.dtype)
     p = torch.softmax(s, dim=-1)
     o = torch.matmul(p, vh)
     return o.transpose(1, 2).reshape(b, tq, hd)
@@ -157,10 +174,11 @@ def attention(
     eps: float,
     context: Optional[Tensor] = None,
     pe: Optional[Tuple[Tensor, Tensor]] = None,
+    mask: Optional[Tensor] = None,
 ) -> Tensor:
     """Attention.__call__ (attention.py:203-253): to_q/k/v (+bias), RMSNorm(weight)
     over the FULL inner dim on q and k (:186-187,231-232), SPLIT RoPE on q,k if pe,
-    SDPA, to_out."""
+    SDPA (additive mask when given), to_out."""
     ctx = x if context is None else context
     q = linear(x, w, prefix + ".to_q")
     k = linear(ctx, w, prefix + ".to_k")
@@ -170,7 +188,7 @@ def attention(
     if pe is not None:
         q = apply_split_rope(q, pe[0], pe[1])
         k = apply_split_rope(k, pe[0], pe[1])
-    o = sdpa(q, k, v, heads)
+    o = sdpa(q, k, v, heads, mask)
     return linear(o, w, prefix + ".to_out.0")
 
 
@@ -191,6 +209,7 @@ def transformer_block(
     w: Dict[str, Tensor],
     i: int,
     cfg: DiTConfig,
+    context_mask: Optional[Tensor] = None,
 ) -> Tensor:
     """BasicTransformerBlock.__call__ (transformer.py:191-238).
     timesteps: [B, T, 6, D] with T in {1, N}; AdaLN row order (shift, scale, gate) (:207-209)."""
@@ -202,7 +221,7 @@ def transformer_block(
     a = attention(h, w, p + ".attn1", cfg.num_attention_heads, cfg.norm_eps, pe=pe)
     x = x + a * gate_msa                                           # _compiled_residual_gate :35-46
     c = attention(rms_norm(x, None, cfg.norm_eps), w, p + ".attn2", cfg.num_attention_heads,
-                  cfg.norm_eps, context=context)                   # :217-226 (no RoPE, no mask)
+                  cfg.norm_eps, context=context, mask=context_mask)   # :217-226 (no RoPE; additive key mask when the Modality carries one)
     x = x + c
     shift_mlp, scale_mlp, gate_mlp = ada[:, :, 3], ada[:, :, 4], ada[:, :, 5]
     h = adaln_forward(x, scale_mlp, shift_mlp, cfg.norm_eps)
@@ -235,6 +254,7 @@ def velocity_model(
     w: Dict[str, Tensor],
     cfg: DiTConfig,
     return_hidden: bool = False,
+    context_mask: Optional[Tensor] = None,
 ):
     """LTXModel.__call__ for VideoOnly (model.py:776-881).
 
@@ -251,8 +271,9 @@ def velocity_model(
     pe = rope_split_tables(positions.float(), cfg.inner_dim, cfg.num_attention_heads,
                            cfg.positional_embedding_theta, cfg.positional_embedding_max_pos)
     hidden = []
+    amask = prepare_attention_mask(context_mask)                     # model.py:266-268
     for i in range(cfg.num_layers):
-        x = transformer_block(x, ctx, emb, pe, w, i, cfg)
+        x = transformer_block(x, ctx, emb, pe, w, i, cfg, amask)
         if return_hidden:
             hidden.append(x)
     # _process_video_output (model.py:744-758): rows (shift, scale); LayerNorm no affine
@@ -265,9 +286,9 @@ def velocity_model(
 
 
 def x0_model(latent: Tensor, context: Tensor, timesteps: Tensor, positions: Tensor,
-             w: Dict[str, Tensor], cfg: DiTConfig) -> Tensor:
+             w: Dict[str, Tensor], cfg: DiTConfig, context_mask: Optional[Tensor] = None) -> Tensor:
     """X0Model.__call__ (model.py:895-936): x0 = latent - sigma * velocity."""
-    v = velocity_model(latent, context, timesteps, positions, w, cfg)
+    v = velocity_model(latent, context, timesteps, positions, w, cfg, context_mask=context_mask)
     t = timesteps.float()
     if t.ndim == 1:
         t = t[:, None, None]

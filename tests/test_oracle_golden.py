@@ -63,6 +63,16 @@ def test_product_host_logic_matches_reference():
     close(VideoLatentPatchifier(1).patchify(lat5), z["patchify"], rtol=0, atol=0)
 
 
+def masked_case(ctx):
+    """The masked-cross-attention case of pin_dit: padded tail + one hole; the masked keys' context rows scaled by 40."""
+    cmask = torch.ones(1, ctx.shape[1], dtype=torch.int32)
+    cmask[0, 11:] = 0
+    cmask[0, 3] = 0
+    ctx_m = ctx.clone()
+    ctx_m[0, cmask[0] == 0] *= 40.0
+    return cmask, ctx_m
+
+
 def test_dit_matches_reference():
     z = g("dit_tiny.npz")
     cfg = dit.DiTConfig(num_attention_heads=2, attention_head_dim=128, num_layers=2, caption_channels=64)
@@ -85,6 +95,13 @@ def test_dit_matches_reference():
     tsp = (torch.rand(1, f * h * wd, 1, generator=gen) > 0.3).float() * 0.909375
     close(dit.velocity_model(lat, ctx, tsp, pos, w, cfg), z["velocity_pertoken"], rtol=2e-3, atol=2e-4)
     close(dit.x0_model(lat, ctx, tsp, pos, w, cfg), z["x0_pertoken"], rtol=2e-3, atol=2e-4)
+    # masked text cross-attention: boolean key mask -> additive -3.4e38 (model.py:163-201, attention.py:38-70); the masked keys carry
+    # 40x larger context rows, so ignoring the mask lands on the recorded control instead
+    cmask, ctx_m = masked_case(ctx)
+    xm = dit.x0_model(lat, ctx_m, ts, pos, w, cfg, context_mask=cmask)
+    close(xm, z["x0_masked"], rtol=2e-3, atol=2e-4)
+    close(dit.x0_model(lat, ctx_m, ts, pos, w, cfg), z["x0_masked_control"], rtol=2e-3, atol=2e-4)
+    assert float(np.abs(z["x0_masked"] - z["x0_masked_control"]).max()) > 5e-3
     # full-width RoPE (dim 4096, 32 heads) and the timestep sinusoid at the distilled sigmas
     posf = loop.video_positions(1, 2, 3, 4, 24.0)
     cf, sf = dit.rope_split_tables(posf, 4096, 32, 10000.0, [20, 2048, 2048])

@@ -957,3 +957,53 @@ def test_stream_k_timeout_is_reported_at_the_next_health_check(dev):
     assert int(flags.abs().sum()) == 0                         # page reset
     m.check_health()
     assert torch.equal(X0Model(m)(mod), a)
+
+
+def test_masked_text_cross_attention_against_oracle_and_reference_vectors(dev):
+    """Modality.context_mask (boolean / 0-1 key mask, model.py:163-201 -> attention.py:38-70): the HIP path against the vector recorded from
+    the reference's own X0Model (tests/golden/dit_tiny.npz `x0_masked`: padded tail + one hole, the masked keys' context rows x 40 so that
+    ignoring the mask lands on `x0_masked_control` instead), against the oracle on a ragged shape, and cleared again by a mask-less call."""
+    import numpy as np
+    import os
+    from oracle import dit, loop
+    from ltx_2_mlx_amd.model.transformer import Modality, X0Model
+    from test_oracle_golden import masked_case
+    cfg, wq, m = make_dit(dev, heads=2, layers=2, cap=64, seed=11)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_tiny.npz"))
+    f, h, wd, S = 3, 4, 4, 16
+    gen = torch.Generator().manual_seed(1234)
+    lat = torch.randn(1, f * h * wd, 128, generator=gen)
+    ctx = 0.1 * torch.randn(1, S, 64, generator=gen)
+    pos = loop.video_positions(1, f, h, wd, 24.0)
+    ts = torch.tensor([0.725])
+    cmask, ctx_m = masked_case(ctx)
+    x0m = X0Model(m)
+
+    def run(mask):
+        return x0m(Modality(latent=lat.to(dev), context=ctx_m.to(dev), context_mask=None if mask is None else mask.to(dev),
+                            timesteps=ts.to(dev), positions=pos.to(dev))).cpu()
+    rm, rc = torch.from_numpy(z["x0_masked"]), torch.from_numpy(z["x0_masked_control"])
+    for mk in (cmask, cmask.bool(), cmask.to(torch.int64)):
+        got = run(mk)
+        assert rel_l2(got, rm) < 3e-2 and pearson(got, rm) > 0.999
+        assert rel_l2(got, rm) < 0.5 * rel_l2(got, rc)            # ... and it is the masked vector, not the control
+    ctl = run(None)                                                 # the mask does not outlive the call that carried it
+    assert rel_l2(ctl, rc) < 3e-2 and rel_l2(ctl, rc) < 0.5 * rel_l2(ctl, rm)
+    assert rel_l2(run(cmask), rm) < 3e-2
+    # float (additive) masks and wrong shapes are refused, not reinterpreted
+    with pytest.raises(NotImplementedError):
+        run(cmask.float())
+    with pytest.raises(ValueError):
+        run(cmask[:, :8])
+    # ragged shape, more keys than one KV tile, V2.3-style per-token timesteps off: against the oracle
+    cfg2, w2, m2 = make_dit(dev, heads=2, layers=2, cap=128)
+    lat2, ctx2, pos2 = inputs(2, 5, 7, 100, 128)
+    mk2 = torch.rand(1, 100, generator=gen) > 0.5
+    ctx2 = ctx2.clone()
+    ctx2[0, ~mk2[0]] *= 40.0
+    sigma = torch.tensor([0.909375])
+    ref = dit.x0_model(lat2, ctx2, sigma, pos2, w2, cfg2, context_mask=mk2)
+    ref_nomask = dit.x0_model(lat2, ctx2, sigma, pos2, w2, cfg2)
+    got = X0Model(m2)(Modality(latent=lat2.to(dev), context=ctx2.to(dev), context_mask=mk2.to(dev), timesteps=sigma.to(dev),
+                               positions=pos2.to(dev))).cpu()
+    assert rel_l2(got, ref) < 2e-2 and pearson(got, ref) > 0.999 and rel_l2(got, ref) < 0.5 * rel_l2(got, ref_nomask)

@@ -86,6 +86,21 @@ def pin_dit():
             out["context_proj"] = tn(args.context.t)
             out["rope_cos"] = tn(args.positional_embeddings[0].t)
             out["rope_sin"] = tn(args.positional_embeddings[1].t)
+    # masked text cross-attention (attention.py:38-70, model.py:163-201): a boolean key mask (B, S) with a padded tail and a hole
+    cmask = torch.ones(1, S, dtype=torch.int32)
+    cmask[0, 11:] = 0
+    cmask[0, 3] = 0
+    ctx_m = ctx.clone()
+    ctx_m[0, cmask[0] == 0] *= 40.0          # the masked keys would dominate the softmax if the mask were ignored
+    video = Modality(latent=A(lat), context=A(ctx_m), context_mask=mx.array(cmask.numpy()), timesteps=A(torch.tensor([0.725])), positions=A(pos))
+    args = model._video_args_preprocessor.prepare(video)
+    vargs, _ = model._process_transformer_blocks(args, None)
+    vel = model._process_video_output(vargs.x, vargs.embedded_timestep)
+    out["x0_masked"] = tn((video.latent - video.timesteps[:, None, None] * vel).t)
+    video = Modality(latent=A(lat), context=A(ctx_m), context_mask=None, timesteps=A(torch.tensor([0.725])), positions=A(pos))
+    args = model._video_args_preprocessor.prepare(video)
+    vargs, _ = model._process_transformer_blocks(args, None)
+    out["x0_masked_control"] = tn((video.latent - video.timesteps[:, None, None] * model._process_video_output(vargs.x, vargs.embedded_timestep)).t)
     # full-width RoPE table slice + sinusoid
     pos_full = oloop.video_positions(1, 2, 3, 4, 24.0)
     c, s = precompute_freqs_cis(A(pos_full), dim=4096, out_dtype=mx.float32, theta=10000.0, max_pos=[20, 2048, 2048],
@@ -432,6 +447,10 @@ def pin_vae():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "text_connector":
         pin_text_connector()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dit":
+        with torch.no_grad():
+            pin_dit()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dit_av":
         with torch.no_grad():
