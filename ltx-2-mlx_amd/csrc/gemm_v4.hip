@@ -53,7 +53,7 @@ struct V4Geo {
     static constexpr int LOOP_BYTES = W_BASE + 2 * W_STAGE;
     static constexpr int EPI_BYTES = (LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5) ? 4 * WM * WN * 2 : 0;      // bf16 outputs leave through LDS (per-wave slabs)
     static constexpr int LDS_BYTES = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
-    static_assert(LAYOUT == 4 ? (BM == 448 || BM == 512) : (BM == 224 || BM == 256), "tile rows");
+    static_assert(LAYOUT == 4 ? (BM == 384 || BM == 448 || BM == 512) : (BM == 224 || BM == 256), "tile rows");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             if constexpr (BM == 224) V4_ASM_CONV(LTX2_V4_L14_M16_RB14_CONV);
             else V4_ASM_CONV(LTX2_V4_L14_M16_RB16_CONV);
         } else {
-            if constexpr (BM == 448) V4_ASM_CONV(LTX2_V4_L41_M16_RB7_CONV);
+            if constexpr (BM == 384) V4_ASM_CONV(LTX2_V4_L41_M16_RB6_CONV);
+            else if constexpr (BM == 448) V4_ASM_CONV(LTX2_V4_L41_M16_RB7_CONV);
             else V4_ASM_CONV(LTX2_V4_L41_M16_RB8_CONV);
         }
     } else if constexpr (LAYOUT == 3) {
@@ -415,19 +416,42 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         if constexpr (EPI == EPI_ADD_BF16) {
             // out = bf16(acc + bias + res): the residual tile comes in through the same slab with whole-row loads; each lane then
             // replaces ITS 8 bytes (4 columns of one row) by the sum, rounded once -- bit-identical to adding from global memory
+            // LDS-DMA: one instruction lands 1 KiB = RPI whole slab rows with no register in between, so the wave's WM / RPI requests are
+            // all in flight at once behind ONE wait (as plain loads hipcc emitted load -> s_waitcnt vmcnt(0) -> ds_write per instruction: a
+            // memory round trip per 1 KiB, 16 of the 128-channel conv's 70 us per tile).  The DMA writes lane i's 16 bytes at byte 16 i, so
+            // the chunk swizzle moves to the source: physical chunk c of slab row r holds the row's chunk c ^ sw(r).
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
             for (int it = 0; it < WM / RPI; ++it) {
                 const int r = it * RPI + lane / CPR, c = lane % CPR;
                 const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
                 const int row = min(m0 + wr * WM + r, p.M - 1);
-                *(u32x4*)(wl + r * ROWB + ((c ^ sw) << 4)) = *(const u32x4*)(p.res + (long)row * p.ldres + n0 + wc * WN + c * 8);
+                const unsigned voff = (unsigned)(((long)row * p.ldres + n0 + wc * WN + (c ^ sw) * 8) * 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(wl + it * 1024), 16, voff, 0, 0, 0);
+#else
+                (void)voff;
+#endif
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
             if (m0 + wr * WM + rb * MB >= p.M) continue;     // no real row in this block (block-uniform): its slab rows are never read as data
             const int r = rb * MB + lr;
             const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
+            // (EPI_ADD_BF16) the row block's residual slots are read up front: in source order read -> add -> write per slot, hipcc keeps
+            // every LDS read behind the previous slot's write (same char* slab) and the block becomes CBW * NG LDS round trips
+            [[maybe_unused]] bf16x4 rsv[CBW][NG];
+            if constexpr (EPI == EPI_ADD_BF16) {
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int gq = 0; gq < NG; ++gq) {
+                        const int byte = (cb * MB + 8 * gq + 4 * kq) * 2;
+                        rsv[cb][gq] = *(const bf16x4*)(wl + r * ROWB + (((byte >> 4) ^ sw) << 4) + (byte & 15));
+                    }
+            }
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
@@ -442,7 +466,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                 const int chunk = (byte >> 4) ^ sw;
                 bf16x4* slot = (bf16x4*)(wl + r * ROWB + chunk * 16 + (byte & 15));
                 if constexpr (EPI == EPI_ADD_BF16) {
-                    const bf16x4 rs = *slot;
+                    const bf16x4 rs = rsv[cb][gq];
                     v += f32x4{bf2f(rs[0]), bf2f(rs[1]), bf2f(rs[2]), bf2f(rs[3])};
                 }
                 *slot = pack_bf16x4(v[0], v[1], v[2], v[3]);
@@ -475,11 +499,22 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                 }
             }
         } else {
+            // slab rows leave in batches of RBATCH instructions: the LDS reads of a batch go out together (one latency per batch, not per row group)
+            constexpr int RBATCH = 4;
+            static_assert((WM / RPI) % RBATCH == 0, "readback batches");
+            u32x4 rbv[RBATCH];
 #pragma unroll
             for (int it = 0; it < WM / RPI; ++it) {
                 const int r = it * RPI + lane / CPR, c = lane % CPR;
-                const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
-                const u32x4 v = *(const u32x4*)(wl + r * ROWB + ((c ^ sw) << 4));
+                if (it % RBATCH == 0) {
+#pragma unroll
+                    for (int b = 0; b < RBATCH; ++b) {
+                        const int rb2 = (it + b) * RPI + lane / CPR;
+                        const int sw2 = CPR == 8 ? ((rb2 >> 1) & 7) : (rb2 & 15);
+                        rbv[b] = *(const u32x4*)(wl + rb2 * ROWB + ((c ^ sw2) << 4));
+                    }
+                }
+                const u32x4 v = rbv[it % RBATCH];
                 const int row = m0 + wr * WM + r;
                 if (row < p.M) *(u32x4*)((bf16*)p.out + (long)row * p.ldo + n0 + wc * WN + c * 8) = v;
                 if constexpr (EPI == EPI_BF16 && !CONV && (LAYOUT == 3 || LAYOUT == 5)) {
@@ -562,6 +597,7 @@ bool gemm_v4_supported(const GemmParams& p, int epilogue, bool conv) {
     if (p.N % 256 != 0 || p.K % 128 != 0 || p.K < 256 || p.M < 1024) return false;
     if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.K * 2 >= (1L << 31)) return false;     // 32-bit buffer offsets
     if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15)) return false;                                       // 16-byte output rows
+    if (epilogue == EPI_ADD_BF16 && (!p.res || (long)p.M * p.ldres * 2 >= (1L << 31) || p.ldres % 8 != 0 || ((uintptr_t)p.res & 15))) return false;      // the residual tile arrives by LDS-DMA
     return true;
 }
 
@@ -670,6 +706,7 @@ bool gemm_v4_conv_supported(const GemmParams& p, int epilogue) {
     if (p.M < 512) return false;
     if ((long)(p.T + 2) * (p.H + 2) * (p.Wd + 2) * p.Cin * 2 >= (1L << 31) || (long)p.N * p.K * 2 >= (1L << 31)) return false;
     if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15)) return false;
+    if (epilogue == EPI_ADD_BF16 && (!p.res || (long)p.M * p.ldres * 2 >= (1L << 31) || p.ldres % 8 != 0 || ((uintptr_t)p.res & 15))) return false;      // the residual tile arrives by LDS-DMA
     return true;
 }
 
@@ -690,9 +727,24 @@ int gemm_v4_conv_launch(const GemmParams& p_in, int epilogue, hipStream_t stream
     GemmParams p = p_in;
     LTX2_CHECK_ARG(gemm_v4_conv_supported(p, epilogue), "gemm_v4 conv: unsupported problem (Cin=%d N=%d M=%d epilogue=%d)", p.Cin, p.N, p.M, epilogue);
     p.splitk = 1;
-    if (p.N % 256 != 0) {       // 128-channel outputs: 512 x 128 tiles
-        if (epilogue == EPI_BF16) return launch_v4<EPI_BF16, 4, 512, true>(p, stream);
-        return launch_v4<EPI_ADD_BF16, 4, 512, true>(p, stream);
+    if (p.N % 256 != 0) {
+        // 128-channel outputs: BM x 128 tiles, BM in {512, 448, 384} by whole rounds of the 256 CUs x rows per round (the last round of a
+        // 512-row grid is often nearly empty: 49 x 128 x 192 positions = 2352 tiles = 9.2 rounds; 448 rows: 10.5 -> 11 x 448 < 10 x 512).
+        // A/B on one box (round 3): 448 rows -1 % on the decode; 320 / 384 rows (the XCD's 32 concurrent tiles + the weight panel inside
+        // the 4 MB L2) the same time as 512 -- the convs are not bound by the fabric re-reads.
+        long best_cost = 0;
+        int bm = 512;
+        for (const int cand : {512, 448, 384}) {
+            const long tiles = ((long)p.M + cand - 1) / cand * (p.N / 128), cost = (tiles + 255) / 256 * cand;
+            if (!best_cost || cost < best_cost) {
+                best_cost = cost;
+                bm = cand;
+            }
+        }
+#define CONV4(E) (bm == 512 ? launch_v4<E, 4, 512, true>(p, stream) : bm == 448 ? launch_v4<E, 4, 448, true>(p, stream) : launch_v4<E, 4, 384, true>(p, stream))
+        if (epilogue == EPI_BF16) return CONV4(EPI_BF16);
+        return CONV4(EPI_ADD_BF16);
+#undef CONV4
     }
     const long t256 = ((long)(p.M + 255) / 256) * (p.N / 256), t224 = ((long)(p.M + 223) / 224) * (p.N / 256);
     const bool b224 = (t224 + 255) / 256 * 224 < (t256 + 255) / 256 * 256 || t224 < 256;

@@ -559,6 +559,10 @@ def main():
                            dma_last=list(range(0, 54, 3)), dma_ks0=[], m0_early=True, conv=conv))
         out.append(variant("LTX2_V4_L41_M16_RB8" + sfx, 8, 8, mb=16, npa=16, npw=4, a_stage=65536, w_base=131072, w_stage=16384,
                            dma_last=list(range(0, 60, 3)), dma_ks0=[], m0_early=True, conv=conv))
+        if conv:
+            # a 384-row tile for grids whose 448 / 512-row forms end in a nearly empty round (gemm_v4_conv_launch picks by whole rounds)
+            out.append(variant("LTX2_V4_L41_M16_RB6" + sfx, 6, 8, mb=16, npa=12, npw=4, a_stage=49152, w_base=98304, w_stage=16384,
+                               dma_last=list(range(0, 48, 3)), dma_ks0=[], m0_early=True, conv=conv))
     # layout 3 with fp8-resident weights: W stage = 256 rows x 64 B
     out.append(variant("LTX2_V4_L14_M16_RB14_W8", 14, 4, mb=16, npa=7, npw=4, w_stage=16384, dma_last=list(range(0, 44, 4)), dma_ks0=[], m0_early=True, w8=True))
     out.append(variant("LTX2_V4_L14_M16_RB16_W8", 16, 4, mb=16, npa=8, npw=4, w_stage=16384, dma_last=list(range(3, 50, 4)), dma_ks0=[], m0_early=True, w8=True))

@@ -109,7 +109,7 @@ GemmParams conv_params(const bf16* x, const bf16* w, const float* b, void* out, 
 // res-block conv on the padded-volume kernel (gemm_v4.hip)?  The producer (pixel norm) must then write the padded layout.
 bool conv_on_v4(int T, int H, int W, int Cin, int Cout, int epi, void* out) {
     if (!vae_v4_enabled()) return false;
-    const GemmParams p = conv_params(nullptr, nullptr, nullptr, out, T, H, W, Cin, Cout, 0, nullptr);
+    const GemmParams p = conv_params(nullptr, nullptr, nullptr, out, T, H, W, Cin, Cout, 0, epi == EPI_ADD_BF16 ? (const bf16*)out : nullptr);
     return gemm_v4_conv_supported(p, epi);
 }
 

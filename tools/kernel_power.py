@@ -1,5 +1,5 @@
 """Socket power while ONE kernel runs back to back for a few seconds (rocm-smi polled from a thread): is it at the 1400 W cap?
-usage: python tools/kernel_power.py attn|attn_cross|gemm|gemm_resid|norm"""
+usage: python tools/kernel_power.py attn|attn_cross|gemm|gemm_resid|norm|vae"""
 import math, os, re, subprocess, sys, threading, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ltx_2_mlx_amd.kernels as K
@@ -14,6 +14,14 @@ if which.startswith("attn"):
     ws = K.flash_attn_workspace(128, dev)
     fn = lambda: K.flash_attn(q, k, vt, H, nkv, workspace=ws if which == "attn" else None)
     flop = 4.0 * N * nkv * D
+elif which == "vae":
+    from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder, decode_latent
+    dec = SimpleVideoDecoder(device=dev)
+    dec.init_random_weights(seed=7)
+    dec.generator = torch.Generator(device=dev).manual_seed(99)
+    z = torch.randn(1, 128, 9, 16, 24, device=dev)
+    fn = lambda: decode_latent(z, dec)
+    flop = 37.7e12
 elif which.startswith("gemm"):
     a = torch.randn(N, D, device=dev).to(torch.bfloat16); w = (torch.randn(4 * D, D, device=dev) / 64).to(torch.bfloat16)
     out = torch.empty(N, 4 * D, device=dev, dtype=torch.bfloat16)
@@ -32,12 +40,13 @@ def poll():
                 f = l.split(",")
                 samples.append((float(f[-1]), int(re.sub(r"\D", "", f[6]))))
 th = threading.Thread(target=poll); th.start()
-for _ in range(20): fn()
+reps = 4 if which == "vae" else 200
+for _ in range(2 if which == "vae" else 20): fn()
 torch.cuda.synchronize()
 t0 = time.time(); n = 0
 while time.time() - t0 < 6.0:
-    for _ in range(200): fn()
-    torch.cuda.synchronize(); n += 200
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); n += reps
 dt = time.time() - t0
 stop = True; th.join()
 busy = [s for s in samples[len(samples) // 4:]]
