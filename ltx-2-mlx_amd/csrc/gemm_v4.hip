@@ -531,6 +531,55 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                 }
             }
         }
+    } else if constexpr (EPI == EPI_D2S_BF16 && CONV && LAYOUT == 3) {
+        // depth-to-space scatter (+ the tiled d2s(x) residual).  Column n = s Cf + c with Cf >= 64 a power of two: the wave's 64 columns share s,
+        // so the sub-position (da, db, dd) is wave-uniform and computed once; a lane's rows advance by MB positions per row block, so (t, h, w)
+        // is stepped, not divided; and the residual elements of a row block (2-byte reads 16 bytes apart: column c of the output is channel
+        // (c mod Cin/sp) sp + s of the input) are all requested before the first is used.  Written per group as in round 2 (epi_store4: three
+        // integer divisions, four loads, a wait and a store per 4 outputs, 56 times per lane) this epilogue cost 17-28 us per tile.
+        const int colw = n0 + wc * WN;
+        const int s_idx = colw >> p.cf_shift, c_base = colw & (p.Cf - 1);
+        const int fhw = p.fh * p.fw;
+        const int da = s_idx / fhw, db = (s_idx - da * fhw) / p.fw, dd = s_idx - da * fhw - db * p.fw;
+        const int sp = p.ft * fhw, cmask = p.c_d2s - 1;
+        const bf16* xs = p.res ? p.res : p.A;
+        const int Ho = p.H * p.fh, Wo = p.Wd * p.fw;
+        int row = m0 + lr;
+        const int hw = p.H * p.Wd;
+        int pt = row / hw, ph = (row - pt * hw) / p.Wd, pw = row - pt * hw - ph * p.Wd;
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb, row += MB) {
+            if (rb) {
+                pw += MB;
+                while (pw >= p.Wd) {
+                    pw -= p.Wd;
+                    if (++ph >= p.H) {
+                        ph = 0;
+                        ++pt;
+                    }
+                }
+            }
+            const int to = pt * p.ft + da - p.drop_first;
+            const bool ok = row < p.M && to >= 0;
+            unsigned short rs[CBW][4];
+            if (p.d2s_residual) {
+                const bf16* xr = xs + (long)min(row, p.M - 1) * p.Cin + s_idx;
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rs[cb][e] = *(const unsigned short*)(xr + ((c_base + cb * MB + 4 * kq + e) & cmask) * sp);
+            }
+            bf16* orow = (bf16*)p.out + (((long)to * Ho + (ph * p.fh + db)) * Wo + (pw * p.fw + dd)) * p.Cf + c_base + 4 * kq;
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                f32x4 v = acc_group(rb, cb, 0) + bias4[cb][0];
+                if (p.d2s_residual) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bf2f(__builtin_bit_cast(bf16, rs[cb][e]));
+                }
+                if (ok) *(bf16x4*)(orow + cb * MB) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+            }
+        }
     } else {
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
@@ -700,7 +749,8 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
 // p.H / p.Wd = the OUTPUT extent, M = T*H*Wd, K = 9*taps_t*Cin, weights [Cout][taps][Cin].
 bool gemm_v4_conv_supported(const GemmParams& p, int epilogue) {
     if (epilogue != EPI_BF16 && epilogue != EPI_ADD_BF16 && epilogue != EPI_D2S_BF16) return false;
-    if (epilogue == EPI_D2S_BF16 && (p.N % 256 != 0 || p.Cf < 4 || (p.d2s_residual && !p.res))) return false;      // depth-to-space scatter: layout 3 only; residual from p.res
+    // depth-to-space scatter: layout 3 only; a wave's 64 columns share the sub-position (Cf >= 64, a power of two); the residual comes from p.res
+    if (epilogue == EPI_D2S_BF16 && (p.N % 256 != 0 || p.Cf < 64 || (p.Cf & (p.Cf - 1)) || (p.d2s_residual && (!p.res || p.c_d2s < 1 || (p.c_d2s & (p.c_d2s - 1)))))) return false;
     if (p.Cin < 128 || (p.Cin & (p.Cin - 1)) || p.N % 128 != 0) return false;          // an even number of K-tiles: 27 * Cin / 64
     if (p.taps_t != 3 && p.taps_t != 1) return false;
     if (p.M < 512) return false;
