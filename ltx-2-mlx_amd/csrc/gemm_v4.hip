@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((W8 || F8) ? (void*)p.W8 : (void*)p.W, 0, 0x7fffffff, 0x00020000);
     const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + w * npa_rt * 1024);
     const unsigned lw = __builtin_amdgcn_readfirstlane(lds0 + G::W_BASE + w * NPW * 1024);
-    const unsigned nk = __builtin_amdgcn_readfirstlane(p.K / (F8 ? 128 : 64) / (p.splitk > 1 ? p.splitk : 1));
-    const unsigned kb = __builtin_amdgcn_readfirstlane(split * nk);
+    // split-K: split i takes K-tiles [2 floor(i h / s), 2 floor((i + 1) h / s)), h = half the K-tiles -- even counts that differ by at most 2
+    const unsigned nkt = p.K / (F8 ? 128 : 64);
+    const unsigned kb = __builtin_amdgcn_readfirstlane(p.splitk > 1 ? 2 * ((unsigned)split * (nkt / 2) / (unsigned)p.splitk) : 0u);
+    const unsigned nk = __builtin_amdgcn_readfirstlane(p.splitk > 1 ? 2 * (((unsigned)split + 1) * (nkt / 2) / (unsigned)p.splitk) - kb : nkt);
     // conv: lane i holds the byte offset of tap i = (a*3 + b)*3 + c (a absent for per-frame 3x3 convs) in the padded volume
     unsigned tapv = 0;
     unsigned lcpt = 0, cptm1 = 0;
@@ -760,17 +762,24 @@ bool gemm_v4_conv_supported(const GemmParams& p, int epilogue) {
     return true;
 }
 
-// splits for a conv with `tiles` output tiles and nk K-tiles: the largest power of two that keeps an even number (>= 8) of
-// K-tiles per block and does not push the grid past ~1.2 rounds of the 256 CUs; 1 when the grid already fills the chip
-static int conv_splits(long tiles, int nk, long mn, long ws_bytes) {
+// splits for a conv with `tiles` output tiles and nk K-tiles (any count 1..16; the kernel deals even K-tile counts that differ by at most 2):
+// the cheapest by a small model in K-tile times -- rounds of the 256 CUs x (the longest split + ~6 for the fp32 tile's way out) + the reduce
+// pass (s slabs of mn floats at ~4 TB/s against ~1.4 us per K-tile).  Round 2 took the largest POWER OF TWO that kept the grid in one round:
+// 48 tiles x 432 K-tiles (the 1024-channel convs of a 7-frame chunk) ran 4 splits on 192 CUs; 5 splits fill 240.
+static int conv_splits(long tiles, int nk, long mn, long ws_bytes, double* cost_out = nullptr) {
     int best = 1;
-    for (int s = 2; s <= 16; s *= 2) {
-        if (nk % (2 * s) != 0 || nk / s < 8) break;
-        if (tiles * s > 308) break;
-        if ((long)s * mn * 4 > ws_bytes) break;
-        best = s;
+    double best_cost = (double)((tiles + 255) / 256) * (nk + 6);
+    for (int s = 2; s <= 16; ++s) {
+        const int h = nk / 2, lo = 2 * (h / s), hi = 2 * ((h + s - 1) / s);
+        if (lo < 8 || (long)s * mn * 4 > ws_bytes) break;
+        const double cost = (double)((tiles * s + 255) / 256) * (hi + 6) + 3.0 + (double)s * (double)mn / 1.44e6;
+        if (cost < best_cost * 0.97) {          // a split must buy at least 3 %
+            best_cost = cost;
+            best = s;
+        }
     }
-    return tiles >= 160 ? 1 : best;
+    if (cost_out) *cost_out = best_cost;
+    return best;
 }
 
 int gemm_v4_conv_launch(const GemmParams& p_in, int epilogue, hipStream_t stream, void* splitk_ws, long ws_bytes) {
@@ -797,10 +806,17 @@ int gemm_v4_conv_launch(const GemmParams& p_in, int epilogue, hipStream_t stream
 #undef CONV4
     }
     const long t256 = ((long)(p.M + 255) / 256) * (p.N / 256), t224 = ((long)(p.M + 223) / 224) * (p.N / 256);
-    const bool b224 = (t224 + 255) / 256 * 224 < (t256 + 255) / 256 * 256 || t224 < 256;
+    bool b224 = (t224 + 255) / 256 * 224 < (t256 + 255) / 256 * 256 || t224 < 256;
     const long mn = (long)p.M * p.N;
     if (epilogue == EPI_D2S_BF16) return b224 ? launch_v4<EPI_D2S_BF16, 3, 224, true>(p, stream) : launch_v4<EPI_D2S_BF16, 3, 256, true>(p, stream);
-    const int splits = (splitk_ws && p.ldo == p.N) ? conv_splits(b224 ? t224 : t256, p.K / 64, mn, ws_bytes) : 1;
+    int splits = 1;
+    if (splitk_ws && p.ldo == p.N) {
+        // tile height and split count together: 96 tiles of 224 rows take 2 splits (192 CUs), the same problem as 84 tiles of 256 rows takes 3 (252)
+        double c224 = 0, c256 = 0;
+        const int s224 = conv_splits(t224, p.K / 64, mn, ws_bytes, &c224), s256 = conv_splits(t256, p.K / 64, mn, ws_bytes, &c256);
+        if (s224 > 1 || s256 > 1) b224 = c224 * 224 <= c256 * 256;
+        splits = b224 ? s224 : s256;
+    }
     if (splits > 1) {
         GemmParams q = p;
         q.splitk = splits;
