@@ -58,6 +58,10 @@ struct Geo {
 #ifndef AT_MAX2
 #define AT_MAX2 0
 #endif
+#ifndef AT_PRIO
+#define AT_PRIO 1       // 1 = s_setprio 1 over the two MFMA clusters of a tile (round 3, same-box A/B: self-attention -0.7 %, text cross-attention -2 %:
+                        // the wave inside an MFMA cluster wins the issue slot, its SIMD partner's softmax VALU fills the gaps); 2 = over the softmax (no gain)
+#endif
 #ifndef AT_SFMA
 #define AT_SFMA 1       // scalar-slot fma / add for the exponent argument and the row sum (round 3, same-box A/B: -2.5 % vs the packed forms)
 #endif
@@ -269,6 +273,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             const int tn = min(t + 1, tb - 1);          // the tail re-stages the last tile into the idle buffer (branch-free body)
             constexpr int nbuf = 1 - PAR;
 
+#if AT_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);
+#endif
             // ---- S^T = K . Q^T  (two 32-key blocks); fragment i = b * NKS + ks ----
             f32x16 s[2];
 #pragma unroll
@@ -321,6 +328,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
             float tmax = -INFINITY;
             mfma_result_guard(s[0], s[1], tmax);
+#if AT_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#elif AT_PRIO == 2
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #if AT_MAX2
             {   // two independent v_max3 chains in two asm blocks (the compiler puts a hazard s_nop behind every single-instruction asm)
                 float ta = -INFINITY, tb2 = -INFINITY;
@@ -395,6 +407,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             l_run += psum2[0] + psum2[1];
 #endif
 
+#if AT_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);
+#elif AT_PRIO == 2
+            __builtin_amdgcn_s_setprio(0);
+#endif
             // ---- O^T += V^T . P^T ----
             static_for<0, NV>([&](auto N) {
                 constexpr int n = decltype(N)::value, i = (n % ND) * 4 + n / ND;
@@ -402,6 +419,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 lds_wait<(n + DV < NV ? DV : NV - 1 - n)>(vf[i]);
                 o[i / 4] = LTX2_MFMA_32x32x16(as_bf16x8(vf[i]), pf[(i % 4) / 2][i % 2], o[i / 4], 0, 0, 0);
             });
+#if AT_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
 
         const int t_unmasked_end = KM ? ta : min(tb, nfull);       // with a key mask EVERY tile takes the masked body

@@ -8,7 +8,13 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_$TAG
-rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_$TAG -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-extra --no-cpu-baseline --no-loader --no-vae --no-graph --no-kernel-pass "$@" > "$OUT/bench_stdout.log" 2>&1
+# LAYER_TRACE_FP8=1: the opt-in fp8 compute mode (tools/fp8_step.py) instead of the bf16 bench loop
+if [ "${LAYER_TRACE_FP8:-0}" = 1 ]; then
+  CMD="python $REPO/tools/fp8_step.py --steps 3"
+else
+  CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline --no-loader --no-vae --no-graph --no-kernel-pass $*"
+fi
+rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_$TAG -o bench -- $CMD > "$OUT/bench_stdout.log" 2>&1
 f=$(find /tmp/rp_$TAG -name "*kernel_trace.csv" | head -1)
 python - "$f" > "$OUT/layer_trace.txt" <<'PY'
 import csv, sys, re, collections
