@@ -353,7 +353,7 @@ int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream
     LTX2_CHECK_ARG(!p.rowss || (!conv && gemm_rowss_supported(p, epilogue)), "gemm: row partial sums need the 4-wave kernel's bf16 epilogue (ask gemm_rowss_supported first)");
     if (p.A8) {     // fp8 compute: both operands e4m3fn codes + scales, fp8 MFMA (gemm_v4.hip layout 5)
         LTX2_CHECK_ARG(!conv && p.out, "gemm: fp8 compute is dense-only");
-        return gemm_v4_launch(p, epilogue, stream, 5, 0);
+        return gemm_v4_launch(p, epilogue, stream, 0, 0);        // layout 6 (16x16x128 blocks) for 224-row tiles, 5 (32x32x64) for 256-row ones
     }
     LTX2_CHECK_ARG(p.A && (p.W || p.W8) && p.out, "gemm: null operand");
     if (p.W8) {     // fp8-resident weights: the 4-wave asm-loop kernel, or the skinny-M kernel where the bf16 path would take it too

@@ -39,7 +39,7 @@ typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 template <int LAYOUT, int BM, bool W8 = false>
 struct V4Geo {
     static constexpr int BN = LAYOUT == 4 ? 128 : 256;
-    static_assert(LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5, "wave layout");
+    static_assert(LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5 || LAYOUT == 6, "wave layout");
     static constexpr int MB = LAYOUT == 5 ? 32 : 16;               // MFMA block
     static constexpr bool L14 = LAYOUT != 4;                       // 1x4 waves (layout 4: 4x1)
     static constexpr int WM = LAYOUT == 4 ? BM / 4 : BM;
@@ -51,19 +51,20 @@ struct V4Geo {
     static constexpr int A_STAGE = LAYOUT == 4 ? BM * 128 : 32768, W_BASE = 2 * A_STAGE, W_STAGE = BN * WROW;
     static_assert(!W8 || LAYOUT == 3, "fp8-resident weights run on layout 3");
     static constexpr int LOOP_BYTES = W_BASE + 2 * W_STAGE;
-    static constexpr int EPI_BYTES = (LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5) ? 4 * WM * WN * 2 : 0;      // bf16 outputs leave through LDS (per-wave slabs)
+    static constexpr int EPI_BYTES = 4 * WM * WN * 2;      // bf16 outputs leave through LDS (per-wave slabs)
     static constexpr int LDS_BYTES = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
     static_assert(LAYOUT == 4 ? (BM == 384 || BM == 448 || BM == 512) : (BM == 224 || BM == 256), "tile rows");
+    static_assert(LAYOUT != 6 || BM == 224, "layout 6 tile rows");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 template <int EPI, int LAYOUT, int BM, bool CONV, int VAR>
 __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     constexpr bool W8 = VAR == 20;          // fp8-resident weights: p.W8 codes [N][K] + p.wscale[N]
-    constexpr bool F8 = LAYOUT == 5;        // fp8 compute: p.A8 codes [M][lda] + p.ascale[M], p.W8 codes [N][K] + p.wscale[N]
+    constexpr bool F8 = LAYOUT == 5 || LAYOUT == 6;        // fp8 compute (5: 32x32x64 blocks, 6: 16x16x128 blocks): p.A8 codes [M][lda] + p.ascale[M], p.W8 codes [N][K] + p.wscale[N]
     using G = V4Geo<LAYOUT, BM, W8>;
     constexpr int TBN = G::BN, NPA = G::NPA, NPW = G::NPW, MB = G::MB, WM = G::WM, WN = G::WN, RBW = G::RBW, CBW = G::CBW, NKS = G::NKS;
-    static_assert(!CONV || LAYOUT != 5, "conv runs on the 16x16x32 layouts");
+    static_assert(!CONV || !(LAYOUT == 5 || LAYOUT == 6), "conv runs on the bf16 layouts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const int tid = threadIdx.x;
@@ -242,6 +243,9 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     } else if constexpr (LAYOUT == 4) {
         if constexpr (BM == 448) V4_ASM(LTX2_V4_L41_M16_RB7);
         else V4_ASM(LTX2_V4_L41_M16_RB8);
+    } else if constexpr (LAYOUT == 6) {     // fp8 x fp8 on 16x16x128 blocks (224-row tiles only: the fragment registers of 16 row blocks do not fit)
+        static_assert(BM == 224, "layout 6 tile rows");
+        V4_ASM(LTX2_V4_F8_M16_RB14);
     } else {                                // layout 5: fp8 x fp8
         if constexpr (BM == 224) V4_ASM(LTX2_V4_F8_RB7);
         else V4_ASM(LTX2_V4_F8_RB8);
@@ -283,9 +287,13 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     auto acc_group = [&](int rb, int cb, int gq) -> f32x4 {
         // accumulator block index as the generator numbers it: rb * cbw + cb (both wave rows share cbw = CBW)
         const int blk = rb * CBW + cb;
-        if constexpr (F8) {
+        if constexpr (F8 && MB == 32) {
             const f32x16& a = acc[blk];
             return f32x4{a[4 * gq], a[4 * gq + 1], a[4 * gq + 2], a[4 * gq + 3]} * (ws4[cb][gq] * as_row[rb]);
+        } else if constexpr (F8) {
+            const f32x16& a = acc[blk >> 2];
+            const int o = (blk & 3) * 4;
+            return f32x4{a[o], a[o + 1], a[o + 2], a[o + 3]} * (ws4[cb][gq] * as_row[rb]);
         } else if constexpr (MB == 32) {
             const f32x16& a = acc[blk];
             return f32x4{a[4 * gq], a[4 * gq + 1], a[4 * gq + 2], a[4 * gq + 3]};
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         }
     };
     constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_SILU_BF16;
-    constexpr bool RESID_LDS_OK = EPI == EPI_RESID_GATE_F32 && (LAYOUT == 3 || LAYOUT == 5) && VAR != 9;
+    constexpr bool RESID_LDS_OK = EPI == EPI_RESID_GATE_F32 && (LAYOUT == 3 || LAYOUT == 5 || LAYOUT == 6) && VAR != 9;
     const bool resid_lds = RESID_LDS_OK && !(p.gate && p.gate_stride != 0);      // block-uniform
     if constexpr (RESID_LDS_OK) {
       if (resid_lds) {
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
             }
         }
       }
-    } else if constexpr ((LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5) && VAR != 9 && (BF16_OUT || EPI == EPI_ADD_BF16)) {
+    } else if constexpr (VAR != 9 && (BF16_OUT || EPI == EPI_ADD_BF16)) {
         // bf16 outputs of the row-slab layouts leave through LDS: a lane's accumulator groups are 4 columns of 16 different
         // rows (8-byte stores into 32-byte row segments); transposed through this wave's share of the (now dead) stage
         // buffers every store instruction writes whole rows: 8 rows x 128 B (layout 3) or 4 rows x 256 B (layout 4).
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                 *slot = pack_bf16x4(v[0], v[1], v[2], v[3]);
               }
         }
-        if ((LAYOUT == 3 || LAYOUT == 5) && EPI == EPI_BF16 && !CONV && p.vt && n0 >= p.vt_col0) {
+        if ((LAYOUT == 3 || LAYOUT == 5 || LAYOUT == 6) && EPI == EPI_BF16 && !CONV && p.vt && n0 >= p.vt_col0) {
             // V tile of a fused QKV projection: this wave's 64 columns are 64 dims of ONE head; leave as V^T rows
             // vt[head][d][.] with attention's key order inside every 32-key block: position 16 ks + 8 hh + 4 g0 + e holds
             // key 8 (2 ks + g0) + 4 hh + e.  One instruction stores 16 dims x 64 bytes (4 chunks of 8 positions); every chunk is
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                 const u32x4 v = rbv[it % RBATCH];
                 const int row = m0 + wr * WM + r;
                 if (row < p.M) *(u32x4*)((bf16*)p.out + (long)row * p.ldo + n0 + wc * WN + c * 8) = v;
-                if constexpr (EPI == EPI_BF16 && !CONV && (LAYOUT == 3 || LAYOUT == 5)) {
+                if constexpr (EPI == EPI_BF16 && !CONV && (LAYOUT == 3 || LAYOUT == 5 || LAYOUT == 6)) {
                     if (p.rowss) {      // (block-uniform) squared norm of this wave's 64-column strip of the row, from the ROUNDED values
                         const bf16x8 h = as_bf16x8(v);
                         float ss = 0.f;
@@ -685,9 +693,15 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
     if (p.A8) {     // fp8 compute: layout 5
         LTX2_CHECK_ARG(gemm_v4_f8_supported(p, epilogue), "gemm_v4: fp8 compute needs A8 + ascale + W8 + wscale, N %% 256 == 0, K %% 256 == 0, K >= 512, a dense bf16/gelu/f32/residual epilogue (N=%d K=%d epilogue=%d)", p.N, p.K, epilogue);
         const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
+#ifndef LTX2_F8_FORCE_L5
+#define LTX2_F8_FORCE_L5 0          // (A/B builds: -DLTX2_F8_FORCE_L5=1 keeps every fp8 GEMM on layout 5)
+#endif
+        const bool l5 = layout == 5 || LTX2_F8_FORCE_L5;
+        // 224-row tiles: the 16x16x128 form (layout 6; +16 % FLOP per joule on random e4m3 operands, tools/micro/mfma_fp8_power.hip); layout 5 keeps
+        // the 256-row tiles (and the 224-row ones when asked for by `layout`)
 #define CASEF(E) \
     case E:      \
-        return b224 ? launch_v4<E, 5, 224>(p, stream) : launch_v4<E, 5, 256>(p, stream);
+        return b224 ? (l5 ? launch_v4<E, 5, 224>(p, stream) : launch_v4<E, 6, 224>(p, stream)) : launch_v4<E, 5, 256>(p, stream);
         switch (epilogue) {
             CASEF(EPI_BF16)
             CASEF(EPI_GELU_BF16)

@@ -72,14 +72,20 @@ class Gen:
         # per K-tile) on 8-VGPR fragments = 32 bytes per lane, read as TWO ds_read_b128 (the lane's two adjacent 16-byte chunks)
         self.f8, self.f8_scaled = f8, f8_scaled
         if f8:
-            assert mb == 32 and not conv and not w8
+            assert mb in (32, 16) and not conv and not w8
+        # f8 with 16x16 blocks: v_mfma_f32_16x16x128_f8f6f4 takes a WHOLE 128-element K-tile per instruction (measured +16 % FLOP per joule over
+        # the 32x32x64 form on random e4m3 operands, tools/micro/mfma_fp8_power.hip), so a K-tile is ONE k-step and its fragments (rbw + cbw of
+        # 8 VGPRs) cannot be double-buffered as a set.  "Rolling" form: the activation fragments have ONE register set -- fragment rb of tile T+1
+        # is read into rb's registers as soon as rb's last MFMA of tile T is behind (the order is rb-major) -- and only the cbw weight fragments,
+        # which every row block uses, have two sets.
+        self.roll = f8 and mb == 16
         self.fr = 8 if f8 else 4                  # VGPRs per fragment
         self.rpf = 2 if f8 else 1                 # ds_read_b128 per fragment
         self.s_kw = S_KW if (conv or w8) else S_KA
         self.kw_shift = 6 if w8 else 7               # weight K-tile = 64 bytes of codes / 128 bytes of bf16
         if w8:
             assert mb == 16 and not conv
-        self.nks = 2 if (mb == 16 or f8) else 4
+        self.nks = 1 if self.roll else (2 if (mb == 16 or f8) else 4)
         self.accsz = 16 if mb == 32 else 4
         self.blk_bytes = mb * 128                 # LDS bytes between consecutive row blocks
         self.npa = npa                            # activation DMA pieces per wave (BM / 32)
@@ -88,6 +94,14 @@ class Gen:
         self.nfrag = rbw + cbw
         self.q_base = P_BASE + self.fr * self.nfrag
         self.vgpr_top = self.q_base + self.fr * self.nfrag
+        if self.roll:                             # A fragments [P_BASE, +8 rbw), weight set P, weight set Q
+            self.wsets = (P_BASE + self.fr * rbw, P_BASE + self.fr * (rbw + cbw))
+            self.q_base = self.wsets[1]
+            # the LAST row block's fragment has two sets too (tile parity): read into its single set it could only be requested behind the
+            # tile's final MFMA, and the lgkmcnt(0) that ends the k-step would wait out a whole LDS latency on every K-tile
+            self.alast = (P_BASE + self.fr * (rbw - 1), self.wsets[1] + self.fr * cbw)
+            self.apar = 0                             # parity of the last fragment's set that frag() hands out (set by kstep_roll)
+            self.vgpr_top = self.alast[1] + self.fr
         if f8 and f8_scaled:                      # one VGPR holding the E8M0 code of 1.0 in every byte (v_mfma_scale_* operands)
             self.one_reg = self.vgpr_top
             self.vgpr_top += 1
@@ -111,7 +125,7 @@ class Gen:
         assert len(dma_last) + len(dma_ks0) == n, (dma_last, dma_ks0, n)
         self.reads_every = reads_every
         self.m0_early = m0_early
-        assert (self.nfrag * self.rpf - 1) * reads_every < self.nmf * (2 if f8 else 1)
+        assert self.roll or (self.nfrag * self.rpf - 1) * reads_every < self.nmf * (2 if f8 else 1)
         self.no_dma, self.no_read, self.no_barrier = no_dma, no_read, no_barrier
         self.out = []
         self.trace = []
@@ -120,6 +134,10 @@ class Gen:
         self.out.extend(s.split("\n"))
 
     def frag(self, setbase, idx):       # idx < rbw: activation fragment rb ; rbw + cb: weight fragment cb
+        if self.roll:                   # setbase = one of self.wsets; the activation fragments have a single set (the last one: two, by self.apar)
+            if idx == self.rbw - 1:
+                return self.alast[self.apar]
+            return P_BASE + self.fr * idx if idx < self.rbw else setbase + self.fr * (idx - self.rbw)
         return setbase + self.fr * idx
 
     def acc(self, rb, cb):
@@ -156,7 +174,7 @@ class Gen:
             a = f"ds_read_b128 v[{f}:{f + 3}], v{base + ks + 2 * stage} offset:{blk}"
         else:
             a = f"ds_read_b128 v[{f}:{f + 3}], v{base + ks} offset:{stage * (self.a_stage if is_a else self.w_stage) + blk}"
-        self.trace.append(("read", (setbase, idx, stage, ks, tile_tag, half)))
+        self.trace.append(("read", ((("AL", self.apar) if idx == self.rbw - 1 else "A") if (self.roll and is_a) else setbase, idx, stage, ks, tile_tag, half)))
         if self.no_read and tile_tag != "prologue":
             return None
         return a
@@ -181,7 +199,9 @@ class Gen:
         a = self.acc(rb, cb)
         w = self.frag(setbase, self.rbw + cb)
         x = self.frag(setbase, rb)
-        self.trace.append(("mfma", (setbase, rb, cb)))
+        self.trace.append(("mfma", (setbase, rb, cb) if not self.roll else (setbase, rb, cb, self.apar)))
+        if self.roll:
+            return f"v_mfma_f32_16x16x128_f8f6f4 a[{a}:{a + 3}], v[{w}:{w + 7}], v[{x}:{x + 7}], a[{a}:{a + 3}]"
         if self.f8:     # cbsz = blgp = 0: both operands OCP e4m3; the scaled form multiplies by 2^(E8M0 - 127) per 32-element block: 1.0 here
             if self.f8_scaled:
                 return (f"v_mfma_scale_f32_32x32x64_f8f6f4 a[{a}:{a + 15}], v[{w}:{w + 7}], v[{x}:{x + 7}], a[{a}:{a + 15}], "
@@ -274,6 +294,52 @@ class Gen:
         self.emit("s_waitcnt lgkmcnt(0)")
         self.trace.append(("lgkm0", None))
 
+    def kstep_roll(self, s):
+        """The single k-step of tile T (stage s): MFMAs rb-major on (A regs, weight set s); reads of tile T+1 from stage o = 1 - s:
+        the weight fragments into set o in the first slots, activation fragment rb one MFMA behind rb's last use (the last one behind
+        wait states: no MFMA follows it); every LDS-DMA piece of tile T+2 -> stage s in the given slots."""
+        o = 1 - s
+        cur, nxt = self.wsets[s], self.wsets[o]
+        order = [(rb, cb if rb % 2 == 0 else self.cbw - 1 - cb) for rb in range(self.rbw) for cb in range(self.cbw)]
+        read_at = {}
+        for cb in range(self.cbw):                                  # weight fragments of T+1: slots 0 .. cbw-1
+            read_at.setdefault(cb, []).extend([(self.rbw + cb, 0), (self.rbw + cb, 1)])
+        read_at.setdefault(self.cbw, []).extend([(self.rbw - 1, 0), (self.rbw - 1, 1)])       # the last activation fragment of T+1 -> its OTHER set
+        for rb in range(self.rbw - 1):                              # activation fragment rb: after the first MFMA of rb + 1
+            read_at.setdefault(self.cbw * (rb + 1) + (1 if rb == 0 else 0), []).extend([(rb, 0), (rb, 1)])
+        dma_at = dict(zip(self.dma_last, range(self.NPIECE)))
+        for i, (rb, cb) in enumerate(order):
+            pre, ins = ([], None)
+            if i in dma_at:
+                pre, ins = self.dma(dma_at[i], s, "T+2")
+            if ins and i == 0:
+                for x in pre:
+                    self.emit(x)
+            self.apar = s                                           # MFMAs of tile T read the last fragment's set s ...
+            self.emit(self.mfma(cur, rb, cb))
+            if ins:
+                self.emit(ins)                                      # M0 was written one slot earlier
+            self.apar = o                                           # ... reads of tile T+1 fill set o
+            for idx, half in read_at.get(i, []):
+                r = self.read(nxt, idx, o, 0, "T+1", half)
+                if r:
+                    self.emit(r)
+            nxt_dma = dma_at.get(i + 1)
+            if nxt_dma is not None and not self.no_dma:
+                self.emit(self.m0_for(nxt_dma, s))
+        self.emit("s_waitcnt lgkmcnt(0)")
+        self.trace.append(("lgkm0", None))
+
+    def tile_roll(self, s):
+        self.trace.append(("tile", s))
+        self.emit("s_waitcnt vmcnt(0)")
+        self.trace.append(("vm", 0))
+        if not self.no_barrier:
+            self.emit("s_barrier")
+        self.trace.append(("barrier", None))
+        self.koff_commit(s)
+        self.kstep_roll(s)
+
     def koff_prefetch(self, s):
         """conv: tile X = min(T + 2, nk - 1) for the tile T living in stage s; tap offset fetched one k-step early."""
         e = self.emit
@@ -360,7 +426,9 @@ class Gen:
             if self.w8:
                 e(f"s_lshl_b32 {S_KW[0]}, %[kb], 6")
                 e(f"s_lshl_b32 {S_KW[1]}, {S_TMP}, 6")
-        # tile 0 -> stage 0 (all pieces), first part of tile 1 -> stage 1
+        # tile 0 -> stage 0 (all pieces), first part of tile 1 -> stage 1 (rolling form: all of it)
+        if self.roll:
+            n1 = NP
         for stage, pieces in ((0, range(NP)), (1, range(n1))):
             for p in pieces:
                 pre, ins = self.dma(p, stage, "prologue")
@@ -376,9 +444,11 @@ class Gen:
         self.trace.append(("vm", n1))
         e("s_barrier")
         self.trace.append(("barrier", None))
+        if self.roll:
+            self.apar = 0
         for idx in self.read_order():
             for half in range(self.rpf):
-                e(self.read(P_BASE, idx, 0, 0, "prologue", half))
+                e(self.read(self.wsets[0] if self.roll else P_BASE, idx, 0, 0, "prologue", half))
         e("s_waitcnt lgkmcnt(0)")
         self.trace.append(("lgkm0", None))
         if self.w8:
@@ -388,8 +458,12 @@ class Gen:
         e(f"s_mov_b32 {S_T}, 0")
         e("LTX2_V4_LOOP_%=:")
         self.trace.append(("loop", None))
-        self.tile(0)
-        self.tile(1)
+        if self.roll:
+            self.tile_roll(0)
+            self.tile_roll(1)
+        else:
+            self.tile(0)
+            self.tile(1)
         e(f"s_add_u32 {S_T}, {S_T}, 2")
         e(f"s_cmp_lt_u32 {S_T}, %[nk]")
         e("s_cbranch_scc1 LTX2_V4_LOOP_%=")
@@ -495,9 +569,10 @@ def check(g, iters=3):
                     frag[(setb, idx)] = (tile, ks)
             pending_reads = []
         elif k == "mfma":
-            setb, rb, cb = pl
+            setb, rb, cb = pl[:3]
             n_mfma += 1
-            ca, cw = frag.get((setb, rb)), frag.get((setb, g.rbw + cb))
+            seta = (("AL", pl[3]) if rb == g.rbw - 1 else "A") if g.roll else setb      # rolling form: one activation fragment set (the last: two)
+            ca, cw = frag.get((seta, rb)), frag.get((setb, g.rbw + cb))
             if ca is None or cw is None:
                 errors.append(f"MFMA at {pos} consumes an unretired fragment")
             elif ca != cw:
@@ -505,8 +580,10 @@ def check(g, iters=3):
             else:
                 key = (ca[0], ca[1], rb, cb)
                 done[key] = done.get(key, 0) + 1
-            frag_last_use[(setb, rb)] = n_mfma
+            frag_last_use[(seta, rb)] = n_mfma
             frag_last_use[(setb, g.rbw + cb)] = n_mfma
+        elif k == "nop":
+            n_mfma += 1             # wait states behind the last MFMA of a k-step count as one MFMA slot for the WAR(reg) rule
     for t in range(2 * iters):
         for ks in range(nks):
             for rb in range(g.rbw):
@@ -572,6 +649,8 @@ def main():
     # (the v_mfma_scale_* form with unit block scales -- f8_scaled=True -- measured the same: 166.4 vs 165.4 us on the QKV shape)
     out.append(variant("LTX2_V4_F8_RB7", 7, 2, npa=7, dma_last=[1, 3, 5, 7, 9, 11, 13], dma_ks0=[0, 2, 4, 6, 8, 10, 12, 13], f8=True))
     out.append(variant("LTX2_V4_F8_RB8", 8, 2, npa=8, dma_last=odd16, dma_ks0=odd16, f8=True))
+    # layout 6: the same operands on v_mfma_f32_16x16x128_f8f6f4 (one k-step per K-tile, rolling activation fragments), 14 x 4 blocks of 16: 224-row tiles
+    out.append(variant("LTX2_V4_F8_M16_RB14", 14, 4, mb=16, npa=7, dma_last=list(range(2, 54, 3))[:15], dma_ks0=[], f8=True))
     if "--probe" in sys.argv:       # ablations of the DiT default for tools/micro/gemm_v4_probe.hip
         out.append(variant("LTX2_V4_L14_M16_RB16_NODMA", 16, 4, mb=16, npa=8, dma_last=d16, dma_ks0=[], m0_early=True, no_dma=True))
         out.append(variant("LTX2_V4_L14_M16_RB16_NOREAD", 16, 4, mb=16, npa=8, dma_last=d16, dma_ks0=[], m0_early=True, no_read=True))
