@@ -423,6 +423,32 @@ def test_gemm_k_loop_generator_checks_its_own_pipeline():
         bad.build()
         bad.trace = [e for e in bad.trace if e[0] != drop]
         assert gen.check(bad), drop
+    # the rolling fp8 loop (layout 6: one k-step per K-tile, single-set activation fragments read behind their last use)
+    roll = dict(mb=16, npa=7, dma_last=list(range(2, 54, 3))[:15], dma_ks0=[], f8=True)
+    ok = gen.Gen(14, 4, **roll)
+    ok.build()
+    assert ok.roll and ok.vgpr_top <= gen.VGPR_TOP_MAX and gen.check(ok) == []
+    for drop in ("barrier", "vm", "lgkm0"):
+        bad = gen.Gen(14, 4, **roll)
+        bad.build()
+        bad.trace = [e for e in bad.trace if e[0] != drop]
+        assert gen.check(bad), drop
+    bad = gen.Gen(14, 4, **roll)            # a fragment read moved IN FRONT of the MFMAs that still use its registers
+    bad.build()
+    tr = bad.trace
+    i = next(k for k, e in enumerate(tr) if e[0] == "read" and e[1][0] == "A" and e[1][4] == "T+1")
+    j = max(k for k in range(i) if tr[k][0] == "mfma" and tr[k][1][1] == tr[i][1][1])          # last MFMA on that row block before the read
+    tr.insert(j - 2, tr.pop(i))
+    assert gen.check(bad)
+
+
+def test_generated_k_loops_are_in_sync_with_their_generator(tmp_path):
+    """gemm_v4_loop.inc is generated code kept in the tree (hipcc needs it): regenerating it must reproduce the committed file byte for byte."""
+    import subprocess
+    csrc = os.path.join(ROOT, "ltx-2-mlx_amd", "csrc")
+    out = tmp_path / "loop.inc"
+    subprocess.check_call([sys.executable, os.path.join(csrc, "gen_gemm_v4.py"), str(out)], stdout=subprocess.DEVNULL)
+    assert out.read_bytes() == open(os.path.join(csrc, "gemm_v4_loop.inc"), "rb").read()
 
 
 def _load_generate():
