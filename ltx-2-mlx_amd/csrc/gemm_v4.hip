@@ -305,10 +305,12 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     };
     constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_SILU_BF16;
     constexpr bool RESID_LDS_OK = EPI == EPI_RESID_GATE_F32 && (LAYOUT == 3 || LAYOUT == 5 || LAYOUT == 6) && VAR != 9;
-    const bool resid_lds = RESID_LDS_OK && !(p.gate && p.gate_stride != 0);      // block-uniform
+    const bool resid_lds = RESID_LDS_OK;
+    const bool rowgate = p.gate && p.gate_stride != 0;          // (block-uniform) per-row gates: per-token timesteps (image conditioning)
     if constexpr (RESID_LDS_OK) {
       if (resid_lds) {
-        // x += gate * (acc + bias) with a ROW-INVARIANT gate (scalar sigma), through LDS: a lane's accumulator groups are 4 columns
+        // x += gate * (acc + bias) through LDS (the gate: row-invariant for a scalar sigma and folded in before the slab; per ROW for per-token
+        // timesteps and then applied at the read-back, its rows prefetched beside the residual's): a lane's accumulator groups are 4 columns
         // of 16 different rows, so touching x straight from them moves 16 x 64 B per instruction -- half of every 128-byte line,
         // twice.  Transposed through this wave's share of the dead stage buffers (half a wave tile at a time: rows x 256 B, 16-byte
         // chunks XOR-swizzled with the row) every global load / store instruction covers 4 whole 256-byte row segments.
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) {
                 g4[cb][gq] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (p.gate || p.gate_table) {
+                if (!rowgate && (p.gate || p.gate_table)) {
                     g4[cb][gq] = gate4[cb][gq];
                     if (p.gate) g4[cb][gq] += *(const f32x4*)(p.gate + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq);
                 }
@@ -332,16 +334,20 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         const int rr = lane >> 4, cc = lane & 15;                            // readback: 4 rows x 16 chunks per instruction
         float* xg = (float*)p.out + (long)(m0 + rr) * p.ldo + n0 + wc * WN + cc * 4;
         const int nparts = min(NP, (p.M - m0 + PR - 1) / PR);                // (block-uniform) ragged last row tile
-        f32x4 xv[3][NIT];
-        auto load_part = [&](int part, f32x4* dst) __attribute__((always_inline)) {
+        f32x4 xv[3][NIT], gv[3][NIT];
+        const float* gg = rowgate ? p.gate + (long)(m0 + rr) * p.gate_stride + n0 + wc * WN + cc * 4 : nullptr;
+        f32x4 gtab = {0.f, 0.f, 0.f, 0.f};              // the read-back lane's 4 columns of the broadcast part
+        if (rowgate && p.gate_table) gtab = *(const f32x4*)(p.gate_table + n0 + wc * WN + cc * 4);
+        auto load_part = [&](int part, int slot) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const long grow = min((long)m0 + part * PR + i * 4 + rr, (long)p.M - 1) - (m0 + rr);
-                dst[i] = *(const f32x4*)(xg + grow * p.ldo);
+                xv[slot][i] = *(const f32x4*)(xg + grow * p.ldo);
+                if (rowgate) gv[slot][i] = *(const f32x4*)(gg + grow * p.gate_stride);
             }
         };
-        load_part(0, xv[0]);
-        if (nparts > 1) load_part(1, xv[1]);
+        load_part(0, 0);
+        if (nparts > 1) load_part(1, 1);
         __syncthreads();                // every wave has finished its fragment reads: the stage buffers are free
 #pragma unroll
         for (int part = 0; part < NP; ++part) {         // (unrolled: the accumulator indices must be compile-time constants)
@@ -359,12 +365,13 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                         *(f32x4*)(sl + row * ROWB + ((chunk ^ (row & 15)) << 4)) = v;
                     }
             }
-            if (part + 2 < nparts) load_part(part + 2, xv[(part + 2) % 3]);
+            if (part + 2 < nparts) load_part(part + 2, (part + 2) % 3);
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int row = i * 4 + rr;
                 asm volatile("" : "+v"(xv[part % 3][i]));       // consume in issue order: counted waits, not vmcnt(0)
-                const f32x4 d = *(const f32x4*)(sl + row * ROWB + ((cc ^ (row & 15)) << 4));
+                f32x4 d = *(const f32x4*)(sl + row * ROWB + ((cc ^ (row & 15)) << 4));
+                if (rowgate) d *= gtab + gv[part % 3][i];
                 if (m0 + part * PR + row < p.M) *(f32x4*)(xg + ((long)part * PR + row - rr) * p.ldo) = xv[part % 3][i] + d;
             }
         }

@@ -137,3 +137,39 @@ def test_dit_48_layer_step_in_float16(dev):
         assert e < 1e-2 and r > 0.9999, (sigma, e, r)
     del w, m
     torch.cuda.empty_cache()
+
+
+def test_text_cross_attention_forms_in_float16(dev):
+    """Round 3's two text-cross-attention forms on float16 tensors: the boolean key mask (attention.py:38-70) and q_norm folded into the
+    softmax row scale (GEMM epilogue partial sums), against fp64 math."""
+    import ltx_2_mlx_amd.kernels as K
+    g = torch.Generator().manual_seed(5)
+    H, hd, Nq, S = 32, 128, 3456, 1024
+    D = H * hd
+    q = torch.randn(Nq, D, generator=g).to(F16).to(dev)
+    k = torch.randn(S, D, generator=g).to(F16).to(dev)
+    v = torch.randn(S, D, generator=g).to(F16).to(dev)
+    vt = K.vt_transpose(v, H)
+    mk = torch.rand(S, generator=g) > 0.3
+    mk[:64] = False                                     # a whole KV tile masked
+    out = K.flash_attn_keymask(q, k, vt, H, S, mk)
+    qh, kh, vh = [t.double().cpu().reshape(-1, H, hd).transpose(0, 1) for t in (q, k, v)]
+    s = (qh @ kh.transpose(1, 2)) / math.sqrt(hd) + (1 - mk.double()) * -3.4e38
+    ref = (torch.softmax(s, dim=-1) @ vh).transpose(0, 1).reshape(Nq, D)
+    assert out.dtype == F16 and rel_l2(out.double().cpu(), ref) < 2e-3
+    # q_norm fold: projection with row partial sums, keys carrying k_norm.weight * q_norm.weight
+    x = torch.randn(Nq, D, generator=g).to(F16).to(dev)
+    wq = (torch.randn(D, D, generator=g) / math.sqrt(D)).to(F16).to(dev)
+    qn, kn = (1 + 0.1 * torch.randn(D, generator=g)).to(dev), (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    qp, rowss = K.gemm_rowss(x, wq, None)
+    assert rowss is not None and qp.dtype == F16
+    kb = k.clone()
+    K.qknorm_rope_(kb, D, hd, 0, kn * qn)
+    o2 = K.flash_attn_rowscale(qp, kb, vt, H, S, rowss)
+    qf = qp.double().cpu()
+    qf = qf * torch.rsqrt((qf * qf).mean(-1, keepdim=True) + 1e-6) * qn.double().cpu()
+    kf = k.double().cpu()
+    kf = kf * torch.rsqrt((kf * kf).mean(-1, keepdim=True) + 1e-6) * kn.double().cpu()
+    qh2, kh2 = [t.reshape(-1, H, hd).transpose(0, 1) for t in (qf, kf)]
+    ref2 = (torch.softmax(qh2 @ kh2.transpose(1, 2) / math.sqrt(hd), dim=-1) @ vh).transpose(0, 1).reshape(Nq, D)
+    assert o2.dtype == F16 and rel_l2(o2.double().cpu(), ref2) < 2e-3
