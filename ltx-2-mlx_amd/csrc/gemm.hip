@@ -244,25 +244,18 @@ inline bool v4_wins_medium_grid(const GemmParams& p) {
     return t_v4 < t_small;
 }
 
-// 224-row tiles when they need fewer CU-rounds of work than 256-row tiles (gemm_v4.hip makes the same choice)
-inline bool prefer_224(const GemmParams& p) {
-    const long nt = p.N / 256, cus = 256;
-    const long t256 = ((long)(p.M + 255) / 256) * nt, t224 = ((long)(p.M + 223) / 224) * nt;
-    return (t224 + cus - 1) / cus * 224 < (t256 + cus - 1) / cus * 256;
-}
-
 // The whole dispatch, as data: gemm_launch follows it, ltx2_gemm_route reports it (round 3: the LTX2_GEMM_TILE / LTX2_V4_LAYOUT /
 // LTX2_PP_BM / LTX2_VT_FUSE overrides are gone -- same-box A/B runs load a second build through LTX2HIP_LIB instead).
 template <bool CONV>
 int route_of(const GemmParams& p, int epi) {
-    if (p.A8) return gemm_v4_f8_supported(p, epi) ? (prefer_224(p) ? ROUTE_V4_F8_224 : ROUTE_V4_F8_256) : ROUTE_INVALID;
+    if (p.A8) return gemm_v4_f8_supported(p, epi) ? (gemm_v4_prefer_224(p) ? ROUTE_V4_F8_224 : ROUTE_V4_F8_256) : ROUTE_INVALID;
     if (p.W8) {
         if (CONV) return ROUTE_INVALID;
         if (gemm_skinny_supported(p, epi)) return ROUTE_SKINNY;
-        return gemm_v4_w8_supported(p, epi) ? (prefer_224(p) ? ROUTE_V4_W8_224 : ROUTE_V4_W8_256) : ROUTE_INVALID;
+        return gemm_v4_w8_supported(p, epi) ? (gemm_v4_prefer_224(p) ? ROUTE_V4_W8_224 : ROUTE_V4_W8_256) : ROUTE_INVALID;
     }
     if (!CONV && epi != EPI_D2S_BF16 && gemm_skinny_supported(p, epi)) return ROUTE_SKINNY;      // M <= 128: the audio stream
-    if (!CONV && (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_supported(p, epi, CONV)) return prefer_224(p) ? ROUTE_V4_224 : ROUTE_V4_256;
+    if (!CONV && (use_big_tile(p) || v4_wins_medium_grid(p)) && gemm_v4_supported(p, epi, CONV)) return gemm_v4_prefer_224(p) ? ROUTE_V4_224 : ROUTE_V4_256;
     if (use_big_tile(p)) return ROUTE_PP;
     if (p.N <= 64 && p.M >= 4096) return ROUTE_NARROW;
     return ROUTE_SMALL;

@@ -648,14 +648,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// 224-row tiles when they need fewer CU-rounds of work than 256-row tiles
-inline bool v4_prefer_224(const GemmParams& p) {
-    const long nt = p.N / 256, cus = 256;
-    const long t256 = ((long)(p.M + 255) / 256) * nt, t224 = ((long)(p.M + 223) / 224) * nt;
-    const long cost256 = (t256 + cus - 1) / cus * 256, cost224 = (t224 + cus - 1) / cus * 224;
-    return cost224 < cost256;
-}
-
 }  // namespace
 
 bool gemm_v4_supported(const GemmParams& p, int epilogue, bool conv) {
@@ -674,7 +666,7 @@ bool gemm_v4_vt_supported(const GemmParams& p, int epilogue, int layout) {
     if (!(p.A8 ? gemm_v4_f8_supported(p, epilogue) : p.W8 ? gemm_v4_w8_supported(p, epilogue) : gemm_v4_supported(p, epilogue, false))) return false;
     if (p.vt_col0 % 256 != 0 || (p.vt_hd != 64 && p.vt_hd != 128) || (p.N - p.vt_col0) % p.vt_hd != 0) return false;
     if (p.vt_npad % 64 != 0 || p.vt_npad < p.M) return false;
-    const int bm = v4_prefer_224(p) ? 224 : 256;
+    const int bm = gemm_v4_prefer_224(p) ? 224 : 256;
     return (long)((p.M + bm - 1) / bm) * bm >= p.vt_npad;
 }
 
@@ -699,7 +691,7 @@ bool gemm_v4_f8_supported(const GemmParams& p, int epilogue) {
 int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int layout, int bm) {
     if (p.A8) {     // fp8 compute: layout 5
         LTX2_CHECK_ARG(gemm_v4_f8_supported(p, epilogue), "gemm_v4: fp8 compute needs A8 + ascale + W8 + wscale, N %% 256 == 0, K %% 256 == 0, K >= 512, a dense bf16/gelu/f32/residual epilogue (N=%d K=%d epilogue=%d)", p.N, p.K, epilogue);
-        const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
+        const bool b224 = bm ? bm == 224 : gemm_v4_prefer_224(p);
 #ifndef LTX2_F8_FORCE_L5
 #define LTX2_F8_FORCE_L5 0          // (A/B builds: -DLTX2_F8_FORCE_L5=1 keeps every fp8 GEMM on layout 5)
 #endif
@@ -720,7 +712,7 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
     }
     if (p.W8) {     // fp8-resident weights: layout 3 only
         LTX2_CHECK_ARG(p.wscale && gemm_v4_w8_supported(p, epilogue), "gemm_v4: fp8-resident weights need N %% 256 == 0, K %% 128 == 0, K >= 256, a dense bf16/gelu/f32/residual epilogue (N=%d K=%d epilogue=%d)", p.N, p.K, epilogue);
-        const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
+        const bool b224 = bm ? bm == 224 : gemm_v4_prefer_224(p);
 #define CASE8(E) \
     case E:      \
         return b224 ? launch_v4<E, 3, 224, false, 20>(p, stream) : launch_v4<E, 3, 256, false, 20>(p, stream);
@@ -748,7 +740,7 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
         }
 #undef CASE4
     }
-    const bool b224 = bm ? bm == 224 : v4_prefer_224(p);
+    const bool b224 = bm ? bm == 224 : gemm_v4_prefer_224(p);
     LTX2_CHECK_ARG(layout == 3, "gemm_v4: wave layout %d (3 = bf16 dense, 4 = 128-column convs, 5 = fp8 compute)", layout);
 #define CASE(E) \
     case E:     \

@@ -659,7 +659,8 @@ def test_gemm_dispatch_routes_of_every_model_gemm():
             t = "256" if (N == 13824 and Nn == 4 * D) else "224"
             assert route(M, Nn, K, epi, 0, vt) == ("ROUTE_V4_" + t, bool(vt)), (nm, N)
             assert route(M, Nn, K, epi, 1, vt) == ("ROUTE_V4_W8_" + t, bool(vt)), (nm, N)       # fp8-resident weights
-            assert route(M, Nn, K, epi, 2, vt) == ("ROUTE_V4_F8_" + t, bool(vt)), (nm, N)       # fp8 compute
+            # fp8 compute: 224-row tiles run the 16x16x128 block (layout 6) and also win ties and near-ties (gemm.h: gemm_v4_prefer_224)
+            assert route(M, Nn, K, epi, 2, vt) == ("ROUTE_V4_F8_224", bool(vt)), (nm, N)
         assert route(N, D, 128, F32)[0] == "ROUTE_PP"                    # patchify_proj: K = 128 is below the asm loop's minimum
         assert route(N, 128, D, F32)[0] == "ROUTE_SMALL"                 # proj_out: 128 output channels
         assert route(N, D, 256, nv.EPI_SILU_BF16)[0] == "ROUTE_V4_224"   # per-token AdaLN MLP (image conditioning)
