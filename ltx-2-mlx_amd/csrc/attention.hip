@@ -102,7 +102,10 @@ struct SkSlot {
 // (the reference adds -3.4e38 to the score, attention.py:38-70: the same softmax, also for a row whose keys are all masked -> uniform)
 #define AT_KEY_MASKED (-1.0e30f)
 
-template <int HD, bool SK, bool QS = false, bool KM = false>
+// PVX: the exponentials of key chunk j + 1 issue between the PV MFMAs of chunk j (same-wave interleave).  It pays where a SIMD holds ONE wave of
+// this kernel -- the partially filled last round of a plain grid (self-attention at N = 3456: 864 workgroups on 512 slots) -- and costs ~1 % where
+// every SIMD has two (tools/micro/mfma_valu_overlap.hip: only a wave's OWN MFMAs cover its VALU work); the launcher picks per grid.
+template <int HD, bool SK, bool QS = false, bool KM = false, bool PVX = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     static_assert(!(SK && KM), "the key mask runs on the plain grid");
     static_assert(!KM || AT_SFMA, "the key mask's exponent form lives in the scalar-fma softmax");
@@ -371,6 +374,40 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             const float mc = m_run * c;
             // two scores per VALU op where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32); v_exp_f32 is scalar
             bf16x8 pf[2][2];
+          if constexpr (PVX) {
+            static_assert(AT_SFMA, "the interleaved form uses the scalar-fma softmax");
+            // Key chunk j = 2 b + h (16 keys: P fragment pf[b][h], elements r = 8 h .. 8 h + 7 of score block b) feeds the ND PV MFMAs of issue slots
+            // [ND j, ND (j + 1)).  Chunk 0's exponentials come first; chunk j + 1's are spread over chunk j's MFMAs (pinned between their fragment
+            // waits), so three quarters of the exponent work issues in the shadow of this wave's own MFMAs.
+            const float nmc = -mc;
+            float ps0 = 0.f, ps1 = 0.f;
+            auto exp_pair = [&](auto J, auto Q) __attribute__((always_inline)) {        // pair Q (0..3) of chunk J
+                constexpr int j = decltype(J)::value, b = j / 2, r = 8 * (j % 2) + 2 * decltype(Q)::value;
+                asm volatile("" : "+v"(s[b][r]), "+v"(s[b][r + 1]));
+                const float e0 = KM ? (s[b][r] - m_run) * c : __builtin_fmaf(s[b][r], c, nmc);
+                const float e1 = KM ? (s[b][r + 1] - m_run) * c : __builtin_fmaf(s[b][r + 1], c, nmc);
+                float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
+                asm volatile("" : "+v"(p0), "+v"(p1));
+                ps0 += p0;
+                ps1 += p1;
+                pf[b][r >> 3][r & 7] = f2bf(p0);
+                pf[b][r >> 3][(r & 7) + 1] = f2bf(p1);
+            };
+            static_for<0, 4>([&](auto Q) { exp_pair(std::integral_constant<int, 0>{}, Q); });
+#if AT_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);
+#endif
+            static_for<0, NV>([&](auto N) __attribute__((always_inline)) {
+                constexpr int n = decltype(N)::value, i = (n % ND) * 4 + n / ND, j = n / ND, d = n % ND;
+                if constexpr (n + DV < NV) read_v(std::integral_constant<int, n + DV>{});
+                lds_wait<(n + DV < NV ? DV : NV - 1 - n)>(vf[i]);
+                o[i / 4] = LTX2_MFMA_32x32x16(as_bf16x8(vf[i]), pf[(i % 4) / 2][i % 2], o[i / 4], 0, 0, 0);
+                if constexpr (j < 3) {      // 4 pairs of chunk j + 1 over the ND MFMAs of chunk j
+                    static_for<(4 * d) / ND, (4 * (d + 1)) / ND>([&](auto Q) { exp_pair(std::integral_constant<int, j + 1>{}, Q); });
+                }
+            });
+            l_run += ps0 + ps1;
+          } else {
 #if AT_SFMA
             // scalar-slot v_fma_f32 / v_add_f32 (packed f32 VALU beside MFMAs costs more than its two scalar halves: MI355X_MICROARCH.md)
             const float nmc = -mc;
@@ -419,6 +456,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 lds_wait<(n + DV < NV ? DV : NV - 1 - n)>(vf[i]);
                 o[i / 4] = LTX2_MFMA_32x32x16(as_bf16x8(vf[i]), pf[(i % 4) / 2][i % 2], o[i / 4], 0, 0, 0);
             });
+          }       // PVX
 #if AT_PRIO == 1
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -596,20 +634,20 @@ static int sk_workers(const AttnParams& p, bool* xcd) {
     const int nqt = (p.Nq + QB - 1) / QB;
     const long units = (long)nqt * p.H;
     if (slots % 8) return 0;
+    // Round 3: the stream-K forms are taken only when asked for (sk_force: the unit tests and tools/attn_sk_time.py).  Same-box, after the PVX form
+    // below and s_setprio: self-attention N = 3456 plain 188.4-189.1 us vs stream-K 192.6-194.1 (round 2: 220 vs 208 -- the plain grid's
+    // half-empty last round is exactly where the same-wave interleave pays); N = 13824 2608 vs 2684; the split-KV form for few query tiles
+    // (68 audio queries x 3456 video keys, head_dim 64) 48.4 vs 38.4-39.1 plain (round 2: 28 vs 38).
+    if (!p.sk_force) return 0;
     if (units * 4 <= slots && p.Nkv >= 16 * KVB) {
-        // FEW query tiles against a long KV range (video -> audio cross-modal attention: 68 audio queries x 32 heads = 32 units, each
-        // walking 54 KV tiles alone): phase B alone cuts every unit's KV range over several workgroups (>= 4 tiles each), the unit's
-        // last workgroup folds the pieces in order -- the split-KV form of the same hand-off (39 -> ~17 us at 68 x 3456, head_dim 64)
+        // FEW query tiles against a long KV range: phase B alone cuts every unit's KV range over several workgroups (>= 4 tiles each), the
+        // unit's last workgroup folds the pieces in order -- the split-KV form of the same hand-off
         const long nt = (p.Nkv + KVB - 1) / KVB;
         const long w = units * nt / 4;
         *xcd = false;
         return (int)(w < slots ? w : slots);
     }
     if (units <= slots) return 0;
-    // Measured (same box): 864 units x 54 KV tiles (0.84 of the last round filled) 211 -> 203 us; 3456 units x 216 tiles (0.96)
-    // 2869 -> 2869 us; short KV (text cross-attention, 16 tiles) 72 -> 78 us: the hand-off costs more than the tail there.
-    const double rounds = (double)units / slots;
-    if (!p.sk_force && (rounds / (double)((units + slots - 1) / slots) > 0.9 || p.Nkv < 32 * KVB)) return 0;
     *xcd = p.H % 8 == 0 && (long)(p.H / 8) * nqt >= slots / 8;
     return slots;
 }
@@ -683,6 +721,28 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
         hipLaunchKernelGGL((attn_fwd_kernel<128, false, true>), grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
         LTX2_CHECK_LAUNCH("attn_fwd_kernel<QS>");
+        return LTX2_OK;
+    }
+    // a grid whose last (or only) round leaves SIMDs with ONE wave of this kernel takes the PVX form (see the kernel's template comment)
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 2 * prop.multiProcessorCount : 512;
+    }
+    const long units = (long)grid.x * grid.y, rem = units % slots;
+    const bool lone = units < slots || (rem != 0 && rem * 10 < (long)slots * 9);
+    if (lone) {
+        static PerDeviceOnce px_once;
+        if (px_once.first()) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BYTES);
+        }
+        if (p.head_dim == 64)
+            hipLaunchKernelGGL((attn_fwd_kernel<64, false, false, false, true>), grid, dim3(256), Geo<64>::LDS_BYTES, stream, p);
+        else
+            hipLaunchKernelGGL((attn_fwd_kernel<128, false, false, false, true>), grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
+        LTX2_CHECK_LAUNCH("attn_fwd_kernel<PVX>");
         return LTX2_OK;
     }
     if (p.head_dim == 64)
