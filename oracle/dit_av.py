@@ -62,7 +62,7 @@ class AVConfig:
 # Attention with separate K RoPE tables and optional per-head gates (attention.py:203-253)
 # ---------------------------------------------------------------------------
 def attention(x: Tensor, w: Dict[str, Tensor], prefix: str, heads: int, eps: float, context: Optional[Tensor] = None,
-              pe: Optional[Tuple[Tensor, Tensor]] = None, k_pe: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
+              pe: Optional[Tuple[Tensor, Tensor]] = None, k_pe: Optional[Tuple[Tensor, Tensor]] = None, mask: Optional[Tensor] = None) -> Tensor:
     ctx = x if context is None else context
     q = D.linear(x, w, prefix + ".to_q")
     k = D.linear(ctx, w, prefix + ".to_k")
@@ -73,7 +73,7 @@ def attention(x: Tensor, w: Dict[str, Tensor], prefix: str, heads: int, eps: flo
         kp = pe if k_pe is None else k_pe
         q = D.apply_split_rope(q, pe[0], pe[1])
         k = D.apply_split_rope(k, kp[0], kp[1])
-    o = D.sdpa(q, k, v, heads)
+    o = D.sdpa(q, k, v, heads, mask)                                # mask: the additive (B, 1, 1, S) text-context mask (attention.py:38-70) or None
     if prefix + ".to_gate_logits.weight" in w:                     # attention.py:241-249
         gates = 2.0 * torch.sigmoid(D.linear(x, w, prefix + ".to_gate_logits"))
         b, t, hd = o.shape
@@ -87,16 +87,16 @@ def _ada(table: Tensor, ts: Tensor, start: int, end: int):
     return tuple(a[:, :, i, :] for i in range(end - start))
 
 
-def _text_cross(x, context, w, prefix, table, prompt_table, ts, prompt_ts, heads, cfg: AVConfig):
-    """_apply_text_cross_attention (transformer.py:427-455)."""
+def _text_cross(x, context, w, prefix, table, prompt_table, ts, prompt_ts, heads, cfg: AVConfig, mask: Optional[Tensor] = None):
+    """_apply_text_cross_attention (transformer.py:427-455); mask = the modality's prepared context mask (model.py:163-201)."""
     if cfg.cross_attention_adaln:
         shift_q, scale_q, gate = _ada(table, ts, 6, 9)
         kv = prompt_table.float()[None, None, :, :] + prompt_ts
         shift_kv, scale_kv = kv[:, :, 0, :], kv[:, :, 1, :]
         h = D.rms_norm(x, None, cfg.norm_eps) * (1 + scale_q) + shift_q
         ehs = context * (1 + scale_kv) + shift_kv
-        return attention(h, w, prefix, heads, cfg.norm_eps, context=ehs) * gate
-    return attention(D.rms_norm(x, None, cfg.norm_eps), w, prefix, heads, cfg.norm_eps, context=context)
+        return attention(h, w, prefix, heads, cfg.norm_eps, context=ehs, mask=mask) * gate
+    return attention(D.rms_norm(x, None, cfg.norm_eps), w, prefix, heads, cfg.norm_eps, context=context, mask=mask)
 
 
 def av_block(vx: Tensor, ax: Tensor, va: dict, aa: dict, w: Dict[str, Tensor], i: int, cfg: AVConfig):
@@ -110,12 +110,12 @@ def av_block(vx: Tensor, ax: Tensor, va: dict, aa: dict, w: Dict[str, Tensor], i
     sh, sc, g = _ada(vt, va["timesteps"], 0, 3)
     vx = vx + attention(D.adaln_forward(vx, sc, sh, eps), w, p + ".attn1", Hv, eps, pe=va["pe"]) * g
     vx = vx + _text_cross(vx, va["context"], w, p + ".attn2", vt, w.get(p + ".prompt_scale_shift_table"),
-                          va["timesteps"], va.get("prompt_timestep"), Hv, cfg)
+                          va["timesteps"], va.get("prompt_timestep"), Hv, cfg, va.get("context_mask"))
     # audio self-attention + text cross-attention (:531-554)
     sh, sc, g = _ada(at, aa["timesteps"], 0, 3)
     ax = ax + attention(D.adaln_forward(ax, sc, sh, eps), w, p + ".audio_attn1", Ha, eps, pe=aa["pe"]) * g
     ax = ax + _text_cross(ax, aa["context"], w, p + ".audio_attn2", at, w.get(p + ".audio_prompt_scale_shift_table"),
-                          aa["timesteps"], aa.get("prompt_timestep"), Ha, cfg)
+                          aa["timesteps"], aa.get("prompt_timestep"), Ha, cfg, aa.get("context_mask"))
     # audio <-> video cross-modal attention (:556-620); table rows (scale_a2v, shift_a2v, scale_v2a, shift_v2a, gate)
     vn, an = D.rms_norm(vx, None, eps), D.rms_norm(ax, None, eps)
 
@@ -147,8 +147,10 @@ def _adaln(t_scaled: Tensor, w, prefix: str, batch: int, dim: int):
     return emb.reshape(batch, -1, emb.shape[-1] // dim, dim), e.reshape(batch, -1, dim)
 
 
-def prepare_modality(latent, context, timesteps, sigma, positions, w, cfg: AVConfig, audio: bool, cross_sigma: Tensor) -> dict:
-    """MultiModalTransformerArgsPreprocessor.prepare(modality, cross_modality) (model.py:366-410)."""
+def prepare_modality(latent, context, timesteps, sigma, positions, w, cfg: AVConfig, audio: bool, cross_sigma: Tensor,
+                     context_mask: Optional[Tensor] = None) -> dict:
+    """MultiModalTransformerArgsPreprocessor.prepare(modality, cross_modality) (model.py:366-410).  context_mask: the boolean / 0-1 (B, S) key
+    mask of the text context, turned into the additive mask by D.prepare_attention_mask (model.py:163-201)."""
     pre = "audio_" if audio else ""
     dim = cfg.audio_inner_dim if audio else cfg.inner_dim
     heads = cfg.audio_heads if audio else cfg.num_attention_heads
@@ -156,7 +158,7 @@ def prepare_modality(latent, context, timesteps, sigma, positions, w, cfg: AVCon
     x = D.linear(latent.float(), w, pre + "patchify_proj")
     ts = timesteps.float().reshape(b, -1) * cfg.timestep_scale_multiplier
     emb, e = _adaln(ts, w, pre + "adaln_single", b, dim)
-    out = {"x": x, "timesteps": emb, "embedded_timestep": e}
+    out = {"x": x, "timesteps": emb, "embedded_timestep": e, "context_mask": D.prepare_attention_mask(context_mask)}
     if cfg.cross_attention_adaln:                                  # model.py:151-161
         s = sigma.float().reshape(b, -1)[:, 0] * cfg.timestep_scale_multiplier
         out["prompt_timestep"], _ = _adaln(s, w, pre + "prompt_adaln_single", b, dim)
@@ -193,8 +195,8 @@ def av_velocity_model(video: dict, audio: dict, w: Dict[str, Tensor], cfg: AVCon
     positions ([B,3,N,2] / [B,1,Ta,2])."""
     vs = video.get("sigma", video["timesteps"])
     as_ = audio.get("sigma", audio["timesteps"])
-    va = prepare_modality(video["latent"], video["context"], video["timesteps"], vs, video["positions"], w, cfg, False, as_)
-    aa = prepare_modality(audio["latent"], audio["context"], audio["timesteps"], as_, audio["positions"], w, cfg, True, vs)
+    va = prepare_modality(video["latent"], video["context"], video["timesteps"], vs, video["positions"], w, cfg, False, as_, video.get("context_mask"))
+    aa = prepare_modality(audio["latent"], audio["context"], audio["timesteps"], as_, audio["positions"], w, cfg, True, vs, audio.get("context_mask"))
     vx, ax = va["x"], aa["x"]
     hidden = []
     for i in range(cfg.num_layers):
@@ -224,7 +226,7 @@ def video_only_x0_model(video: dict, w, cfg: AVConfig) -> Tensor:
     cross-attention -- with the prompt AdaLN driven by Modality.sigma, model.py:151-158 -- and the video feed-forward).  This is
     also what a VideoOnly LTXModel with cross_attention_adaln / apply_gated_attention computes."""
     vs = video.get("sigma", video["timesteps"])
-    va = prepare_modality(video["latent"], video["context"], video["timesteps"], vs, video["positions"], w, cfg, False, vs)
+    va = prepare_modality(video["latent"], video["context"], video["timesteps"], vs, video["positions"], w, cfg, False, vs, video.get("context_mask"))
     x, eps, H = va["x"], cfg.norm_eps, cfg.num_attention_heads
     for i in range(cfg.num_layers):
         p = f"transformer_blocks.{i}"
@@ -232,7 +234,7 @@ def video_only_x0_model(video: dict, w, cfg: AVConfig) -> Tensor:
         sh, sc, g = _ada(vt, va["timesteps"], 0, 3)
         x = x + attention(D.adaln_forward(x, sc, sh, eps), w, p + ".attn1", H, eps, pe=va["pe"]) * g
         x = x + _text_cross(x, va["context"], w, p + ".attn2", vt, w.get(p + ".prompt_scale_shift_table"), va["timesteps"],
-                            va.get("prompt_timestep"), H, cfg)
+                            va.get("prompt_timestep"), H, cfg, va.get("context_mask"))
         sh, sc, g = _ada(vt, va["timesteps"], 3, 6)
         x = x + D.feed_forward(D.adaln_forward(x, sc, sh, eps), w, p + ".ff") * g
     v = _output(x, va["embedded_timestep"], w, "", cfg.inner_dim, eps)

@@ -218,6 +218,42 @@ def test_av_dit_matches_reference(v23):
             close(ax0, z[f"{tag}_{tsk}_audio_x0"], rtol=2e-4, atol=2e-5)
 
 
+def av_masked_case(v23: bool):
+    """The masked case of pin_dit_av: a different boolean context mask per modality, the masked keys' context rows x 40."""
+    cfg, w, cases = av_tiny_case(v23)
+    video, audio = dict(cases["scalar"][0]), dict(cases["scalar"][1])
+    S = video["context"].shape[1]
+    vm = torch.ones(1, S, dtype=torch.int32)
+    vm[0, 10:] = 0
+    vm[0, 2] = 0
+    am = torch.ones(1, S, dtype=torch.int32)
+    am[0, :5] = 0
+    video["context"] = video["context"].clone()
+    audio["context"] = audio["context"].clone()
+    video["context"][0, vm[0] == 0] *= 40.0
+    audio["context"][0, am[0] == 0] *= 40.0
+    return cfg, w, video, audio, vm, am
+
+
+@pytest.mark.parametrize("v23", [False, True])
+def test_av_masked_text_cross_attention_matches_reference(v23):
+    """Each modality's Modality.context_mask reaches ITS text cross-attention (transformer.py:523, 551): the oracle with both masks against the
+    reference's X0Model output, and without them against the recorded control (which differs: the masked keys' rows are 40x larger)."""
+    from oracle import dit_av
+    z = g("dit_av_tiny.npz")
+    tag = "v23" if v23 else "v1"
+    cfg, w, video, audio, vm, am = av_masked_case(v23)
+    with torch.no_grad():
+        vx0, ax0 = dit_av.av_x0_model(dict(video, context_mask=vm), dict(audio, context_mask=am), w, cfg)
+        close(vx0, z[f"{tag}_masked_video_x0"], rtol=2e-4, atol=2e-5)
+        close(ax0, z[f"{tag}_masked_audio_x0"], rtol=2e-4, atol=2e-5)
+        vx0, ax0 = dit_av.av_x0_model(video, audio, w, cfg)
+        close(vx0, z[f"{tag}_masked_control_video_x0"], rtol=2e-4, atol=2e-5)
+        close(ax0, z[f"{tag}_masked_control_audio_x0"], rtol=2e-4, atol=2e-5)
+    assert float(np.abs(z[f"{tag}_masked_video_x0"] - z[f"{tag}_masked_control_video_x0"]).max()) > 5e-2
+    assert float(np.abs(z[f"{tag}_masked_audio_x0"] - z[f"{tag}_masked_control_audio_x0"]).max()) > 1e-2
+
+
 def av_videoonly_case(v23: bool):
     """The video-only-inference case of pin_dit_av: the AudioVideo model called without audio, per-token timesteps of an image-
     conditioned state (token 0 clean, first latent frame at strength 0.95), Modality.sigma set."""

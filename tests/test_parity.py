@@ -1007,3 +1007,36 @@ def test_masked_text_cross_attention_against_oracle_and_reference_vectors(dev):
     got = X0Model(m2)(Modality(latent=lat2.to(dev), context=ctx2.to(dev), context_mask=mk2.to(dev), timesteps=sigma.to(dev),
                                positions=pos2.to(dev))).cpu()
     assert rel_l2(got, ref) < 2e-2 and pearson(got, ref) > 0.999 and rel_l2(got, ref) < 0.5 * rel_l2(got, ref_nomask)
+
+
+@pytest.mark.parametrize("v23", [False, True])
+def test_av_masked_text_cross_attention_against_reference_vectors(dev, v23):
+    """Modality.context_mask on the AudioVideo engine (19B-style blocks and V2.3): each modality's mask reaches ITS text cross-attention
+    (transformer.py:523, 551; audio: head_dim 64, the KM form of the 64-wide kernel) -- against the vectors recorded from the reference's own
+    X0Model with both masks (tests/golden/dit_av_tiny.npz), whose no-mask control differs visibly, and cleared again by a mask-less call."""
+    import numpy as np
+    import os
+    from test_oracle_golden import av_masked_case
+    from ltx_2_mlx_amd.model.transformer import Modality, X0Model
+    cfg, w, video, audio, vm, am = av_masked_case(v23)
+    _, _, wq, m = make_av(dev, v23, seed=17 + v23)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_av_tiny.npz"))
+    tag = "v23" if v23 else "v1"
+
+    def run(vmask, amask):
+        def mod(d, mk):
+            return Modality(latent=d["latent"].to(dev), context=d["context"].to(dev), context_mask=None if mk is None else mk.to(dev),
+                            timesteps=d["timesteps"].to(dev), positions=d["positions"].to(dev), sigma=d["sigma"].to(dev))
+        vx0, ax0 = X0Model(m)(mod(video, vmask), mod(audio, amask))
+        return vx0.cpu(), ax0.cpu()
+    gv, ga = [torch.from_numpy(z[f"{tag}_masked_{k}_x0"]) for k in ("video", "audio")]
+    cv, ca = [torch.from_numpy(z[f"{tag}_masked_control_{k}_x0"]) for k in ("video", "audio")]
+    vx0, ax0 = run(vm, am.bool())
+    assert rel_l2(vx0, gv) < 3e-2 and rel_l2(ax0, ga) < 3e-2
+    assert rel_l2(vx0, gv) < 0.5 * rel_l2(vx0, cv)                  # the masked vector, not the control
+    if v23:
+        assert rel_l2(ax0, ga) < 0.5 * rel_l2(ax0, ca)              # (v1's audio vectors differ by 5e-3 only: inside the 16-bit tolerance)
+    vx0, ax0 = run(None, None)                                      # no mask outlives its call
+    assert rel_l2(vx0, cv) < 3e-2 and rel_l2(vx0, cv) < 0.5 * rel_l2(vx0, gv)
+    vx0, ax0 = run(vm, None)                                        # one modality masked, the other not
+    assert rel_l2(vx0, gv) < 0.5 * rel_l2(vx0, cv)

@@ -170,6 +170,25 @@ def pin_dit_av():
         res = X0Model(model)(video, None)
         vx0 = res[0] if isinstance(res, tuple) else res
         out[f"{tag}_videoonly_x0"] = tn(vx0.t)
+        # masked text cross-attention of BOTH modalities (transformer.py:523, 551 hand each modality's context_mask to its attn2): different
+        # boolean key masks, the masked keys' context rows x 40 so that ignoring a mask lands on the recorded control instead
+        vm = torch.ones(1, S, dtype=torch.int32)
+        vm[0, 10:] = 0
+        vm[0, 2] = 0
+        am = torch.ones(1, S, dtype=torch.int32)
+        am[0, :5] = 0
+        vctx_m, actx_m = vctx.clone(), actx.clone()
+        vctx_m[0, vm[0] == 0] *= 40.0
+        actx_m[0, am[0] == 0] *= 40.0
+        ts1 = torch.tensor([sigma])
+        for name, vmask_, amask_ in (("masked", vm, am), ("masked_control", None, None)):
+            video = Modality(latent=A(vlat), context=A(vctx_m), context_mask=None if vmask_ is None else mx.array(vmask_.numpy()), timesteps=A(ts1),
+                             positions=A(vpos), sigma=A(ts1))
+            audio = Modality(latent=A(alat), context=A(actx_m), context_mask=None if amask_ is None else mx.array(amask_.numpy()), timesteps=A(ts1),
+                             positions=A(apos), sigma=A(ts1))
+            vx0, ax0 = X0Model(model)(video, audio)
+            out[f"{tag}_{name}_video_x0"] = tn(vx0.t)
+            out[f"{tag}_{name}_audio_x0"] = tn(ax0.t)
     np.savez_compressed(os.path.join(GOLD, "dit_av_tiny.npz"), **out)
     print("dit_av_tiny.npz", {k: v.shape for k, v in out.items()})
 
