@@ -513,7 +513,7 @@ class LTXModel:
 
     def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None, perturbations=None):
         self._check_inputs(video, audio, perturbations)
-        if self.is_av and (audio is None or audio.latent.shape[1] == 0):
+        if self.is_av and (audio is None or not audio.enabled or audio.latent.shape[1] == 0):     # transformer.py:480: run_ax needs audio.enabled and tokens
             # video-only inference on an AudioVideo model (model.py:829-840, 866-874): (video velocity, empty audio output)
             v = self._video_twin()(video, None, perturbations=perturbations)
             return v, torch.zeros(1, 0, self.AUDIO_OUT_CHANNELS, device=self.device)

@@ -299,6 +299,11 @@ def test_video_only_inference_on_an_audiovideo_model(dev, v23):
     assert torch.equal(x0v, ref) and x0a.shape == (1, 0, 128)
     vel, aud = av(vid)
     assert torch.equal(vel, vo(vid)) and aud.shape == (1, 0, 128)
+    # an audio modality that is present but DISABLED is the same thing (transformer.py:480: run_ax needs audio.enabled; model.py:868-872)
+    off = Modality(latent=torch.randn(1, 10, 128, generator=g).to(dev), context=(0.1 * torch.randn(1, 64, cfg.caption_channels or cfg.audio_inner_dim, generator=g)).to(dev),
+                   context_mask=None, timesteps=s.to(dev), positions=dit_av.audio_positions(1, 10).to(dev), enabled=False, sigma=s.to(dev))
+    vel2, aud2 = av(vid, off)
+    assert torch.equal(vel2, vel) and aud2.shape == (1, 0, 128)
 
 
 def test_video_dit_against_reference_vectors(dev):
