@@ -170,6 +170,7 @@ class LTXModel:
         self._prep_key = None
         self._mask_refs = {}
         self._prep_refs = None
+        self._clone: Optional["LTXModel"] = None       # clone_sharing_weights()
         self._twin: Optional["LTXModel"] = None        # VideoOnly engine over the SAME weight tensors (video-only inference on an AV model)
         self._sigma_dev: Dict[float, torch.Tensor] = {}  # device scalars of the step sigmas (no host-to-device copy inside the loop)
         self._ctor = dict(num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim, in_channels=in_channels,
@@ -189,6 +190,17 @@ class LTXModel:
                 t._register(k, v)
             self._twin = t
         return self._twin
+
+    def clone_sharing_weights(self) -> "LTXModel":
+        """A second engine context of the SAME model over the SAME weight tensors (nothing is copied): its own workspace and per-prompt
+        setup.  The guided loops evaluate the negative prompt through it, so neither context re-projects its text K / V every step."""
+        if self._clone is None:
+            extra = dict(av_ca_timestep_scale_multiplier=self.av_ca_timestep_scale_multiplier, audio_attention_heads=self.audio_heads) if self.is_av else {}
+            t = LTXModel(model_type=self.model_type, **self._ctor, **extra)
+            for k, v in self._w.items():
+                t._register(k, v)
+            self._clone = t
+        return self._clone
 
     def __del__(self):
         try:
@@ -566,6 +578,8 @@ class LTXModel:
         nv.check(self._L.ltx2_dit_health(self._h, nv.stream()))
         if self._twin is not None:
             self._twin.check_health()
+        if self._clone is not None:
+            self._clone.check_health()
 
     # ------------------------------------------------------------------ fused sampling step / graph
     def denoise_step_(self, latent: torch.Tensor, video: Modality, sigma: float, sigma_next: float,

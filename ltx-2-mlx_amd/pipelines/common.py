@@ -100,7 +100,8 @@ def audio_modality_from_state(state: LatentState, context: torch.Tensor, sigma: 
 
 def joint_denoise_loop(transformer, is_av_model: bool, video_state: LatentState, audio_state: Optional[LatentState], sigmas,
                        video_context: torch.Tensor, audio_context: Optional[torch.Tensor], stepper, callback=None,
-                       use_hip_graph: bool = False):
+                       use_hip_graph: bool = False, *, negative_video_context: Optional[torch.Tensor] = None,
+                       negative_audio_context: Optional[torch.Tensor] = None, video_guider=None, audio_guider=None):
     """The guidance-free sampling loop every pipeline here shares (reference pipelines/distilled.py:198-271 and the
     `need_cfg == False` branch of pipelines/one_stage.py:466-568 / :224-330).  Per step and modality:
     Modality(timesteps = denoise_mask * sigma) -> X0Model -> post_process_latent -> EulerDiffusionStep.
@@ -117,7 +118,17 @@ def joint_denoise_loop(transformer, is_av_model: bool, video_state: LatentState,
         model = model._video_twin()        # no audio tokens: the video half alone (reference model.py:829-840), same weights
     states = [video_state] + ([audio_state] if joint else [])
     uniform = all(bool((st.denoise_mask == 1).all()) for st in states)        # no conditioning tokens
-    if use_hip_graph and callback is None and uniform:
+    # classifier-free guidance (pipelines/one_stage.py:224-330 video, :466-568 joint): a second evaluation with the negative prompt whenever a
+    # guider is enabled(); BOTH modalities are then guided by their own guider (a guider at scale 1 returns cond).  The negative prompt runs
+    # through a second engine context over the same weights, so each context keeps its own per-prompt text K / V.
+    need_cfg = (video_guider is not None and video_guider.enabled()) or (joint and audio_guider is not None and audio_guider.enabled())
+    neg = None
+    if need_cfg:
+        if negative_video_context is None or (joint and negative_audio_context is None):
+            raise ValueError("guidance needs the negative prompt's encoding(s)")
+        from ..model.transformer import X0Model
+        neg = X0Model(model.clone_sharing_weights())
+    if use_hip_graph and callback is None and uniform and not need_cfg:
         lat = video_state.latent[0].float().contiguous()
         alat = audio_state.latent[0].float().contiguous() if joint else None
         if joint:
@@ -142,6 +153,14 @@ def joint_denoise_loop(transformer, is_av_model: bool, video_state: LatentState,
         else:
             out = transformer(vm)
             vx0, ax0 = (out[0] if isinstance(out, tuple) else out), None
+        if need_cfg:
+            nvm = modality_from_state(video_state, negative_video_context, sig[i], uniform=uniform)
+            if joint:
+                nvx0, nax0 = neg(nvm, audio_modality_from_state(audio_state, negative_audio_context, sig[i], uniform=uniform))
+                ax0 = audio_guider.guide(ax0, nax0) if audio_guider is not None else ax0
+            else:
+                nvx0 = neg(nvm)
+            vx0 = video_guider.guide(vx0, nvx0) if video_guider is not None else vx0
         vx0 = post_process_latent(vx0, video_state.denoise_mask, video_state.clean_latent)
         video_state = video_state.replace(latent=stepper.step(sample=video_state.latent, denoised_sample=vx0, sigmas=sig, step_index=i))
         if joint:

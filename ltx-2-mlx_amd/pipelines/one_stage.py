@@ -1,4 +1,4 @@
-"""Single-stage generation pipeline on MI355X: the guidance-free branches of the reference's OneStagePipeline.
+"""Single-stage generation pipeline on MI355X: the Euler branches of the reference's OneStagePipeline, with or without classifier-free guidance.
 
 Mirrors reference LTX_2_MLX/pipelines/one_stage.py:52-110 (OneStageCFGConfig, field names and defaults verbatim),
 :113-160 (constructor), :224-330 / :466-568 (`_denoise_loop_cfg`, `_denoise_loop_cfg_av` with `need_cfg == False`) and
@@ -8,8 +8,10 @@ branch: `use_internal_audio_branch`), VAE decode (tiled above 4000 latent voxels
 takes for LTX-2.3 checkpoints and for `--generate-audio` (scripts/generate.py:1638-1735; distilled models run it with
 cfg_scale = audio_cfg_scale = 1, i.e. one transformer evaluation per step).
 
-Outside the MI355X hot path, rejected with NotImplementedError: classifier-free / STG / APG guidance (any guider whose
-`enabled()` is true), the Heun sampler, GE velocity correction, cross-attention scaling, the temporal upscaler, audio VAE /
+Classifier-free guidance (round 3): `cfg_scale` / `audio_cfg_scale` != 1 evaluate the negative prompt too (a second engine context over the same
+weights) and combine the two predictions with CFGGuider or, for `rescale_scale > 0`, CFGStarRescalingGuider -- per modality, as :793-807.
+
+Outside the MI355X hot path, rejected with NotImplementedError: STG / APG guidance (`stg_scale`, `guider_override`), the Heun sampler, GE velocity correction, cross-attention scaling, the temporal upscaler, audio VAE /
 vocoder decode (with `audio_enabled` the audio LATENT is returned in place of the waveform).
 """
 from __future__ import annotations
@@ -19,7 +21,8 @@ from typing import Callable, List, Optional, Tuple, Union
 
 import torch
 
-from ..components import AudioPatchifier, EulerDiffusionStep, GaussianNoiser, LTX2Scheduler, VideoLatentPatchifier
+from ..components import (AudioPatchifier, CFGGuider, CFGStarRescalingGuider, EulerDiffusionStep, GaussianNoiser, LTX2Scheduler,
+                          VideoLatentPatchifier)
 from ..conditioning.tools import AudioLatentTools, VideoLatentTools
 from ..model.transformer import LTXModel, LTXModelType, X0Model
 from ..model.video_vae import SimpleVideoDecoder, TilingConfig, decode_latent, decode_tiled
@@ -36,9 +39,9 @@ class OneStageCFGConfig:
     seed: int = 42
     fps: float = 24.0
     num_inference_steps: int = 30
-    cfg_scale: float = 3.0          # video text guidance; only 1.0 (no guidance) runs here
-    audio_cfg_scale: float = 7.0    # audio text guidance; only 1.0 runs here
-    rescale_scale: float = 0.7
+    cfg_scale: float = 3.0          # video text guidance (1.0: none, one transformer evaluation per step)
+    audio_cfg_scale: float = 7.0    # audio text guidance
+    rescale_scale: float = 0.7      # > 0: CFGStarRescalingGuider, else CFGGuider (one_stage.py:796-805)
     tiling_config: Optional[TilingConfig] = None
     dtype: torch.dtype = torch.float32
     audio_enabled: bool = False
@@ -92,14 +95,9 @@ class OneStagePipeline:
     @staticmethod
     def _require_no_guidance(config: OneStageCFGConfig, joint: bool, stg_scale, guider_override, ge_gamma, sampler, temporal_upscaler,
                              cross_attn_scale):
-        """The reference builds CFGGuider / CFGStarRescalingGuider(scale) per modality and evaluates the negative prompt only
-        when one of them is `enabled()` (scale != 1, one_stage.py:490, guiders.py:46-47,75-76): that second evaluation, STG's
-        third one and everything below are not built here."""
+        """Everything beyond classifier-free guidance and the Euler step is not built here."""
         if guider_override is not None:
             raise NotImplementedError("guider_override (APG / custom guiders) is outside the MI355X hot path")
-        if config.cfg_scale != 1.0 or (joint and config.audio_cfg_scale != 1.0):
-            raise NotImplementedError(f"cfg_scale={config.cfg_scale} / audio_cfg_scale={config.audio_cfg_scale}: classifier-free guidance is "
-                                      "outside the MI355X hot path (distilled checkpoints run with both at 1.0)")
         if stg_scale != 0.0:
             raise NotImplementedError("STG guidance is outside the MI355X hot path")
         if ge_gamma != 0.0:
@@ -120,7 +118,7 @@ class OneStagePipeline:
                  initial_audio_noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """-> (video, audio): video uint8 frames (F, H, W, 3) (or the final latent when no decoder is set); audio = the audio
         LATENT (B, 8, T_a, 16) when config.audio_enabled (the reference returns the vocoder's waveform), else None.
-        The negative encodings are accepted for signature compatibility and never evaluated (no guidance).  initial_noise /
+        The negative encodings are evaluated when a guider is enabled (cfg_scale / audio_cfg_scale != 1).  initial_noise /
         initial_audio_noise (keyword-only, MI355X addition): supplied N(0,1) tensors of the patchified latent shapes, so
         results can be compared with the oracle loop (MLX's RNG stream is not reproducible here)."""
         images = images or []
@@ -152,8 +150,17 @@ class OneStagePipeline:
             audio_state = noiser(audio_tools.create_initial_state(dtype=config.dtype, device=dev), noise_scale=1.0, noise=initial_audio_noise)
 
         actx = positive_audio_encoding.to(dev) if (internal_audio_active and positive_audio_encoding is not None) else None
+        # one guider per modality (one_stage.py:793-807)
+        mk = CFGStarRescalingGuider if config.rescale_scale > 0 else CFGGuider
+        video_guider, audio_guider = mk(scale=config.cfg_scale), mk(scale=config.audio_cfg_scale)
+        need_cfg = video_guider.enabled() or (internal_audio_active and audio_guider.enabled())
+        if need_cfg and (negative_encoding is None or (internal_audio_active and negative_audio_encoding is None)):
+            raise ValueError("cfg_scale / audio_cfg_scale != 1 need the negative prompt's encoding(s)")
+        nactx = negative_audio_encoding.to(dev) if (need_cfg and internal_audio_active) else None
         video_state, audio_state = joint_denoise_loop(self.transformer, self.is_av_model, video_state, audio_state, sigmas,
-                                                      positive_encoding.to(dev), actx, self.diffusion_step, callback, config.use_hip_graph)
+                                                      positive_encoding.to(dev), actx, self.diffusion_step, callback, config.use_hip_graph,
+                                                      negative_video_context=negative_encoding.to(dev) if need_cfg else None,
+                                                      negative_audio_context=nactx, video_guider=video_guider, audio_guider=audio_guider)
 
         video_state = video_tools.unpatchify(video_tools.clear_conditioning(video_state))
         final_video_latent = video_state.latent

@@ -379,7 +379,9 @@ def generate_video(
         print(f"  WARNING: Distilled model requires CFG=1.0 (no guidance). You requested {cfg_scale}.\n  Forcing CFG=1.0 (reference :1207-1216).")
         cfg_scale, guidance_rescale, audio_cfg_scale, rescale_scale = 1.0, 0.0, 1.0, 0.0
     if cfg_scale > 1.0:
-        raise NotImplementedError(f"cfg_scale={cfg_scale}: classifier-free guidance is outside the MI355X hot path (single-pass only)")
+        raise NotImplementedError(f"cfg_scale={cfg_scale}: classifier-free guidance needs the NEGATIVE prompt's encoding, and the text encoder is outside this "
+                                  "build (scripts/generate.py takes pre-computed positive features only); OneStagePipeline(...)(positive_encoding, negative_encoding, "
+                                  "OneStageCFGConfig(cfg_scale=...)) runs it when both encodings are supplied")
     if low_memory or fast_mode:
         print("  low_memory / fast_mode: no effect here (weights and caches stay resident in HBM, the loop is one hipGraph)")
     have_ckpt = bool(weights_path) and os.path.exists(weights_path)

@@ -627,12 +627,30 @@ def test_one_stage_config_and_guidance_gate():
     ok = OneStageCFGConfig(cfg_scale=1.0, audio_cfg_scale=1.0)
     gate(ok, True, 0.0, None, 0.0, "euler", None, 1.0)
     gate(OneStageCFGConfig(cfg_scale=1.0), False, 0.0, None, 0.0, "euler", None, 1.0)     # audio scale is irrelevant without the audio branch
-    for bad in (dict(config=OneStageCFGConfig()), dict(config=OneStageCFGConfig(cfg_scale=1.0), joint=True), dict(stg_scale=1.0), dict(ge_gamma=2.0),
+    gate(OneStageCFGConfig(), True, 0.0, None, 0.0, "euler", None, 1.0)                   # classifier-free guidance (the default scales 3 / 7) is built
+    for bad in (dict(stg_scale=1.0), dict(ge_gamma=2.0),
                 dict(sampler="heun"), dict(temporal_upscaler=object()), dict(cross_attn_scale=5.0), dict(guider_override=object())):
         a = dict(config=ok, joint=False, stg_scale=0.0, guider_override=None, ge_gamma=0.0, sampler="euler", temporal_upscaler=None, cross_attn_scale=1.0)
         a.update(bad)
         with pytest.raises(NotImplementedError):
             gate(**a)
+
+
+def test_guiders_match_reference():
+    """CFGGuider / CFGStarRescalingGuider / projection_coef against the vectors recorded from the reference's own components/guiders.py
+    (tests/golden/guiders.npz, tools/pin_oracle_against_reference.py guiders)."""
+    import numpy as np
+    from ltx_2_mlx_amd.components import CFGGuider, CFGStarRescalingGuider, projection_coef
+    z = np.load(os.path.join(ROOT, "tests", "golden", "guiders.npz"))
+    g = torch.Generator().manual_seed(4242)
+    cond = torch.randn(1, 48, 128, generator=g)
+    uncond = 0.7 * cond + 0.5 * torch.randn(1, 48, 128, generator=g)
+    assert np.allclose(projection_coef(cond, uncond).numpy(), z["projection_coef"], rtol=1e-5, atol=1e-6)
+    for sc in (1.0, 3.0, 7.0):
+        assert np.allclose(CFGGuider(scale=sc).guide(cond, uncond).numpy(), z[f"cfg_{sc}"], rtol=1e-5, atol=1e-5)
+        assert np.allclose(CFGStarRescalingGuider(scale=sc).guide(cond, uncond).numpy(), z[f"cfgstar_{sc}"], rtol=1e-5, atol=1e-5)
+    assert not CFGGuider(scale=1.0).enabled() and not CFGStarRescalingGuider(scale=1.0).enabled() and CFGGuider(scale=3.0).enabled()
+    assert torch.equal(CFGGuider(scale=1.0).guide(cond, uncond), cond)
 
 
 def test_gemm_dispatch_routes_of_every_model_gemm():

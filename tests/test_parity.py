@@ -858,8 +858,22 @@ def test_one_stage_pipeline_against_oracle_loop(dev, family):
         assert aud is None and rel_l2(lat.cpu(), loop.unpatchify(rv, f, h, wd)) < 3e-2
         lat_g, _ = pipe(ctx.to(dev), None, OneStageCFGConfig(use_hip_graph=True, **kw), initial_noise=noise.to(dev))
         assert rel_l2(lat_g.cpu(), lat.cpu()) < 1e-5
-        with pytest.raises(NotImplementedError, match="cfg_scale"):
-            pipe(ctx.to(dev), ctx.to(dev), OneStageCFGConfig(**dict(kw, cfg_scale=3.0)))
+        # classifier-free guidance (one_stage.py:224-330): two evaluations per step, CFGStarRescalingGuider for rescale_scale > 0 else CFGGuider
+        from ltx_2_mlx_amd.components import CFGGuider, CFGStarRescalingGuider
+        nctx = 2.0 * torch.randn(1, S, 64, generator=g)        # (a tiny random DiT hardly listens to its prompt: a loud negative prompt and a
+        SC = 10.0                                               #  large scale make the guided trajectory measurably different)
+        for rescale, guider in ((0.7, CFGStarRescalingGuider(scale=SC)), (0.0, CFGGuider(scale=SC))):
+            rv = noise.clone()
+            for i in range(steps):
+                s = float(sig[i])
+                pos, ngt = dit.x0_model(rv, ctx, torch.tensor([s]), vpos, wq, cfg), dit.x0_model(rv, nctx, torch.tensor([s]), vpos, wq, cfg)
+                rv = loop.euler_step(rv, guider.guide(pos, ngt), s, float(sig[i + 1]))
+            lat_c, _ = pipe(ctx.to(dev), nctx.to(dev), OneStageCFGConfig(**dict(kw, cfg_scale=SC, rescale_scale=rescale)), initial_noise=noise.to(dev))
+            ref_c = loop.unpatchify(rv, f, h, wd)
+            assert rel_l2(lat_c.cpu(), ref_c) < 3e-2, rescale
+            assert rel_l2(ref_c, lat.cpu()) > 2e-2 and rel_l2(lat_c.cpu(), ref_c) < 0.5 * rel_l2(lat_c.cpu(), lat.cpu())      # the guided trajectory, not the plain one
+        with pytest.raises(ValueError, match="negative"):
+            pipe(ctx.to(dev), None, OneStageCFGConfig(**dict(kw, cfg_scale=3.0)))
         return
     v23 = family == "av_v23"
     cfg, w, wq, m = make_av(dev, v23, seed=23)
@@ -887,6 +901,23 @@ def test_one_stage_pipeline_against_oracle_loop(dev, family):
     lat_g, aud_g = pipe(vctx.to(dev), None, OneStageCFGConfig(use_hip_graph=True, **kw), positive_audio_encoding=actx.to(dev),
                         initial_noise=noise.to(dev), initial_audio_noise=anoise.to(dev))
     assert aud_g is None and rel_l2(lat_g.cpu(), lat.cpu()) < 1e-5
+    # classifier-free guidance on the joint loop (one_stage.py:466-568): one guider per modality, the reference's default scales 3 / 7
+    from ltx_2_mlx_amd.components import CFGStarRescalingGuider
+    nvctx = 0.1 * torch.randn(1, S, cfg.caption_channels or cfg.inner_dim, generator=g)
+    nactx = 0.1 * torch.randn(1, S, cfg.caption_channels or cfg.audio_inner_dim, generator=g)
+    gv, ga = CFGStarRescalingGuider(scale=3.0), CFGStarRescalingGuider(scale=7.0)
+    rv, ra = noise.clone(), anoise.clone()
+    for i in range(steps):
+        s = torch.tensor([float(sig[i])])
+        mv, ma = dict(latent=rv, timesteps=s, sigma=s, positions=vpos), dict(latent=ra, timesteps=s, sigma=s, positions=apos)
+        pv, pa = dit_av.av_x0_model(dict(mv, context=vctx), dict(ma, context=actx), wq, cfg)
+        nv_, na_ = dit_av.av_x0_model(dict(mv, context=nvctx), dict(ma, context=nactx), wq, cfg)
+        rv = loop.euler_step(rv, gv.guide(pv, nv_), float(sig[i]), float(sig[i + 1]))
+        ra = loop.euler_step(ra, ga.guide(pa, na_), float(sig[i]), float(sig[i + 1]))
+    lat_c, aud_c = pipe(vctx.to(dev), nvctx.to(dev), OneStageCFGConfig(audio_enabled=True, **dict(kw, cfg_scale=3.0, audio_cfg_scale=7.0, rescale_scale=0.7)),
+                        positive_audio_encoding=actx.to(dev), negative_audio_encoding=nactx.to(dev), initial_noise=noise.to(dev), initial_audio_noise=anoise.to(dev))
+    assert rel_l2(lat_c.cpu(), loop.unpatchify(rv, f, h, wd)) < 3e-2
+    assert rel_l2(aud_c.cpu(), AudioPatchifier(patch_size=1).unpatchify(ra, AudioLatentShape(1, 8, Ta, 16))) < 5e-2
     # use_internal_audio_branch=False on an AV model: the video half alone (reference model.py:829-840), no audio encoding needed
     lat_v, _ = pipe(vctx.to(dev), None, OneStageCFGConfig(use_internal_audio_branch=False, **kw), initial_noise=noise.to(dev))
     assert lat_v.shape == lat.shape and torch.isfinite(lat_v).all() and rel_l2(lat_v.cpu(), lat.cpu()) > 1e-3

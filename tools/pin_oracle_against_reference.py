@@ -463,7 +463,27 @@ def pin_vae():
     print("vae_tiny.npz", {k: v.shape for k, v in out.items()})
 
 
+# ------------------------------------------------------------------------------------------ guiders
+def pin_guiders():
+    """CFGGuider / CFGStarRescalingGuider / projection_coef of the reference (components/guiders.py:26-77, 290-306) on seeded tensors."""
+    from LTX_2_MLX.components.guiders import CFGGuider, CFGStarRescalingGuider, projection_coef
+    g = torch.Generator().manual_seed(4242)
+    cond = torch.randn(1, 48, 128, generator=g)
+    uncond = 0.7 * cond + 0.5 * torch.randn(1, 48, 128, generator=g)
+    out = {"projection_coef": tn(projection_coef(A(cond), A(uncond)).t)}
+    for sc in (1.0, 3.0, 7.0):
+        out[f"cfg_{sc}"] = tn(CFGGuider(scale=sc).guide(A(cond), A(uncond)).t)
+        out[f"cfgstar_{sc}"] = tn(CFGStarRescalingGuider(scale=sc).guide(A(cond), A(uncond)).t)
+    assert not CFGGuider(scale=1.0).enabled() and CFGStarRescalingGuider(scale=3.0).enabled()
+    np.savez_compressed(os.path.join(GOLD, "guiders.npz"), **out)
+    print("guiders.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "guiders":
+        with torch.no_grad():
+            pin_guiders()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "text_connector":
         pin_text_connector()
         sys.exit(0)
@@ -482,4 +502,5 @@ if __name__ == "__main__":
         pin_upscaler()
         pin_vae_encoder()
         pin_vae()
+        pin_guiders()
     print("golden vectors written to", GOLD)
