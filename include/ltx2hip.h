@@ -43,6 +43,9 @@ extern "C" {
 #define LTX2_ABI_VERSION 2
 
 const char* ltx2_last_error(void);
+/* forget the calling thread's message (a binding that loads several builds of the library reads every build's message after a failure and
+ * clears them all, so a stale message of one build is never reported for a failure in another; round 4, additive) */
+void ltx2_clear_error(void);
 int ltx2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------

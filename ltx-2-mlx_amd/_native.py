@@ -48,6 +48,7 @@ class VaeConfig(C.Structure):
 # name -> (restype, argtypes); every symbol of include/ltx2hip.h
 SIGNATURES = {
     "ltx2_last_error": (C.c_char_p, []),
+    "ltx2_clear_error": (None, []),
     "ltx2_abi_version": (i32, []),
     "ltx2_gemm_bf16": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp, i64, vp]),
     "ltx2_gemm_qkv_vt": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp]),
@@ -157,7 +158,11 @@ def lib(dtype: Optional[torch.dtype] = None) -> C.CDLL:
 
 def last_error() -> str:
     # every loaded build keeps its own thread-local message; the one that just failed is the non-empty one
+    # (messages are cleared once read, so a handled failure of one build cannot resurface beside a later failure of another)
     msgs = [l.ltx2_last_error().decode("utf-8", "replace") for l in _libs.values()]
+    for l in _libs.values():
+        if hasattr(l, "ltx2_clear_error"):
+            l.ltx2_clear_error()
     return " | ".join(m for m in msgs if m) or "unknown error"
 
 

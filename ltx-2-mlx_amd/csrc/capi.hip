@@ -20,6 +20,7 @@ void ltx2_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* ltx2_last_error(void) { return g_err; }
+void ltx2_clear_error(void) { g_err[0] = 0; }
 int ltx2_abi_version(void) { return LTX2_ABI_VERSION; }
 
 int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M,

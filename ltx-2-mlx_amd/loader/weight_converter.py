@@ -92,6 +92,11 @@ class SafetensorsStream:
             return out
         from concurrent.futures import ThreadPoolExecutor
         copy_stream = torch.cuda.Stream(device=self.device)
+        # The arenas are allocated on the CURRENT stream and filled on copy_stream: the caching allocator may hand back a block that
+        # kernels still queued on the current stream read (the previous model's weights, a load_state_dict temporary), so the copies
+        # must start after everything enqueued there so far; record_stream below keeps a freed arena away from reuse
+        # until the copy stream is done with it.
+        copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         stage = [torch.empty(self.stage_bytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
         pool = ThreadPoolExecutor(max_workers=8)
         PIECE = 16 << 20
@@ -123,6 +128,7 @@ class SafetensorsStream:
             la, lb = self.header[last_n]["data_offsets"]
             span = last_off + (lb - la)
             arena = torch.empty(max(span, 1), dtype=torch.uint8, device=self.device)
+            arena.record_stream(copy_stream)
             done = 0
             while done < span:                           # (one pass unless a single tensor exceeds the staging buffer)
                 k = bi % 2 if span <= self.stage_bytes else (done // self.stage_bytes) % 2
@@ -220,6 +226,8 @@ def load_transformer_weights(model, weights_path: str, strict: bool = False, use
 
 
 def load_av_transformer_weights(model, weights_path: str, strict: bool = False, use_fp8: bool = False,
-                                target_dtype: str = "float16"):
-    """load_transformer_weights(include_audio=True) (weight_converter.py:527-553)."""
-    return load_transformer_weights(model, weights_path, strict=strict, use_fp8=use_fp8, include_audio=True, target_dtype=target_dtype)
+                                target_dtype: str = "float16", lora_configs=None, fp8_resident: bool = False):
+    """load_transformer_weights(include_audio=True) (weight_converter.py:527-553).  `lora_configs` / `fp8_resident`: as there (the
+    reference fuses LoRA into whichever transformer is loaded, scripts/generate.py:1186-1202)."""
+    return load_transformer_weights(model, weights_path, strict=strict, use_fp8=use_fp8, include_audio=True, target_dtype=target_dtype,
+                                    lora_configs=lora_configs, fp8_resident=fp8_resident)

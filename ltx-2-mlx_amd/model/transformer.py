@@ -354,7 +354,8 @@ class LTXModel:
             else:
                 self._register(k, Fv(k))
         self._prep_key = None
-        self._twin = None
+        self._twin = None           # contexts over the OLD tensors: rebuilt on demand over the new ones
+        self._clone = None
 
     def init_random_weights(self, seed: int = 0, std: float = 0.02, fp8_resident: bool = False) -> None:
         """Synthetic N(0, std) weights generated directly in HBM in the engine's fused layout (bench /
@@ -406,6 +407,7 @@ class LTXModel:
                 self._register(k, rf(*shp))
         self._prep_key = None
         self._twin = None
+        self._clone = None
 
     def weight_tensors(self) -> Dict[str, torch.Tensor]:
         """Engine-layout device tensors (used by the RCCL weight broadcast)."""

@@ -98,6 +98,17 @@ def audio_modality_from_state(state: LatentState, context: torch.Tensor, sigma: 
     return modality_from_state(state, context, sigma, enabled, uniform)
 
 
+_eager_noted = set()
+
+
+def _note_eager_once(why: str) -> None:
+    """use_hip_graph=True but the loop cannot be replayed from the captured graph (say so once per reason)."""
+    if why not in _eager_noted:
+        _eager_noted.add(why)
+        import sys
+        print(f"  note: hipGraph replay skipped, the sampling loop runs eagerly: {why}", file=sys.stderr)
+
+
 def joint_denoise_loop(transformer, is_av_model: bool, video_state: LatentState, audio_state: Optional[LatentState], sigmas,
                        video_context: torch.Tensor, audio_context: Optional[torch.Tensor], stepper, callback=None,
                        use_hip_graph: bool = False, *, negative_video_context: Optional[torch.Tensor] = None,
@@ -128,6 +139,9 @@ def joint_denoise_loop(transformer, is_av_model: bool, video_state: LatentState,
             raise ValueError("guidance needs the negative prompt's encoding(s)")
         from ..model.transformer import X0Model
         neg = X0Model(model.clone_sharing_weights())
+    if use_hip_graph and not (callback is None and uniform and not need_cfg):
+        _note_eager_once("a step callback" if callback is not None else "classifier-free guidance (two evaluations per step)" if need_cfg else
+                         "conditioning tokens (per-token timesteps)")
     if use_hip_graph and callback is None and uniform and not need_cfg:
         lat = video_state.latent[0].float().contiguous()
         alat = audio_state.latent[0].float().contiguous() if joint else None

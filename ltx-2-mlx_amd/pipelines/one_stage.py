@@ -93,14 +93,14 @@ class OneStagePipeline:
         return AudioLatentTools(patchifier=self.audio_patchifier, target_shape=target_shape)
 
     @staticmethod
-    def _require_no_guidance(config: OneStageCFGConfig, joint: bool, stg_scale, guider_override, ge_gamma, sampler, temporal_upscaler,
-                             cross_attn_scale):
-        """Everything beyond classifier-free guidance and the Euler step is not built here."""
+    def _require_no_guidance(stg_scale, guider_override, ge_gamma, sampler, temporal_upscaler, cross_attn_scale):
+        """Everything beyond classifier-free guidance and the Euler step is not built here.  The reference enables STG / GE only for
+        values > 0 (pipelines/one_stage.py:867, :301): a zero or negative value is a no-op there and passes here."""
         if guider_override is not None:
             raise NotImplementedError("guider_override (APG / custom guiders) is outside the MI355X hot path")
-        if stg_scale != 0.0:
+        if stg_scale > 0:
             raise NotImplementedError("STG guidance is outside the MI355X hot path")
-        if ge_gamma != 0.0:
+        if ge_gamma > 0:
             raise NotImplementedError("GE velocity correction is outside the MI355X hot path")
         if sampler != "euler":
             raise NotImplementedError(f"sampler={sampler!r}: only the Euler step is built")
@@ -118,7 +118,8 @@ class OneStagePipeline:
                  initial_audio_noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """-> (video, audio): video uint8 frames (F, H, W, 3) (or the final latent when no decoder is set); audio = the audio
         LATENT (B, 8, T_a, 16) when config.audio_enabled (the reference returns the vocoder's waveform), else None.
-        The negative encodings are evaluated when a guider is enabled (cfg_scale / audio_cfg_scale != 1).  initial_noise /
+        The negative encodings are evaluated when a guider is enabled (cfg_scale / audio_cfg_scale != 1); unlike the reference
+        (one_stage.py:776-780, which demands negative_audio_encoding whenever the audio branch runs) they may be None when no guider is.  initial_noise /
         initial_audio_noise (keyword-only, MI355X addition): supplied N(0,1) tensors of the patchified latent shapes, so
         results can be compared with the oracle loop (MLX's RNG stream is not reproducible here)."""
         images = images or []
@@ -128,7 +129,7 @@ class OneStagePipeline:
                 raise ValueError("Audio encoding required for AudioVideo generation. Provide positive_audio_encoding and negative_audio_encoding.")
         if config.audio_enabled and not self.is_av_model:
             raise ValueError("audio_enabled needs an AudioVideo transformer")
-        self._require_no_guidance(config, internal_audio_active, stg_scale, guider_override, ge_gamma, sampler, temporal_upscaler, cross_attn_scale)
+        self._require_no_guidance(stg_scale, guider_override, ge_gamma, sampler, temporal_upscaler, cross_attn_scale)
 
         dev = self.transformer.velocity_model.device
         noiser = GaussianNoiser(generator=torch.Generator(device=dev).manual_seed(config.seed))

@@ -182,16 +182,21 @@ def _dtype_of(compute_dtype):
 
 def load_transformer(weights_path, num_layers: int = 48, compute_dtype=None, use_fp8: bool = False, low_memory: bool = False,
                      fast_mode: bool = False, *, num_heads: int = 32, caption_channels: int = 3840, seed: int = 0, device="cuda",
-                     lora_path=None, lora_strength: float = 1.0, fp8_resident: bool = False):
+                     lora_path=None, lora_strength: float = 1.0, fp8_resident: bool = False, fp8_compute: bool = False):
     """LTXModel(VideoOnly, 32x128, caption 3840) with checkpoint weights (reference load_transformer :788-835; same leading
     parameters).  A missing checkpoint file means random init with the reference's warning.  low_memory / fast_mode have
-    no effect here; keyword-only extras are MI355X additions."""
+    no effect here; keyword-only extras are MI355X additions.  fp8_compute (BASELINE config 3, "fp8 weights (CDNA4 fp8 MFMA)"):
+    the video stream's projections run fp8 x fp8 on the fp8 MFMA -- an fp8 checkpoint's codes stay resident (as fp8_resident),
+    a bf16 / fp16 checkpoint is quantised per output channel at load; activations are quantised per token inside the step.  Not
+    bit-identical to the reference's dequantise-at-load (`use_fp8`), which stays the default (reference :2424-2436,
+    loader/fp8_loader.py:54-130)."""
     model = LTXModel(num_attention_heads=num_heads, attention_head_dim=128, num_layers=num_layers, caption_channels=caption_channels,
-                     compute_dtype=_dtype_of(compute_dtype), device=device)
+                     compute_dtype=_dtype_of(compute_dtype), device=device, fp8_compute=fp8_compute)
     if weights_path and os.path.exists(weights_path):
         from ltx_2_mlx_amd.loader import LoRAConfig, is_fp8_checkpoint, load_transformer_weights
         fp8 = use_fp8 or is_fp8_checkpoint(weights_path)
-        load_transformer_weights(model, weights_path, strict=True, use_fp8=fp8, fp8_resident=fp8_resident and fp8,
+        # LoRA fusion needs dequantised weights; with fp8_compute they are re-quantised per channel after the fuse (load_state_dict)
+        load_transformer_weights(model, weights_path, strict=True, use_fp8=fp8, fp8_resident=(fp8_resident or fp8_compute) and fp8 and not lora_path,
                                  lora_configs=[LoRAConfig(lora_path, lora_strength)] if lora_path else None)
     elif lora_path:
         raise ValueError("--lora needs --weights (an adapter is fused into checkpoint weights)")
@@ -204,19 +209,26 @@ def load_transformer(weights_path, num_layers: int = 48, compute_dtype=None, use
 
 def load_av_transformer(weights_path, num_layers: int = 48, compute_dtype=None, use_fp8: bool = False, low_memory: bool = False,
                         caption_channels=3840, cross_attention_adaln: bool = False, apply_gated_attention: bool = False, *,
-                        num_heads: int = 32, seed: int = 0, device="cuda"):
+                        num_heads: int = 32, seed: int = 0, device="cuda", lora_path=None, lora_strength: float = 1.0,
+                        fp8_compute: bool = False):
     """AudioVideo LTXModel (video 32x128 + audio 32x64 heads) with checkpoint weights (reference load_av_transformer :838-902,
     same parameters): caption_channels = 3840 for LTX-2.0, None for LTX-2.3 (the feature extractor already projects to the
     transformer widths); cross_attention_adaln / apply_gated_attention = the LTX-2.3 block variant;
-    av_ca_timestep_scale_multiplier = 1000 as the reference passes it."""
+    av_ca_timestep_scale_multiplier = 1000 as the reference passes it.  lora_path / lora_strength (keyword-only): the adapter is fused
+    into whichever transformer is loaded, as the reference does (:1186-1202, loader/lora_loader.py:129-195); fp8_compute: as load_transformer
+    (the VIDEO stream's projections; the audio stream and the cross-modal attention stay on the 16-bit path)."""
     from ltx_2_mlx_amd.model.transformer import LTXModelType
     model = LTXModel(model_type=LTXModelType.AudioVideo, num_attention_heads=num_heads, attention_head_dim=128, num_layers=num_layers,
                      caption_channels=caption_channels, audio_attention_heads=num_heads, cross_attention_adaln=cross_attention_adaln,
                      apply_gated_attention=apply_gated_attention, av_ca_timestep_scale_multiplier=1000,
-                     compute_dtype=_dtype_of(compute_dtype), device=device)
+                     compute_dtype=_dtype_of(compute_dtype), device=device, fp8_compute=fp8_compute)
     if weights_path and os.path.exists(weights_path):
-        from ltx_2_mlx_amd.loader import is_fp8_checkpoint, load_av_transformer_weights
-        load_av_transformer_weights(model, weights_path, strict=True, use_fp8=use_fp8 or is_fp8_checkpoint(weights_path))
+        from ltx_2_mlx_amd.loader import LoRAConfig, is_fp8_checkpoint, load_av_transformer_weights
+        fp8 = use_fp8 or is_fp8_checkpoint(weights_path)
+        load_av_transformer_weights(model, weights_path, strict=True, use_fp8=fp8, fp8_resident=fp8_compute and fp8 and not lora_path,
+                                    lora_configs=[LoRAConfig(lora_path, lora_strength)] if lora_path else None)
+    elif lora_path:
+        raise ValueError("--lora needs --weights (an adapter is fused into checkpoint weights)")
     else:
         if weights_path:
             print(f"  Warning: Weights not found at {weights_path}, using random init")
@@ -325,6 +337,7 @@ def generate_video(
     fp8_resident: bool = False,
     model_version=None,
     compute_dtype=None,
+    fp8_compute: bool = False,
 ):
     """Generate video from a text prompt: denoise loop + VAE decode on MI355X behind the reference's signature.
 
@@ -336,7 +349,8 @@ def generate_video(
     MI355X extras: two_stage_distilled=True runs the reference's DistilledPipeline class (8 steps at half resolution, x2
     upscale, 3 steps; pipelines/distilled.py:274-505), which the reference's own CLI never wires; model_version="2.3" builds
     the LTX-2.3 architecture without a checkpoint (random init, for tests and benchmarks); fp8_resident keeps fp8 checkpoint
-    weights as codes in HBM; vae_base_channels overrides the checkpoint's decoder_base_channels; compute_dtype="bfloat16" runs the
+    weights as codes in HBM; fp8_compute runs the video stream's projections fp8 x fp8 on the fp8 MFMA (BASELINE config 3; per-token /
+    per-channel e4m3fn scales, not bit-identical to dequantise-at-load); vae_base_channels overrides the checkpoint's decoder_base_channels; compute_dtype="bfloat16" runs the
     bfloat16 build instead of the reference's float16 default (use_fp16=True)."""
     given = dict(upscale_temporal=upscale_temporal, early_layers_only=early_layers_only,
                  enhance_prompt_flag=enhance_prompt_flag and use_gemma, cross_attn_scale=cross_attn_scale, distilled_lora=distilled_lora,
@@ -378,10 +392,32 @@ def generate_video(
     if model_variant == "distilled" and cfg_scale > 1.2:
         print(f"  WARNING: Distilled model requires CFG=1.0 (no guidance). You requested {cfg_scale}.\n  Forcing CFG=1.0 (reference :1207-1216).")
         cfg_scale, guidance_rescale, audio_cfg_scale, rescale_scale = 1.0, 0.0, 1.0, 0.0
-    if cfg_scale > 1.0:
-        raise NotImplementedError(f"cfg_scale={cfg_scale}: classifier-free guidance needs the NEGATIVE prompt's encoding, and the text encoder is outside this "
-                                  "build (scripts/generate.py takes pre-computed positive features only); OneStagePipeline(...)(positive_encoding, negative_encoding, "
-                                  "OneStageCFGConfig(cfg_scale=...)) runs it when both encodings are supplied")
+    # Guidance scales are resolved BEFORE any model is loaded: the AudioVideo branch's defaults for a non-distilled variant are
+    # audio_cfg_scale 7.0 / rescale 0.7 (reference :1713-1716), i.e. guidance even at --cfg 1.0, and guidance needs negative encodings.
+    if audio_cfg_scale is None:
+        audio_cfg_scale = 1.0 if model_variant == "distilled" else 7.0
+    if rescale_scale is None:
+        rescale_scale = 0.0 if model_variant == "distilled" else 0.7
+    negative_encoding = negative_audio_encoding = None
+    if embedding_path and os.path.exists(embedding_path):
+        with np.load(embedding_path) as z:                # optional entries of the pre-computed embedding file: the negative prompt's encodings
+            if "negative_embedding" in z:
+                negative_encoding = torch.from_numpy(z["negative_embedding"]).float()
+                negative_encoding = negative_encoding[None] if negative_encoding.dim() == 2 else negative_encoding
+            if "negative_audio_embedding" in z:
+                negative_audio_encoding = torch.from_numpy(z["negative_audio_embedding"]).float()
+                negative_audio_encoding = negative_audio_encoding[None] if negative_audio_encoding.dim() == 2 else negative_audio_encoding
+    _av_branch = generate_audio or str(model_version or "").startswith("2.3") or \
+        (bool(weights_path) and os.path.exists(weights_path) and model_version is None and detect_model_version(weights_path).startswith("2.3"))
+    # the video-only loop of the reference guides only for cfg_scale > 1 (:1935); OneStagePipeline's guiders are enabled for any scale != 1
+    _need_cfg = (cfg_scale != 1.0 or audio_cfg_scale != 1.0) if _av_branch else cfg_scale > 1.0
+    if _need_cfg and not _av_branch:
+        raise NotImplementedError(f"cfg_scale={cfg_scale}: classifier-free guidance is built in OneStagePipeline (the AudioVideo / LTX-2.3 branch); the "
+                                  "standard video-only loop of this script runs the distilled model's cfg = 1")
+    if _need_cfg and (negative_encoding is None or negative_audio_encoding is None):
+        raise NotImplementedError(f"cfg_scale={cfg_scale} / audio_cfg_scale={audio_cfg_scale}: classifier-free guidance needs the NEGATIVE prompt's encodings and the text "
+                                  "encoder is outside this build: add `negative_embedding` and `negative_audio_embedding` arrays to the --embedding file, or pass "
+                                  "cfg_scale=1.0, audio_cfg_scale=1.0 (what --model-variant distilled does)")
     if low_memory or fast_mode:
         print("  low_memory / fast_mode: no effect here (weights and caches stay resident in HBM, the loop is one hipGraph)")
     have_ckpt = bool(weights_path) and os.path.exists(weights_path)
@@ -420,15 +456,14 @@ def generate_video(
     if use_placeholder:
         print("  Skipping model load (placeholder mode)")
     elif use_av_encoder:
-        if lora_path:
-            raise NotImplementedError("--lora with the AudioVideo transformer")
         model = X0Model(load_av_transformer(weights_path, num_layers=num_layers, compute_dtype=cdt, use_fp8=use_fp8, low_memory=low_memory,
                                             caption_channels=None if v2 else text_encoding.shape[-1], cross_attention_adaln=v2,
-                                            apply_gated_attention=v2, num_heads=num_heads, seed=seed, device=device))
+                                            apply_gated_attention=v2, num_heads=num_heads, seed=seed, device=device,
+                                            lora_path=lora_path, lora_strength=lora_strength, fp8_compute=fp8_compute))
     else:
         model = X0Model(load_transformer(weights_path, num_layers=num_layers, compute_dtype=cdt, use_fp8=use_fp8, low_memory=low_memory, fast_mode=fast_mode,
                                          num_heads=num_heads, caption_channels=text_encoding.shape[-1], seed=seed, device=device,
-                                         lora_path=lora_path, lora_strength=lora_strength, fp8_resident=fp8_resident))
+                                         lora_path=lora_path, lora_strength=lora_strength, fp8_resident=fp8_resident, fp8_compute=fp8_compute))
     print("[3/5] VAE decoder")
     vae_decoder = None
     if not skip_vae:
@@ -512,13 +547,13 @@ def generate_video(
             height=height, width=width, num_frames=num_frames, seed=seed,
             fps=25.0,  # matches the upstream frame_rate for the audio latent shape (reference :1704-1712)
             num_inference_steps=num_steps, cfg_scale=cfg_scale,
-            audio_cfg_scale=audio_cfg_scale if audio_cfg_scale is not None else (1.0 if model_variant == "distilled" else 7.0),
-            rescale_scale=rescale_scale if rescale_scale is not None else (0.0 if model_variant == "distilled" else 0.7),
+            audio_cfg_scale=audio_cfg_scale, rescale_scale=rescale_scale,
             audio_enabled=generate_audio, use_hip_graph=use_hip_graph, tiling_config=TilingConfig.default() if tiled_vae else None)
         print(f"[5/5] Running audio-video generation ({num_steps} steps)...")
         t0 = time.time()
-        video, audio_latent = av_pipeline(positive_encoding=text_encoding, negative_encoding=None, config=av_config, images=images,
-                                          positive_audio_encoding=text_audio_encoding, negative_audio_encoding=None)
+        video, audio_latent = av_pipeline(positive_encoding=text_encoding, negative_encoding=negative_encoding if _need_cfg else None, config=av_config,
+                                          images=images, positive_audio_encoding=text_audio_encoding,
+                                          negative_audio_encoding=negative_audio_encoding if _need_cfg else None)
         frames = _frames_from_video(video)
         torch.cuda.synchronize()
         print(f"  audio-video pipeline: {(time.time() - t0):.3f} s -> {tuple(frames.shape)}")
@@ -628,7 +663,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--embedding", type=str, default=None)
     p.add_argument("--gemma-path", type=str, default="weights/gemma-3-12b")
     p.add_argument("--no-gemma", action="store_true", help="dummy text embeddings")
-    p.add_argument("--fp16", action="store_true", default=True, help="reference default; here: bf16 operands, fp32 accumulate (a notice is printed)")
+    p.add_argument("--fp16", action="store_true", default=True, help="reference default: float16 operands (libltx2hip_f16.so), fp32 accumulate / residual stream; --bf16 selects the bfloat16 build")
     p.add_argument("--fp32", "--no-fp16", action="store_true", dest="fp32")
     p.add_argument("--fp8", action="store_true")
     p.add_argument("--model-variant", type=str, choices=["distilled", "dev"], default="distilled")
@@ -670,6 +705,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--no-hip-graph", action="store_true", help="run the step loop eagerly instead of replaying the captured hipGraph")
     p.add_argument("--two-stage-distilled", action="store_true", help="DistilledPipeline: 8 steps at half resolution, x2 latent upscale (--spatial-upscaler-weights), 3 steps")
     p.add_argument("--fp8-resident", action="store_true", help="keep fp8 checkpoint weights as codes in HBM (bit-identical to dequantising at load)")
+    p.add_argument("--fp8-compute", action="store_true", help="BASELINE config 3: the video stream's projections fp8 x fp8 on the CDNA4 fp8 MFMA (per-token / per-channel e4m3fn scales; "
+                   "an fp8 checkpoint's codes stay resident, a 16-bit checkpoint is quantised at load); --fp8 alone keeps the reference's dequantise-at-load arithmetic")
     p.add_argument("--bf16", action="store_true", help="bfloat16 operands instead of the reference's float16 default (both: fp32 accumulate / residual stream)")
     p.add_argument("--model-version", type=str, default=None, help="force the architecture family (e.g. 2.3) instead of reading the checkpoint metadata")
     p.add_argument("--layers", type=int, default=48, help="debug: number of DiT layers for random-weight runs")
@@ -704,7 +741,7 @@ def kwargs_from_args(a) -> dict:
         keyframes=a.keyframe, ic_lora_weights=a.ic_lora_weights,
         # MI355X extras
         text_features_path=a.text_features, use_hip_graph=not a.no_hip_graph, two_stage_distilled=a.two_stage_distilled,
-        fp8_resident=a.fp8_resident, model_version=a.model_version, compute_dtype="bfloat16" if a.bf16 else None, num_layers=a.layers, num_heads=a.heads,
+        fp8_resident=a.fp8_resident, fp8_compute=a.fp8_compute, model_version=a.model_version, compute_dtype="bfloat16" if a.bf16 else None, num_layers=a.layers, num_heads=a.heads,
         vae_base_channels=a.vae_base_channels, save_mp4=not a.no_video_file)
 
 

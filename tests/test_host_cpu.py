@@ -624,13 +624,11 @@ def test_one_stage_config_and_guidance_gate():
     with pytest.raises(ValueError, match="divisible by 32"):
         OneStageCFGConfig(height=500)
     gate = OneStagePipeline._require_no_guidance
-    ok = OneStageCFGConfig(cfg_scale=1.0, audio_cfg_scale=1.0)
-    gate(ok, True, 0.0, None, 0.0, "euler", None, 1.0)
-    gate(OneStageCFGConfig(cfg_scale=1.0), False, 0.0, None, 0.0, "euler", None, 1.0)     # audio scale is irrelevant without the audio branch
-    gate(OneStageCFGConfig(), True, 0.0, None, 0.0, "euler", None, 1.0)                   # classifier-free guidance (the default scales 3 / 7) is built
+    gate(0.0, None, 0.0, "euler", None, 1.0)
+    gate(-1.0, None, -0.5, "euler", None, 1.0)          # the reference enables STG / GE only for values > 0 (one_stage.py:867, :301)
     for bad in (dict(stg_scale=1.0), dict(ge_gamma=2.0),
                 dict(sampler="heun"), dict(temporal_upscaler=object()), dict(cross_attn_scale=5.0), dict(guider_override=object())):
-        a = dict(config=ok, joint=False, stg_scale=0.0, guider_override=None, ge_gamma=0.0, sampler="euler", temporal_upscaler=None, cross_attn_scale=1.0)
+        a = dict(stg_scale=0.0, guider_override=None, ge_gamma=0.0, sampler="euler", temporal_upscaler=None, cross_attn_scale=1.0)
         a.update(bad)
         with pytest.raises(NotImplementedError):
             gate(**a)
