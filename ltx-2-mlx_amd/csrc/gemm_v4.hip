@@ -197,6 +197,36 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
                                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     if constexpr (HOIST_COL_VECTORS) load_bias();
+    // ---- gated fp32-residual epilogue (EPI_RESID_GATE_F32 through LDS, below): the read-back side's geometry, declared here because the FIRST
+    //      part's residual rows are requested BEFORE the K loop where the loop leaves registers (224-row dense bf16 loops end at v179; round 4):
+    //      x is this tile's alone, so the rows can be read any time, and the epilogue then starts with its first 32 rows already on chip
+    //      instead of behind an HBM round trip that all 256 tiles of a one-round grid take at the same moment ----
+    constexpr bool RESID_LDS_OK = EPI == EPI_RESID_GATE_F32 && (LAYOUT == 3 || LAYOUT == 5 || LAYOUT == 6) && VAR != 9;
+    constexpr bool RESID_PRELOAD = RESID_LDS_OK && LAYOUT == 3 && BM == 224 && !W8 && !CONV;        // (must match launch_v4's LDS size)
+    constexpr int ROWB = WN * 4, PR = 32, RPP = PR / MB, NP = RBW / RPP, NIT = PR / 4;   // bytes per slab row, rows / row blocks per part, parts, readback steps per part
+    const bool rowgate = p.gate && p.gate_stride != 0;          // (block-uniform) per-row gates: per-token timesteps (image conditioning)
+    const int rr = lane >> 4, cc = lane & 15;                            // readback: 4 rows x 16 chunks per instruction
+    float* xg = (float*)p.out + (long)(m0 + rr) * p.ldo + n0 + wc * WN + cc * 4;
+    const int nparts = min(NP, (p.M - m0 + PR - 1) / PR);                // (block-uniform) ragged last row tile
+    const float* gg = rowgate ? p.gate + (long)(m0 + rr) * p.gate_stride + n0 + wc * WN + cc * 4 : nullptr;
+    // (as plain loads into registers the compiler spilled them around the asm block: the LDS-DMA needs no register; the 32 KiB above the
+    //  stage buffers are this kernel's alone: 8 KiB per wave = one part of 32 rows x 256 B, lane i's 16 bytes at byte 16 i of every KiB)
+    constexpr int X0_OFF = G::LOOP_BYTES;
+    if constexpr (RESID_PRELOAD) {
+        if (!rowgate) {
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const long grow = min((long)m0 + i * 4 + rr, (long)p.M - 1);
+                const unsigned voff = (unsigned)((grow * p.ldo + n0 + wc * WN + cc * 4) * 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + X0_OFF + w * (PR * ROWB) + i * 1024), 16, voff, 0, 0, 0);
+#else
+                (void)voff;
+#endif
+            }
+        }
+    }
     f32x16 acc[16];
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
@@ -304,9 +334,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         }
     };
     constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_SILU_BF16;
-    constexpr bool RESID_LDS_OK = EPI == EPI_RESID_GATE_F32 && (LAYOUT == 3 || LAYOUT == 5 || LAYOUT == 6) && VAR != 9;
     const bool resid_lds = RESID_LDS_OK;
-    const bool rowgate = p.gate && p.gate_stride != 0;          // (block-uniform) per-row gates: per-token timesteps (image conditioning)
     if constexpr (RESID_LDS_OK) {
       if (resid_lds) {
         // x += gate * (acc + bias) through LDS (the gate: row-invariant for a scalar sigma and folded in before the slab; per ROW for per-token
@@ -314,67 +342,80 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         // of 16 different rows, so touching x straight from them moves 16 x 64 B per instruction -- half of every 128-byte line,
         // twice.  Transposed through this wave's share of the dead stage buffers (half a wave tile at a time: rows x 256 B, 16-byte
         // chunks XOR-swizzled with the row) every global load / store instruction covers 4 whole 256-byte row segments.
-        constexpr int ROWB = WN * 4, PR = 32, RPP = PR / MB, NP = RBW / RPP, NIT = PR / 4;   // bytes per slab row, rows / row blocks per part, parts, readback steps per part
         static_assert(RBW % RPP == 0 && ROWB == 256 && 4 * 2 * PR * ROWB <= G::LDS_BYTES, "resid epilogue slab");
-        f32x4 g4[CBW][NG];
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-            for (int gq = 0; gq < NG; ++gq) {
-                g4[cb][gq] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (!rowgate && (p.gate || p.gate_table)) {
-                    g4[cb][gq] = gate4[cb][gq];
-                    if (p.gate) g4[cb][gq] += *(const f32x4*)(p.gate + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq);
-                }
-            }
         // The wave tile leaves in parts of two row blocks (32 rows).  Each wave owns a double-buffered slab of its own, so after
         // the one barrier that ends the K loop nothing synchronises: slab write of part p, then the residual rows of part p + 2
         // are requested, then part p is read back row-contiguously, added and stored -- two parts' loads are always in flight.
-        char* wl = smem + w * (2 * PR * ROWB);
-        const int rr = lane >> 4, cc = lane & 15;                            // readback: 4 rows x 16 chunks per instruction
-        float* xg = (float*)p.out + (long)(m0 + rr) * p.ldo + n0 + wc * WN + cc * 4;
-        const int nparts = min(NP, (p.M - m0 + PR - 1) / PR);                // (block-uniform) ragged last row tile
-        f32x4 xv[3][NIT], gv[3][NIT];
-        const float* gg = rowgate ? p.gate + (long)(m0 + rr) * p.gate_stride + n0 + wc * WN + cc * 4 : nullptr;
-        f32x4 gtab = {0.f, 0.f, 0.f, 0.f};              // the read-back lane's 4 columns of the broadcast part
-        if (rowgate && p.gate_table) gtab = *(const f32x4*)(p.gate_table + n0 + wc * WN + cc * 4);
-        auto load_part = [&](int part, int slot) __attribute__((always_inline)) {
+        // Written as straight-line code over compile-time part numbers, once per gate form (round 4: with a runtime `break` in the
+        // unrolled loop and the gate form tested inside it hipcc kept the in-flight rows in a scratch array -- global_load ->
+        // s_waitcnt vmcnt(0) -> scratch_store per row group).
+        auto run = [&](auto RG) __attribute__((always_inline)) {
+            constexpr bool ROWGATE = decltype(RG)::value;
+            f32x4 g4[CBW][NG];
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const long grow = min((long)m0 + part * PR + i * 4 + rr, (long)p.M - 1) - (m0 + rr);
-                xv[slot][i] = *(const f32x4*)(xg + grow * p.ldo);
-                if (rowgate) gv[slot][i] = *(const f32x4*)(gg + grow * p.gate_stride);
-            }
-        };
-        load_part(0, 0);
-        if (nparts > 1) load_part(1, 1);
-        __syncthreads();                // every wave has finished its fragment reads: the stage buffers are free
+            for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-        for (int part = 0; part < NP; ++part) {         // (unrolled: the accumulator indices must be compile-time constants)
-            if (part >= nparts) break;
-            char* sl = wl + (part & 1) * (PR * ROWB);
-#pragma unroll
-            for (int r = 0; r < RPP; ++r) {
-                const int rb = part * RPP + r, row = r * MB + lr;
-#pragma unroll
-                for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-                    for (int gq = 0; gq < NG; ++gq) {
-                        const f32x4 v = g4[cb][gq] * (acc_group(rb, cb, gq) + bias4[cb][gq]);
-                        const int chunk = (cb * MB + 8 * gq + 4 * kq) >> 2;          // 16-byte chunk of this lane's 4 columns
-                        *(f32x4*)(sl + row * ROWB + ((chunk ^ (row & 15)) << 4)) = v;
+                for (int gq = 0; gq < NG; ++gq) {
+                    g4[cb][gq] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (!ROWGATE && (p.gate || p.gate_table)) {
+                        g4[cb][gq] = gate4[cb][gq];
+                        if (p.gate) g4[cb][gq] += *(const f32x4*)(p.gate + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq);
                     }
-            }
-            if (part + 2 < nparts) load_part(part + 2, (part + 2) % 3);
+                }
+            char* wl = smem + w * (2 * PR * ROWB);
+            f32x4 gtab = {0.f, 0.f, 0.f, 0.f};              // the read-back lane's 4 columns of the broadcast part
+            if (ROWGATE && p.gate_table) gtab = *(const f32x4*)(p.gate_table + n0 + wc * WN + cc * 4);
+            f32x4 xv[3][NIT];
+            [[maybe_unused]] f32x4 gv[ROWGATE ? 3 : 1][NIT];
+            auto load_part = [&](auto PART) __attribute__((always_inline)) {
+                constexpr int part = decltype(PART)::value, slot = part % 3;
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int row = i * 4 + rr;
-                asm volatile("" : "+v"(xv[part % 3][i]));       // consume in issue order: counted waits, not vmcnt(0)
-                f32x4 d = *(const f32x4*)(sl + row * ROWB + ((cc ^ (row & 15)) << 4));
-                if (rowgate) d *= gtab + gv[part % 3][i];
-                if (m0 + part * PR + row < p.M) *(f32x4*)(xg + ((long)part * PR + row - rr) * p.ldo) = xv[part % 3][i] + d;
+                for (int i = 0; i < NIT; ++i) {
+                    const long grow = min((long)m0 + part * PR + i * 4 + rr, (long)p.M - 1) - (m0 + rr);
+                    xv[slot][i] = *(const f32x4*)(xg + grow * p.ldo);
+                    if constexpr (ROWGATE) gv[slot][i] = *(const f32x4*)(gg + grow * p.gate_stride);
+                }
+            };
+            if constexpr (RESID_PRELOAD && !ROWGATE) {      // landed long ago (the K loop waits vmcnt(0) every K-tile): 8 conflict-free LDS reads
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) xv[0][i] = *(const f32x4*)(smem + X0_OFF + w * (PR * ROWB) + i * 1024 + lane * 16);
+            } else {
+                load_part(std::integral_constant<int, 0>{});
             }
-        }
+            if (nparts > 1) load_part(std::integral_constant<int, 1>{});
+            __syncthreads();                // every wave has finished its fragment reads: the stage buffers are free
+            static_for<0, NP>([&](auto PART) __attribute__((always_inline)) {
+                constexpr int part = decltype(PART)::value;
+                if (part < nparts) {            // (block-uniform)
+                    char* sl = wl + (part & 1) * (PR * ROWB);
+#pragma unroll
+                    for (int r = 0; r < RPP; ++r) {
+                        const int rb = part * RPP + r, row = r * MB + lr;
+#pragma unroll
+                        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                            for (int gq = 0; gq < NG; ++gq) {
+                                const f32x4 v = g4[cb][gq] * (acc_group(rb, cb, gq) + bias4[cb][gq]);
+                                const int chunk = (cb * MB + 8 * gq + 4 * kq) >> 2;          // 16-byte chunk of this lane's 4 columns
+                                *(f32x4*)(sl + row * ROWB + ((chunk ^ (row & 15)) << 4)) = v;
+                            }
+                    }
+                    if constexpr (part + 2 < NP) {
+                        if (part + 2 < nparts) load_part(std::integral_constant<int, part + 2>{});
+                    }
+#pragma unroll
+                    for (int i = 0; i < NIT; ++i) {
+                        const int row = i * 4 + rr;
+                        asm volatile("" : "+v"(xv[part % 3][i]));       // consume in issue order: counted waits, not vmcnt(0)
+                        f32x4 d = *(const f32x4*)(sl + row * ROWB + ((cc ^ (row & 15)) << 4));
+                        if constexpr (ROWGATE) d *= gtab + gv[part % 3][i];
+                        if (m0 + part * PR + row < p.M) *(f32x4*)(xg + ((long)part * PR + row - rr) * p.ldo) = xv[part % 3][i] + d;
+                    }
+                }
+            });
+        };
+        if (rowgate) run(std::true_type{});
+        else run(std::false_type{});
       }
     }
     if constexpr (EPI == EPI_RESID_GATE_F32) {
@@ -621,12 +662,16 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
 template <int EPI, int LAYOUT, int BM, bool CONV = false, int VAR = 0>
 int launch_v4(const GemmParams& p, hipStream_t stream) {
     using G = V4Geo<LAYOUT, BM, VAR == 20>;
+    // the gated-residual kernel of the 224-row dense bf16 loop parks the first 32 residual rows of every wave above the stage buffers
+    // (RESID_PRELOAD in the kernel): + 32 KiB = the CU's whole 160 KiB
+    constexpr int LDS = G::LDS_BYTES + ((EPI == EPI_RESID_GATE_F32 && LAYOUT == 3 && BM == 224 && !CONV && VAR != 20 && VAR != 9) ? 32768 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS");
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }
     const int Mt = (p.M + BM - 1) / BM, Nt = p.N / G::BN;
-    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt * (p.splitk > 1 ? p.splitk : 1)), dim3(256), G::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt * (p.splitk > 1 ? p.splitk : 1)), dim3(256), LDS, stream, p);
     LTX2_CHECK_LAUNCH("gemm_v4_kernel");
     return LTX2_OK;
 }

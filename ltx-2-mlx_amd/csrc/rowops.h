@@ -19,6 +19,15 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
 int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off,
                        const float* const* weights, float eps, const float* cos, const float* sin, hipStream_t stream);
 
+// In place on bf16 rows [rows][ld] (width D at column 0 of buf): y = x * rsqrt(sum_j ss[row * ss_ld + j] / D + eps) * weight, then (tab != null)
+// SPLIT RoPE per head -- qknorm_rope for ONE segment whose squared row norms were left as ss_n <= 64 partial sums by the producing GEMM
+// (GemmParams::rowss); the tables in either form of rope.h.
+struct RopeTab;
+int rownorm_ss_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, const float* weight, const float* ss, int ss_ld, int ss_n, float eps,
+                           const RopeTab* tab, hipStream_t stream);
+// ct[i] = (cos[i], sin[i]): the interleaved compact table of rope.h
+int rope_interleave_launch(const float* cosb, const float* sinb, float* ct, long n, hipStream_t stream);
+
 // out_bf16[row][d] = ctx_bf16[row][d] * (1 + scale_tab[d] + scale_emb[d]) + shift_tab[d] + shift_emb[d]
 // (V2.3 prompt modulation of the text context, transformer.py:441-451)
 int ctx_mod_launch(const bf16* ctx, bf16* out, int rows, int D, const float* scale_tab, const float* shift_tab,

@@ -12,6 +12,7 @@
 //   x0 / euler        model.py:912-918; components/diffusion_steps.py:36-67; pipelines/common.py:169-190
 //   vae_*             video_vae/simple_decoder.py:339-342,228-238,492-498,528-553; ops.py:109-125
 #include "rowops.h"
+#include "rope.h"
 
 namespace {
 
@@ -252,6 +253,66 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16* __restrict__ buf
             *(bf16x8*)(xr + ib) = ob;
         }
     }
+}
+
+// K side of the self-attention's QK-norm + RoPE when the projection GEMM's epilogue already left the partial sums of squares of its
+// (rounded) output rows (round 4; GemmParams::rowss): k <- rope(k * rsqrt(sum / D + eps) * w), in place, one read + one write of the K
+// third only.  The Q side never makes this round trip: its row factor is a softmax scale and its weight + rotation happen in the
+// attention kernel's prologue (attention.hip, QR form).  One block per row (4 waves; every wave adds the row's <= 64 partials itself:
+// no block barrier), thread t owns pairs [8t, 8t + 8) as qknorm_rope_kernel does.
+__global__ __launch_bounds__(256) void rownorm_ss_rope_kernel(bf16* __restrict__ buf, long ld, int rows, int D, int head_dim,
+                                                              const float* __restrict__ wt, const float* __restrict__ ss, int ss_ld, int ss_n,
+                                                              float eps, RopeTab tab, int with_rope) {
+    const int half = head_dim >> 1;
+    const int p0 = threadIdx.x * 8, lane = threadIdx.x & 63;
+    const bool act = p0 < D / 2;
+    const int ia = act ? (p0 / half) * head_dim + (p0 % half) : 0;
+    const int ib = ia + half;
+    float wa[8], wb[8];
+    {
+        const f32x4 a0 = *(const f32x4*)(wt + ia), a1 = *(const f32x4*)(wt + ia + 4);
+        const f32x4 b0 = *(const f32x4*)(wt + ib), b1 = *(const f32x4*)(wt + ib + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            wa[e] = a0[e];
+            wa[4 + e] = a1[e];
+            wb[e] = b0[e];
+            wb[4 + e] = b1[e];
+        }
+    }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        bf16* xr = buf + row * ld;
+        bf16x8 va, vb;
+        if (act) {
+            va = *(const bf16x8*)(xr + ia);
+            vb = *(const bf16x8*)(xr + ib);
+        }
+        const float part = lane < ss_n ? ss[row * ss_ld + lane] : 0.f;
+        float c[8], sn[8];
+        if (act && with_rope) rope_cs8(tab, (int)row, p0, c, sn);
+        const float rstd = rsqrtf(wave_sum(part) / (float)D + eps);
+        if (!act) continue;
+        bf16x8 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = bf2f(va[e]) * rstd * wa[e];
+            const float b = bf2f(vb[e]) * rstd * wb[e];
+            if (with_rope) {
+                oa[e] = f2bf(a * c[e] - b * sn[e]);
+                ob[e] = f2bf(b * c[e] + a * sn[e]);
+            } else {
+                oa[e] = f2bf(a);
+                ob[e] = f2bf(b);
+            }
+        }
+        *(bf16x8*)(xr + ia) = oa;
+        *(bf16x8*)(xr + ib) = ob;
+    }
+}
+
+// compact RoPE tables (rope.h): ct[u][slot] = (cos[u][slot], sin[u][slot])
+__global__ void rope_interleave_kernel(const float* __restrict__ cosb, const float* __restrict__ sinb, f32x2* __restrict__ ct, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ct[i] = f32x2{cosb[i], sinb[i]};
 }
 
 __global__ void ctx_mod_kernel(const bf16* __restrict__ ctx, bf16* __restrict__ out, long n4, int D,
@@ -898,6 +959,25 @@ int latent_normalize_nchw_launch(const bf16* x, const float* mean, const float* 
     LTX2_CHECK_ARG(x && mean && stdv && out && C > 0 && P > 0, "latent_normalize: bad argument");
     hipLaunchKernelGGL(latent_normalize_nchw_kernel, dim3((int)((P + 63) / 64), (C + 63) / 64), dim3(256), 0, stream, x, mean, stdv, out, C, P);
     LTX2_CHECK_LAUNCH("latent_normalize_nchw_kernel");
+    return LTX2_OK;
+}
+
+int rownorm_ss_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, const float* weight, const float* ss, int ss_ld, int ss_n, float eps,
+                           const RopeTab* tab, hipStream_t stream) {
+    LTX2_CHECK_ARG(buf && weight && ss && rows > 0, "rownorm_ss_rope: null operand");
+    LTX2_CHECK_ARG(head_dim % 16 == 0 && D % head_dim == 0 && ld % 8 == 0 && D <= 4096, "rownorm_ss_rope: head_dim %% 16, D %% head_dim, ld %% 8, D <= 4096");
+    LTX2_CHECK_ARG(ss_n >= 1 && ss_n <= 64 && ss_ld >= ss_n, "rownorm_ss_rope: 1..64 partial sums per row (got %d)", ss_n);
+    LTX2_CHECK_ARG(!tab || tab->half == D / 2, "rownorm_ss_rope: table width %d != D / 2", tab ? tab->half : 0);
+    RopeTab t{};
+    if (tab) t = *tab;
+    hipLaunchKernelGGL(rownorm_ss_rope_kernel, dim3(rows), dim3(256), 0, stream, buf, ld, rows, D, head_dim, weight, ss, ss_ld, ss_n, eps, t, tab ? 1 : 0);
+    LTX2_CHECK_LAUNCH("rownorm_ss_rope_kernel");
+    return LTX2_OK;
+}
+
+int rope_interleave_launch(const float* cosb, const float* sinb, float* ct, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(rope_interleave_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, stream, cosb, sinb, (f32x2*)ct, n);
+    LTX2_CHECK_LAUNCH("rope_interleave_kernel");
     return LTX2_OK;
 }
 
