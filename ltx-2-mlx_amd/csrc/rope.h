@@ -18,6 +18,10 @@ struct RopeTab {
     int half;               // D / 2 slots per token
     int pad;                // identity slots in front: half - 3 * n_freq (compact form: 3 axes)
     int N;                  // tokens (stride of idx)
+    // AXIS-MAJOR compact form (row kernels): cta[(d * U + u) * n_freq + f] = (cos, sin) of slot pad + 3 f + d at the u-th distinct coordinate of
+    // axis d -- a token's table is three CONTIGUOUS runs of n_freq entries, which a block loads coalesced and re-reads from LDS in slot order
+    const f32x2* cta;
+    int U, n_freq;
 };
 
 // (cos, sin) of 8 consecutive slots [p0, p0 + 8) of token `row`

@@ -19,12 +19,14 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
 int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off,
                        const float* const* weights, float eps, const float* cos, const float* sin, hipStream_t stream);
 
-// In place on bf16 rows [rows][ld] (width D at column 0 of buf): y = x * rsqrt(sum_j ss[row * ss_ld + j] / D + eps) * weight, then (tab != null)
-// SPLIT RoPE per head -- qknorm_rope for ONE segment whose squared row norms were left as ss_n <= 64 partial sums by the producing GEMM
-// (GemmParams::rowss); the tables in either form of rope.h.
+// qknorm_rope_launch for segments whose squared row norms were left as partial sums by the producing GEMM (GemmParams::rowss): segment g of row r is
+// scaled by rsqrt(sum_{j < ss_n} ss[r * ss_ld + g * ss_n + j] / D + eps) * weight_g, then (tab != null) rotated; the tables in any form of rope.h
+// (the axis-major compact form is staged through LDS: no HBM traffic for the tables).
 struct RopeTab;
-int rownorm_ss_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, const float* weight, const float* ss, int ss_ld, int ss_n, float eps,
-                           const RopeTab* tab, hipStream_t stream);
+int rownorm_ss_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off, const float* const* weights, const float* ss,
+                           int ss_ld, int ss_n, float eps, const RopeTab* tab, hipStream_t stream);
+// cta[(d * U + u) * n_freq + f] = (cos_c, sin_c)[u][pad + 3 f + d]: the axis-major compact table of rope.h from the U x half rows of ltx2_rope_tables
+int rope_axis_major_launch(const float* cos_c, const float* sin_c, float* cta, int U, int half, int n_freq, hipStream_t stream);
 // ct[i] = (cos[i], sin[i]): the interleaved compact table of rope.h
 int rope_interleave_launch(const float* cosb, const float* sinb, float* ct, long n, hipStream_t stream);
 

@@ -255,58 +255,109 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16* __restrict__ buf
     }
 }
 
-// K side of the self-attention's QK-norm + RoPE when the projection GEMM's epilogue already left the partial sums of squares of its
-// (rounded) output rows (round 4; GemmParams::rowss): k <- rope(k * rsqrt(sum / D + eps) * w), in place, one read + one write of the K
-// third only.  The Q side never makes this round trip: its row factor is a softmax scale and its weight + rotation happen in the
-// attention kernel's prologue (attention.hip, QR form).  One block per row (4 waves; every wave adds the row's <= 64 partials itself:
-// no block barrier), thread t owns pairs [8t, 8t + 8) as qknorm_rope_kernel does.
-__global__ __launch_bounds__(256) void rownorm_ss_rope_kernel(bf16* __restrict__ buf, long ld, int rows, int D, int head_dim,
-                                                              const float* __restrict__ wt, const float* __restrict__ ss, int ss_ld, int ss_n,
-                                                              float eps, RopeTab tab, int with_rope) {
+// QK-norm + RoPE of the self-attention when the projection GEMM's epilogue already left the partial sums of squares of its (rounded) output
+// rows (round 4; GemmParams::rowss): for each of NSEG segments (q, k) x <- rope(x * rsqrt(sum / D + eps) * w), in place -- qknorm_rope_kernel
+// without its block reduction (every wave adds the row's <= 64 partials itself) and, with the axis-major compact table of rope.h, without the
+// 57 MB of fp32 cos / sin rows per call: the token's three runs of n_freq (cos, sin) entries (16 KB, L2-resident) are loaded coalesced into
+// LDS and read back in slot order.  One block per row, thread t owns pairs [8t, 8t + 8) as qknorm_rope_kernel does.
+template <int NSEG>
+__global__ __launch_bounds__(256) void rownorm_ss_rope_kernel(bf16* __restrict__ buf, long ld, int rows, int D, int head_dim, QKSegs segs,
+                                                              const float* __restrict__ ss, int ss_ld, int ss_n, float eps, RopeTab tab,
+                                                              int with_rope) {
+    extern __shared__ __attribute__((aligned(16))) char smem_rs[];
+    f32x2* lt = (f32x2*)smem_rs;                // [3 * n_freq] this row's (cos, sin), axis-major
     const int half = head_dim >> 1;
     const int p0 = threadIdx.x * 8, lane = threadIdx.x & 63;
     const bool act = p0 < D / 2;
     const int ia = act ? (p0 / half) * head_dim + (p0 % half) : 0;
     const int ib = ia + half;
-    float wa[8], wb[8];
-    {
+    float wa[NSEG][8], wb[NSEG][8];
+#pragma unroll
+    for (int g = 0; g < NSEG; ++g) {
+        const float* wt = segs.w[g];
         const f32x4 a0 = *(const f32x4*)(wt + ia), a1 = *(const f32x4*)(wt + ia + 4);
         const f32x4 b0 = *(const f32x4*)(wt + ib), b1 = *(const f32x4*)(wt + ib + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            wa[e] = a0[e];
-            wa[4 + e] = a1[e];
-            wb[e] = b0[e];
-            wb[4 + e] = b1[e];
+            wa[g][e] = a0[e];
+            wa[g][4 + e] = a1[e];
+            wb[g][e] = b0[e];
+            wb[g][4 + e] = b1[e];
         }
     }
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        bf16* xr = buf + row * ld;
-        bf16x8 va, vb;
-        if (act) {
-            va = *(const bf16x8*)(xr + ia);
-            vb = *(const bf16x8*)(xr + ib);
-        }
-        const float part = lane < ss_n ? ss[row * ss_ld + lane] : 0.f;
-        float c[8], sn[8];
-        if (act && with_rope) rope_cs8(tab, (int)row, p0, c, sn);
-        const float rstd = rsqrtf(wave_sum(part) / (float)D + eps);
-        if (!act) continue;
-        bf16x8 oa, ob;
+    const bool staged = with_rope && tab.cta;
+    const int nf = tab.n_freq, ntab = 3 * nf;
+    // slot p0 + e -> LDS entry: j = slot - pad, axis j % 3, frequency j / 3 (slots < pad are the identity)
+    int lofs[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float a = bf2f(va[e]) * rstd * wa[e];
-            const float b = bf2f(vb[e]) * rstd * wb[e];
-            if (with_rope) {
-                oa[e] = f2bf(a * c[e] - b * sn[e]);
-                ob[e] = f2bf(b * c[e] + a * sn[e]);
-            } else {
-                oa[e] = f2bf(a);
-                ob[e] = f2bf(b);
+    for (int e = 0; e < 8; ++e) {
+        const int j = p0 + e - tab.pad;
+        lofs[e] = j < 0 ? -1 : (j % 3) * nf + j / 3;
+    }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        bf16x8 va[NSEG], vb[NSEG];
+        float part[NSEG];
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) {
+            bf16* xr = buf + row * ld + segs.off[g];
+            if (act) {
+                va[g] = *(const bf16x8*)(xr + ia);
+                vb[g] = *(const bf16x8*)(xr + ib);
             }
+            part[g] = lane < ss_n ? ss[row * ss_ld + g * ss_n + lane] : 0.f;
         }
-        *(bf16x8*)(xr + ia) = oa;
-        *(bf16x8*)(xr + ib) = ob;
+        float c[8], sn[8];
+        if (staged) {
+            const int i0 = tab.idx[row], i1 = tab.idx[tab.N + row], i2 = tab.idx[2 * tab.N + row];
+            if (row != (long)blockIdx.x) __syncthreads();          // the previous row's reads of lt are done
+            for (int i = threadIdx.x; i < ntab; i += 256) {
+                const int d = i >= 2 * nf ? 2 : i >= nf ? 1 : 0;
+                const int u = d == 0 ? i0 : d == 1 ? i1 : i2;
+                lt[i] = tab.cta[((long)d * tab.U + u) * nf + (i - d * nf)];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f32x2 v = lofs[e] < 0 ? f32x2{1.f, 0.f} : lt[lofs[e]];
+                c[e] = v[0];
+                sn[e] = v[1];
+            }
+        } else if (act && with_rope) {
+            rope_cs8(tab, (int)row, p0, c, sn);
+        }
+        if (!act) continue;
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) {
+            bf16* xr = buf + row * ld + segs.off[g];
+            const float rstd = rsqrtf(wave_sum(part[g]) / (float)D + eps);
+            bf16x8 oa, ob;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = bf2f(va[g][e]) * rstd * wa[g][e];
+                const float b = bf2f(vb[g][e]) * rstd * wb[g][e];
+                if (with_rope) {
+                    oa[e] = f2bf(a * c[e] - b * sn[e]);
+                    ob[e] = f2bf(b * c[e] + a * sn[e]);
+                } else {
+                    oa[e] = f2bf(a);
+                    ob[e] = f2bf(b);
+                }
+            }
+            *(bf16x8*)(xr + ia) = oa;
+            *(bf16x8*)(xr + ib) = ob;
+        }
+    }
+}
+
+// axis-major compact RoPE table (rope.h): cta[(d * U + u) * n_freq + f] = (cos_c, sin_c)[u][pad + 3 f + d]
+__global__ void rope_axis_major_kernel(const float* __restrict__ cosb, const float* __restrict__ sinb, f32x2* __restrict__ cta, int U, int half,
+                                       int n_freq) {
+    const long n = 3L * U * n_freq;
+    const int pad = half - 3 * n_freq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % n_freq), u = (int)((i / n_freq) % U), d = (int)(i / ((long)n_freq * U));
+        const long src = (long)u * half + pad + 3 * f + d;
+        cta[i] = f32x2{cosb[src], sinb[src]};
     }
 }
 
@@ -962,16 +1013,33 @@ int latent_normalize_nchw_launch(const bf16* x, const float* mean, const float* 
     return LTX2_OK;
 }
 
-int rownorm_ss_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, const float* weight, const float* ss, int ss_ld, int ss_n, float eps,
-                           const RopeTab* tab, hipStream_t stream) {
-    LTX2_CHECK_ARG(buf && weight && ss && rows > 0, "rownorm_ss_rope: null operand");
+int rownorm_ss_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off, const float* const* weights, const float* ss,
+                           int ss_ld, int ss_n, float eps, const RopeTab* tab, hipStream_t stream) {
+    LTX2_CHECK_ARG(buf && weights && ss && rows > 0 && (nseg == 1 || nseg == 2), "rownorm_ss_rope: null operand / nseg must be 1 or 2");
     LTX2_CHECK_ARG(head_dim % 16 == 0 && D % head_dim == 0 && ld % 8 == 0 && D <= 4096, "rownorm_ss_rope: head_dim %% 16, D %% head_dim, ld %% 8, D <= 4096");
-    LTX2_CHECK_ARG(ss_n >= 1 && ss_n <= 64 && ss_ld >= ss_n, "rownorm_ss_rope: 1..64 partial sums per row (got %d)", ss_n);
+    LTX2_CHECK_ARG(ss_n >= 1 && ss_n <= 64 && ss_ld >= nseg * ss_n, "rownorm_ss_rope: 1..64 partial sums per row and segment (got %d)", ss_n);
     LTX2_CHECK_ARG(!tab || tab->half == D / 2, "rownorm_ss_rope: table width %d != D / 2", tab ? tab->half : 0);
+    QKSegs s{};
+    for (int i = 0; i < nseg; ++i) {
+        LTX2_CHECK_ARG(seg_off[i] % 8 == 0 && weights[i], "rownorm_ss_rope: bad segment");
+        s.off[i] = seg_off[i];
+        s.w[i] = weights[i];
+    }
     RopeTab t{};
     if (tab) t = *tab;
-    hipLaunchKernelGGL(rownorm_ss_rope_kernel, dim3(rows), dim3(256), 0, stream, buf, ld, rows, D, head_dim, weight, ss, ss_ld, ss_n, eps, t, tab ? 1 : 0);
+    const int lds = (tab && t.cta) ? 3 * t.n_freq * 8 : 0;
+    LTX2_CHECK_ARG(lds <= 48 * 1024 && (!t.cta || t.pad == t.half - 3 * t.n_freq), "rownorm_ss_rope: compact table geometry");
+    if (nseg == 2)
+        hipLaunchKernelGGL((rownorm_ss_rope_kernel<2>), dim3(rows), dim3(256), lds, stream, buf, ld, rows, D, head_dim, s, ss, ss_ld, ss_n, eps, t, tab ? 1 : 0);
+    else
+        hipLaunchKernelGGL((rownorm_ss_rope_kernel<1>), dim3(rows), dim3(256), lds, stream, buf, ld, rows, D, head_dim, s, ss, ss_ld, ss_n, eps, t, tab ? 1 : 0);
     LTX2_CHECK_LAUNCH("rownorm_ss_rope_kernel");
+    return LTX2_OK;
+}
+
+int rope_axis_major_launch(const float* cosb, const float* sinb, float* cta, int U, int half, int n_freq, hipStream_t stream) {
+    hipLaunchKernelGGL(rope_axis_major_kernel, dim3(grid_for(3L * U * n_freq, 256, 2048)), dim3(256), 0, stream, cosb, sinb, (f32x2*)cta, U, half, n_freq);
+    LTX2_CHECK_LAUNCH("rope_axis_major_kernel");
     return LTX2_OK;
 }
 

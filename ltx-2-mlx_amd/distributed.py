@@ -48,13 +48,37 @@ def shard_units(n_units: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_units, world))
 
 
-def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 256 << 20) -> int:
+def _bcast_flat(flat: torch.Tensor, src: int, mode: str) -> None:
+    """One flat buffer from rank `src` to everyone.  "ring": dist.broadcast (RCCL's ring / tree: every byte crosses ONE xGMI link per hop,
+    ~153 GB/s).  "scatter": the root deals the buffer out in world_size chunks (chunk r to rank r: the root's 7 links carry different bytes in
+    parallel) and an all-gather completes every rank's copy over all links at once -- the two-phase broadcast of SURVEY 5 for a point-to-point
+    fabric.  Same result; which one is faster on the node is for the first 8-GPU run to say (bench.py reports the GB/s of the one it used)."""
+    world = dist.get_world_size()
+    if mode == "ring" or world == 1 or flat.numel() < world:
+        dist.broadcast(flat, src=src)
+        return
+    n = flat.numel()
+    per = (n + world - 1) // world
+    padded = flat if per * world == n else torch.cat([flat, flat.new_zeros(per * world - n)])
+    mine = torch.empty(per, dtype=flat.dtype, device=flat.device)
+    chunks = list(padded.view(world, per).unbind(0)) if dist.get_rank() == src else None
+    dist.scatter(mine, chunks, src=src)
+    gathered = torch.empty(per * world, dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(gathered, mine)
+    flat.copy_(gathered[:n])
+
+
+def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 256 << 20, mode: Optional[str] = None) -> int:
     """Broadcast every tensor of `tensors` from rank `src`, in place, as large flat per-dtype
     buckets (few, large collectives: xGMI is point-to-point, ~153 GB/s per link, so ring traffic
     is per-link bound and small messages waste it).  All ranks must hold identically shaped
-    tensors under identical names.  Returns the number of collectives issued."""
+    tensors under identical names.  mode: "ring" (dist.broadcast) or "scatter" (scatter + all-gather, _bcast_flat); default: the
+    LTX2_BCAST environment variable, else "ring".  Returns the number of buckets sent."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
+    mode = mode or os.environ.get("LTX2_BCAST", "ring")
+    if mode not in ("ring", "scatter"):
+        raise ValueError(f"broadcast mode {mode!r}: ring or scatter")
     names = sorted(tensors.keys())
     by_dtype: Dict[torch.dtype, List[str]] = {}
     for n in names:
@@ -70,7 +94,7 @@ def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_byt
             if not t0.is_contiguous():
                 raise ValueError(f"broadcast_tensors: {group[i]} is not contiguous")
             if t0.numel() >= cap:
-                dist.broadcast(t0, src=src)
+                _bcast_flat(t0.view(-1), src, mode)
                 n_coll += 1
                 i += 1
                 continue
@@ -85,7 +109,7 @@ def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_byt
                     k = tensors[n].numel()
                     flat[off:off + k].copy_(tensors[n].reshape(-1))
                     off += k
-            dist.broadcast(flat, src=src)
+            _bcast_flat(flat, src, mode)
             n_coll += 1
             off = 0
             if dist.get_rank() != src:
@@ -95,6 +119,34 @@ def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_byt
                     off += k
             i = j
     return n_coll
+
+
+def tensors_checksum(tensors: Dict[str, torch.Tensor]) -> int:
+    """Order-independent-free 63-bit checksum of the BYTES of every tensor (names in sorted order, each tensor's bytes summed as int64 words with a
+    position weight): equal on two ranks iff -- up to a 2^-63 accident -- the replicas hold identical weights."""
+    acc = 0
+    for i, n in enumerate(sorted(tensors.keys())):
+        t = tensors[n].contiguous().view(torch.uint8).reshape(-1)
+        pad = (-t.numel()) % 8
+        if pad:
+            t = torch.cat([t, t.new_zeros(pad)])
+        w = t.view(torch.int64)
+        # position-weighted sum (wraps mod 2^64): a permutation of words inside a tensor changes it
+        k = torch.arange(1, w.numel() + 1, device=w.device, dtype=torch.int64)
+        acc = (acc * 1000003 + int((w * k).sum().item()) + (i + 1) * 7919) & 0x7FFFFFFFFFFFFFFF
+    return acc
+
+
+def replicas_identical(tensors: Dict[str, torch.Tensor], device: Optional[torch.device] = None) -> bool:
+    """All ranks hold byte-identical `tensors`: the MIN and the MAX over ranks of tensors_checksum() agree (two all-reduces of one int64)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return True
+    c = tensors_checksum(tensors)
+    dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    lo, hi = torch.tensor([c], dtype=torch.int64, device=dev), torch.tensor([c], dtype=torch.int64, device=dev)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return int(lo.item()) == int(hi.item())
 
 
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:

@@ -307,38 +307,49 @@ def test_shard_units():
 _WORKER = r"""
 import os, sys, torch
 sys.path.insert(0, {root!r})
-from ltx_2_mlx_amd.distributed import init_distributed, broadcast_tensors, shard_units, max_over_ranks, barrier, count_ranks, gather_floats
+from ltx_2_mlx_amd.distributed import (init_distributed, broadcast_tensors, shard_units, max_over_ranks, barrier, count_ranks, gather_floats,
+                                       replicas_identical, tensors_checksum)
 rank, world, _ = init_distributed("gloo")
-g = torch.Generator().manual_seed(100 + rank)          # different content per rank before the broadcast
-t = {{"a.weight": torch.randn(300, 7, generator=g).to(torch.bfloat16), "b.bias": torch.randn(11, generator=g),
-     "c.weight": torch.randn(5000, generator=g).to(torch.bfloat16), "d.table": torch.randn(6, 16, generator=g)}}
-n = broadcast_tensors(t, src=0, bucket_bytes=4096)
-g0 = torch.Generator().manual_seed(100)
-ref = {{"a.weight": torch.randn(300, 7, generator=g0).to(torch.bfloat16), "b.bias": torch.randn(11, generator=g0),
-       "c.weight": torch.randn(5000, generator=g0).to(torch.bfloat16), "d.table": torch.randn(6, 16, generator=g0)}}
-assert all(torch.equal(t[k], ref[k]) for k in t), "broadcast mismatch"
-assert n >= 3
-units = shard_units(5, rank, world)
-assert units == ([0, 2, 4] if rank == 0 else [1, 3])
+def draw(seed):
+    g = torch.Generator().manual_seed(seed)
+    return {{"a.weight": torch.randn(300, 7, generator=g).to(torch.bfloat16), "b.bias": torch.randn(11, generator=g),
+            "c.weight": torch.randn(5000, generator=g).to(torch.bfloat16), "d.table": torch.randn(6, 16, generator=g),
+            "e.codes": torch.randint(0, 255, (37, 5), generator=g).to(torch.uint8)}}
+ref = draw(100)
+for mode in ("ring", "scatter"):                       # the ring broadcast and the scatter + all-gather form (LTX2_BCAST=scatter)
+    t = draw(100 + rank)                               # different content per rank before the broadcast
+    assert not replicas_identical(t, torch.device("cpu"))
+    n = broadcast_tensors(t, src=0, bucket_bytes=4096, mode=mode)
+    assert all(torch.equal(t[k], ref[k]) for k in t), "broadcast mismatch (%s)" % mode
+    assert n >= 3
+    assert replicas_identical(t, torch.device("cpu")) and tensors_checksum(t) == tensors_checksum(ref)
+    if rank == world - 1:                              # one flipped bit on one rank is seen by every rank
+        t["c.weight"].view(torch.int16)[1234] ^= 1
+    assert not replicas_identical(t, torch.device("cpu"))
+units = shard_units(world * 2 + 1, rank, world)
+assert units == list(range(rank, world * 2 + 1, world))
 m = max_over_ranks(float(rank + 1), device=torch.device("cpu"))
-assert m == 2.0
-assert count_ranks(torch.device("cpu")) == 2          # counted through the process group, not read from WORLD_SIZE
-assert gather_floats([10.0 + rank, -1.0]) == [[10.0, -1.0], [11.0, -1.0]]
+assert m == float(world)
+assert count_ranks(torch.device("cpu")) == world      # counted through the process group, not read from WORLD_SIZE
+assert gather_floats([10.0 + rank, -1.0]) == [[10.0 + r, -1.0] for r in range(world)]
 barrier()
 open(os.path.join({out!r}, "ok_%d" % rank), "w").write("OK")
 """
 
 
-def test_gloo_world2_broadcast_and_sharding(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_world2_broadcast_and_sharding(tmp_path, world):
+    """The N > 1 host logic over gloo: both broadcast forms (ring, scatter + all-gather), the replica checksum (and that it sees one flipped
+    bit), sharding, the reductions bench.py uses -- at world sizes 2 and 4."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path)))
-    port = 29500 + (os.getpid() % 2000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    port = 29500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+    assert all((tmp_path / f"ok_{i}").exists() for i in range(world))
 
 
 def test_save_video_command_and_png_fallback(tmp_path, monkeypatch):
