@@ -97,32 +97,6 @@ int ltx2_gemm_bf16_rowss(const void* A, int64_t lda, const void* W, const float*
 int ltx2_flash_attn_rowscale(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
                              int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, void* stream);
 
-/* Self-attention QK-norm + RoPE without a pass over Q (attention.py:203-253 with rope.py:92-144; round 4).  The fused QKV projection
- * (ltx2_gemm_qkv_vt with a rowss buffer, below) leaves the partial sums of squares of its rounded Q / K rows; then
- *   ltx2_rownorm_ss_rope : ltx2_qknorm_rope on those sums, in place: segment g (q at q_off, k at k_off; k_weight null = q only) of row r is
- *                          scaled by rsqrt(sum_{j < ss_n} ss[r][g ss_n + j] / D + eps) * weight_g and rotated; tables: full (rope_cos / rope_sin)
- *                          or axis-major compact (rope_cta from ltx2_rope_compact_axis_major + rope_idx, rope_u = n_coords)
- *   ltx2_flash_attn_qfold: attention on the RAW projected Q rows: q_norm.weight and the SPLIT rotation are applied to the fragments
- *                          in the kernel's prologue, the row's RMS factor becomes its softmax scale (as ltx2_flash_attn_rowscale)
- * -- equal to ltx2_qknorm_rope + ltx2_flash_attn up to the rounding of the normalised Q.  RoPE tables: the full cos / sin [N][D/2] of
- * ltx2_rope_tables, or the COMPACT pair: rope_ct [U][D/2] (cos, sin) interleaved by ltx2_rope_compact_pack from the cos / sin rows
- * ltx2_rope_tables writes for the U distinct coordinates (row u: every axis at its u-th distinct coordinate), rope_idx int32 [3][N] =
- * each token's coordinate number per axis, rope_pad = D/2 - 3 n_freq identity slots; both forms give identical results (three position
- * axes; pass the full tables otherwise).                                                                                      */
-/* ltx2_gemm_qkv_vt that also writes rowss[m][N / 64] for the 64-column strips of the columns < vt_col0 (*fused = 1), or, on shapes the
- * 4-wave kernel does not take, the plain projection + transpose pass with rowss untouched (*fused = 0). */
-int ltx2_gemm_qkv_vt_rowss(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K,
-                           void* vt, int vt_col0, int Npad, int head_dim, float* rowss, int* fused, void* stream);
-int ltx2_rownorm_ss_rope(void* buf, int64_t ld, int rows, int D, int head_dim, int q_off, const float* q_weight, int k_off, const float* k_weight,
-                         const float* ss, int ss_ld, int ss_n, float eps, const float* rope_cos, const float* rope_sin, const float* rope_cta,
-                         const int* rope_idx, int rope_u, void* stream);
-/* cta[(d * n_coords + u) * (half / 3) + f] = (cos_c, sin_c)[u][half % 3 + 3 f + d]: a token's table as three contiguous runs */
-int ltx2_rope_compact_axis_major(const float* cos_c, const float* sin_c, float* cta, int n_coords, int half, void* stream);
-int ltx2_rope_compact_pack(const float* cos_c, const float* sin_c, float* ct, int64_t n, void* stream);
-int ltx2_flash_attn_qfold(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
-                          int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_ss_n, int q_norm_dim, float q_eps, const float* q_weight,
-                          const float* rope_cos, const float* rope_sin, const float* rope_ct, const int* rope_idx, int rope_pad, void* stream);
-
 /* flash attention with a key mask (attention.py:38-70 with the additive mask model.py:163-201 builds from a boolean (B, S) context
  * mask): mask fp32 [Nkv], non-zero = the key may be attended; a masked key takes no weight unless every key is masked (then the
  * row averages V over all keys, as the reference's -finfo.max bias does).  words: scratch of Npad / 8 bytes on the device.        */
@@ -397,18 +371,9 @@ int ltx2_dit_set_context_mask(ltx2_dit* ctx, int modality, const float* mask, in
  *   "fp8_compute" = 1: every linear of the VIDEO stream whose weight is registered fp8-resident (LTX2_DTYPE_FP8_E4M3FN codes +
  *   `<name>_scale`) and whose GEMM has M >= 1024 rows runs as ltx2_gemm_fp8 on activations quantised per token
  *   (ltx2_quantize_rows_fp8).  Default 0: fp8-resident weights are expanded to bf16 inside the GEMM (bit-identical to the
- *   reference's dequantise-at-load).
- *   "qk_fold" = 0 (any time; the next ltx2_dit_prepare applies it): keep the stand-alone QK-norm + RoPE pass between the QKV projection and the
- *   video self-attention instead of folding it around the projection (default 1 where the shapes allow; same result up to the rounding
- *   of the normalised Q -- for A/B timing and tests).                                                                   */
+ *   reference's dequantise-at-load).                                                                                    */
 int ltx2_dit_set_option(ltx2_dit* ctx, const char* name, int value);
 
-/* Optional, after ltx2_dit_prepare (it belongs to that call's positions): the compact form of the video self-attention's RoPE tables
- * (see ltx2_rownorm_ss_rope above): idx int32 [3][N] = each token's coordinate number per position axis, cos_c / sin_c [n_coords][D/2] =
- * the rows ltx2_rope_tables writes for "tokens" whose every axis sits at its u-th distinct coordinate.  The step then reads 0.4 MB of
- * L2-resident table instead of 57 MB from HBM per layer; results are identical.  n_dims must be 3, n_coords <= 64.  (round 4, additive) */
-int ltx2_dit_set_rope_compact(ltx2_dit* ctx, int modality, const int* idx, const float* cos_c, const float* sin_c, int n_dims, int n_coords,
-                              void* stream);
 
 /* Health check at a host synchronisation point (per prompt / after a sampling loop): synchronises `stream`, reads the sticky error
  * word of the stream-K attention hand-off (a consumer that waited ~0.2 s for a partial result gives up instead of hanging the GPU,

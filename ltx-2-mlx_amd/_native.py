@@ -55,12 +55,6 @@ SIGNATURES = {
     "ltx2_gemm_w8a16": (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
     "ltx2_gemm_bf16_rowss": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, C.POINTER(i32), vp]),
     "ltx2_flash_attn_keymask": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, vp, vp]),
-    "ltx2_gemm_qkv_vt_rowss": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, vp, C.POINTER(i32), vp]),
-    "ltx2_rownorm_ss_rope": (i32, [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, f32, vp, vp, vp, vp, i32, vp]),
-    "ltx2_rope_compact_axis_major": (i32, [vp, vp, vp, i32, i32, vp]),
-    "ltx2_rope_compact_pack": (i32, [vp, vp, vp, i64, vp]),
-    "ltx2_flash_attn_qfold": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, i32, vp]),
-    "ltx2_dit_set_rope_compact": (i32, [vp, i32, vp, vp, vp, i32, i32, vp]),
     "ltx2_flash_attn_rowscale": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, i32, f32, vp]),
     "ltx2_gemm_route": (i32, [i32, i32, i32, i32, i32, i32]),
     "ltx2_quantize_rows_fp8": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),

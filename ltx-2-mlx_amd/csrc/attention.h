@@ -1,7 +1,6 @@
 // Flash-attention forward (head_dim 128 / 64) + V^T re-layout: parameter block and host launchers.
 #pragma once
 #include "common.h"
-#include "rope.h"
 
 struct AttnParams {
     const bf16* Q;   // [Nq][ldq], head h at columns h*128
@@ -26,12 +25,6 @@ struct AttnParams {
     const float* q_ss;
     int q_ss_ld, q_norm_dim;
     float q_eps;
-    int q_ss_n;         // partial sums per row (0 = q_ss_ld): a row's partials may be the leading q_ss_n of a wider record
-    // QR form (round 4, the DiT's self-attention): Q arrives as the projection's RAW rows; the prologue applies q_norm's weight q_w[H * head_dim]
-    // and the SPLIT rotation of q_rope to the fragments it holds in registers (pairs (j, j + 64) of a head are one lane's), and the
-    // row's RMS factor comes in through q_ss as above -- no pass over Q between the projection and this kernel.  Needs q_ss; head_dim 128.
-    const float* q_w;
-    RopeTab q_rope;
     // Key mask (reference attention.py:38-70 with the boolean (B, S) context mask of model.py:163-201): bit i of kmask[t] = key 64 t + i may be
     // attended; a masked key's score is replaced by -1e30 (the reference ADDS -3.4e38 to it: the same softmax, including the uniform
     // result over the masked keys of a row whose keys are all masked).  null = no mask.  Plain grid only.

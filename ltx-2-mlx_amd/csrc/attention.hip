@@ -105,10 +105,9 @@ struct SkSlot {
 // PVX: the exponentials of key chunk j + 1 issue between the PV MFMAs of chunk j (same-wave interleave).  It pays where a SIMD holds ONE wave of
 // this kernel -- the partially filled last round of a plain grid (self-attention at N = 3456: 864 workgroups on 512 slots) -- and costs ~1 % where
 // every SIMD has two (tools/micro/mfma_valu_overlap.hip: only a wave's OWN MFMAs cover its VALU work); the launcher picks per grid.
-template <int HD, bool SK, bool QS = false, bool KM = false, bool PVX = false, bool QR = false>
+template <int HD, bool SK, bool QS = false, bool KM = false, bool PVX = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     static_assert(!(SK && KM), "the key mask runs on the plain grid");
-    static_assert(!QR || (QS && HD == 128 && !SK && !KM), "the QR form: per-row scale, head_dim 128, plain grid");
     static_assert(!KM || AT_SFMA, "the key mask's exponent form lives in the scalar-fma softmax");
     using G = Geo<HD>;
     constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NKS = G::NKS, ND = G::ND, NJ = G::NJ;
@@ -222,27 +221,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             const bf16* qp = p.Q + (long)qrow * p.ldq + head * HD + 8 * hi;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
-            if constexpr (QR) {
-                // raw projection rows -> q_norm.weight (.) then the SPLIT rotation, in fp32, rounded once: this lane holds dims
-                // 16 ks + 8 hi + e of the head, i.e. both halves (ks, ks + NKS / 2) of the 8 rotation pairs head * HD / 2 + 16 ks + 8 hi + e
-                const float* wq = p.q_w + head * HD + 8 * hi;
-#pragma unroll
-                for (int ks = 0; ks < NKS / 2; ++ks) {
-                    float c[8], sn[8];
-                    rope_cs8(p.q_rope, qrow, head * (HD / 2) + 16 * ks + 8 * hi, c, sn);
-                    const f32x4 wa0 = *(const f32x4*)(wq + 16 * ks), wa1 = *(const f32x4*)(wq + 16 * ks + 4);
-                    const f32x4 wb0 = *(const f32x4*)(wq + 16 * ks + HD / 2), wb1 = *(const f32x4*)(wq + 16 * ks + HD / 2 + 4);
-                    bf16x8 a = qf[ks], b = qf[ks + NKS / 2];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float fa = bf2f(a[e]) * (e < 4 ? wa0[e & 3] : wa1[e & 3]), fb = bf2f(b[e]) * (e < 4 ? wb0[e & 3] : wb1[e & 3]);
-                        a[e] = f2bf(fa * c[e] - fb * sn[e]);
-                        b[e] = f2bf(fb * c[e] + fa * sn[e]);
-                    }
-                    qf[ks] = a;
-                    qf[ks + NKS / 2] = b;
-                }
-            }
         }
         const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.K + head * HD), 0, (int)k_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.VT + (long)head * p.vt_head_stride), 0, (int)v_bytes, 0x00020000);
@@ -270,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         float c = p.scale_log2e;
         if constexpr (QS) {
             // the two lanes of a row (hi = 0 / 1) add one half of its partial sums each; the loads of a half are independent
-            const int half = p.q_ss_n >> 1;
+            const int half = p.q_ss_ld >> 1;
             const float* sp = p.q_ss + (long)min(q0 + l31, p.Nq - 1) * p.q_ss_ld + hi * half;
             float ss = 0.f;
 #pragma unroll 8
@@ -679,10 +657,7 @@ long attn_sk_workspace_bytes(int head_dim) {
     return 4096 + 1024L * slot;            // the flags (one 4-KiB page, zero before first use) + up to 1024 workgroup slots
 }
 
-int attn_launch(const AttnParams& p_in, hipStream_t stream) {
-    AttnParams pn = p_in;
-    if (pn.q_ss && pn.q_ss_n == 0) pn.q_ss_n = pn.q_ss_ld;
-    const AttnParams& p = pn;
+int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.Nq > 0 && p.Nkv > 0 && p.H > 0, "attention: empty problem");
     LTX2_CHECK_ARG(p.head_dim == 0 || p.head_dim == 128 || p.head_dim == 64, "attention: head_dim=%d, only 128 and 64 are implemented", p.head_dim);
     LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
@@ -703,12 +678,8 @@ int attn_launch(const AttnParams& p_in, hipStream_t stream) {
     // workgroup never waits on an unfinished one.
     bool xcd = false;
     if (p.q_ss)
-        LTX2_CHECK_ARG(p.head_dim != 64 && p.q_ss_ld >= p.q_ss_n && p.q_ss_n > 0 && p.q_ss_n % 8 == 0 && p.q_ss_ld % 4 == 0 && p.q_norm_dim > 0,
-                       "attention: the per-row scale form needs head_dim 128 and a multiple of 8 partial sums per row");
-    if (p.q_w)
-        LTX2_CHECK_ARG(p.q_ss && !p.kmask && (p.q_rope.ct || (p.q_rope.cosb && p.q_rope.sinb)) && p.q_rope.half == p.H * 64,
-                       "attention: the QR form (q_norm weight + RoPE in the prologue) needs q_ss, RoPE tables of H * 64 slots and no key mask");
-    const int workers = (p.sk_ws && !p.kmask && !p.q_w) ? sk_workers(p, &xcd) : 0;
+        LTX2_CHECK_ARG(p.head_dim != 64 && p.q_ss_ld > 0 && p.q_ss_ld % 8 == 0 && p.q_norm_dim > 0, "attention: the per-row scale form needs head_dim 128 and q_ss_ld %% 8 == 0");
+    const int workers = (p.sk_ws && !p.kmask) ? sk_workers(p, &xcd) : 0;
     if (workers > 0) {
         LTX2_CHECK_ARG(workers < 1024 && p.sk_ws_bytes >= attn_sk_workspace_bytes(p.head_dim), "attention: stream-K workspace too small");
         AttnParams q = p;
@@ -744,28 +715,6 @@ int attn_launch(const AttnParams& p_in, hipStream_t stream) {
         LTX2_CHECK_LAUNCH("attn_fwd_kernel<KM>");
         return LTX2_OK;
     }
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 2 * prop.multiProcessorCount : 512;
-    }
-    // a grid whose last (or only) round leaves SIMDs with ONE wave of this kernel takes the PVX form (see the kernel's template comment)
-    const long units = (long)grid.x * grid.y, rem = units % slots;
-    const bool lone = units < slots || (rem != 0 && rem * 10 < (long)slots * 9);
-    if (p.q_w) {        // self-attention on raw projection rows: weight + rotation in the prologue, the row factor as its softmax scale
-        static PerDeviceOnce qr_once;
-        if (qr_once.first()) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BYTES);
-        }
-        if (lone)
-            hipLaunchKernelGGL((attn_fwd_kernel<128, false, true, false, true, true>), grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
-        else
-            hipLaunchKernelGGL((attn_fwd_kernel<128, false, true, false, false, true>), grid, dim3(256), Geo<128>::LDS_BYTES, stream, p);
-        LTX2_CHECK_LAUNCH("attn_fwd_kernel<QR>");
-        return LTX2_OK;
-    }
     if (p.q_ss) {
         static PerDeviceOnce qs_once;
         if (qs_once.first())
@@ -774,6 +723,15 @@ int attn_launch(const AttnParams& p_in, hipStream_t stream) {
         LTX2_CHECK_LAUNCH("attn_fwd_kernel<QS>");
         return LTX2_OK;
     }
+    // a grid whose last (or only) round leaves SIMDs with ONE wave of this kernel takes the PVX form (see the kernel's template comment)
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 2 * prop.multiProcessorCount : 512;
+    }
+    const long units = (long)grid.x * grid.y, rem = units % slots;
+    const bool lone = units < slots || (rem != 0 && rem * 10 < (long)slots * 9);
     if (lone) {
         static PerDeviceOnce px_once;
         if (px_once.first()) {

@@ -199,38 +199,6 @@ int ltx2_gemm_qkv_vt(const void* A, int64_t lda, const void* W, const float* bia
     return vt_transpose_launch((const bf16*)out + vt_col0, ldo, (bf16*)vt, M, Npad, (N - vt_col0) / head_dim, (hipStream_t)stream, head_dim);
 }
 
-int ltx2_gemm_qkv_vt_rowss(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K,
-                           void* vt, int vt_col0, int Npad, int head_dim, float* rowss, int* fused, void* stream) {
-    LTX2_CHECK_ARG(A && W && out && vt && rowss && fused, "gemm_qkv_vt_rowss: null operand");
-    LTX2_CHECK_ARG(head_dim == 64 || head_dim == 128, "gemm_qkv_vt_rowss: head_dim=%d, only 128 and 64 are implemented", head_dim);
-    LTX2_CHECK_ARG(vt_col0 > 0 && vt_col0 < N && (N - vt_col0) % head_dim == 0 && Npad % 64 == 0 && Npad >= M, "gemm_qkv_vt_rowss: bad V column range / Npad");
-    GemmParams p{};
-    p.A = (const bf16*)A;
-    p.lda = lda;
-    p.W = (const bf16*)W;
-    p.bias = bias;
-    p.out = out;
-    p.ldo = ldo;
-    p.M = M;
-    p.N = N;
-    p.K = K;
-    p.vt = (bf16*)vt;
-    p.vt_col0 = vt_col0;
-    p.vt_npad = Npad;
-    p.vt_hd = head_dim;
-    p.vt_head_stride = (long)head_dim * Npad;
-    const bool f = gemm_vt_fused(p, EPI_BF16) && gemm_rowss_supported(p, EPI_BF16);
-    *fused = f ? 1 : 0;
-    if (!f) {           // not a shape of the 4-wave kernel: plain projection + transpose pass, no partial sums (the caller normalises with ltx2_qknorm_rope)
-        p.vt = nullptr;
-        const int rc = gemm_launch(p, EPI_BF16, false, (hipStream_t)stream);
-        if (rc != LTX2_OK) return rc;
-        return vt_transpose_launch((const bf16*)out + vt_col0, ldo, (bf16*)vt, M, Npad, (N - vt_col0) / head_dim, (hipStream_t)stream, head_dim);
-    }
-    p.rowss = rowss;
-    return gemm_launch(p, EPI_BF16, false, (hipStream_t)stream);
-}
-
 int ltx2_gemm_fp8_qkv_vt(const void* A8, int64_t lda, const float* ascale, const void* W8, const float* wscale, const float* bias, void* out,
                          int64_t ldo, int M, int N, int K, void* vt, int vt_col0, int Npad, int head_dim, int* fused, void* stream) {
     LTX2_CHECK_ARG(A8 && ascale && W8 && wscale && out && vt, "gemm_fp8_qkv_vt: null operand");
@@ -310,74 +278,6 @@ int ltx2_qknorm_rope(void* buf, int64_t ld, int rows, int D, int head_dim, int q
     const float* wts[2] = {q_weight, k_weight};
     return qknorm_rope_launch((bf16*)buf, ld, rows, D, head_dim, k_weight ? 2 : 1, offs, wts, eps, cos, sin,
                               (hipStream_t)stream);
-}
-
-static RopeTab make_rope_tab(const float* cosb, const float* sinb, const float* ct, const int* idx, int half, int pad, int N) {
-    RopeTab t{};
-    t.cosb = cosb;
-    t.sinb = sinb;
-    t.ct = (const f32x2*)ct;
-    t.idx = idx;
-    t.half = half;
-    t.pad = pad;
-    t.N = N;
-    return t;
-}
-
-int ltx2_rownorm_ss_rope(void* buf, int64_t ld, int rows, int D, int head_dim, int q_off, const float* q_weight, int k_off, const float* k_weight,
-                         const float* ss, int ss_ld, int ss_n, float eps, const float* rope_cos, const float* rope_sin, const float* rope_cta,
-                         const int* rope_idx, int rope_u, void* stream) {
-    LTX2_CHECK_ARG(buf && q_weight && ss, "rownorm_ss_rope: null operand");
-    LTX2_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr) && (rope_cta == nullptr) == (rope_idx == nullptr), "rownorm_ss_rope: RoPE tables come in pairs");
-    const bool rope = rope_cos || rope_cta;
-    RopeTab t = make_rope_tab(rope_cos, rope_sin, nullptr, rope_idx, D / 2, (D / 2) % 3, rows);
-    t.cta = (const f32x2*)rope_cta;
-    t.U = rope_u;
-    t.n_freq = D / 6;
-    const int offs[2] = {q_off, k_off};
-    const float* wts[2] = {q_weight, k_weight};
-    return rownorm_ss_rope_launch((bf16*)buf, ld, rows, D, head_dim, k_weight ? 2 : 1, offs, wts, ss, ss_ld, ss_n, eps, rope ? &t : nullptr, (hipStream_t)stream);
-}
-
-int ltx2_rope_compact_axis_major(const float* cos_c, const float* sin_c, float* cta, int n_coords, int half, void* stream) {
-    LTX2_CHECK_ARG(cos_c && sin_c && cta && n_coords > 0 && half >= 3, "rope_compact_axis_major: bad argument");
-    return rope_axis_major_launch(cos_c, sin_c, cta, n_coords, half, half / 3, (hipStream_t)stream);
-}
-
-int ltx2_rope_compact_pack(const float* cos_c, const float* sin_c, float* ct, int64_t n, void* stream) {
-    LTX2_CHECK_ARG(cos_c && sin_c && ct && n > 0, "rope_compact_pack: null operand");
-    return rope_interleave_launch(cos_c, sin_c, ct, (long)n, (hipStream_t)stream);
-}
-
-int ltx2_flash_attn_qfold(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
-                          int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_ss_n, int q_norm_dim, float q_eps, const float* q_weight,
-                          const float* rope_cos, const float* rope_sin, const float* rope_ct, const int* rope_idx, int rope_pad, void* stream) {
-    LTX2_CHECK_ARG(Q && K && VT && out && q_ss && q_weight, "flash_attn_qfold: null operand");
-    LTX2_CHECK_ARG(head_dim == 128, "flash_attn_qfold: head_dim=%d, only 128 is implemented", head_dim);
-    LTX2_CHECK_ARG((rope_cos && rope_sin) || (rope_ct && rope_idx), "flash_attn_qfold: RoPE tables (full cos / sin, or the compact ct / idx pair) are required");
-    AttnParams a{};
-    a.Q = (const bf16*)Q;
-    a.ldq = ldq;
-    a.K = (const bf16*)K;
-    a.ldk = ldk;
-    a.VT = (const bf16*)VT;
-    a.vt_head_stride = (long)head_dim * Npad;
-    a.head_dim = head_dim;
-    a.O = (bf16*)out;
-    a.ldo = ldo;
-    a.Nq = Nq;
-    a.Nkv = Nkv;
-    a.Npad = Npad;
-    a.H = H;
-    a.scale_log2e = scale * 1.4426950408889634f;
-    a.q_ss = q_ss;
-    a.q_ss_ld = q_ss_ld;
-    a.q_ss_n = q_ss_n;
-    a.q_norm_dim = q_norm_dim;
-    a.q_eps = q_eps;
-    a.q_w = q_weight;
-    a.q_rope = make_rope_tab(rope_cos, rope_sin, rope_ct, rope_idx, H * head_dim / 2, rope_pad, Nq);
-    return attn_launch(a, (hipStream_t)stream);
 }
 
 int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, int H, int head_dim, void* stream) {

@@ -21,7 +21,6 @@
 #include "../../include/ltx2hip.h"
 #include "attention.h"
 #include "gemm.h"
-#include "rope.h"
 #include "rowops.h"
 
 #define TRY(expr)                       \
@@ -82,22 +81,11 @@ struct Mod {        // per-modality geometry + workspace
     float* qss = nullptr;           // text cross-attention with q_norm folded in: partial row sums of squares of the projected queries [N][D/64]
     float* knq = nullptr;           //   and k_norm.weight * q_norm.weight per layer [L][D] (the per-dim q weight moves onto the cached keys)
     bool qfold = false;             //   decided per prepare: the query projection runs on a kernel that writes the partial sums
-    // self-attention with QK-norm + RoPE folded around the projection (round 4): the QKV GEMM's epilogue leaves the partial sums of squares of its Q / K
-    // rows (qkss [N][3 D / 64]); the K third is normalised + rotated in place by one pass, the Q third is weighted + rotated in the attention prologue
-    // and its RMS factor becomes the row's softmax scale.  Decided per prepare (qkfold); the RoPE tables in compact form when the caller supplied them.
-    float* qkss = nullptr;
-    bool qkfold = false;
-    int* rope_idx = nullptr;        // compact RoPE (rope.h): [3][N] coordinate numbers, rope_ct [ROPE_U_MAX][D / 2] (cos, sin)
-    float* rope_ct = nullptr;
-    float* rope_cta = nullptr;      // the same entries axis-major [3][ROPE_U_MAX][n_freq] (cos, sin): the row pass stages a token's three runs through LDS
-    int rope_u = 0;
-    bool rope_compact = false;
     unsigned char* a8 = nullptr;    // fp8 compute: per-token e4m3fn codes of the current GEMM's activation operand [N][<= 4D]
     float* a8s = nullptr;           //              and their row scales [N]
 };
 
 inline long align_up(long v, long a = 256) { return (v + a - 1) / a * a; }
-constexpr int ROPE_U_MAX = 64;      // distinct coordinates per position axis the compact RoPE table holds (a 768x512x65 latent has 9 / 16 / 24)
 }  // namespace
 
 struct ltx2_dit {
@@ -116,8 +104,6 @@ struct ltx2_dit {
     // up here to hand the GEMM (codes, per-row scale) instead of bf16 weights.  Per context (a second context over the same tensors
     // -- the video twin of an AudioVideo model -- keeps its own entries); rebuilt whenever the weights are resolved again.
     std::unordered_map<const void*, const float*> fp8_scale;
-    bool no_qkfold = false;            // ltx2_dit_set_option("qk_fold", 0)
-    int qkfold_mode = 1;               //   1: one pass over Q and K on the GEMM's partial sums; 2: K pass + Q in the attention prologue
     bool fp8_compute = false;          // ltx2_dit_set_option("fp8_compute"): fp8-resident weights x per-token fp8 activations on the fp8 MFMA
     void* sk_ws = nullptr;             // stream-K attention scratch (attention.h); main-stream launches only
     long sk_bytes = 0;
@@ -168,10 +154,6 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         m.kmask = (unsigned long long*)take(8L * (spad / 64));
         m.qss = (float*)take(4L * n * (D / 64));
         m.knq = (float*)take(4L * L * D);
-        m.qkss = (float*)take(k == 0 ? 4L * n * (3 * D / 64) : 0);
-        m.rope_idx = (int*)take(k == 0 ? 4L * 3 * n : 0);
-        m.rope_ct = (float*)take(k == 0 ? 8L * ROPE_U_MAX * (D / 2) : 0);
-        m.rope_cta = (float*)take(k == 0 ? 8L * 3 * ROPE_U_MAX * (D / 6) : 0);
         m.a8 = (unsigned char*)take((c->fp8_compute && k == 0) ? n * 4 * D : 0);
         m.a8s = (float*)take((c->fp8_compute && k == 0) ? 4L * n : 0);
         m.sin_f = (float*)take(4L * 256);
@@ -393,55 +375,6 @@ bool text_qfold_ok(ltx2_dit* c, int k) {
     return gemm_rowss_supported(q, EPI_BF16);
 }
 
-// the video modality's self-attention with QK-norm + RoPE folded around the QKV projection (see Mod::qkss): head_dim 128, D / 64 <= 64 partial sums per
-// row and third, and the projection on a kernel that writes V^T AND the partial sums from its epilogue
-bool self_qkfold_ok(ltx2_dit* c, int k) {
-    const Mod& m = c->m[k];
-    if (c->no_qkfold || k != 0 || !m.qkss || m.hd != 128 || m.D % 512 != 0 || m.D > 4096) return false;
-    const bf16* W = c->layers[0].m[k].self.qkv_w;
-    GemmParams q{};
-    q.M = m.N;
-    q.N = 3 * m.D;
-    q.K = m.D;
-    q.lda = m.D;
-    q.ldo = 3 * m.D;
-    q.out = m.qkv;
-    q.vt = m.vt;
-    q.vt_col0 = 2 * m.D;
-    q.vt_npad = m.Npad;
-    q.vt_hd = m.hd;
-    q.vt_head_stride = (long)m.hd * m.Npad;
-    if (f8_route(c, W, m.N, 3 * m.D, m.D, EPI_BF16)) {
-        q.A8 = m.a8;
-        q.ascale = m.a8s;
-    } else {
-        q.A = m.h;
-    }
-    auto f8 = c->fp8_scale.find((const void*)W);
-    if (f8 != c->fp8_scale.end()) {
-        q.W8 = (const unsigned char*)W;
-        q.wscale = f8->second;
-    } else {
-        q.W = W;
-    }
-    return gemm_rowss_supported(q, EPI_BF16);
-}
-
-RopeTab mod_rope(const Mod& m) {
-    RopeTab t{};
-    t.cosb = m.cosb;
-    t.sinb = m.sinb;
-    t.ct = m.rope_compact ? (const f32x2*)m.rope_ct : nullptr;
-    t.idx = m.rope_compact ? m.rope_idx : nullptr;
-    t.half = m.D / 2;
-    t.pad = (m.D / 2) % 3;          // D / 2 - 3 floor(D / 6): the identity slots in front (rope.py:290-296)
-    t.N = m.N;
-    t.cta = m.rope_compact ? (const f32x2*)m.rope_cta : nullptr;
-    t.U = m.rope_u;
-    t.n_freq = m.D / 6;
-    return t;
-}
-
 __global__ void vec_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] * b[i];
@@ -544,19 +477,14 @@ int adaln_chain(ltx2_dit* c, Mod& m, const AdaW& a, const float* ts, long t_stri
 // attention runs beside them on the side stream and keeps the plain grid).
 int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int npad, bf16* out, long ldo, int nq,
            int nkv, int H, int hd, hipStream_t st, ltx2_dit* sk = nullptr, const float* q_ss = nullptr, float q_eps = 0.f,
-           const unsigned long long* kmask = nullptr, int q_ss_ld = 0, const float* q_w = nullptr, const RopeTab* q_rope = nullptr) {
+           const unsigned long long* kmask = nullptr) {
     AttnParams a{};
     a.kmask = kmask;
-    if (q_ss) {         // q_norm as a per-row softmax scale from the projection's partial sums (text cross-attention; self-attention's QR form)
+    if (q_ss) {         // q_norm as a per-row softmax scale from the projection's partial sums (text cross-attention)
         a.q_ss = q_ss;
-        a.q_ss_n = H * hd / 64;
-        a.q_ss_ld = q_ss_ld ? q_ss_ld : a.q_ss_n;
+        a.q_ss_ld = H * hd / 64;
         a.q_norm_dim = H * hd;
         a.q_eps = q_eps;
-    }
-    if (q_w) {          // raw projection rows: q_norm.weight + RoPE in the attention prologue
-        a.q_w = q_w;
-        a.q_rope = *q_rope;
     }
     if (sk) {
         a.sk_ws = sk->sk_ws;
@@ -640,32 +568,14 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     TRY(gate_logits(c, m, w.self, m.h, D, N, H, st));
     const VtOut vo{m.vt, 2 * D, m.Npad, hd};
     bool vt_done = false;           // the QKV GEMM's epilogue writes V^T itself where it can (gemm_v4.hip)
-    TRY(dense(c, m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done, q1, m.qkfold ? m.qkss : nullptr));
-    if (m.qkfold) {
-        // QK-norm + RoPE folded around the projection: one pass over the K third only; Q stays as projected (attention prologue + row scale)
-        if (!vt_done) {
-            ltx2_set_error("dit: the folded QK-norm path was chosen but the QKV projection did not write V^T");
-            return LTX2_E_STATE;
-        }
-        const RopeTab rt = mod_rope(m);
-        if (c->qkfold_mode == 2) {          // K pass + Q in the attention prologue
-            const int offs[1] = {0};
-            const float* wts[1] = {w.self.kn};
-            TRY(rownorm_ss_rope_launch(m.qkv + D, 3 * D, N, D, hd, 1, offs, wts, m.qkss + D / 64, 3 * D / 64, D / 64, eps, &rt, st));
-            TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, nullptr, m.qkss, eps, nullptr, 3 * D / 64, w.self.qn, &rt));
-        } else {                            // one pass over Q and K, no block reduction, tables from LDS
-            const int offs[2] = {0, D};
-            const float* wts[2] = {w.self.qn, w.self.kn};
-            TRY(rownorm_ss_rope_launch(m.qkv, 3 * D, N, D, hd, 2, offs, wts, m.qkss, 3 * D / 64, D / 64, eps, &rt, st));
-            TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, k == 0 ? c : nullptr));
-        }
-    } else {
+    TRY(dense(c, m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done, q1));
+    {
         const int offs[2] = {0, D};
         const float* wts[2] = {w.self.qn, w.self.kn};
         TRY(qknorm_rope_launch(m.qkv, 3 * D, N, D, hd, 2, offs, wts, eps, m.cosb, m.sinb, st));
-        if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
-        TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, k == 0 ? c : nullptr));
     }
+    if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
+    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, k == 0 ? c : nullptr));
     TRY(gate_apply(c, m, m.att, N, H, hd, st));
     TRY(dense(c, m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 2 * D, es, w.sst + 2 * D));
 
@@ -874,8 +784,6 @@ int prepare_modality(ltx2_dit* c, int k, const float* context, int S, const floa
         m.ctx = m.ctxp;
     }
     m.qfold = text_qfold_ok(c, k);
-    m.qkfold = self_qkfold_ok(c, k);
-    m.rope_compact = false;         // (ltx2_dit_set_rope_compact, after prepare)
     if (m.qfold)
         for (int l = 0; l < c->cfg.num_layers; ++l) {
             const AttnW& tw = c->layers[l].m[k].text;
@@ -1205,36 +1113,8 @@ int ltx2_dit_set_context_mask(ltx2_dit* c, int modality, const float* mask, int 
     return LTX2_OK;
 }
 
-int ltx2_dit_set_rope_compact(ltx2_dit* c, int modality, const int* idx, const float* cos_c, const float* sin_c, int n_dims, int n_coords, void* stream) {
-    LTX2_CHECK_ARG(c && idx && cos_c && sin_c, "dit_set_rope_compact: null argument");
-    LTX2_CHECK_ARG(modality == 0, "dit_set_rope_compact: only the video modality's self-attention reads the compact table");
-    Mod& m = c->m[modality];
-    if (!c->prepared || !m.rope_ct) {
-        ltx2_set_error("dit_set_rope_compact: call ltx2_dit_prepare first (the table lives in the bound workspace and belongs to that prompt's positions)");
-        return LTX2_E_STATE;
-    }
-    LTX2_CHECK_ARG(n_dims == 3 && n_coords >= 1 && n_coords <= ROPE_U_MAX, "dit_set_rope_compact: 3 position axes with at most %d distinct coordinates each (got %d axes, %d)",
-                   ROPE_U_MAX, n_dims, n_coords);
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemcpyAsync(m.rope_idx, idx, 4L * 3 * m.N, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-        ltx2_set_error("dit_set_rope_compact: index copy failed");
-        return LTX2_E_HIP;
-    }
-    TRY(rope_interleave_launch(cos_c, sin_c, m.rope_ct, (long)n_coords * (m.D / 2), st));
-    TRY(rope_axis_major_launch(cos_c, sin_c, m.rope_cta, n_coords, m.D / 2, m.D / 6, st));
-    m.rope_u = n_coords;
-    m.rope_compact = true;
-    return LTX2_OK;
-}
-
 int ltx2_dit_set_option(ltx2_dit* c, const char* name, int value) {
     LTX2_CHECK_ARG(c && name, "dit_set_option: null argument");
-    if (!strcmp(name, "qk_fold")) {         // 0: keep the QK-norm + RoPE pass between the QKV projection and the self-attention (A/B runs, tests)
-        c->no_qkfold = value == 0;
-        c->qkfold_mode = value;
-        c->prepared = false;
-        return LTX2_OK;
-    }
     if (!strcmp(name, "fp8_compute")) {
         if (c->ws && (value != 0) != c->fp8_compute) {
             ltx2_set_error("dit_set_option: fp8_compute must be set before the workspace is bound");

@@ -42,8 +42,7 @@ struct GemmParams {
     int vt_col0, vt_npad, vt_hd;
     // gemm_v4.hip, EPI_BF16, dense, layouts 3 / 5: rowss[m * (N / 64) + n / 64] = sum over the 64-column strip of out[m][n]^2 (of the
     // ROUNDED outputs): the partial sums of a row's squared norm, for a consumer that folds an RMS normalisation of `out` into its own
-    // arithmetic (text cross-attention: q_norm as a per-row softmax scale).  null = off.  gemm_rowss_supported() says when.  Together with a fused
-    // V^T output (vt): the strips of the columns < vt_col0 only (self-attention: the Q and K thirds; round 4).
+    // arithmetic (text cross-attention: q_norm as a per-row softmax scale).  null = off.  gemm_rowss_supported() says when.
     float* rowss;
     int splitk;          // gemm_v4.hip: K split over this many blocks per tile (fp32 slabs + reduce); 0 / 1 = off
     void* dbg;           // ping-pong kernel: optional device buffer for interval timestamps (debug)      // ping-pong kernel: which wave bit selects the staggered group (tuning knob)

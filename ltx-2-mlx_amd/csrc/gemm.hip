@@ -332,8 +332,7 @@ bool gemm_vt_fused(const GemmParams& p, int epilogue) {
 }
 
 bool gemm_rowss_supported(const GemmParams& p, int epilogue) {
-    if (epilogue != EPI_BF16 || p.N % 64 != 0) return false;
-    if (p.vt) return gemm_vt_fused(p, epilogue);        // fused QKV projection: the Q / K tiles write the partial sums, the V tiles V^T (no sums for columns >= vt_col0)
+    if (epilogue != EPI_BF16 || p.vt || p.N % 64 != 0) return false;
     const int r = route_of<false>(p, epilogue);
     return r == ROUTE_V4_224 || r == ROUTE_V4_256 || r == ROUTE_V4_W8_224 || r == ROUTE_V4_W8_256 || r == ROUTE_V4_F8_224 || r == ROUTE_V4_F8_256;
 }

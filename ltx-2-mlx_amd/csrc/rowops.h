@@ -19,17 +19,6 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
 int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off,
                        const float* const* weights, float eps, const float* cos, const float* sin, hipStream_t stream);
 
-// qknorm_rope_launch for segments whose squared row norms were left as partial sums by the producing GEMM (GemmParams::rowss): segment g of row r is
-// scaled by rsqrt(sum_{j < ss_n} ss[r * ss_ld + g * ss_n + j] / D + eps) * weight_g, then (tab != null) rotated; the tables in any form of rope.h
-// (the axis-major compact form is staged through LDS: no HBM traffic for the tables).
-struct RopeTab;
-int rownorm_ss_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off, const float* const* weights, const float* ss,
-                           int ss_ld, int ss_n, float eps, const RopeTab* tab, hipStream_t stream);
-// cta[(d * U + u) * n_freq + f] = (cos_c, sin_c)[u][pad + 3 f + d]: the axis-major compact table of rope.h from the U x half rows of ltx2_rope_tables
-int rope_axis_major_launch(const float* cos_c, const float* sin_c, float* cta, int U, int half, int n_freq, hipStream_t stream);
-// ct[i] = (cos[i], sin[i]): the interleaved compact table of rope.h
-int rope_interleave_launch(const float* cosb, const float* sinb, float* ct, long n, hipStream_t stream);
-
 // out_bf16[row][d] = ctx_bf16[row][d] * (1 + scale_tab[d] + scale_emb[d]) + shift_tab[d] + shift_emb[d]
 // (V2.3 prompt modulation of the text context, transformer.py:441-451)
 int ctx_mod_launch(const bf16* ctx, bf16* out, int rows, int D, const float* scale_tab, const float* shift_tab,

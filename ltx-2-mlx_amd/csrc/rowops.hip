@@ -12,7 +12,6 @@
 //   x0 / euler        model.py:912-918; components/diffusion_steps.py:36-67; pipelines/common.py:169-190
 //   vae_*             video_vae/simple_decoder.py:339-342,228-238,492-498,528-553; ops.py:109-125
 #include "rowops.h"
-#include "rope.h"
 
 namespace {
 
@@ -253,117 +252,6 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16* __restrict__ buf
             *(bf16x8*)(xr + ib) = ob;
         }
     }
-}
-
-// QK-norm + RoPE of the self-attention when the projection GEMM's epilogue already left the partial sums of squares of its (rounded) output
-// rows (round 4; GemmParams::rowss): for each of NSEG segments (q, k) x <- rope(x * rsqrt(sum / D + eps) * w), in place -- qknorm_rope_kernel
-// without its block reduction (every wave adds the row's <= 64 partials itself) and, with the axis-major compact table of rope.h, without the
-// 57 MB of fp32 cos / sin rows per call: the token's three runs of n_freq (cos, sin) entries (16 KB, L2-resident) are loaded coalesced into
-// LDS and read back in slot order.  One block per row, thread t owns pairs [8t, 8t + 8) as qknorm_rope_kernel does.
-template <int NSEG>
-__global__ __launch_bounds__(256) void rownorm_ss_rope_kernel(bf16* __restrict__ buf, long ld, int rows, int D, int head_dim, QKSegs segs,
-                                                              const float* __restrict__ ss, int ss_ld, int ss_n, float eps, RopeTab tab,
-                                                              int with_rope) {
-    extern __shared__ __attribute__((aligned(16))) char smem_rs[];
-    f32x2* lt = (f32x2*)smem_rs;                // [3 * n_freq] this row's (cos, sin), axis-major
-    const int half = head_dim >> 1;
-    const int p0 = threadIdx.x * 8, lane = threadIdx.x & 63;
-    const bool act = p0 < D / 2;
-    const int ia = act ? (p0 / half) * head_dim + (p0 % half) : 0;
-    const int ib = ia + half;
-    float wa[NSEG][8], wb[NSEG][8];
-#pragma unroll
-    for (int g = 0; g < NSEG; ++g) {
-        const float* wt = segs.w[g];
-        const f32x4 a0 = *(const f32x4*)(wt + ia), a1 = *(const f32x4*)(wt + ia + 4);
-        const f32x4 b0 = *(const f32x4*)(wt + ib), b1 = *(const f32x4*)(wt + ib + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            wa[g][e] = a0[e];
-            wa[g][4 + e] = a1[e];
-            wb[g][e] = b0[e];
-            wb[g][4 + e] = b1[e];
-        }
-    }
-    const bool staged = with_rope && tab.cta;
-    const int nf = tab.n_freq, ntab = 3 * nf;
-    // slot p0 + e -> LDS entry: j = slot - pad, axis j % 3, frequency j / 3 (slots < pad are the identity)
-    int lofs[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int j = p0 + e - tab.pad;
-        lofs[e] = j < 0 ? -1 : (j % 3) * nf + j / 3;
-    }
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        bf16x8 va[NSEG], vb[NSEG];
-        float part[NSEG];
-#pragma unroll
-        for (int g = 0; g < NSEG; ++g) {
-            bf16* xr = buf + row * ld + segs.off[g];
-            if (act) {
-                va[g] = *(const bf16x8*)(xr + ia);
-                vb[g] = *(const bf16x8*)(xr + ib);
-            }
-            part[g] = lane < ss_n ? ss[row * ss_ld + g * ss_n + lane] : 0.f;
-        }
-        float c[8], sn[8];
-        if (staged) {
-            const int i0 = tab.idx[row], i1 = tab.idx[tab.N + row], i2 = tab.idx[2 * tab.N + row];
-            if (row != (long)blockIdx.x) __syncthreads();          // the previous row's reads of lt are done
-            for (int i = threadIdx.x; i < ntab; i += 256) {
-                const int d = i >= 2 * nf ? 2 : i >= nf ? 1 : 0;
-                const int u = d == 0 ? i0 : d == 1 ? i1 : i2;
-                lt[i] = tab.cta[((long)d * tab.U + u) * nf + (i - d * nf)];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const f32x2 v = lofs[e] < 0 ? f32x2{1.f, 0.f} : lt[lofs[e]];
-                c[e] = v[0];
-                sn[e] = v[1];
-            }
-        } else if (act && with_rope) {
-            rope_cs8(tab, (int)row, p0, c, sn);
-        }
-        if (!act) continue;
-#pragma unroll
-        for (int g = 0; g < NSEG; ++g) {
-            bf16* xr = buf + row * ld + segs.off[g];
-            const float rstd = rsqrtf(wave_sum(part[g]) / (float)D + eps);
-            bf16x8 oa, ob;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = bf2f(va[g][e]) * rstd * wa[g][e];
-                const float b = bf2f(vb[g][e]) * rstd * wb[g][e];
-                if (with_rope) {
-                    oa[e] = f2bf(a * c[e] - b * sn[e]);
-                    ob[e] = f2bf(b * c[e] + a * sn[e]);
-                } else {
-                    oa[e] = f2bf(a);
-                    ob[e] = f2bf(b);
-                }
-            }
-            *(bf16x8*)(xr + ia) = oa;
-            *(bf16x8*)(xr + ib) = ob;
-        }
-    }
-}
-
-// axis-major compact RoPE table (rope.h): cta[(d * U + u) * n_freq + f] = (cos_c, sin_c)[u][pad + 3 f + d]
-__global__ void rope_axis_major_kernel(const float* __restrict__ cosb, const float* __restrict__ sinb, f32x2* __restrict__ cta, int U, int half,
-                                       int n_freq) {
-    const long n = 3L * U * n_freq;
-    const int pad = half - 3 * n_freq;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int f = (int)(i % n_freq), u = (int)((i / n_freq) % U), d = (int)(i / ((long)n_freq * U));
-        const long src = (long)u * half + pad + 3 * f + d;
-        cta[i] = f32x2{cosb[src], sinb[src]};
-    }
-}
-
-// compact RoPE tables (rope.h): ct[u][slot] = (cos[u][slot], sin[u][slot])
-__global__ void rope_interleave_kernel(const float* __restrict__ cosb, const float* __restrict__ sinb, f32x2* __restrict__ ct, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ct[i] = f32x2{cosb[i], sinb[i]};
 }
 
 __global__ void ctx_mod_kernel(const bf16* __restrict__ ctx, bf16* __restrict__ out, long n4, int D,
@@ -1010,42 +898,6 @@ int latent_normalize_nchw_launch(const bf16* x, const float* mean, const float* 
     LTX2_CHECK_ARG(x && mean && stdv && out && C > 0 && P > 0, "latent_normalize: bad argument");
     hipLaunchKernelGGL(latent_normalize_nchw_kernel, dim3((int)((P + 63) / 64), (C + 63) / 64), dim3(256), 0, stream, x, mean, stdv, out, C, P);
     LTX2_CHECK_LAUNCH("latent_normalize_nchw_kernel");
-    return LTX2_OK;
-}
-
-int rownorm_ss_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int nseg, const int* seg_off, const float* const* weights, const float* ss,
-                           int ss_ld, int ss_n, float eps, const RopeTab* tab, hipStream_t stream) {
-    LTX2_CHECK_ARG(buf && weights && ss && rows > 0 && (nseg == 1 || nseg == 2), "rownorm_ss_rope: null operand / nseg must be 1 or 2");
-    LTX2_CHECK_ARG(head_dim % 16 == 0 && D % head_dim == 0 && ld % 8 == 0 && D <= 4096, "rownorm_ss_rope: head_dim %% 16, D %% head_dim, ld %% 8, D <= 4096");
-    LTX2_CHECK_ARG(ss_n >= 1 && ss_n <= 64 && ss_ld >= nseg * ss_n, "rownorm_ss_rope: 1..64 partial sums per row and segment (got %d)", ss_n);
-    LTX2_CHECK_ARG(!tab || tab->half == D / 2, "rownorm_ss_rope: table width %d != D / 2", tab ? tab->half : 0);
-    QKSegs s{};
-    for (int i = 0; i < nseg; ++i) {
-        LTX2_CHECK_ARG(seg_off[i] % 8 == 0 && weights[i], "rownorm_ss_rope: bad segment");
-        s.off[i] = seg_off[i];
-        s.w[i] = weights[i];
-    }
-    RopeTab t{};
-    if (tab) t = *tab;
-    const int lds = (tab && t.cta) ? 3 * t.n_freq * 8 : 0;
-    LTX2_CHECK_ARG(lds <= 48 * 1024 && (!t.cta || t.pad == t.half - 3 * t.n_freq), "rownorm_ss_rope: compact table geometry");
-    if (nseg == 2)
-        hipLaunchKernelGGL((rownorm_ss_rope_kernel<2>), dim3(rows), dim3(256), lds, stream, buf, ld, rows, D, head_dim, s, ss, ss_ld, ss_n, eps, t, tab ? 1 : 0);
-    else
-        hipLaunchKernelGGL((rownorm_ss_rope_kernel<1>), dim3(rows), dim3(256), lds, stream, buf, ld, rows, D, head_dim, s, ss, ss_ld, ss_n, eps, t, tab ? 1 : 0);
-    LTX2_CHECK_LAUNCH("rownorm_ss_rope_kernel");
-    return LTX2_OK;
-}
-
-int rope_axis_major_launch(const float* cosb, const float* sinb, float* cta, int U, int half, int n_freq, hipStream_t stream) {
-    hipLaunchKernelGGL(rope_axis_major_kernel, dim3(grid_for(3L * U * n_freq, 256, 2048)), dim3(256), 0, stream, cosb, sinb, (f32x2*)cta, U, half, n_freq);
-    LTX2_CHECK_LAUNCH("rope_axis_major_kernel");
-    return LTX2_OK;
-}
-
-int rope_interleave_launch(const float* cosb, const float* sinb, float* ct, long n, hipStream_t stream) {
-    hipLaunchKernelGGL(rope_interleave_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, stream, cosb, sinb, (f32x2*)ct, n);
-    LTX2_CHECK_LAUNCH("rope_interleave_kernel");
     return LTX2_OK;
 }
 

@@ -69,64 +69,6 @@ def gemm_qkv_vt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     return out, vt, bool(fused.value)
 
 
-def gemm_qkv_vt_rowss(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], heads: int, head_dim: int = 128):
-    """gemm_qkv_vt that also returns the partial sums of squares of the rounded Q / K rows over 64-column strips:
-    (qkv, vt, rowss [M, 3D/64] fp32 -- strips of the V third unwritten --, fused); fused False: plain projection + transpose, rowss None."""
-    assert a.dtype in ACT16 and w.dtype == a.dtype
-    a, w = _c(a), _c(w)
-    M, K = a.shape
-    N = w.shape[0]
-    D = heads * head_dim
-    assert N == 3 * D
-    npad = (M + 63) // 64 * 64
-    out = torch.empty(M, N, device=a.device, dtype=a.dtype)
-    vt = torch.empty(heads, head_dim, npad, device=a.device, dtype=a.dtype)
-    rowss = torch.zeros(M, N // 64, device=a.device, dtype=torch.float32)
-    import ctypes
-    fused = ctypes.c_int(0)
-    nv.check(_L(a).ltx2_gemm_qkv_vt_rowss(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K,
-                                            nv.ptr(vt), 2 * D, npad, head_dim, nv.ptr(rowss), ctypes.byref(fused), nv.stream()))
-    return out, vt, (rowss if fused.value else None), bool(fused.value)
-
-
-def rownorm_ss_rope_(buf: torch.Tensor, D: int, head_dim: int, q_off: int, q_weight: torch.Tensor, ss: torch.Tensor, ss_n: int,
-                     k_off: int = 0, k_weight: Optional[torch.Tensor] = None, eps: float = 1e-6,
-                     cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None, compact=None) -> torch.Tensor:
-    """qknorm_rope_ on partial sums: in place on buf [rows, ld], segment g (q at q_off, k at k_off when k_weight is given) of row r becomes
-    x * rsqrt(sum(ss[r, g * ss_n: (g + 1) * ss_n]) / D + eps) * weight_g, then SPLIT RoPE from the full tables (cos, sin) or the axis-major
-    compact pair compact = (cta, idx, U) (rope_compact_axis_major)."""
-    assert buf.dtype in ACT16 and buf.dim() == 2 and buf.stride(1) == 1 and ss.dtype == torch.float32 and ss.stride(1) == 1
-    cta, idx, u = compact if compact is not None else (None, None, 0)
-    nv.check(_L(buf).ltx2_rownorm_ss_rope(nv.ptr(buf), buf.stride(0), buf.shape[0], D, head_dim, q_off, nv.ptr(q_weight), k_off, nv.ptr(k_weight),
-                                           nv.ptr(ss), ss.stride(0), ss_n, eps, nv.ptr(cos), nv.ptr(sin), nv.ptr(cta), nv.ptr(idx), u, nv.stream()))
-    return buf
-
-
-def rope_compact_axis_major(cos_c: torch.Tensor, sin_c: torch.Tensor) -> torch.Tensor:
-    """[3, U, half // 3, 2] fp32: the compact rows of rope_compact() regrouped by position axis (a token's table = three contiguous runs)."""
-    u, half = cos_c.shape
-    cta = torch.empty(3, u, half // 3, 2, device=cos_c.device, dtype=torch.float32)
-    nv.check(nv.lib().ltx2_rope_compact_axis_major(nv.ptr(_c(cos_c)), nv.ptr(_c(sin_c)), nv.ptr(cta), u, half, nv.stream()))
-    return cta
-
-
-def flash_attn_qfold(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, q_ss: torch.Tensor, q_ss_n: int, q_weight: torch.Tensor,
-                     eps: float = 1e-6, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None, compact=None,
-                     scale: Optional[float] = None) -> torch.Tensor:
-    """Self-attention on RAW projected q rows: q_norm.weight + SPLIT RoPE in the kernel's prologue, the RMS factor of row i (from the leading
-    q_ss_n partial sums of q_ss[i]) as its softmax scale; k already normalised + rotated (rownorm_ss_rope_)."""
-    assert q.dtype in ACT16 and q_ss.dtype == torch.float32 and q_ss.stride(1) == 1 and q.stride(1) == 1 and k.stride(1) == 1
-    nq, hd = q.shape[0], vt.shape[1]
-    out = torch.empty(nq, heads * hd, device=q.device, dtype=q.dtype)
-    if scale is None:
-        scale = 1.0 / math.sqrt(float(hd))
-    ct, idx, pad = compact if compact is not None else (None, None, 0)
-    nv.check(_L(q).ltx2_flash_attn_qfold(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out), out.stride(0), nq, nkv,
-                                         heads, hd, scale, nv.ptr(q_ss), q_ss.stride(0), q_ss_n, heads * hd, eps, nv.ptr(q_weight),
-                                         nv.ptr(cos), nv.ptr(sin), nv.ptr(ct), nv.ptr(idx), pad, nv.stream()))
-    return out
-
-
 def gemm_rowss(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None):
     """out = a @ w^T + bias (16-bit) plus the row partial sums of squares of out over 64-column strips -> (out, rowss [M, N/64] fp32 or None
     when the shape does not run on the kernel that writes them)."""
@@ -446,42 +388,6 @@ def rope_tables(positions: torch.Tensor, dim: int, theta: float, max_pos) -> Tup
     nv.check(nv.lib().ltx2_rope_tables(nv.ptr(pos), nv.ptr(grid), nv.ptr(mp), N, n_dims, n_freq, dim // 2, nv.ptr(cos), nv.ptr(sin),
                                        nv.stream()))
     return cos, sin
-
-
-ROPE_COMPACT_MAX = 64      # distinct coordinates per axis the engine's compact table holds (dit_engine.hip ROPE_U_MAX)
-
-
-def rope_compact(positions: torch.Tensor, dim: int, theta: float, max_pos):
-    """The compact form of rope_tables() for positions on a grid (csrc/rope.h): -> (idx int32 [3, N], cos_c, sin_c fp32 [U, dim/2], U) or None
-    when the positions have more than ROPE_COMPACT_MAX distinct coordinates on an axis (or not three axes).  Row u of cos_c / sin_c is what
-    ltx2_rope_tables writes for a token whose every axis sits at its u-th distinct coordinate (mid = (start + end) / 2, the kernel's own
-    arithmetic), so a slot of axis d read at row idx[d, n] is bit-identical to the full table's entry for token n."""
-    pos = _c(positions[0].float())
-    n_dims = pos.shape[0]
-    if n_dims != 3 or n_dims != len(max_pos):
-        return None
-    mid = (pos[:, :, 0] + pos[:, :, 1]) * 0.5                              # [3, N], the table kernel's fp32 arithmetic
-    uniq, idx = [], []
-    for d in range(3):
-        u, inv = torch.unique(mid[d], return_inverse=True)
-        if u.numel() > ROPE_COMPACT_MAX:
-            return None
-        uniq.append(u)
-        idx.append(inv.to(torch.int32))
-    U = max(u.numel() for u in uniq)
-    cpos = torch.zeros(1, 3, U, 2, device=pos.device, dtype=torch.float32)
-    for d in range(3):
-        cpos[0, d, :uniq[d].numel(), 0] = uniq[d]
-        cpos[0, d, :uniq[d].numel(), 1] = uniq[d]                          # start = end = mid: (m + m) * 0.5 == m exactly
-    cos_c, sin_c = rope_tables(cpos, dim, theta, max_pos)
-    return torch.stack(idx, 0).contiguous(), cos_c, sin_c, U
-
-
-def rope_compact_pack(cos_c: torch.Tensor, sin_c: torch.Tensor) -> torch.Tensor:
-    """(cos, sin) interleaved [U, half, 2] fp32: the `ct` operand of rownorm_ss_rope_ / flash_attn_qfold."""
-    ct = torch.empty(*cos_c.shape, 2, device=cos_c.device, dtype=torch.float32)
-    nv.check(nv.lib().ltx2_rope_compact_pack(nv.ptr(_c(cos_c)), nv.ptr(_c(sin_c)), nv.ptr(ct), cos_c.numel(), nv.stream()))
-    return ct
 
 
 def timestep_sinusoid(t: torch.Tensor, mult: float, dim: int = 256) -> torch.Tensor:

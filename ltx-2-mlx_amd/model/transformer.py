@@ -180,12 +180,6 @@ class LTXModel:
                           cross_attention_adaln=cross_attention_adaln, apply_gated_attention=apply_gated_attention, device=device,
                           fp8_compute=fp8_compute, compute_dtype=compute_dtype)
 
-    def set_option(self, name: str, value: int) -> None:
-        """Engine option by name (ltx2_dit_set_option): "qk_fold" = 0 keeps the stand-alone QK-norm + RoPE pass of the video self-attention
-        (A/B timing, tests); takes effect at the next prepare()."""
-        nv.check(self._L.ltx2_dit_set_option(self._h, name.encode(), int(value)))
-        self._prep_key = None
-
     def _video_twin(self) -> "LTXModel":
         """The video half of this AudioVideo model as a VideoOnly engine: with no audio tokens the reference's blocks run only
         video self-attention, text cross-attention and the video feed-forward (transformer.py:479-483: run_ax and run_a2v are
@@ -461,7 +455,6 @@ class LTXModel:
             self._bind(n, s, per_token)
             nv.check(self._L.ltx2_dit_prepare(self._h, nv.ptr(ctx), s, nv.ptr(cos), nv.ptr(sin), nv.stream()))
             self._prep_refs = (originals, positions, cos, sin, ctx)     # keep pointers alive / unaliased
-            self._set_rope_compact(positions, theta)
         else:
             if audio_context is None or audio_positions is None:
                 raise ValueError("AudioVideo model: audio context and positions are required")
@@ -478,18 +471,7 @@ class LTXModel:
                                                   nv.ptr(actx), sa, nv.ptr(acos), nv.ptr(asin), nv.ptr(acc), nv.ptr(acs),
                                                   nv.stream()))
             self._prep_refs = (originals, positions, audio_positions, cos, sin, ctx, acos, asin, vcc, vcs, acc, acs, actx)
-            self._set_rope_compact(positions, theta)
         self._prep_key = key
-
-    def _set_rope_compact(self, positions: torch.Tensor, theta: float) -> None:
-        """Hand the engine the compact form of the video RoPE tables when the positions lie on a grid (they do for every latent the
-        pipelines build: few distinct coordinates per axis): the self-attention then reads a 0.4 MB L2-resident table instead of
-        57 MB from HBM per layer.  Same values as the full tables (kernels.rope_compact); skipped silently otherwise."""
-        rc = K.rope_compact(positions, self.inner_dim, theta, self.positional_embedding_max_pos)
-        if rc is None:
-            return
-        idx, cos_c, sin_c, u = rc
-        nv.check(self._L.ltx2_dit_set_rope_compact(self._h, 0, nv.ptr(idx), nv.ptr(cos_c), nv.ptr(sin_c), 3, u, nv.stream()))
 
     @staticmethod
     def _key(context, positions, audio_context=None, audio_positions=None):

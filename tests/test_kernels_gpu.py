@@ -772,101 +772,3 @@ def test_flash_attention_key_mask(dev, hd, H, Nq, S):
         assert rel_l2(out.double().cpu(), ref) < 6e-3, (tag, rel_l2(out.double().cpu(), ref))
     # an all-ones mask is the unmasked kernel up to the exponent's rounding
     assert rel_l2(KK.flash_attn_keymask(q, k, vt, H, S, masks["all"]).float().cpu(), KK.flash_attn(q, k, vt, H, S).float().cpu()) < 2e-3
-
-
-# ------------------------------------------------------------------------------------------ QK-norm + RoPE folded around the QKV projection (round 4)
-def _grid_positions(dev, f, h, w):
-    from oracle import loop
-    return loop.video_positions(1, f, h, w, 24.0).to(dev)
-
-
-@pytest.mark.parametrize("grid,dim", [((9, 16, 24), 4096), ((2, 3, 5), 512), ((3, 4, 4), 1024)])
-def test_rope_compact_equals_full_tables(K, dev, grid, dim):
-    """The compact RoPE form (csrc/rope.h): idx [3, N] + the cos / sin rows of the distinct coordinates reproduce the full [N, D/2] tables
-    BIT FOR BIT (slot s of token n = row idx[(s - pad) % 3, n]; the identity slots in front are the identity in every row)."""
-    pos = _grid_positions(dev, *grid)
-    cos, sin = K.rope_tables(pos, dim, 10000.0, [20, 2048, 2048])
-    idx, cos_c, sin_c, U = K.rope_compact(pos, dim, 10000.0, [20, 2048, 2048])
-    assert U == max(grid) and tuple(idx.shape) == (3, pos.shape[2]) and cos_c.shape == (U, dim // 2)
-    half = dim // 2
-    pad = half - 3 * (dim // 6)
-    slot = torch.arange(half, device=dev)
-    axis = torch.where(slot >= pad, (slot - pad) % 3, torch.zeros_like(slot))
-    rows = idx.long()[axis]                                   # [half, N]: table row of (slot, token)
-    assert torch.equal(cos_c[rows, slot[:, None]].t(), cos) and torch.equal(sin_c[rows, slot[:, None]].t(), sin)
-    ct = K.rope_compact_pack(cos_c, sin_c)
-    assert torch.equal(ct[..., 0], cos_c) and torch.equal(ct[..., 1], sin_c)
-    # more than 64 distinct coordinates on an axis, or not three axes: no compact form
-    assert K.rope_compact(_grid_positions(dev, 1, 2, 70), dim, 10000.0, [20, 2048, 2048]) is None
-    assert K.rope_compact(pos[:, :1], 2048, 10000.0, [20]) is None
-
-
-@pytest.mark.parametrize("grid,heads", [((9, 16, 24), 32), ((4, 20, 20), 16), ((3, 20, 20), 8)])
-def test_qk_fold_kernels_against_the_qknorm_pass(K, dev, grid, heads):
-    """ltx2_gemm_qkv_vt_rowss + ltx2_rownorm_ss_rope (QK-norm + RoPE on the GEMM's partial sums; full tables and the axis-major compact
-    form staged through LDS: identical results) and ltx2_flash_attn_qfold (Q side in the attention prologue) against the path they replace
-    -- projection, ltx2_qknorm_rope over Q and K, ltx2_flash_attn -- and against fp64 math, at the DiT's self-attention geometry, a ragged
-    smaller one, and one the 4-wave kernel does not take (no partial sums: the caller keeps the old pass)."""
-    N, D = grid[0] * grid[1] * grid[2], heads * 128
-    g = torch.Generator().manual_seed(2024 + heads)
-    x = torch.randn(N, D, generator=g).to(BF).to(dev)
-    w = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(BF).to(dev)
-    b = (0.1 * torch.randn(3 * D, generator=g)).to(dev)
-    qn, kn = (1 + 0.1 * torch.randn(D, generator=g)).to(dev), (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
-    pos = _grid_positions(dev, *grid)
-    cos, sin = K.rope_tables(pos, D, 10000.0, [20, 2048, 2048])
-    idx, cos_c, sin_c, U = K.rope_compact(pos, D, 10000.0, [20, 2048, 2048])
-    cta = K.rope_compact_axis_major(cos_c, sin_c)
-    half, nf = D // 2, D // 6
-    pad = half - 3 * nf
-    assert torch.equal(cta[..., 0].permute(1, 2, 0).reshape(U, 3 * nf), cos_c[:, pad:]) and torch.equal(cta[..., 1].permute(1, 2, 0).reshape(U, 3 * nf), sin_c[:, pad:])
-    # reference path
-    qkv0, vt0, fused0 = K.gemm_qkv_vt(x, w, b, heads)
-    ref_buf = qkv0.clone()
-    K.qknorm_rope_(ref_buf, D, 128, 0, qn, D, kn, 1e-6, cos, sin)
-    ref = K.flash_attn(ref_buf[:, :D], ref_buf[:, D:2 * D], vt0, heads, N)
-    # folded path
-    qkv, vt, rowss, fused = K.gemm_qkv_vt_rowss(x, w, b, heads)
-    assert fused == fused0 and torch.equal(vt, vt0) and torch.equal(qkv[:, :2 * D], qkv0[:, :2 * D])
-    if heads == 8:                  # 8 x 1200-row problem: the 128 x 128 tile, which writes no partial sums
-        assert not fused and rowss is None
-        return
-    assert fused
-    ss_ref = (qkv[:, :2 * D].float() ** 2).reshape(N, 2 * D // 64, 64).sum(-1)
-    assert rel_l2(rowss[:, :2 * D // 64].cpu(), ss_ref.cpu()) < 1e-6
-    outs = []
-    for tabs in (dict(cos=cos, sin=sin), dict(compact=(cta, idx, U))):
-        buf = qkv.clone()
-        K.rownorm_ss_rope_(buf, D, 128, 0, qn, rowss, D // 64, D, kn, 1e-6, **tabs)
-        assert torch.equal(buf[:, 2 * D:], qkv[:, 2 * D:])                       # V untouched
-        # the same numbers as the qknorm pass up to the summation order of the row norm (a bf16 ulp here and there)
-        assert rel_l2(buf[:, :2 * D].float().cpu(), ref_buf[:, :2 * D].float().cpu()) < 2e-3
-        outs.append(buf)
-        o = K.flash_attn(buf[:, :D], buf[:, D:2 * D], vt, heads, N)
-        assert rel_l2(o.float().cpu(), ref.float().cpu()) < 6e-3
-        # K only (q_off = the K third), Q stays raw for the attention prologue form
-        kbuf = qkv.clone()
-        K.rownorm_ss_rope_(kbuf, D, 128, D, kn, rowss[:, D // 64:], D // 64, eps=1e-6, **tabs)
-        assert torch.equal(kbuf[:, :D], qkv[:, :D]) and torch.equal(kbuf[:, D:2 * D], buf[:, D:2 * D])
-    assert torch.equal(outs[0], outs[1])                       # compact tables == full tables, bit for bit
-    kbuf = outs[0]
-    ct = K.rope_compact_pack(cos_c, sin_c)
-    oq = [K.flash_attn_qfold(qkv[:, :D], kbuf[:, D:2 * D], vt, heads, N, rowss, D // 64, qn, 1e-6, **t)
-          for t in (dict(cos=cos, sin=sin), dict(compact=(ct, idx, pad)))]
-    assert torch.equal(oq[0], oq[1]) and rel_l2(oq[0].float().cpu(), ref.float().cpu()) < 6e-3
-    # fp64: q_norm / k_norm over the full width, SPLIT rotation per head, softmax attention (K rounded to 16 bits as the kernel stores it)
-    def rot(t):
-        th = t.reshape(N, heads, 2, 64)
-        c, s = cos.double().reshape(N, heads, 64), sin.double().reshape(N, heads, 64)
-        a, bb = th[:, :, 0], th[:, :, 1]
-        return torch.stack([a * c - bb * s, bb * c + a * s], 2).reshape(N, D)
-    qf, kf = qkv[:, :D].double(), qkv[:, D:2 * D].double()
-    qf = rot(qf * torch.rsqrt((qf * qf).mean(-1, keepdim=True) + 1e-6) * qn.double())
-    kf = rot(kf * torch.rsqrt((kf * kf).mean(-1, keepdim=True) + 1e-6) * kn.double()).to(BF).double()
-    vf = (x.double() @ w[2 * D:].double().t() + b[2 * D:].double()).to(BF).double()
-    qh, kh, vh = [t.reshape(N, heads, 128).transpose(0, 1) for t in (qf, kf, vf)]
-    exact = (torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(128), dim=-1) @ vh).transpose(0, 1).reshape(N, D)
-    e_old = rel_l2(ref.double().cpu(), exact.cpu())
-    for o in (K.flash_attn(kbuf[:, :D], kbuf[:, D:2 * D], vt, heads, N), oq[0]):
-        e_new = rel_l2(o.double().cpu(), exact.cpu())
-        assert e_new < 6e-3 and e_new <= 1.2 * e_old

@@ -749,33 +749,6 @@ def test_dit_full_size_denoise_loop(dev):
     assert rel_l2(z.cpu(), ref[0]) < 3e-2 and pearson(z.cpu(), ref[0]) > 0.999
 
 
-def test_qk_fold_engine_paths_agree(dev):
-    """Round 4: at the BASELINE width the video self-attention's QK-norm + RoPE is folded around the QKV projection (partial sums from the
-    GEMM epilogue, one pass over K, Q's weight + rotation in the attention prologue, compact RoPE tables).  The folded step (the default),
-    the same step with the stand-alone pass (option qk_fold = 0), and the fp32 oracle: both engine paths within the DiT tolerance of the
-    oracle and within rounding of each other -- with the compact tables and, for positions that are not a grid, the full ones."""
-    from oracle import dit
-    from ltx_2_mlx_amd.model.transformer import Modality, X0Model
-    cfg, w, m = make_dit(dev, heads=32, layers=2, cap=3840, seed=41)
-    lat, ctx, pos = inputs(9, 16, 24, 1024, 3840, seed=42)
-    jit = pos.clone()
-    jit[:, 2] += torch.linspace(0, 0.9, pos.shape[2])[None, :, None]          # every token its own w coordinate: no compact form
-    ts = torch.tensor([0.725])
-    wg = {k: v.to(dev) for k, v in w.items()}
-    for positions in (pos, jit):
-        with torch.device(dev), torch.no_grad():
-            ref = dit.x0_model(lat.to(dev), ctx.to(dev), ts.to(dev), positions.to(dev), wg, cfg).cpu()
-        outs = {}
-        for fold in (1, 2, 0):
-            m.set_option("qk_fold", fold)
-            mod = Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=positions.to(dev))
-            outs[fold] = X0Model(m)(mod).cpu()
-            assert rel_l2(outs[fold], ref) < 2e-2 and pearson(outs[fold], ref) > 0.999, fold
-        assert rel_l2(outs[1], outs[0]) < 1e-3 and rel_l2(outs[2], outs[0]) < 4e-3
-        assert not torch.equal(outs[1], outs[0]) and not torch.equal(outs[2], outs[1])            # (the option really switches paths)
-    m.set_option("qk_fold", 1)
-
-
 @pytest.mark.parametrize("v23", [False, True])
 def test_av_full_size_step(dev, v23):
     """BASELINE config 4 geometry: AudioVideo DiT at full width (video 32 x 128, audio 32 x 64), N = 3456 video tokens,
