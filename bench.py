@@ -42,6 +42,22 @@ def dit_algorithmic_flops(N, S, D, L):
     return per_layer * L
 
 
+def dit_executed_flops(N, S, D, L):
+    """What the engine EXECUTES per step: the text cross-attention K / V projections (4 S D^2 per layer in the algorithmic count; the reference
+    recomputes them every step, model.py:262-271) are step-invariant for the 19B model and run once per prompt in ltx2_dit_prepare."""
+    return dit_algorithmic_flops(N, S, D, L) - 4 * S * D * D * L
+
+
+def kernel_source_sha():
+    """sha256 of the dominant kernel's sources (tools/pmc_traffic.py stores the same digest beside the PMC traffic figure)"""
+    import hashlib
+    root = os.path.join(ROOT, "ltx-2-mlx_amd", "csrc")
+    h = hashlib.sha256()
+    for f in ("gemm_v4.hip", "gemm_v4_loop.inc", "gemm_epilogue.h", "gemm.h", "common.h"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(threads):
     """The oracle (fp32 PyTorch CPU port of the reference's arithmetic, kind "port") timed on the host cores, as SURVEY.md
     8(d) defines the CPU leg -- bounded to about half a minute:
@@ -323,7 +339,8 @@ def main():
     ap.add_argument("--layers", type=int, default=48, help="debug only; the headline config is 48")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay section (rocprofv3 --pmc passes)")
+    ap.add_argument("--no-graph", action="store_true", help="no hipGraph anywhere: K eager steps are timed (rocprofv3 --pmc passes, per-dispatch traces)")
+    ap.add_argument("--eager", action="store_true", help="time K eager ltx2_dit_denoise_step calls as the headline (the graph replay is then reported beside it)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (AudioVideo step, two-stage pipeline)")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi socket-power samples taken during an extra graph replay")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (instrumented) pass that times the dominant GEMM")
@@ -353,16 +370,19 @@ def main():
     # ---------------- model (random init of the 19B architecture; rank 0 -> RCCL broadcast) ----------------
     L = args.layers
     model = LTXModel(num_layers=L, device=dev)
-    model.init_random_weights(seed=0 if rank == 0 else 1000 + rank)
+    model.init_random_weights(seed=0, fill=(rank == 0))         # ranks > 0 only ALLOCATE (whatever the allocator hands back): their weights arrive by the broadcast
     wt = model.weight_tensors()
     w_bytes = sum(t.numel() * t.element_size() for t in wt.values())
     torch.cuda.synchronize()
     D.barrier()
     t0 = time.time()
-    n_coll = D.broadcast_tensors(wt, src=0, bucket_bytes=1 << 30)
+    bcast_mode = os.environ.get("LTX2_BCAST", "ring")
+    n_coll = D.broadcast_tensors(wt, src=0, bucket_bytes=1 << 30, mode=bcast_mode)
     torch.cuda.synchronize()
     D.barrier()
     bcast_s = time.time() - t0
+    # every replica holds the same bytes: MIN and MAX over ranks of a 63-bit checksum of all weight tensors agree
+    weights_identical = D.replicas_identical(wt, dev) if world > 1 else None
 
     # ---------------- per-rank prompt / seed ----------------
     shape = VideoLatentShape.from_pixel_shape(VideoPixelShape(1, 65, 512, 768, 24.0))
@@ -391,18 +411,47 @@ def main():
             m = Modality(latent=lat[None], context=ctx, context_mask=None, timesteps=ts_dev[i % 8:i % 8 + 1], positions=state.positions)
             model.denoise_step_(lat, m, s0, s1)
 
+    # The hot path as the pipelines run it (north_star; pipelines/common.py use_hip_graph=True): the 8-step distilled loop is ONE captured hipGraph,
+    # replayed.  With K a multiple of 8 the timed region replays it K / 8 times (the same kernels as K eager steps, enqueued by one call per 8
+    # steps); any other K, or --eager, times K eager ltx2_dit_denoise_step calls.  The other form is timed afterwards and reported beside it.
+    use_graph = (K % 8 == 0) and not args.eager and not args.no_graph
+    side = torch.cuda.Stream()
+
+    def run_graph(n_steps):
+        for _ in range(n_steps // 8):
+            model.replay_denoise_graph()
+
+    def timed(fn, n):
+        """exactly n steps between barrier + synchronize on both sides -> (this rank's seconds, max over ranks)"""
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(n)
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0                 # this rank's own steps (before the closing barrier)
+        D.barrier()
+        return mine, D.max_over_ranks(time.perf_counter() - t0, dev)
+
     run_steps(W)
     torch.cuda.synchronize()
+    graph_err = None
+    if use_graph or not args.no_graph:
+        try:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                lat.copy_(noise)
+                model.capture_denoise_graph(lat, sig)
+                model.replay_denoise_graph()            # warm-up replay
+            side.synchronize()
+        except Exception as e:  # noqa: BLE001
+            graph_err, use_graph = f"failed: {e}", False
 
     # ---------------- timed region: exactly K steps, nothing else on the stream ----------------
-    D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(K)
-    torch.cuda.synchronize()
-    dt_rank = time.perf_counter() - t0                  # this rank's own K steps (before the closing barrier)
-    D.barrier()
-    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    if use_graph:
+        with torch.cuda.stream(side):
+            dt_rank, dt = timed(run_graph, K)
+    else:
+        dt_rank, dt = timed(run_steps, K)
     n_joined = D.count_ranks(dev)                       # counted through the process group (an RCCL all-reduce on device tensors)
 
     # ---------------- second pass (not part of `value`): HIP events around every launch of the dominant GEMM ----------------
@@ -414,25 +463,23 @@ def main():
         torch.cuda.synchronize()
         k_ms, k_n, k_fl = model.profile_end()
 
-    # ---------------- hipGraph replay of the 8-step loop (reported beside the headline) ----------------
-    graph_ms = None
+    # ---------------- the OTHER launch form of the same K steps (reported beside the headline, not part of `value`) ----------------
+    graph_ms, eager_ms = None, None
     power = None
     try:
-        if args.no_graph:
-            raise RuntimeError("skipped (--no-graph)")
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
+        if use_graph:
+            graph_ms = dt / K * 1e3
+            _, e = timed(run_steps, K)
+            eager_ms = e / K * 1e3
+        else:
+            eager_ms = dt / K * 1e3
+        if args.no_graph or graph_err:
+            raise RuntimeError(graph_err or "skipped (--no-graph)")
         with torch.cuda.stream(side):
-            lat.copy_(noise)
-            model.capture_denoise_graph(lat, sig)
-            model.replay_denoise_graph()
-            side.synchronize()
-            reps = max(1, K // 8)
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                model.replay_denoise_graph()
-            side.synchronize()
-            graph_ms = (time.perf_counter() - t0) / (reps * 8) * 1e3
+            if not use_graph:
+                reps = max(1, K // 8)
+                _, g = timed(run_graph, reps * 8)
+                graph_ms = g / (reps * 8) * 1e3
             # socket power while the same graph keeps replaying (rank 0, ~3 s, outside every timed region): the step time on this
             # part is set by the 1400 W cap, so the line carries the evidence
             # every rank samples ITS socket while all ranks keep replaying (the node at full load, as in the timed region)
@@ -440,7 +487,8 @@ def main():
                 power = socket_power_during(lambda: (model.replay_denoise_graph(), side.synchronize()), seconds=3.0, smi_device=local)
         torch.cuda.current_stream().wait_stream(side)
     except Exception as e:  # noqa: BLE001
-        graph_ms = f"failed: {e}"
+        if graph_ms is None:
+            graph_ms = f"failed: {e}"
 
     # ---------------- VAE decode: latent in HBM -> uint8 frames in HBM ----------------
     vae_fps, vae_ms = None, None
@@ -469,14 +517,17 @@ def main():
     steps_per_s = world * K / dt
     ms_per_step = dt / K * 1e3
     alg = dit_algorithmic_flops(N, S, Dm, L)
+    exe = dit_executed_flops(N, S, Dm, L)
     # HBM/fabric traffic of the dominant kernel cannot be collected from inside the process: it comes from the committed
     # rocprofv3 --pmc passes of THIS kernel version (the newest profiles/r*_pmc_traffic.json names the commit), null if absent.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_stale = None, None, None
     try:
         import glob
         with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
             tj = json.load(f)
             traffic, traffic_src = tj.get("per_launch_avg_bytes"), tj.get("commit")
+            # stale = the kernel's sources changed since the counters were collected (files without the digest predate round 4: stale)
+            traffic_stale = tj.get("kernel_source_sha16") != kernel_source_sha()
     except Exception:  # noqa: BLE001
         pass
     kern_avg_ms = k_ms / max(k_n, 1)
@@ -490,9 +541,15 @@ def main():
                    "parallelism": f"prompt-parallel x{world} (independent prompt/seed per GPU, one RCCL weight broadcast)"},
         "vae_decode_frames_per_sec": None if vae_fps is None else round(vae_fps, 2),
         "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),
+        "timed_with": ("hipGraph replay of the captured 8-step loop (K / 8 launches)" if use_graph else "K eager ltx2_dit_denoise_step calls"),
         "step_algorithmic_tflop": round(alg / 1e12, 3),
         "step_mfma_roofline_frac": round(alg / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "step_executed_tflop": round(exe / 1e12, 3),
+        "step_executed_mfma_frac": round(exe / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "step_executed_note": "executed = algorithmic minus the text cross-attention K / V projections (4 S D^2 per layer), which are step-invariant "
+                              "and run once per prompt (prompt_setup_ms); the reference recomputes them every step",
         "hipgraph_ms_per_step": graph_ms if not isinstance(graph_ms, float) else round(graph_ms, 3),
+        "eager_ms_per_step": eager_ms if not isinstance(eager_ms, float) else round(eager_ms, 3),
         "prompt_setup_ms": round(prep_ms, 1),
         "socket_power": power,
         "rccl_ranks": n_joined, "rccl_ranks_how": "all_reduce(sum) of a device-resident 1 over the process group",
@@ -500,13 +557,14 @@ def main():
                                  "all": [round(r[0], 3) for r in per_rank]},
         "per_rank_socket_power_w": None if args.no_power else {"mean": [r[1] for r in per_rank], "max": [r[2] for r in per_rank]},
         "collective_backend": (torch.distributed.get_backend() if world > 1 else None), "weight_bytes": w_bytes, "weight_broadcast_s": round(bcast_s, 3),
-        "weight_broadcast_collectives": n_coll,
+        "weight_broadcast_collectives": n_coll, "weight_broadcast_mode": bcast_mode if world > 1 else None,
+        "weights_identical": weights_identical,
         "weight_broadcast_gbps": round(w_bytes / bcast_s / 1e9, 1) if world > 1 and bcast_s > 0 else None,
         "roofline": {"kernel": "gemm_v4_kernel<EPI_RESID_GATE_F32, layout 3, 224> (224x256x64 tile, 4 waves, generated asm K loop, "
                                "v_mfma_f32_16x16x32_bf16: attn1/attn2 to_out and ff.net.2 + bias + gate * (.) added into the fp32 residual)",
                      "bound": "mfma", "achieved": None if kern_tflops is None else round(kern_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": None if kern_tflops is None else round(kern_tflops / PEAK_BF16_TFLOPS, 4),
-                     "traffic": traffic, "traffic_source_commit": traffic_src,
+                     "traffic": traffic, "traffic_source_commit": traffic_src, "traffic_stale": traffic_stale,
                      "launches": k_n, "avg_launch_us": round(kern_avg_ms * 1e3, 2),
                      "algorithmic_flops_per_launch": round(k_fl / max(k_n, 1)),
                      "measured": "HIP events around every launch of this kernel in a separate pass of the same K steps (not in `value`)"},

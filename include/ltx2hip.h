@@ -182,6 +182,10 @@ int ltx2_latent_normalize_nchw(const void* x, const float* mean, const float* st
 int ltx2_adaln_rmsnorm(const float* x, int64_t ldx, void* out, int64_t ldo, int rows, int D, float eps,
                        int layer_norm, const float* scale_tab, const float* shift_tab, const float* scale_emb,
                        const float* shift_emb, int64_t emb_stride, void* stream);
+/* Two modulations of ONE RMS-normalised stream from one read of x (round 4; the cross-modal attention's a2v / v2a inputs, transformer.py:556-620):
+ * out_g = rms_norm(x) * (1 + scale_g) + shift_g, g = 0, 1 (row-invariant fp32 vectors [D], any may be null).  D <= 4096.            */
+int ltx2_adaln_rmsnorm2(const float* x, int64_t ldx, void* out0, void* out1, int64_t ldo, int rows, int D, float eps, const float* scale0,
+                        const float* shift0, const float* scale1, const float* shift1, void* stream);
 
 /* The same with the fp8 compute path's per-token quantiser fused in: codes[rows][ldq] + scale[rows] = ltx2_quantize_rows_fp8 of the
  * bf16-rounded outputs, bit for bit; out_bf16 may be NULL (the GEMM that follows reads only the codes).                    */
@@ -219,6 +223,11 @@ int ltx2_flash_attn_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, c
  * = x[rows][Dq] @ gate_w[H][Dq]^T + gate_b ; att[:, h*hd:(h+1)*hd] *= 2*sigmoid(logits[:, h]).  H <= 32. */
 int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const void* gate_w, const float* gate_b,
                         float* logits, int rows, int Dq, int H, int head_dim, void* stream);
+
+/* ltx2_flash_attn with the per-head gates applied in the kernel's epilogue (round 4: the engine's form -- the gate multiplies the fp32 result
+ * before it is rounded, instead of a pass over the rounded output): out[q, h*hd:(h+1)*hd] = 2*sigmoid(gate_logits[q*gate_ld + h]) * attention. */
+int ltx2_flash_attn_gated(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
+                          int H, int head_dim, float scale, const float* gate_logits, int gate_ld, void* stream);
 
 /* SPLIT-RoPE tables (precompute_freqs_cis with use_middle_indices_grid, rope.py:214-328,365-418): positions fp32
  * [n_dims][N][2] = [start, end) per axis, freq_grid [n_freq] = theta^linspace(0,1,n_freq)*pi/2 (host-computed, exact),
@@ -357,6 +366,15 @@ int ltx2_dit_denoise_step_av(ltx2_dit* ctx, float* v_latent, float* a_latent, co
 /* hipGraph: capture n_steps of ltx2_dit_denoise_step over host_sigmas[n_steps+1] with a uniform
  * sigma per step (timesteps = sigma for every token), then replay.  latent is updated in place. */
 int ltx2_dit_graph_capture(ltx2_dit* ctx, float* latent, const float* host_sigmas, int n_steps, void* stream);
+/* The same for CONDITIONED loops (image-to-video; reference pipelines/common.py:193-232, pipelines/distilled.py:214-253): mask fp32 [N] = the
+ * denoise mask (1 = free token), clean fp32 [N][C] = the clean latent of the conditioned tokens.  Step i runs with per-token timesteps
+ * mask * sigma_i (formed on the device inside the captured step) and blends x0 with `clean` before the Euler update, exactly as
+ * ltx2_dit_denoise_step with n_timesteps = N, mask and clean.  The workspace must be bound with per_token = 1.  A null mask (per modality in
+ * the _av form) = no conditioning tokens there.  (round 4, additive)                                                             */
+int ltx2_dit_graph_capture_cond(ltx2_dit* ctx, float* latent, const float* host_sigmas, int n_steps, const float* mask, const float* clean,
+                                void* stream);
+int ltx2_dit_graph_capture_cond_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps, const float* v_mask,
+                                   const float* v_clean, const float* a_mask, const float* a_clean, void* stream);
 int ltx2_dit_graph_capture_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps,
                               void* stream);
 int ltx2_dit_graph_launch(ltx2_dit* ctx, void* stream);

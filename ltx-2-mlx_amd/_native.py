@@ -55,6 +55,8 @@ SIGNATURES = {
     "ltx2_gemm_w8a16": (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
     "ltx2_gemm_bf16_rowss": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, C.POINTER(i32), vp]),
     "ltx2_flash_attn_keymask": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "ltx2_adaln_rmsnorm2": (i32, [vp, i64, vp, vp, i64, i32, i32, f32, vp, vp, vp, vp, vp]),
+    "ltx2_flash_attn_gated": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, vp]),
     "ltx2_flash_attn_rowscale": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, i32, f32, vp]),
     "ltx2_gemm_route": (i32, [i32, i32, i32, i32, i32, i32]),
     "ltx2_quantize_rows_fp8": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),
@@ -101,6 +103,8 @@ SIGNATURES = {
     "ltx2_dit_forward": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "ltx2_dit_denoise_step": (i32, [vp, vp, vp, i32, vp, vp, vp, f32, f32, vp, vp]),
     "ltx2_dit_graph_capture": (i32, [vp, vp, C.POINTER(f32), i32, vp]),
+    "ltx2_dit_graph_capture_cond": (i32, [vp, vp, C.POINTER(f32), i32, vp, vp, vp]),
+    "ltx2_dit_graph_capture_cond_av": (i32, [vp, vp, vp, C.POINTER(f32), i32, vp, vp, vp, vp, vp]),
     "ltx2_dit_graph_launch": (i32, [vp, vp]),
     "ltx2_dit_health": (i32, [vp, vp]),
     "ltx2_dit_set_context_mask": (i32, [vp, i32, vp, i32, vp]),

@@ -29,6 +29,10 @@ struct AttnParams {
     // attended; a masked key's score is replaced by -1e30 (the reference ADDS -3.4e38 to it: the same softmax, including the uniform
     // result over the masked keys of a row whose keys are all masked).  null = no mask.  Plain grid only.
     const unsigned long long* kmask;
+    // Per-head output gates (V2.3 apply_gated_attention, attention.py:241-249): out[q, h] *= 2 * sigmoid(gate[q * gate_ld + h]), applied to the fp32
+    // result before it is rounded (round 4: was a pass over the attention output).  null = none.
+    const float* gate;
+    int gate_ld;
     int sk_force;       // 1: stream-K whenever there are more units than slots (unit tests); 0: only when the plain grid's last round is badly filled
 };
 

@@ -557,8 +557,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         float l_lo, l_hi;
         half_pair(l_run, l_lo, l_hi);
         const float l_tot = l_lo + l_hi;
-        const float inv = 1.0f / l_tot;
+        float inv = 1.0f / l_tot;
         const int qrow = q0 + l31;
+        if (p.gate && qrow < p.Nq) inv *= 2.f / (1.f + __expf(-p.gate[(long)qrow * p.gate_ld + head]));        // per-head gate, folded into the normaliser
         if (qrow < p.Nq) {
             bf16* op = p.O + (long)qrow * p.ldo + head * HD + 4 * hi;
 #pragma unroll

@@ -46,6 +46,15 @@ int ltx2_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
     return gemm_launch(p, epilogue, false, (hipStream_t)stream);
 }
 
+int ltx2_adaln_rmsnorm2(const float* x, int64_t ldx, void* out0, void* out1, int64_t ldo, int rows, int D, float eps, const float* scale0,
+                        const float* shift0, const float* scale1, const float* shift1, void* stream) {
+    LTX2_CHECK_ARG(x && out0 && out1, "adaln_rmsnorm2: null operand");
+    const float* sct[2] = {scale0, scale1};
+    const float* sht[2] = {shift0, shift1};
+    const float* none[2] = {nullptr, nullptr};
+    return norm_mod2_launch(x, ldx, (bf16*)out0, (bf16*)out1, ldo, rows, D, eps, sct, sht, none, none, (hipStream_t)stream);
+}
+
 int ltx2_gemm_bf16_rowss(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K, float* rowss,
                          int* written, void* stream) {
     LTX2_CHECK_ARG(A && W && out && rowss && written, "gemm_bf16_rowss: null argument");
@@ -291,6 +300,30 @@ int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const
     int rc = gate_logits_launch((const bf16*)x, ldx, (const bf16*)gate_w, gate_b, logits, H, rows, Dq, H, (hipStream_t)stream);
     if (rc != LTX2_OK) return rc;
     return head_gate_launch((bf16*)att, ld, logits, H, rows, H, head_dim, (hipStream_t)stream);
+}
+
+int ltx2_flash_attn_gated(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
+                          int H, int head_dim, float scale, const float* gate_logits, int gate_ld, void* stream) {
+    LTX2_CHECK_ARG(Q && K && VT && out && gate_logits && gate_ld >= H, "flash_attn_gated: null operand / gate_ld < H");
+    LTX2_CHECK_ARG(head_dim == 128 || head_dim == 64, "flash_attn_gated: head_dim=%d, only 128 and 64 are implemented", head_dim);
+    AttnParams a{};
+    a.Q = (const bf16*)Q;
+    a.ldq = ldq;
+    a.K = (const bf16*)K;
+    a.ldk = ldk;
+    a.VT = (const bf16*)VT;
+    a.vt_head_stride = (long)head_dim * Npad;
+    a.head_dim = head_dim;
+    a.O = (bf16*)out;
+    a.ldo = ldo;
+    a.Nq = Nq;
+    a.Nkv = Nkv;
+    a.Npad = Npad;
+    a.H = H;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.gate = gate_logits;
+    a.gate_ld = gate_ld;
+    return attn_launch(a, (hipStream_t)stream);
 }
 
 int64_t ltx2_flash_attn_workspace_bytes(int head_dim) { return attn_sk_workspace_bytes(head_dim); }

@@ -78,6 +78,7 @@ struct Mod {        // per-modality geometry + workspace
     const bf16* ctx = nullptr;      // projected text context (ctxp or ctx_in)
     unsigned long long* kmask = nullptr;   // text cross-attention key mask as 64-bit words (Modality.context_mask); used when has_kmask
     bool has_kmask = false;
+    float* ts_tok = nullptr;        // per-token timesteps of a captured conditioned step: denoise_mask * sigma, formed on the device (per_token workspaces)
     float* qss = nullptr;           // text cross-attention with q_norm folded in: partial row sums of squares of the projected queries [N][D/64]
     float* knq = nullptr;           //   and k_norm.weight * q_norm.weight per layer [L][D] (the per-dim q weight moves onto the cached keys)
     bool qfold = false;             //   decided per prepare: the query projection runs on a kernel that writes the partial sums
@@ -164,6 +165,7 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         m.prompt_emb = (float*)take(c->v2 ? 4L * 2 * D : 0);
         m.cross_ss = (float*)take(c->av ? 4L * 4 * D : 0);
         m.cross_gate = (float*)take(c->av ? 4L * D : 0);
+        m.ts_tok = (float*)take(per_token ? 4L * n : 0);
         m.sin_b = (bf16*)take(per_token ? 2L * n * 256 : 0);
         m.e1_b = (bf16*)take(per_token ? 2L * n * D : 0);
         m.es_b = (bf16*)take(per_token ? 2L * n * D : 0);
@@ -446,6 +448,12 @@ int dense(ltx2_dit* c, const bf16* A, long lda, const bf16* W, const float* bias
     return rc;
 }
 
+// timesteps of a conditioned step (reference pipelines/common.py:193-232 timesteps_from_mask): ts[n] = mask[n] * sigma, sigma read on the device
+__global__ void mask_sigma_kernel(const float* __restrict__ mask, const float* __restrict__ sigma, float* __restrict__ ts, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ts[i] = mask[i] * sigma[0];
+}
+
 __global__ void silu_cast_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         out[i] = f2bf(silu_f(in[i]));
@@ -477,9 +485,11 @@ int adaln_chain(ltx2_dit* c, Mod& m, const AdaW& a, const float* ts, long t_stri
 // attention runs beside them on the side stream and keeps the plain grid).
 int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int npad, bf16* out, long ldo, int nq,
            int nkv, int H, int hd, hipStream_t st, ltx2_dit* sk = nullptr, const float* q_ss = nullptr, float q_eps = 0.f,
-           const unsigned long long* kmask = nullptr) {
+           const unsigned long long* kmask = nullptr, const float* gate = nullptr) {
     AttnParams a{};
     a.kmask = kmask;
+    a.gate = gate;          // per-head gate logits [nq][H] (V2.3): out *= 2 sigmoid(.) in the kernel's epilogue
+    a.gate_ld = H;
     if (q_ss) {         // q_norm as a per-row softmax scale from the projection's partial sums (text cross-attention)
         a.q_ss = q_ss;
         a.q_ss_ld = H * hd / 64;
@@ -529,16 +539,32 @@ int stream_after(ltx2_dit* c, hipStream_t from, hipStream_t to) {
     return LTX2_OK;
 }
 
+// split form of stream_after: record now (the point on `from` others may wait for), make `to` wait later
+hipEvent_t event_record(ltx2_dit* c, hipStream_t from) {
+    hipEvent_t e = next_event(c);
+    if (!e || hipEventRecord(e, from) != hipSuccess) {
+        ltx2_set_error("dit: event record failed: %s", hipGetErrorString(hipGetLastError()));
+        return nullptr;
+    }
+    return e;
+}
+
+int event_wait(hipEvent_t e, hipStream_t to) {
+    if (!e || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
+        ltx2_set_error("dit: stream wait failed: %s", hipGetErrorString(hipGetLastError()));
+        return LTX2_E_HIP;
+    }
+    return LTX2_OK;
+}
+
 // Per-head gates (attention.py:241-249): att[:, h*hd:(h+1)*hd] *= 2*sigmoid(x @ Wg^T + bg)[:, h]
 int gate_logits(ltx2_dit* c, Mod& m, const AttnW& w, const bf16* xin, int Dq, int rows, int H, hipStream_t st) {
     if (!c->gated) return LTX2_OK;
     return gate_logits_launch(xin, Dq, w.g_w, w.g_b, m.glog, H, rows, Dq, H, st);
 }
 
-int gate_apply(ltx2_dit* c, Mod& m, bf16* att, int rows, int H, int hd, hipStream_t st) {
-    if (!c->gated) return LTX2_OK;
-    return head_gate_launch(att, (long)H * hd, m.glog, H, rows, H, hd, st);
-}
+// the gate logits gate_logits() left for the attention that follows (null for ungated models): the kernel's epilogue applies 2 sigmoid(.) per head
+const float* glog(ltx2_dit* c, const Mod& m) { return c->gated ? m.glog : nullptr; }
 
 // K (k_norm applied, optional RoPE) and V^T of a text / cross-modal context
 int project_kv(ltx2_dit* c, const bf16* ctx, int rows, int Dc, const AttnW& w, int Di, int H, int hd, float eps, const float* cosb,
@@ -575,8 +601,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
         TRY(qknorm_rope_launch(m.qkv, 3 * D, N, D, hd, 2, offs, wts, eps, m.cosb, m.sinb, st));
     }
     if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
-    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, k == 0 ? c : nullptr));
-    TRY(gate_apply(c, m, m.att, N, H, hd, st));
+    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, k == 0 ? c : nullptr, nullptr, 0.f, nullptr, glog(c, m)));
     TRY(dense(c, m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 2 * D, es, w.sst + 2 * D));
 
     // text cross-attention: no RoPE, no mask.  V1: plain RMSNorm on x, K/V cached per prompt.
@@ -609,8 +634,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
         TRY(qknorm_rope_launch(m.qkv, D, N, D, hd, 1, offs, wts, eps, nullptr, nullptr, st));
     }
     TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st, k == 0 ? c : nullptr, m.qfold ? m.qss : nullptr, eps,
-               m.has_kmask ? m.kmask : nullptr));
-    TRY(gate_apply(c, m, m.att, N, H, hd, st));
+               m.has_kmask ? m.kmask : nullptr, glog(c, m)));
     if (c->v2)
         TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 8 * D, es, w.sst + 8 * D));
     else
@@ -635,39 +659,81 @@ int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
 // Audio <-> video cross-modal attention (transformer.py:556-620).  Table rows
 // (scale_a2v, shift_a2v, scale_v2a, shift_v2a, gate); both directions read the SAME pre-update
 // RMS-normalised streams, so all four modulated inputs are formed before x is touched.
-int block_cross_modal(ltx2_dit* c, int l, hipStream_t st) {
+//
+// Round 4 schedule (was: 23 kernels in one chain on the main stream, ~500 us per layer with the chip mostly idle).  Only the audio -> video
+// direction feeds the video stream (its feed-forward reads the a2v update); the video -> audio direction updates the AUDIO stream only.  So:
+//   main (video): ONE norm launch for both modulations of vx -> a2v query projection -> rope(q) -> [audio K/V ready] -> a2v attention ->
+//                 out-projection into vx -> (caller) video feed-forward
+//   side (audio): ONE norm launch for both modulations of ax -> a2v K/V from audio (skinny) -> [signal] -> v2a query (skinny) -> [vx modulations
+//                 ready] -> v2a key / value projection (the other big video-side GEMM) -> k-norm + rope -> v2a attention -> out-projection into ax ->
+//                 (caller) audio feed-forward
+// Buffers: the video modality's qkv scratch holds the a2v queries [N][Da] and, behind them, the v2a keys / values [N][2 Da]; the audio modality's
+// holds the a2v keys / values [Na][2 Da] and, behind them, the v2a queries [Na][Da] -- the two directions never share a region.
+int block_cross_modal(ltx2_dit* c, int l, hipStream_t st, hipStream_t sa) {
     Mod &v = c->m[0], &a = c->m[1];
     const LayerW& w = c->layers[l];
     const int Dv = v.D, Da = a.D, H = a.H, hd = a.hd;
     const float eps = c->cfg.norm_eps;
     const float *tv = w.ca[0], *ta = w.ca[1];
-    TRY(norm_mod_launch(v.x, Dv, v.h, Dv, v.N, Dv, eps, 0, tv, tv + Dv, v.cross_ss, v.cross_ss + Dv, 0, st));                      // a2v query side
-    TRY(norm_mod_launch(v.x, Dv, v.h2, Dv, v.N, Dv, eps, 0, tv + 2 * Dv, tv + 3 * Dv, v.cross_ss + 2 * Dv, v.cross_ss + 3 * Dv, 0, st));  // v2a context side
-    TRY(norm_mod_launch(a.x, Da, a.h, Da, a.N, Da, eps, 0, ta, ta + Da, a.cross_ss, a.cross_ss + Da, 0, st));                      // a2v context side
-    TRY(norm_mod_launch(a.x, Da, a.h2, Da, a.N, Da, eps, 0, ta + 2 * Da, ta + 3 * Da, a.cross_ss + 2 * Da, a.cross_ss + 3 * Da, 0, st));  // v2a query side
     const int offs[1] = {0};
-    // audio -> video: Q from video (Dv -> Da), K/V from audio
+    bf16* v_q = v.qkv;                              // a2v queries  [N][Da]
+    bf16* v_kv = v.qkv + (long)v.N * Da;            // v2a keys | values [N][2 Da]
+    bf16* a_kv = a.qkv;                             // a2v keys | values [Na][2 Da]
+    bf16* a_q = a.qkv + (long)a.N * 2 * Da;         // v2a queries [Na][Da]
+    // Capture order matters under hipGraph: a node's FIRST captured child continues its stream's run list (ROCm executes a run list serially), so
+    // after every event record the recording stream's own next kernel is enqueued before the other stream's wait + consumer.
+    // ---- video side, main stream: both modulations of vx, the two video-side projections ----
+    {
+        const float* sct[2] = {tv, tv + 2 * Dv};
+        const float* sht[2] = {tv + Dv, tv + 3 * Dv};
+        const float* sce[2] = {v.cross_ss, v.cross_ss + 2 * Dv};
+        const float* she[2] = {v.cross_ss + Dv, v.cross_ss + 3 * Dv};
+        TRY(norm_mod2_launch(v.x, Dv, v.h, v.h2, Dv, v.N, Dv, eps, sct, sht, sce, she, st));       // a2v query side | v2a context side
+    }
+    // the v2a key / value projection (the other big video-side GEMM) runs on the side stream from here, beside the main stream's a2v chain: same-box
+    // A/B of the LTX-2.3 step, hipGraph: 104.0 ms against 106.0 with both projections in ONE launch on the main stream (128 + 256 tiles are two rounds
+    // of the 256 CUs whichever way they are launched; on two streams the second round overlaps the a2v chain's small kernels)
+    bool vt_done = false;
+    const VtOut vo{v.vt, Da, v.Npad, hd};
+    hipEvent_t video_norm = event_record(c, st);
+    if (!video_norm) return LTX2_E_HIP;
     TRY(gate_logits(c, v, w.a2v, v.h, Dv, v.N, H, st));
-    TRY(dense(c, v.h, Dv, w.a2v.q_w, w.a2v.q_b, v.qkv, Da, v.N, Da, Dv, EPI_BF16, st));
+    TRY(dense(c, v.h, Dv, w.a2v.q_w, w.a2v.q_b, v_q, Da, v.N, Da, Dv, EPI_BF16, st));
     {
         const float* wts[1] = {w.a2v.qn};
-        TRY(qknorm_rope_launch(v.qkv, Da, v.N, Da, hd, 1, offs, wts, eps, v.ccos, v.csin, st));
+        TRY(qknorm_rope_launch(v_q, Da, v.N, Da, hd, 1, offs, wts, eps, v.ccos, v.csin, st));
     }
-    TRY(project_kv(c, a.h, a.N, Da, w.a2v, Da, H, hd, eps, a.ccos, a.csin, a.qkv, a.vt, a.Npad, st));
-    TRY(attend(v.qkv, Da, a.qkv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st, c));
-    TRY(gate_apply(c, v, v.att, v.N, H, hd, st));
-    TRY(dense(c, v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, v.cross_gate, 0, tv + 4 * Dv));
-    // video -> audio: Q from audio, K/V from video (Dv -> Da)
-    TRY(gate_logits(c, a, w.v2a, a.h2, Da, a.N, H, st));
-    TRY(dense(c, a.h2, Da, w.v2a.q_w, w.v2a.q_b, a.qkv, Da, a.N, Da, Da, EPI_BF16, st));
+    // ---- audio side, side stream: both modulations of ax, a2v K / V, v2a Q ----
+    {
+        const float* sct[2] = {ta, ta + 2 * Da};
+        const float* sht[2] = {ta + Da, ta + 3 * Da};
+        const float* sce[2] = {a.cross_ss, a.cross_ss + 2 * Da};
+        const float* she[2] = {a.cross_ss + Da, a.cross_ss + 3 * Da};
+        TRY(norm_mod2_launch(a.x, Da, a.h, a.h2, Da, a.N, Da, eps, sct, sht, sce, she, sa));       // a2v context side | v2a query side
+    }
+    TRY(project_kv(c, a.h, a.N, Da, w.a2v, Da, H, hd, eps, a.ccos, a.csin, a_kv, a.vt, a.Npad, sa));
+    hipEvent_t audio_kv = event_record(c, sa);
+    if (!audio_kv) return LTX2_E_HIP;
+    TRY(gate_logits(c, a, w.v2a, a.h2, Da, a.N, H, sa));
+    TRY(dense(c, a.h2, Da, w.v2a.q_w, w.v2a.q_b, a_q, Da, a.N, Da, Da, EPI_BF16, sa));
     {
         const float* wts[1] = {w.v2a.qn};
-        TRY(qknorm_rope_launch(a.qkv, Da, a.N, Da, hd, 1, offs, wts, eps, a.ccos, a.csin, st));
+        TRY(qknorm_rope_launch(a_q, Da, a.N, Da, hd, 1, offs, wts, eps, a.ccos, a.csin, sa));
     }
-    TRY(project_kv(c, v.h2, v.N, Dv, w.v2a, Da, H, hd, eps, v.ccos, v.csin, v.qkv, v.vt, v.Npad, st));
-    TRY(attend(a.qkv, Da, v.qkv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, st, c));        // few queries, long KV: the split-KV launch form
-    TRY(gate_apply(c, a, a.att, a.N, H, hd, st));
-    TRY(dense(c, a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, st, a.cross_gate, 0, ta + 4 * Da));
+    // ---- audio -> video attention (main): Q from video, K / V from audio ----
+    TRY(event_wait(audio_kv, st));
+    TRY(attend(v_q, Da, a_kv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st, c, nullptr, 0.f, nullptr, glog(c, v)));
+    TRY(dense(c, v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, v.cross_gate, 0, tv + 4 * Dv));
+    // ---- video -> audio attention (side): Q from audio, K / V from video ----
+    TRY(event_wait(video_norm, sa));
+    TRY(dense(c, v.h2, Dv, w.v2a.kv_w, w.v2a.kv_b, v_kv, 2 * Da, v.N, 2 * Da, Dv, EPI_BF16, sa, nullptr, 0, nullptr, &vo, &vt_done));
+    {
+        const float* wts[1] = {w.v2a.kn};
+        TRY(qknorm_rope_launch(v_kv, 2 * Da, v.N, Da, hd, 1, offs, wts, eps, v.ccos, v.csin, sa));
+    }
+    if (!vt_done) TRY(vt_transpose_launch(v_kv + Da, 2 * Da, v.vt, v.N, v.Npad, H, sa, hd));
+    TRY(attend(a_q, Da, v_kv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, sa, nullptr, nullptr, 0.f, nullptr, glog(c, a)));     // few queries, long KV (side stream: the plain grid)
+    TRY(dense(c, a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, sa, a.cross_gate, 0, ta + 4 * Da));
     return LTX2_OK;
 }
 
@@ -714,9 +780,7 @@ int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = t
         }
         TRY(block_attention(c, 0, l, es[0], st));
         if (c->av) {
-            TRY(stream_after(c, sa, st));
-            TRY(block_cross_modal(c, l, st));
-            TRY(stream_after(c, st, sa));
+            TRY(block_cross_modal(c, l, st, sa));      // main: the video side; side: the audio side (events inside)
             TRY(block_ffn(c, 1, l, es[1], sa));
         }
         TRY(block_ffn(c, 0, l, es[0], st));
@@ -906,6 +970,8 @@ int ltx2_dit_create(const ltx2_dit_config* cfg, ltx2_dit** out) {
         a.Cout = cfg->audio_out_channels;
     }
     if (c->av) {
+        // (round 4: a high-priority side stream measured the same as the default priority, eager and under hipGraph; a LOW priority one 144 vs 105 ms
+        // eager -- the audio chain then starves behind the video GEMMs' queued tiles)
         const bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
         if (!ok) {
             ltx2_set_error("dit_create: side stream / event creation failed");
@@ -1047,6 +1113,60 @@ int ltx2_dit_graph_capture(ltx2_dit* c, float* latent, const float* host_sigmas,
         ModIn in[1] = {{latent, c->sigmas_dev + i, 1, c->sigmas_dev + i, nullptr}};
         const StepIo io[1] = {{latent, nullptr, nullptr, nullptr}};
         rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st, i == 0);
+    }
+    return end_capture(c, rc, st);
+}
+
+// Conditioned loops (image-to-video: some tokens carry a denoise mask < 1): per step the timesteps are mask * sigma_i, formed on the device
+// inside the captured step, and the Euler update blends x0 with the clean latent as ltx2_dit_denoise_step does.
+namespace {
+int cond_modality(ltx2_dit* c, int k, const float* mask, const float* clean, const float* sigma_i, ModIn& in, StepIo& io, hipStream_t st) {
+    Mod& m = c->m[k];
+    if (!mask) return LTX2_OK;           // this modality has no conditioning tokens: the uniform form
+    LTX2_CHECK_ARG(clean, "dit_graph_capture_cond: a denoise mask needs the clean latent");
+    if (!c->per_token || !m.ts_tok) {
+        ltx2_set_error("dit_graph_capture_cond: the workspace was not bound for per-token timesteps");
+        return LTX2_E_STATE;
+    }
+    hipLaunchKernelGGL(mask_sigma_kernel, dim3((m.N + 255) / 256), dim3(256), 0, st, mask, sigma_i, m.ts_tok, m.N);
+    LTX2_CHECK_LAUNCH("mask_sigma_kernel");
+    in.ts = m.ts_tok;
+    in.n_ts = m.N;
+    io.mask = mask;
+    io.clean = clean;
+    return LTX2_OK;
+}
+}  // namespace
+
+int ltx2_dit_graph_capture_cond(ltx2_dit* c, float* latent, const float* host_sigmas, int n_steps, const float* mask, const float* clean, void* stream) {
+    LTX2_CHECK_ARG(latent && host_sigmas && n_steps > 0 && n_steps < 64, "dit_graph_capture_cond: bad argument");
+    TRY(check_ready(c, "dit_graph_capture_cond", false));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(begin_capture(c, host_sigmas, n_steps, st));
+    int rc = LTX2_OK;
+    for (int i = 0; i < n_steps && rc == LTX2_OK; ++i) {
+        ModIn in[1] = {{latent, c->sigmas_dev + i, 1, c->sigmas_dev + i, nullptr}};
+        StepIo io[1] = {{latent, nullptr, nullptr, nullptr}};
+        rc = cond_modality(c, 0, mask, clean, c->sigmas_dev + i, in[0], io[0], st);
+        if (rc == LTX2_OK) rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st, i == 0);
+    }
+    return end_capture(c, rc, st);
+}
+
+int ltx2_dit_graph_capture_cond_av(ltx2_dit* c, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps, const float* v_mask,
+                                   const float* v_clean, const float* a_mask, const float* a_clean, void* stream) {
+    LTX2_CHECK_ARG(v_latent && a_latent && host_sigmas && n_steps > 0 && n_steps < 64, "dit_graph_capture_cond_av: bad argument");
+    TRY(check_ready(c, "dit_graph_capture_cond_av", true));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(begin_capture(c, host_sigmas, n_steps, st));
+    int rc = LTX2_OK;
+    for (int i = 0; i < n_steps && rc == LTX2_OK; ++i) {
+        const float* s = c->sigmas_dev + i;
+        ModIn in[2] = {{v_latent, s, 1, s, nullptr}, {a_latent, s, 1, s, nullptr}};
+        StepIo io[2] = {{v_latent, nullptr, nullptr, nullptr}, {a_latent, nullptr, nullptr, nullptr}};
+        rc = cond_modality(c, 0, v_mask, v_clean, s, in[0], io[0], st);
+        if (rc == LTX2_OK) rc = cond_modality(c, 1, a_mask, a_clean, s, in[1], io[1], st);
+        if (rc == LTX2_OK) rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st, i == 0);
     }
     return end_capture(c, rc, st);
 }

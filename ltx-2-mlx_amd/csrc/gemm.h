@@ -49,9 +49,6 @@ struct GemmParams {
 };
 
 int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream);
-// The 4-wave kernel's tile height: 224-row tiles when they need fewer CU-rounds x rows of work than 256-row tiles.  fp8 compute: the 224-row
-// form runs on the 16x16x128 block (layout 6), measured 6-10 % faster than the 32x32x64 block the 256-row form has to use, so it also wins ties
-// and near-ties (within 8 %).  One definition: the dispatch (gemm.hip), the launcher and the fused-V^T test (gemm_v4.hip) must agree.
 inline bool gemm_v4_prefer_224(const GemmParams& p) {
     const long nt = p.N / 256, cus = 256;
     const long t256 = ((long)(p.M + 255) / 256) * nt, t224 = ((long)(p.M + 223) / 224) * nt;

@@ -58,8 +58,10 @@ struct V4Geo {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+// One output tile (the whole kernel body); `bid` = this workgroup's block number.  Must be inlined exactly once per kernel: the K loop is an
+// asm block over physical registers.
 template <int EPI, int LAYOUT, int BM, bool CONV, int VAR>
-__global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid) {
     constexpr bool W8 = VAR == 20;          // fp8-resident weights: p.W8 codes [N][K] + p.wscale[N]
     constexpr bool F8 = LAYOUT == 5 || LAYOUT == 6;        // fp8 compute (5: 32x32x64 blocks, 6: 16x16x128 blocks): p.A8 codes [M][lda] + p.ascale[M], p.W8 codes [N][K] + p.wscale[N]
     using G = V4Geo<LAYOUT, BM, W8>;
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     // fp32 partial tile into slab `split` of p.out ([splitk][M][ldo] fp32); splitk_reduce_kernel adds the slabs
     const int Mt = (p.M + BM - 1) / BM, Nt = p.N / TBN;
     const int ntiles = Mt * Nt;
-    const int split = p.splitk > 1 ? (int)blockIdx.x / ntiles : 0;
-    const int id = xcd_remap((int)blockIdx.x - split * ntiles, ntiles);
+    const int split = p.splitk > 1 ? bid / ntiles : 0;
+    const int id = xcd_remap(bid - split * ntiles, ntiles);
     constexpr int GROUP = 8;
     const int per_group = GROUP * Nt;
     const int g = id / per_group;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
     }
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
-    if (p.dbg && blockIdx.x == 0 && tid == 0) {
+    if (p.dbg && bid == 0 && tid == 0) {
         ((unsigned long long*)p.dbg)[0] = t_loop1 - t_loop0;
         ((unsigned long long*)p.dbg)[2] = t_loop0 - t_k0;
     }
@@ -655,8 +657,13 @@ __global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
         }
     }
 #ifdef LTX2_V4_PROBE
-    if (p.dbg && blockIdx.x == 0 && tid == 0) ((unsigned long long*)p.dbg)[1] = __builtin_amdgcn_s_memtime() - t_k0;
+    if (p.dbg && bid == 0 && tid == 0) ((unsigned long long*)p.dbg)[1] = __builtin_amdgcn_s_memtime() - t_k0;
 #endif
+}
+
+template <int EPI, int LAYOUT, int BM, bool CONV, int VAR>
+__global__ __launch_bounds__(256) void gemm_v4_kernel(const GemmParams p) {
+    gemm_v4_tile<EPI, LAYOUT, BM, CONV, VAR>(p, (int)blockIdx.x);
 }
 
 template <int EPI, int LAYOUT, int BM, bool CONV = false, int VAR = 0>

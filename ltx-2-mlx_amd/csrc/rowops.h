@@ -13,6 +13,11 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
 // q8 / qscale (fp8 compute path): the row additionally (out may then be null: instead) leaves as per-token e4m3fn codes + scale,
 // quantised from the bf16-ROUNDED outputs exactly as quant_rows_fp8_launch would quantise `out`
 
+// out_g[row][:] = rms_norm(x[row][:]) * (1 + scale_tab[g] + scale_emb[g]) + shift_tab[g] + shift_emb[g] for g = 0, 1 (row-invariant tables; any
+// pointer may be null): two modulations of one normalised stream from ONE read of x (the AudioVideo block's cross-modal attention inputs)
+int norm_mod2_launch(const float* x, long ldx, bf16* out0, bf16* out1, long ldo, int rows, int D, float eps, const float* const* scale_tab,
+                     const float* const* shift_tab, const float* const* scale_emb, const float* const* shift_emb, hipStream_t stream);
+
 // In-place on bf16 rows: for each of nseg segments (q, k) at column offsets seg_off[i] of width D:
 //   y = x * rsqrt(mean(x^2) + eps) * weight_i ;  then (if cos != null) SPLIT RoPE per head:
 //   pairs (h*hd + j, h*hd + hd/2 + j) rotated with cos/sin[row][h*hd/2 + j].

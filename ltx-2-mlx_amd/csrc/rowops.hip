@@ -172,6 +172,63 @@ __global__ __launch_bounds__(256) void norm_mod_shared_kernel(const float* __res
     }
 }
 
+// Two modulations of ONE normalised row (row-invariant tables): out_g = norm(x) * (1 + scale_g) + shift_g, g = 0, 1.  The AudioVideo block's
+// cross-modal attention reads the SAME pre-update RMS-normalised stream twice (transformer.py:556-620: the a2v and the v2a scale / shift rows),
+// which two norm_mod launches re-read and re-reduced (round 4: one read of x, one reduction, two stores).
+struct NormMod2Tabs {
+    const float* scale_tab[2];
+    const float* shift_tab[2];
+    const float* scale_emb[2];
+    const float* shift_emb[2];
+};
+template <int NV>
+__global__ __launch_bounds__(256) void norm_mod_shared2_kernel(const float* __restrict__ x, long ldx, bf16* __restrict__ out0, bf16* __restrict__ out1,
+                                                               long ldo, int rows, int D, float eps, NormMod2Tabs t) {
+    __shared__ float red[8];
+    f32x4 sc1[2][NV], sh[2][NV];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int d = threadIdx.x * 4 + i * 1024;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, h = {0.f, 0.f, 0.f, 0.f};
+            if (d < D) {
+                if (t.scale_tab[g]) sc += *(const f32x4*)(t.scale_tab[g] + d);
+                if (t.scale_emb[g]) sc += *(const f32x4*)(t.scale_emb[g] + d);
+                if (t.shift_tab[g]) h += *(const f32x4*)(t.shift_tab[g] + d);
+                if (t.shift_emb[g]) h += *(const f32x4*)(t.shift_emb[g] + d);
+            }
+            sc1[g][i] = sc;
+            sh[g][i] = h;
+        }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* xr = x + row * ldx;
+        f32x4 v[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int d = threadIdx.x * 4 + i * 1024;
+            v[i] = (d < D) ? *(const f32x4*)(xr + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s2 += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+        block_sum2_256(s1, s2, red);
+        const float rstd = rsqrtf(s2 / (float)D + eps);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16* orow = (g ? out1 : out0) + row * ldo;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int d = threadIdx.x * 4 + i * 1024;
+                if (d >= D) continue;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(v[i][e] * rstd * sc1[g][i][e] + sh[g][i][e]);
+                *(bf16x4*)(orow + d) = o;
+            }
+        }
+    }
+}
+
 struct QKSegs {
     int off[2];
     const float* w[2];
@@ -284,8 +341,26 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16* __restrict
     const bf16* w0 = Wg + (long)min(r16, H - 1) * K + wv * kw + kq * 8;
     const bf16* w1 = Wg + (long)min(16 + r16, H - 1) * K + wv * kw + kq * 8;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // 216 blocks x 4 waves is 3.4 waves per CU: the kernel is bound by the bytes each wave keeps in flight, so a wave requests DEPTH
+    // k-steps (3 x 1 KiB each) before it consumes the first (round 4: DEPTH 4 ran the 28 MB of X at 1.4 TB/s, 20 us at 3456 x 4096)
+    constexpr int DEPTH = 16;
+    int k = 0;
+    for (; k + 32 * DEPTH <= kw; k += 32 * DEPTH) {
+        bf16x8 a[DEPTH], b0[DEPTH], b1[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            a[j] = *(const bf16x8*)(xp + k + 32 * j);
+            b0[j] = *(const bf16x8*)(w0 + k + 32 * j);
+            b1[j] = *(const bf16x8*)(w1 + k + 32 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            acc0 = LTX2_MFMA_16x16x32(a[j], b0[j], acc0, 0, 0, 0);
+            acc1 = LTX2_MFMA_16x16x32(a[j], b1[j], acc1, 0, 0, 0);
+        }
+    }
 #pragma unroll 4
-    for (int k = 0; k < kw; k += 32) {
+    for (; k < kw; k += 32) {
         const bf16x8 a = *(const bf16x8*)(xp + k);
         const bf16x8 b0 = *(const bf16x8*)(w0 + k);
         const bf16x8 b1 = *(const bf16x8*)(w1 + k);
@@ -809,6 +884,23 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
                            scale_tab, shift_tab, scale_emb, shift_emb, emb_stride, q8, ldq, qscale);
     }
     LTX2_CHECK_LAUNCH("norm_mod_kernel");
+    return LTX2_OK;
+}
+
+int norm_mod2_launch(const float* x, long ldx, bf16* out0, bf16* out1, long ldo, int rows, int D, float eps, const float* const* scale_tab,
+                     const float* const* shift_tab, const float* const* scale_emb, const float* const* shift_emb, hipStream_t stream) {
+    LTX2_CHECK_ARG(x && out0 && out1 && rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && D <= 4096, "norm_mod2: bad operand (D <= 4096, multiples of 4)");
+    NormMod2Tabs t{};
+    for (int g = 0; g < 2; ++g) {
+        t.scale_tab[g] = scale_tab[g];
+        t.shift_tab[g] = shift_tab[g];
+        t.scale_emb[g] = scale_emb[g];
+        t.shift_emb[g] = shift_emb[g];
+    }
+    const int per_block = (rows + 1023) / 1024;
+    const int grid = (rows + per_block - 1) / per_block;
+    hipLaunchKernelGGL((norm_mod_shared2_kernel<4>), dim3(grid), dim3(256), 0, stream, x, ldx, out0, out1, ldo, rows, D, eps, t);
+    LTX2_CHECK_LAUNCH("norm_mod_shared2_kernel");
     return LTX2_OK;
 }
 

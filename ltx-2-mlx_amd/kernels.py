@@ -69,6 +69,16 @@ def gemm_qkv_vt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     return out, vt, bool(fused.value)
 
 
+def adaln_rmsnorm2(x: torch.Tensor, scale0, shift0, scale1, shift1, eps: float = 1e-6, dtype: torch.dtype = BF16):
+    """(rms_norm(x) * (1 + scale0) + shift0, rms_norm(x) * (1 + scale1) + shift1) from one read of x [rows, D] fp32."""
+    x = _c(x.float())
+    o0 = torch.empty(x.shape, device=x.device, dtype=dtype)
+    o1 = torch.empty_like(o0)
+    nv.check(nv.lib(dtype).ltx2_adaln_rmsnorm2(nv.ptr(x), x.stride(0), nv.ptr(o0), nv.ptr(o1), o0.stride(0), x.shape[0], x.shape[1], eps,
+                                               nv.ptr(scale0), nv.ptr(shift0), nv.ptr(scale1), nv.ptr(shift1), nv.stream()))
+    return o0, o1
+
+
 def gemm_rowss(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None):
     """out = a @ w^T + bias (16-bit) plus the row partial sums of squares of out over 64-column strips -> (out, rowss [M, N/64] fp32 or None
     when the shape does not run on the kernel that writes them)."""
@@ -95,6 +105,19 @@ def flash_attn_rowscale(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, head
         scale = 1.0 / math.sqrt(float(hd))
     nv.check(_L(q).ltx2_flash_attn_rowscale(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out), out.stride(0), nq, nkv,
                                             heads, hd, scale, nv.ptr(q_ss), q_ss.shape[1], heads * hd, eps, nv.stream()))
+    return out
+
+
+def flash_attn_gated(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, gate_logits: torch.Tensor,
+                     scale: Optional[float] = None) -> torch.Tensor:
+    """flash_attn with per-head output gates 2*sigmoid(gate_logits[q, h]) applied in the epilogue (fp32, before the rounding)."""
+    assert q.dtype in ACT16 and gate_logits.dtype == torch.float32 and gate_logits.stride(1) == 1
+    nq, hd = q.shape[0], vt.shape[1]
+    out = torch.empty(nq, heads * hd, device=q.device, dtype=q.dtype)
+    if scale is None:
+        scale = 1.0 / math.sqrt(float(hd))
+    nv.check(_L(q).ltx2_flash_attn_gated(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out), out.stride(0), nq, nkv,
+                                         heads, hd, scale, nv.ptr(gate_logits), gate_logits.stride(0), nv.stream()))
     return out
 
 

@@ -180,6 +180,10 @@ class LTXModel:
                           cross_attention_adaln=cross_attention_adaln, apply_gated_attention=apply_gated_attention, device=device,
                           fp8_compute=fp8_compute, compute_dtype=compute_dtype)
 
+    def set_option(self, name: str, value: int) -> None:
+        """Engine option by name (ltx2_dit_set_option; include/ltx2hip.h lists them)."""
+        nv.check(self._L.ltx2_dit_set_option(self._h, name.encode(), int(value)))
+
     def _video_twin(self) -> "LTXModel":
         """The video half of this AudioVideo model as a VideoOnly engine: with no audio tokens the reference's blocks run only
         video self-attention, text cross-attention and the video feed-forward (transformer.py:479-483: run_ax and run_a2v are
@@ -357,19 +361,27 @@ class LTXModel:
         self._twin = None           # contexts over the OLD tensors: rebuilt on demand over the new ones
         self._clone = None
 
-    def init_random_weights(self, seed: int = 0, std: float = 0.02, fp8_resident: bool = False) -> None:
+    def init_random_weights(self, seed: int = 0, std: float = 0.02, fp8_resident: bool = False, fill: bool = True) -> None:
         """Synthetic N(0, std) weights generated directly in HBM in the engine's fused layout (bench /
         smoke; no checkpoints exist in this environment).  fp8_resident: the video stream's attention / feed-forward
-        projections are quantised to float8_e4m3fn + per-tensor scale and stay fp8 in HBM (BASELINE config 3)."""
+        projections are quantised to float8_e4m3fn + per-tensor scale and stay fp8 in HBM (BASELINE config 3).
+        fill=False: only ALLOCATE and register the tensors (same names, shapes, dtypes; contents undefined) -- a replica whose
+        weights arrive by the RCCL broadcast from rank 0 (bench.py ranks > 0) does not draw 26 GB of random numbers first."""
         fp8_resident = fp8_resident or self.fp8_compute
         g = torch.Generator(device=self.device).manual_seed(seed)
         fused_fp8 = re.compile(r"^transformer_blocks\.\d+\.(attn1|attn2)\.(to_qkv|to_q|to_kv|to_out\.0)\.weight$|^transformer_blocks\.\d+\.ff\.net\.(0\.proj|2)\.weight$")
 
         def rw(*shape):
+            if not fill:
+                return torch.empty(*shape, device=self.device, dtype=self.compute_dtype)
             return (torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32) * std).to(self.compute_dtype)
 
         def put_w(name, rows, cols):
             if fp8_resident and fused_fp8.match(name) and rows % 256 == 0 and cols % 128 == 0 and cols >= 256:
+                if not fill:
+                    self._register(name, torch.empty(rows, cols, device=self.device, dtype=torch.uint8))
+                    self._register(name + "_scale", torch.empty(rows, dtype=torch.float32, device=self.device))
+                    return
                 w = torch.randn(rows, cols, generator=g, device=self.device, dtype=torch.float32) * std
                 scale = float(w.abs().max() / 448.0)
                 self._register(name, (w / scale).to(torch.float8_e4m3fn).view(torch.uint8))
@@ -378,6 +390,8 @@ class LTXModel:
                 self._register(name, rw(rows, cols))
 
         def rf(*shape, scale=std, base=0.0):
+            if not fill:
+                return torch.empty(*shape, device=self.device, dtype=torch.float32)
             return base + scale * torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32)
 
         fuse = {}
@@ -608,17 +622,32 @@ class LTXModel:
                                                    nv.ptr(sg), nv.ptr(denoise_mask), nv.ptr(clean_latent), nv.ptr(audio_denoise_mask),
                                                    nv.ptr(audio_clean_latent), float(sigma), float(sigma_next), None, None, nv.stream()))
 
-    def capture_denoise_graph(self, latent: torch.Tensor, sigmas: Sequence[float], audio_latent: Optional[torch.Tensor] = None) -> None:
+    def capture_denoise_graph(self, latent: torch.Tensor, sigmas: Sequence[float], audio_latent: Optional[torch.Tensor] = None,
+                              denoise_mask: Optional[torch.Tensor] = None, clean_latent: Optional[torch.Tensor] = None,
+                              audio_denoise_mask: Optional[torch.Tensor] = None, audio_clean_latent: Optional[torch.Tensor] = None) -> None:
         """hipGraph-capture len(sigmas)-1 steps over `latent` (N, C fp32; plus the audio latent for
-        AudioVideo models), updated in place on replay."""
+        AudioVideo models), updated in place on replay.  denoise_mask (N,) fp32 + clean_latent (N, C) fp32 (per modality): the CONDITIONED
+        loop of image-to-video runs -- per-token timesteps mask * sigma_i and the x0 / clean blend inside every captured step
+        (ltx2_dit_graph_capture_cond; prepare(..., per_token=True) first).  The tensors must stay alive while the graph is replayed."""
         assert self._prep_key is not None, "call prepare() first"
         arr = (C.c_float * len(sigmas))(*[float(s) for s in sigmas])
         st = torch.cuda.current_stream()
         if st.cuda_stream == 0:
             raise RuntimeError("graph capture needs a non-default stream: use `with torch.cuda.stream(torch.cuda.Stream()):`")
+        cond = denoise_mask is not None or audio_denoise_mask is not None
+        for mk, cl in ((denoise_mask, clean_latent), (audio_denoise_mask, audio_clean_latent)):
+            if mk is not None:
+                assert cl is not None and mk.dtype == torch.float32 and cl.dtype == torch.float32 and mk.is_contiguous() and cl.is_contiguous() and mk.dim() == 1
+        self._graph_refs = (latent, audio_latent, denoise_mask, clean_latent, audio_denoise_mask, audio_clean_latent)
         if self.is_av:
             assert audio_latent is not None
-            nv.check(self._L.ltx2_dit_graph_capture_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), arr, len(sigmas) - 1, st.cuda_stream))
+            if cond:
+                nv.check(self._L.ltx2_dit_graph_capture_cond_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), arr, len(sigmas) - 1, nv.ptr(denoise_mask),
+                                                                nv.ptr(clean_latent), nv.ptr(audio_denoise_mask), nv.ptr(audio_clean_latent), st.cuda_stream))
+            else:
+                nv.check(self._L.ltx2_dit_graph_capture_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), arr, len(sigmas) - 1, st.cuda_stream))
+        elif cond:
+            nv.check(self._L.ltx2_dit_graph_capture_cond(self._h, nv.ptr(latent), arr, len(sigmas) - 1, nv.ptr(denoise_mask), nv.ptr(clean_latent), st.cuda_stream))
         else:
             nv.check(self._L.ltx2_dit_graph_capture(self._h, nv.ptr(latent), arr, len(sigmas) - 1, st.cuda_stream))
 

@@ -139,20 +139,27 @@ def joint_denoise_loop(transformer, is_av_model: bool, video_state: LatentState,
             raise ValueError("guidance needs the negative prompt's encoding(s)")
         from ..model.transformer import X0Model
         neg = X0Model(model.clone_sharing_weights())
-    if use_hip_graph and not (callback is None and uniform and not need_cfg):
-        _note_eager_once("a step callback" if callback is not None else "classifier-free guidance (two evaluations per step)" if need_cfg else
-                         "conditioning tokens (per-token timesteps)")
-    if use_hip_graph and callback is None and uniform and not need_cfg:
+    if use_hip_graph and not (callback is None and not need_cfg):
+        _note_eager_once("a step callback" if callback is not None else "classifier-free guidance (two evaluations per step)")
+    if use_hip_graph and callback is None and not need_cfg:
         lat = video_state.latent[0].float().contiguous()
         alat = audio_state.latent[0].float().contiguous() if joint else None
+        # conditioning tokens (image-to-video): the captured steps form timesteps = denoise_mask * sigma_i on the device and blend x0 with the
+        # clean latent (reference pipelines/common.py:193-232); a modality whose mask is all ones takes the uniform form
+        cond = {}
+        if not uniform:
+            for key, st_ in (("", video_state),) + ((("audio_", audio_state),) if joint else ()):
+                if not bool((st_.denoise_mask == 1).all()):
+                    cond[key + "denoise_mask"] = st_.denoise_mask[0].reshape(-1).float().contiguous()
+                    cond[key + "clean_latent"] = st_.clean_latent[0].float().contiguous()
         if joint:
-            model.prepare(video_context, video_state.positions, audio_context=audio_context, audio_positions=audio_state.positions)
+            model.prepare(video_context, video_state.positions, per_token=not uniform, audio_context=audio_context, audio_positions=audio_state.positions)
         else:
-            model.prepare(video_context, video_state.positions)
+            model.prepare(video_context, video_state.positions, per_token=not uniform)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            model.capture_denoise_graph(lat, sig, audio_latent=alat)
+            model.capture_denoise_graph(lat, sig, audio_latent=alat, **cond)
             model.replay_denoise_graph()
         torch.cuda.current_stream().wait_stream(side)
         model.check_health()            # host sync at the end of the loop: a stream-K hand-off that timed out raises here

@@ -772,3 +772,37 @@ def test_flash_attention_key_mask(dev, hd, H, Nq, S):
         assert rel_l2(out.double().cpu(), ref) < 6e-3, (tag, rel_l2(out.double().cpu(), ref))
     # an all-ones mask is the unmasked kernel up to the exponent's rounding
     assert rel_l2(KK.flash_attn_keymask(q, k, vt, H, S, masks["all"]).float().cpu(), KK.flash_attn(q, k, vt, H, S).float().cpu()) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------ round 4: the AudioVideo block's cross-modal section
+@pytest.mark.parametrize("rows,D", [(3456, 4096), (68, 2048), (5, 512)])
+def test_adaln_rmsnorm2_equals_two_passes(K, dev, rows, D):
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, D, generator=g).to(dev)
+    t = [(0.1 * torch.randn(D, generator=g)).to(dev) for _ in range(4)]
+    o0, o1 = K.adaln_rmsnorm2(x, t[0], t[1], t[2], t[3])
+    r0 = K.adaln_rmsnorm(x, 1e-6, False, t[0], t[1])
+    r1 = K.adaln_rmsnorm(x, 1e-6, False, t[2], t[3])
+    assert torch.equal(o0, r0) and torch.equal(o1, r1)
+    p0, p1 = K.adaln_rmsnorm2(x, None, None, t[2], None)
+    assert torch.equal(p0, K.adaln_rmsnorm(x)) and torch.equal(p1, K.adaln_rmsnorm(x, 1e-6, False, t[2], None))
+
+
+@pytest.mark.parametrize("heads,hd,Nq,Nkv", [(32, 128, 1100, 1024), (32, 64, 68, 3456), (4, 64, 300, 68)])
+def test_flash_attn_gated_epilogue(K, dev, heads, hd, Nq, Nkv):
+    """Per-head gates folded into the attention epilogue (round 4) against attention followed by the gating pass it replaces, and fp64."""
+    g = torch.Generator().manual_seed(Nq + Nkv)
+    D = heads * hd
+    qq = torch.randn(Nq, D, generator=g).to(BF).to(dev)
+    kk = torch.randn(Nkv, D, generator=g).to(BF).to(dev)
+    vv = torch.randn(Nkv, D, generator=g).to(BF).to(dev)
+    logits = (2.0 * torch.randn(Nq, heads, generator=g)).to(dev)
+    vt = K.vt_transpose(vv, heads, head_dim=hd)
+    plain = K.flash_attn(qq, kk, vt, heads, Nkv)
+    out = K.flash_attn_gated(qq, kk, vt, heads, Nkv, logits)
+    gate = (2 * torch.sigmoid(logits.double()))[..., None]
+    two_pass = (plain.double().reshape(Nq, heads, hd) * gate).reshape(Nq, D)
+    assert rel_l2(out.double().cpu(), two_pass.cpu()) < 4e-3
+    qh, kh, vh = [t.double().reshape(-1, heads, hd).transpose(0, 1) for t in (qq, kk, vv)]
+    exact = ((torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(hd), dim=-1) @ vh).transpose(0, 1) * gate).reshape(Nq, D)
+    assert rel_l2(out.double().cpu(), exact.cpu()) < 6e-3

@@ -80,6 +80,33 @@ def test_dit_per_token_timesteps(dev):
     assert rel_l2(a.cpu(), dit.x0_model(lat, ctx, uni, pos, w, cfg)) < 2e-2
 
 
+def test_conditioned_loop_through_the_hipgraph(dev):
+    """Image-to-video loops (some tokens conditioned: denoise mask < 1): the captured graph forms timesteps = mask * sigma_i on the device and
+    blends x0 with the clean latent inside every step (ltx2_dit_graph_capture_cond) -- against the eager loop of X0Model + post_process_latent +
+    EulerDiffusionStep calls (reference pipelines/common.py:193-232, distilled.py:214-253): the same kernels, so the same numbers."""
+    from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES, EulerDiffusionStep
+    from ltx_2_mlx_amd.model.transformer import X0Model
+    from ltx_2_mlx_amd.pipelines.common import joint_denoise_loop
+    from ltx_2_mlx_amd.types import LatentState
+    cfg, w, m = make_dit(dev, heads=2, layers=2, cap=128)
+    lat, ctx, pos = inputs(3, 4, 6, 64, 128)
+    N = lat.shape[1]
+    g = torch.Generator().manual_seed(21)
+    mask = torch.ones(1, N, 1)
+    mask[:, :24] = 0.0                       # the first latent frame is the conditioning image
+    mask[:, 24:30] = 0.05                    # a partially noised band
+    clean = torch.randn(1, N, 128, generator=g)
+    outs = []
+    for graph in (False, True):
+        st = LatentState(latent=lat.clone().to(dev), denoise_mask=mask.to(dev), positions=pos.to(dev), clean_latent=clean.to(dev))
+        vs, _ = joint_denoise_loop(X0Model(m), False, st, None, DISTILLED_SIGMA_VALUES, ctx.to(dev), None, EulerDiffusionStep(), use_hip_graph=graph)
+        outs.append(vs.latent.float().cpu())
+    assert torch.isfinite(outs[1]).all()
+    assert rel_l2(outs[1], outs[0]) < 1e-5
+    # the conditioned tokens end at their clean values, the free ones moved
+    assert rel_l2(outs[1][:, :24], clean[:, :24]) < 1e-5 and rel_l2(outs[1][:, 30:], lat[:, 30:]) > 0.1
+
+
 def test_dit_full_width_block(dev):
     """Full-width (D=4096, 32 heads, caption 3840) single block at N=288, S=128."""
     from oracle import dit
