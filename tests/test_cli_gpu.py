@@ -49,24 +49,28 @@ def test_generate_cli_plumbing(dev, tmp_path):
     assert os.path.exists(tmp_path / "a.mp4") or len(os.listdir(tmp_path / "a_frames")) == 17
 
 
-def test_bench_two_rank_rehearsal(dev):
+@pytest.mark.parametrize("world,bcast", [(2, "ring"), (8, "scatter")])
+def test_bench_multi_rank_rehearsal(dev, world, bcast):
     """The N > 1 path of bench.py (torchrun env, weight broadcast, barrier-bracketed timing, MAX over ranks, rank-0
-    JSON line) with two ranks sharing this box's single GPU over gloo -- what the driver launches with one rank per
-    GPU over RCCL."""
+    JSON line) with `world` ranks sharing this box's single GPU over gloo -- what the driver launches with one rank per
+    GPU over RCCL.  world = 8 is the dry run of the 8-GPU line (rendezvous, 8-way sharding of prompts / seeds, JSON gathering, the
+    scatter + all-gather form of the weight broadcast); every rank but 0 only ALLOCATES its weights, so `weights_identical` proves the broadcast."""
     import json
     import subprocess
-    env = dict(os.environ, LTX2_DIST_BACKEND="gloo", LTX2_LOCAL_DEVICE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "1", "--layers", "2",
-           "--no-vae", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    env = dict(os.environ, LTX2_DIST_BACKEND="gloo", LTX2_LOCAL_DEVICE="0", LTX2_BCAST=bcast)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29533 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "8", "--warmup", "1", "--layers", "2",
+           "--no-vae", "--no-cpu-baseline", "--no-power"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 only
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 8 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["weight_broadcast_collectives"] >= 1 and out["rccl_ranks"] == 2 and out["weight_broadcast_gbps"] > 0
-    assert abs(out["value"] - 2 * 8 / (out["ms_per_step"] * 8e-3)) < 1e-2 * out["value"]
+    assert out["n_gpus"] == world and out["steps"] == 8 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["weight_broadcast_collectives"] >= 1 and out["rccl_ranks"] == world and out["weight_broadcast_gbps"] > 0
+    assert out["weight_broadcast_mode"] == bcast and out["weights_identical"] is True
+    assert len(out["per_rank_ms_per_step"]["all"]) == world
+    assert abs(out["value"] - world * 8 / (out["ms_per_step"] * 8e-3)) < 1e-2 * out["value"]
 
 
 def test_bench_self_launch(dev):

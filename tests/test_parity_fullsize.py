@@ -265,8 +265,9 @@ def test_fp8_compute_trajectory_and_outlier_channels(dev):
     full-width model through the hipGraph against the fp32 oracle's loop -- the per-step error feeds the next step through the Euler update;
     (ii) the same with OUTLIER input channels (x20 on 0.1 % of the input channels of every attention / feed-forward projection, the case a
     per-token activation scale + per-output-channel weight scale handles worst: the outlier sets the scale of its whole row).  The bf16 engine
-    runs the same two trajectories as the yardstick.  Bars: end-of-trajectory Pearson > 0.99 / rel-L2 < 0.15 (the reference's own acceptance
-    bar against upstream is Pearson >= 0.95 for ONE forward, reference tests/test_parity.py:38)."""
+    runs the same two trajectories as the yardstick.  Bars: the fp8 mode's single-forward bars hold for the END of the trajectory too (rel-L2 < 0.10,
+    Pearson > 0.995; measured on MI355X: 0.057 / 0.9984 and, with the outlier channels, 0.062 / 0.9981; bf16: 0.0022 / 1.0000 both times --
+    the reference's own acceptance bar against upstream is Pearson >= 0.95 for ONE forward, reference tests/test_parity.py:38)."""
     import re
     from oracle import dit, loop
     from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES
@@ -309,7 +310,7 @@ def test_fp8_compute_trajectory_and_outlier_channels(dev):
         print(f"8-step trajectory, 48 layers, outlier channels {outliers}: bf16 rel-L2 {res[False][0]:.4f} Pearson {res[False][1]:.5f} | "
               f"fp8 compute rel-L2 {res[True][0]:.4f} Pearson {res[True][1]:.5f}")
         assert res[False][0] < 3e-2 and res[False][1] > 0.999, res
-        assert res[True][0] < 0.15 and res[True][1] > 0.99, res
+        assert res[True][0] < FP8_COMPUTE_REL_L2 and res[True][1] > FP8_COMPUTE_PEARSON, res
         del w
         torch.cuda.empty_cache()
 
