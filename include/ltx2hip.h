@@ -224,6 +224,14 @@ int ltx2_flash_attn_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, c
 int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const void* gate_w, const float* gate_b,
                         float* logits, int rows, int Dq, int H, int head_dim, void* stream);
 
+/* ltx2_flash_attn / ltx2_flash_attn_rowscale (q_ss != NULL) on a NAMED kernel form (round 4; tests and same-box timing): form 1 = 32 query rows per
+ * wave, two workgroups per CU (what the launcher uses); form 2 = the 64-rows-per-wave experiment (two 32-row blocks sharing every K / V^T fragment,
+ * one workgroup per CU; head_dim 128, no q_ss -- measured slower, never picked: profiles/r04_attn_64row_negative.md); form 2 + flags = its
+ * timing-experiment builds (1: no exponentials, 16: no row maximum; wrong results by construction); form 0 = what the launcher would pick.
+ * Forms 1 and 2 agree to the bf16 rounding of the pre-scaled Q.                                                                              */
+int ltx2_flash_attn_form(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
+                         int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, int form, void* stream);
+
 /* ltx2_flash_attn with the per-head gates applied in the kernel's epilogue (round 4: the engine's form -- the gate multiplies the fp32 result
  * before it is rounded, instead of a pass over the rounded output): out[q, h*hd:(h+1)*hd] = 2*sigmoid(gate_logits[q*gate_ld + h]) * attention. */
 int ltx2_flash_attn_gated(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
