@@ -39,7 +39,9 @@ extern "C" {
 /* Version of THIS header's signatures.  ltx2_abi_version() returns the version the library was built with; a caller compares the
  * two before its first compute call (the Python binding refuses to load a library that reports another version).  History:
  * 1 = round 1;  2 = round 2 added the `sigma` / `sigma_dev` argument to ltx2_dit_forward / ltx2_dit_denoise_step (in the middle of
- * the list: an old caller's arguments would shift silently), round 3 added ltx2_dit_health. */
+ * the list: an old caller's arguments would shift silently), round 3 added ltx2_dit_health; round 4 added entry points only
+ * (ltx2_clear_error, ltx2_adaln_rmsnorm2, ltx2_flash_attn_gated, ltx2_flash_attn_form, ltx2_dit_graph_capture_cond[_av], the
+ * "av_side_priority" option): no existing signature changed, the version stays 2. */
 #define LTX2_ABI_VERSION 2
 
 const char* ltx2_last_error(void);
