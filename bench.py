@@ -413,10 +413,11 @@ def main():
 
     # The hot path has two launch forms of the SAME kernels: K calls of the fused step (ltx2_dit_denoise_step: what the pipelines run with a per-step
     # callback or guidance) and the replay of the captured 8-step hipGraph (pipelines/common.py use_hip_graph=True: one call per 8 steps).  Both are
-    # timed over exactly K steps under the same barrier + synchronize contract (the graph form when K is a multiple of 8 and neither --eager nor
-    # --no-graph is given); `value` is the faster of the two on this box and `timed_with` names it -- on ROCm 7.2 a replayed graph of ~600 large
-    # kernels per step runs 0-2 % SLOWER than the in-order stream (every node edge is a barrier packet), while the two-stream AudioVideo step is
-    # faster as a graph; which form wins depends on the box.  Both figures are on the line (eager_ms_per_step / hipgraph_ms_per_step).
+    # timed over exactly K steps under the same barrier + synchronize contract, the in-order form first (the graph form when K is a multiple of 8 and
+    # neither --eager nor --no-graph is given); `value` is the faster of the two and `timed_with` names it.  Measured in round 4: the two forms are
+    # within +-0.3 % of each other, and whichever is timed SECOND reads ~1 % faster (three boxes, both orders: the socket's power management is still
+    # settling during the first timed region after the set-up work), so the pick is usually the graph.  Both figures are on the line
+    # (eager_ms_per_step / hipgraph_ms_per_step).
     use_graph = (K % 8 == 0) and not args.eager and not args.no_graph
     side = torch.cuda.Stream()
 
