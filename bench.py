@@ -414,9 +414,9 @@ def main():
     # The hot path has two launch forms of the SAME kernels: K calls of the fused step (ltx2_dit_denoise_step: what the pipelines run with a per-step
     # callback or guidance) and the replay of the captured 8-step hipGraph (pipelines/common.py use_hip_graph=True: one call per 8 steps).  Both are
     # timed over exactly K steps under the same barrier + synchronize contract, the in-order form first (the graph form when K is a multiple of 8 and
-    # neither --eager nor --no-graph is given); `value` is the faster of the two and `timed_with` names it.  Measured in round 4: the two forms are
-    # within +-0.3 % of each other, and whichever is timed SECOND reads ~1 % faster (three boxes, both orders: the socket's power management is still
-    # settling during the first timed region after the set-up work), so the pick is usually the graph.  Both figures are on the line
+    # neither --eager nor --no-graph is given); `value` is the faster of the two and `timed_with` names it.  Measured in round 4: with the warm-up
+    # steps directly in front of the timed regions the two forms are within 0.4 % of each other (76.24 / 76.55, 76.30 / 76.56 ms per step); a timed
+    # region that directly followed the capture's idle time read 1.0-1.7 % slow whichever form it held.  Both figures are on the line
     # (eager_ms_per_step / hipgraph_ms_per_step).
     use_graph = (K % 8 == 0) and not args.eager and not args.no_graph
     side = torch.cuda.Stream()
@@ -436,7 +436,9 @@ def main():
         D.barrier()
         return mine, D.max_over_ranks(time.perf_counter() - t0, dev)
 
-    run_steps(W)
+    # set-up first (one eager step so every lazily sized buffer exists, then the capture), the W warm-up steps LAST: the timed region starts on a socket
+    # that has just been running the same kernels (a timed region that follows the capture's idle time directly reads ~1 % slow)
+    run_steps(1)
     torch.cuda.synchronize()
     graph_err = None
     if use_graph or not args.no_graph:
@@ -449,6 +451,8 @@ def main():
             side.synchronize()
         except Exception as e:  # noqa: BLE001
             graph_err, use_graph = f"failed: {e}", False
+    run_steps(W)
+    torch.cuda.synchronize()
 
     # ---------------- timed regions: exactly K steps each, nothing else on the stream ----------------
     dt_rank_e, dt_e = timed(run_steps, K)
