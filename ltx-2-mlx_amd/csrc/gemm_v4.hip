@@ -5,6 +5,8 @@
 //   3  BN 256, 1x4 waves, 16x16x32: 14|16 x 4 blocks of 16 (BM 224|256; balanced for 224 rows) -- the DiT default
 //   4  BN 128, 4x1 waves, 16x16x32: wave w owns rows [BM/4 w, +BM/4) x all 128 columns, 7|8 x 8 blocks (BM 448|512) -- the
 //      VAE decoder's 128-channel convs
+//   7  (round 4) BN 64, 4x1 waves, 16x16x32: 8 x 4 blocks per wave (BM 512), conv only, N <= 64 with the columns past N masked -- the VAE
+//      decoder's conv_out (128 -> 48 channels)
 //   5  fp8 COMPUTE (round 3, BASELINE config 3): BOTH operands e4m3fn codes, K-tile = 128 elements (the same 128-byte LDS rows, swizzle
 //      and DMA schedule as 64 bf16), 1x4 waves, v_mfma_f32_32x32x64_f8f6f4 (fp8 x fp8 at twice the bf16 rate): 7|8 x 2 blocks of 32;
 //      the per-row activation scale and the per-column weight scale multiply the accumulators in the epilogue
@@ -38,22 +40,23 @@ typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 
 template <int LAYOUT, int BM, bool W8 = false>
 struct V4Geo {
-    static constexpr int BN = LAYOUT == 4 ? 128 : 256;
-    static_assert(LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5 || LAYOUT == 6, "wave layout");
+    static constexpr bool L41 = LAYOUT == 4 || LAYOUT == 7;        // 4x1 waves: wave w owns rows [BM/4 w, +BM/4) x all BN columns
+    static constexpr int BN = LAYOUT == 4 ? 128 : LAYOUT == 7 ? 64 : 256;
+    static_assert(LAYOUT == 3 || LAYOUT == 4 || LAYOUT == 5 || LAYOUT == 6 || LAYOUT == 7, "wave layout");
     static constexpr int MB = LAYOUT == 5 ? 32 : 16;               // MFMA block
-    static constexpr bool L14 = LAYOUT != 4;                       // 1x4 waves (layout 4: 4x1)
-    static constexpr int WM = LAYOUT == 4 ? BM / 4 : BM;
+    static constexpr bool L14 = !L41;                              // 1x4 waves
+    static constexpr int WM = L41 ? BM / 4 : BM;
     static constexpr int WN = LAYOUT == 4 ? 128 : 64;
     static constexpr int RBW = (WM + MB - 1) / MB, CBW = WN / MB;  // blocks per wave (first wave row)
     static constexpr int NKS = MB == 16 ? 2 : 4;
     static constexpr int WROW = W8 ? 64 : 128;                     // bytes of one weight row per K-tile (fp8 codes / bf16)
     static constexpr int NPA = BM / 32, NPW = BN * WROW / 4096;    // 1-KiB LDS-DMA pieces per wave and K-tile
-    static constexpr int A_STAGE = LAYOUT == 4 ? BM * 128 : 32768, W_BASE = 2 * A_STAGE, W_STAGE = BN * WROW;
+    static constexpr int A_STAGE = L41 ? BM * 128 : 32768, W_BASE = 2 * A_STAGE, W_STAGE = BN * WROW;
     static_assert(!W8 || LAYOUT == 3, "fp8-resident weights run on layout 3");
     static constexpr int LOOP_BYTES = W_BASE + 2 * W_STAGE;
     static constexpr int EPI_BYTES = 4 * WM * WN * 2;      // bf16 outputs leave through LDS (per-wave slabs)
     static constexpr int LDS_BYTES = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
-    static_assert(LAYOUT == 4 ? (BM == 384 || BM == 448 || BM == 512) : (BM == 224 || BM == 256), "tile rows");
+    static_assert(LAYOUT == 4 ? (BM == 384 || BM == 448 || BM == 512) : LAYOUT == 7 ? BM == 512 : (BM == 224 || BM == 256), "tile rows");
     static_assert(LAYOUT != 6 || BM == 224, "layout 6 tile rows");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -72,7 +75,7 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = LAYOUT == 4 ? w : 0, wc = LAYOUT == 4 ? 0 : w;
+    const int wr = G::L41 ? w : 0, wc = G::L41 ? 0 : w;
 #ifdef LTX2_V4_PROBE
     const unsigned long long t_k0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -80,7 +83,7 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // ---- block -> tile (XCD-contiguous, grouped row-tiles; as gemm_pp.hip) ----
     // split-K (p.splitk > 1): blockIdx = split * tiles + tile; this block accumulates K-tiles [split * nk, +nk) and writes an
     // fp32 partial tile into slab `split` of p.out ([splitk][M][ldo] fp32); splitk_reduce_kernel adds the slabs
-    const int Mt = (p.M + BM - 1) / BM, Nt = p.N / TBN;
+    const int Mt = (p.M + BM - 1) / BM, Nt = LAYOUT == 7 ? 1 : p.N / TBN;        // (layout 7: ONE column tile, N <= 64, columns >= N masked)
     const int ntiles = Mt * Nt;
     const int split = p.splitk > 1 ? bid / ntiles : 0;
     const int id = xcd_remap(bid - split * ntiles, ntiles);
@@ -125,7 +128,8 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
         } else {
             const int r = (w * NPW + j) * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-            voffB[j] = (unsigned)(n0 + r) * (unsigned)(p.K * (F8 ? 1 : 2)) + chunk * 16;
+            const int wrow = LAYOUT == 7 ? min(n0 + r, p.N - 1) : n0 + r;      // (layout 7: weight rows past N repeat the last one; their columns are never stored)
+            voffB[j] = (unsigned)wrow * (unsigned)(p.K * (F8 ? 1 : 2)) + chunk * 16;
         }
     }
     // ---- fragment read addresses (first block of the wave): row lr, 16-byte chunk (kchunk(ks) + kq) ^ ((row >> 1) & 7) ----
@@ -188,7 +192,8 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
         for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq)
-                bias4[cb][gq] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bias4[cb][gq] = (p.bias && (LAYOUT != 7 || n0 + wc * WN + cb * MB + 8 * gq + 4 * kq < p.N)) ? *(const f32x4*)(p.bias + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq)
+                                                                                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto load_gate = [&]() __attribute__((always_inline)) {       // (the gated-residual kernel has no room to carry these across the loop too)
 #pragma unroll
@@ -255,7 +260,8 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
             if constexpr (BM == 224) V4_ASM_CONV(LTX2_V4_L14_M16_RB14_CONV);
             else V4_ASM_CONV(LTX2_V4_L14_M16_RB16_CONV);
         } else {
-            if constexpr (BM == 384) V4_ASM_CONV(LTX2_V4_L41_M16_RB6_CONV);
+            if constexpr (LAYOUT == 7) V4_ASM_CONV(LTX2_V4_L41N_M16_RB8_CONV);
+            else if constexpr (BM == 384) V4_ASM_CONV(LTX2_V4_L41_M16_RB6_CONV);
             else if constexpr (BM == 448) V4_ASM_CONV(LTX2_V4_L41_M16_RB7_CONV);
             else V4_ASM_CONV(LTX2_V4_L41_M16_RB8_CONV);
         }
@@ -576,7 +582,7 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
                 }
                 const u32x4 v = rbv[it % RBATCH];
                 const int row = m0 + wr * WM + r;
-                if (row < p.M) *(u32x4*)((bf16*)p.out + (long)row * p.ldo + n0 + wc * WN + c * 8) = v;
+                if (row < p.M && (LAYOUT != 7 || n0 + wc * WN + c * 8 < p.N)) *(u32x4*)((bf16*)p.out + (long)row * p.ldo + n0 + wc * WN + c * 8) = v;
                 if constexpr (EPI == EPI_BF16 && !CONV && (LAYOUT == 3 || LAYOUT == 5 || LAYOUT == 6)) {
                     if (p.rowss) {      // (block-uniform) squared norm of this wave's 64-column strip of the row, from the ROUNDED values
                         const bf16x8 h = as_bf16x8(v);
@@ -677,7 +683,7 @@ int launch_v4(const GemmParams& p, hipStream_t stream) {
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }
-    const int Mt = (p.M + BM - 1) / BM, Nt = p.N / G::BN;
+    const int Mt = (p.M + BM - 1) / BM, Nt = LAYOUT == 7 ? 1 : p.N / G::BN;
     hipLaunchKernelGGL((gemm_v4_kernel<EPI, LAYOUT, BM, CONV, VAR>), dim3(Mt * Nt * (p.splitk > 1 ? p.splitk : 1)), dim3(256), LDS, stream, p);
     LTX2_CHECK_LAUNCH("gemm_v4_kernel");
     return LTX2_OK;
@@ -818,7 +824,12 @@ bool gemm_v4_conv_supported(const GemmParams& p, int epilogue) {
     if (epilogue != EPI_BF16 && epilogue != EPI_ADD_BF16 && epilogue != EPI_D2S_BF16) return false;
     // depth-to-space scatter: layout 3 only; a wave's 64 columns share the sub-position (Cf >= 64, a power of two); the residual comes from p.res
     if (epilogue == EPI_D2S_BF16 && (p.N % 256 != 0 || p.Cf < 64 || (p.Cf & (p.Cf - 1)) || (p.d2s_residual && (!p.res || p.c_d2s < 1 || (p.c_d2s & (p.c_d2s - 1)))))) return false;
-    if (p.Cin < 128 || (p.Cin & (p.Cin - 1)) || p.N % 128 != 0) return false;          // an even number of K-tiles: 27 * Cin / 64
+#ifdef LTX2_NO_CONV7        // (same-box A/B builds: tools/ab_build.py noconv7 gemm_v4.hip=-DLTX2_NO_CONV7)
+    const bool narrow = false;
+#else
+    const bool narrow = epilogue == EPI_BF16 && p.N <= 64 && p.N % 8 == 0 && p.N >= 8 && p.ldo == p.N;      // layout 7: one masked 64-column tile
+#endif
+    if (p.Cin < 128 || (p.Cin & (p.Cin - 1)) || (p.N % 128 != 0 && !narrow)) return false;          // an even number of K-tiles: 27 * Cin / 64
     if (p.taps_t != 3 && p.taps_t != 1) return false;
     if (p.M < 512) return false;
     if ((long)(p.T + 2) * (p.H + 2) * (p.Wd + 2) * p.Cin * 2 >= (1L << 31) || (long)p.N * p.K * 2 >= (1L << 31)) return false;
@@ -851,6 +862,7 @@ int gemm_v4_conv_launch(const GemmParams& p_in, int epilogue, hipStream_t stream
     GemmParams p = p_in;
     LTX2_CHECK_ARG(gemm_v4_conv_supported(p, epilogue), "gemm_v4 conv: unsupported problem (Cin=%d N=%d M=%d epilogue=%d)", p.Cin, p.N, p.M, epilogue);
     p.splitk = 1;
+    if (p.N <= 64) return launch_v4<EPI_BF16, 7, 512, true>(p, stream);
     if (p.N % 256 != 0) {
         // 128-channel outputs: BM x 128 tiles, BM in {512, 448, 384} by whole rounds of the 256 CUs x rows per round (the last round of a
         // 512-row grid is often nearly empty: 49 x 128 x 192 positions = 2352 tiles = 9.2 rounds; 448 rows: 10.5 -> 11 x 448 < 10 x 512).

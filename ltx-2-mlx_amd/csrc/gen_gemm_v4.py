@@ -637,6 +637,9 @@ def main():
         out.append(variant("LTX2_V4_L41_M16_RB8" + sfx, 8, 8, mb=16, npa=16, npw=4, a_stage=65536, w_base=131072, w_stage=16384,
                            dma_last=list(range(0, 60, 3)), dma_ks0=[], m0_early=True, conv=conv))
         if conv:
+            # round 4, layout 7: BN = 64, 4x1 waves, 8 x 4 blocks per wave (tile 512 x 64): the decoder's conv_out (128 -> 48 channels)
+            out.append(variant("LTX2_V4_L41N_M16_RB8" + sfx, 8, 4, mb=16, npa=16, npw=2, a_stage=65536, w_base=131072, w_stage=8192,
+                               dma_last=list(range(0, 30, 2)) + [29, 30, 31], dma_ks0=[], m0_early=True, conv=conv))
             # a 384-row tile for grids whose 448 / 512-row forms end in a nearly empty round (gemm_v4_conv_launch picks by whole rounds)
             out.append(variant("LTX2_V4_L41_M16_RB6" + sfx, 6, 8, mb=16, npa=12, npw=4, a_stage=49152, w_base=98304, w_stage=16384,
                                dma_last=list(range(0, 48, 3)), dma_ks0=[], m0_early=True, conv=conv))

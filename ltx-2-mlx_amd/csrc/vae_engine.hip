@@ -372,13 +372,20 @@ int ltx2_vae_decode(ltx2_vae* c, const float* latent, int T, int H, int W, float
         TRY(gemv_launch(te_h, hid, w2, b2, te, 2L * ch, 1, 2 * ch, (int)hid, 0, 0, st));
         ltep = te;
     }
-    TRY(pixnorm_mod_silu_launch(X, Y, P, ch, eps, ltab, ltep, 0, 1, st));
     {
         const bf16* w = W_BF16("vae.decoder.conv_out.conv.weight", 48L * 27 * ch);
         NEED(w);
         const float* b = W_F32("vae.decoder.conv_out.conv.bias", 48);
         NEED(b);
-        TRY(conv(Y, w, b, Z, T, H, W, ch, 48, causal, EPI_BF16, nullptr, 1, 1, 1, 0, st));
+        if (conv_on_v4(T, H, W, ch, 48, EPI_BF16, Z)) {
+            // round 4: conv_out on the asm-loop kernel too (layout 7: one 512 x 64 tile column, the 16 columns past Cout = 48 masked); the
+            // pixel norm writes the padded volume as for the res-block convs
+            TRY(pixnorm_mod_silu_padded_launch(X, Y, T, H, W, ch, eps, ltab, ltep, 0, 1, causal ? 2 : 1, st));
+            TRY(gemm_v4_conv_launch(conv_params(Y, w, b, Z, T, H, W, ch, 48, causal, nullptr), EPI_BF16, st, skws, SPLITK_WS_BYTES));
+        } else {
+            TRY(pixnorm_mod_silu_launch(X, Y, P, ch, eps, ltab, ltep, 0, 1, st));
+            TRY(conv(Y, w, b, Z, T, H, W, ch, 48, causal, EPI_BF16, nullptr, 1, 1, 1, 0, st));
+        }
     }
     TRY(vae_unpatchify_launch(Z, video, T, H, W, st));
 #undef W_BF16
