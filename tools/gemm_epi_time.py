@@ -18,8 +18,13 @@ for (M, N, Kk) in [(3456, 4096, 4096), (3456, 4096, 16384)]:
     b = torch.randn(N, device=dev)
     ob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     x = torch.zeros(M, N, device=dev)
-    gate = torch.randn(1, N, device=dev)
+    gate = 0.01 * torch.randn(1, N, device=dev)      # small: x += gate * (.) over the timing loop stays finite (the socket is power-limited: saturated operands run faster)
     t0 = timeit(lambda: K.gemm(a, w, b, out=ob))
+    x.zero_()
     t1 = timeit(lambda: K.gemm(a, w, b, epilogue=nv.EPI_RESID_GATE_F32, out=x, gate_table=gate[0]))
     t2 = timeit(lambda: K.gemm(a, w, b, epilogue=nv.EPI_F32, out=x))
-    print(f"M={M} N={N} K={Kk}: bf16 out {t0:7.1f} us | f32 out {t2:7.1f} us | gated fp32 residual {t1:7.1f} us")
+    x.zero_()
+    t3 = timeit(lambda: K.gemm(a, w, b, epilogue=nv.EPI_RESID_GATE_F32, out=x, gate=gate, gate_table=gate[0]))
+    x.zero_()
+    t1b = timeit(lambda: K.gemm(a, w, b, epilogue=nv.EPI_RESID_GATE_F32, out=x, gate_table=gate[0]))      # table + a row-invariant gate row read per row (the engine's shared-AdaLN call before round 4)
+    print(f"M={M} N={N} K={Kk}: bf16 out {t0:7.1f} us | f32 out {t2:7.1f} us | gated fp32 residual, table only {t1:7.1f} us | table + stride-0 gate row {t3:7.1f} us | table only again {t1b:7.1f} us")
