@@ -41,7 +41,7 @@ extern "C" {
  * 1 = round 1;  2 = round 2 added the `sigma` / `sigma_dev` argument to ltx2_dit_forward / ltx2_dit_denoise_step (in the middle of
  * the list: an old caller's arguments would shift silently), round 3 added ltx2_dit_health; round 4 added entry points only
  * (ltx2_clear_error, ltx2_adaln_rmsnorm2, ltx2_flash_attn_gated, ltx2_flash_attn_form, ltx2_dit_graph_capture_cond[_av], the
- * "av_side_priority" option): no existing signature changed, the version stays 2. */
+ * "adaln_combine" option): no existing signature changed, the version stays 2. */
 #define LTX2_ABI_VERSION 2
 
 const char* ltx2_last_error(void);
@@ -395,11 +395,13 @@ int ltx2_dit_graph_launch(ltx2_dit* ctx, void* stream);
  * (binding clears it).  Every pipeline of the reference passes context_mask = None (pipelines/common.py:223-232).                  */
 int ltx2_dit_set_context_mask(ltx2_dit* ctx, int modality, const float* mask, int S, void* stream);
 
-/* Engine options, by name (set before ltx2_dit_bind_workspace; unknown names -> LTX2_E_INVALID):
- *   "fp8_compute" = 1: every linear of the VIDEO stream whose weight is registered fp8-resident (LTX2_DTYPE_FP8_E4M3FN codes +
+/* Engine options, by name (unknown names -> LTX2_E_INVALID):
+ *   "fp8_compute" = 1 (before ltx2_dit_bind_workspace): every linear of the VIDEO stream whose weight is registered fp8-resident (LTX2_DTYPE_FP8_E4M3FN codes +
  *   `<name>_scale`) and whose GEMM has M >= 1024 rows runs as ltx2_gemm_fp8 on activations quantised per token
  *   (ltx2_quantize_rows_fp8).  Default 0: fp8-resident weights are expanded to bf16 inside the GEMM (bit-identical to the
- *   reference's dequantise-at-load).                                                                                    */
+ *   reference's dequantise-at-load).
+ *   "adaln_combine" = 0 (any time): tables and timestep embeddings reach every kernel separately, as in round 3.  Default 1: with one
+ *   timestep per modality the sums of all layers are formed by one launch at the top of the step (bit-identical results).              */
 int ltx2_dit_set_option(ltx2_dit* ctx, const char* name, int value);
 
 

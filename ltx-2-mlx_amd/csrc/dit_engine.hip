@@ -70,13 +70,14 @@ struct Mod {        // per-modality geometry + workspace
     int D = 0, H = 0, hd = 0, Cin = 0, Cout = 0;
     int N = 0, Npad = 0, S = 0, Spad = 0;
     float *x = nullptr, *sin_f = nullptr, *e1_f = nullptr, *e_f = nullptr, *emb = nullptr, *vel = nullptr, *x0 = nullptr,
-          *cosb = nullptr, *sinb = nullptr, *ccos = nullptr, *csin = nullptr, *aux_e = nullptr, *prompt_emb = nullptr,
+          *cosb = nullptr, *sinb = nullptr, *ccos = nullptr, *csin = nullptr, *aux_e = nullptr, *prompt_emb = nullptr, *sst_all = nullptr, *comb = nullptr,
           *cross_ss = nullptr, *cross_gate = nullptr, *glog = nullptr;
     bf16 *lat = nullptr, *h = nullptr, *h2 = nullptr, *qkv = nullptr, *vt = nullptr, *att = nullptr, *ff = nullptr,
          *sin_b = nullptr, *e1_b = nullptr, *es_b = nullptr, *ctx_in = nullptr, *c1 = nullptr, *ctxp = nullptr,
          *ctxm = nullptr, *kv2 = nullptr, *vt2 = nullptr;
     const bf16* ctx = nullptr;      // projected text context (ctxp or ctx_in)
     unsigned long long* kmask = nullptr;   // text cross-attention key mask as 64-bit words (Modality.context_mask); used when has_kmask
+    bool use_comb = false;             // this forward reads the combined AdaLN rows (comb) instead of (sst, emb)
     bool has_kmask = false;
     float* ts_tok = nullptr;        // per-token timesteps of a captured conditioned step: denoise_mask * sigma, formed on the device (per_token workspaces)
     float* qss = nullptr;           // text cross-attention with q_norm folded in: partial row sums of squares of the projected queries [N][D/64]
@@ -105,6 +106,7 @@ struct ltx2_dit {
     // up here to hand the GEMM (codes, per-row scale) instead of bf16 weights.  Per context (a second context over the same tensors
     // -- the video twin of an AudioVideo model -- keeps its own entries); rebuilt whenever the weights are resolved again.
     std::unordered_map<const void*, const float*> fp8_scale;
+    bool adaln_combine = true;         // ltx2_dit_set_option("adaln_combine"): round 4, see forward()
     bool fp8_compute = false;          // ltx2_dit_set_option("fp8_compute"): fp8-resident weights x per-token fp8 activations on the fp8 MFMA
     void* sk_ws = nullptr;             // stream-K attention scratch (attention.h); main-stream launches only
     long sk_bytes = 0;
@@ -163,6 +165,9 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         m.e_f = (float*)take(4L * T * D);
         m.emb = (float*)take(4L * T * rows * D);
         m.prompt_emb = (float*)take(c->v2 ? 4L * 2 * D : 0);
+        // round 4: every layer's scale_shift_table in one block (copied at prepare) and its per-step sum with the timestep embedding (adaln_combine)
+        m.sst_all = (float*)take(4L * L * rows * D);
+        m.comb = (float*)take(4L * L * rows * D);
         m.cross_ss = (float*)take(c->av ? 4L * 4 * D : 0);
         m.cross_gate = (float*)take(c->av ? 4L * D : 0);
         m.ts_tok = (float*)take(per_token ? 4L * n : 0);
@@ -585,11 +590,14 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     const BlockW& w = c->layers[l].m[k];
     const int N = m.N, D = m.D, H = m.H, hd = m.hd;
     const float eps = c->cfg.norm_eps;
-    const float* emb = m.emb;
+    // AdaLN rows: table row r + embedding row r; with one timestep per modality the sum was formed for every layer at the top of forward()
+    const float* const tab = m.use_comb ? m.comb + (long)l * (c->v2 ? 9 : 6) * D : w.sst;
+    const float* const emb0 = m.use_comb ? nullptr : m.emb;
+    auto E = [&](int r) { return emb0 ? emb0 + (long)r * D : nullptr; };
     // self-attention: AdaLN rows (shift, scale, gate) = sst[0:3] + emb[0:3]
     // fp8 compute: the norm kernels hand the following GEMM per-token e4m3fn codes directly (and skip the bf16 copy nobody else reads)
     const bool q1 = k == 0 && f8_route(c, w.self.qkv_w, N, 3 * D, D, EPI_BF16);
-    TRY(norm_mod_launch(m.x, D, (q1 && !c->gated) ? nullptr : m.h, D, N, D, eps, 0, w.sst + D, w.sst, emb + D, emb, es, st, q1 ? m.a8 : nullptr, D,
+    TRY(norm_mod_launch(m.x, D, (q1 && !c->gated) ? nullptr : m.h, D, N, D, eps, 0, tab + D, tab, E(1), E(0), es, st, q1 ? m.a8 : nullptr, D,
                         q1 ? m.a8s : nullptr));
     TRY(gate_logits(c, m, w.self, m.h, D, N, H, st));
     const VtOut vo{m.vt, 2 * D, m.Npad, hd};
@@ -602,7 +610,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     }
     if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
     TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, k == 0 ? c : nullptr, nullptr, 0.f, nullptr, glog(c, m)));
-    TRY(dense(c, m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 2 * D, es, w.sst + 2 * D));
+    TRY(dense(c, m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(2), es, tab + 2 * D));
 
     // text cross-attention: no RoPE, no mask.  V1: plain RMSNorm on x, K/V cached per prompt.
     // V2.3 (transformer.py:427-455): q side modulated by rows (6,7) and gated by row 8; the context
@@ -614,7 +622,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     unsigned char* a8q = q2 ? m.a8 : nullptr;
     float* a8sq = q2 ? m.a8s : nullptr;
     if (c->v2) {
-        TRY(norm_mod_launch(m.x, D, h2, D, N, D, eps, 0, w.sst + 7 * D, w.sst + 6 * D, emb + 7 * D, emb + 6 * D, es, st, a8q, D, a8sq));
+        TRY(norm_mod_launch(m.x, D, h2, D, N, D, eps, 0, tab + 7 * D, tab + 6 * D, E(7), E(6), es, st, a8q, D, a8sq));
         TRY(ctx_mod_launch(m.ctx, m.ctxm, m.S, D, w.prompt_sst + D, w.prompt_sst, m.prompt_emb + D, m.prompt_emb, st));
         TRY(project_kv(c, m.ctxm, m.S, D, w.text, D, H, hd, eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st, m.qfold ? m.knq + (long)l * D : nullptr));
         kk = m.kv2;
@@ -636,7 +644,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st, k == 0 ? c : nullptr, m.qfold ? m.qss : nullptr, eps,
                m.has_kmask ? m.kmask : nullptr, glog(c, m)));
     if (c->v2)
-        TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, emb + 8 * D, es, w.sst + 8 * D));
+        TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(8), es, tab + 8 * D));
     else
         TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st));
     return LTX2_OK;
@@ -647,12 +655,14 @@ int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     Mod& m = c->m[k];
     const BlockW& w = c->layers[l].m[k];
     const int N = m.N, D = m.D;
-    const float* emb = m.emb;
+    const float* const tab = m.use_comb ? m.comb + (long)l * (c->v2 ? 9 : 6) * D : w.sst;
+    const float* const emb0 = m.use_comb ? nullptr : m.emb;
+    auto E = [&](int r) { return emb0 ? emb0 + (long)r * D : nullptr; };
     const bool q3 = k == 0 && f8_route(c, w.ff1_w, N, 4 * D, D, EPI_GELU_BF16);
-    TRY(norm_mod_launch(m.x, D, q3 ? nullptr : m.h, D, N, D, c->cfg.norm_eps, 0, w.sst + 4 * D, w.sst + 3 * D, emb + 4 * D, emb + 3 * D, es, st,
+    TRY(norm_mod_launch(m.x, D, q3 ? nullptr : m.h, D, N, D, c->cfg.norm_eps, 0, tab + 4 * D, tab + 3 * D, E(4), E(3), es, st,
                         q3 ? m.a8 : nullptr, D, q3 ? m.a8s : nullptr));
     TRY(dense(c, m.h, D, w.ff1_w, w.ff1_b, m.ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st, nullptr, 0, nullptr, nullptr, nullptr, q3));
-    TRY(dense(c, m.ff, 4 * D, w.ff2_w, w.ff2_b, m.x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, emb + 5 * D, es, w.sst + 5 * D));
+    TRY(dense(c, m.ff, 4 * D, w.ff2_w, w.ff2_b, m.x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, E(5), es, tab + 5 * D));
     return LTX2_OK;
 }
 
@@ -762,7 +772,12 @@ int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = t
         if (in[k].n_ts > 1) {
             es[k] = (long)w.ada.rows * m.D;
             ee[k] = m.D;
+        } else if (c->adaln_combine) {
+            // one timestep for the whole modality (every loop but the conditioned ones): table + embedding of all layers in one launch; the
+            // blocks then pass the sums as tables (rows_of()), the norm kernels read half the vectors and the gated-residual GEMMs no per-row gate
+            TRY(adaln_combine_launch(m.sst_all, m.emb, m.comb, c->cfg.num_layers, (long)w.ada.rows * m.D, st));
         }
+        m.use_comb = in[k].n_ts == 1 && c->adaln_combine;
         if (c->v2)           // prompt AdaLN from this modality's sigma (model.py:151-161)
             TRY(adaln_chain(c, m, w.prompt, in[k].sigma, 0, 1, c->cfg.timestep_scale, m.prompt_emb, nullptr, st));
         if (c->av) {         // cross-modal AdaLN from the OTHER modality's sigma (model.py:346-364,392-404)
@@ -846,6 +861,14 @@ int prepare_modality(ltx2_dit* c, int k, const float* context, int S, const floa
         TRY(dense(c, m.ctx_in, Cctx, w.cap1_w, w.cap1_b, m.c1, D, S, D, Cctx, EPI_GELU_BF16, st));
         TRY(dense(c, m.c1, D, w.cap2_w, w.cap2_b, m.ctxp, D, S, D, D, EPI_BF16, st));
         m.ctx = m.ctxp;
+    }
+    {   // every layer's scale_shift_table side by side: forward() adds the step's timestep embedding to all of them in one launch
+        const long n = (long)(c->v2 ? 9 : 6) * D;
+        for (int l = 0; l < c->cfg.num_layers; ++l)
+            if (hipMemcpyAsync(m.sst_all + l * n, c->layers[l].m[k].sst, 4L * n, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                ltx2_set_error("dit_prepare: scale_shift_table copy failed");
+                return LTX2_E_HIP;
+            }
     }
     m.qfold = text_qfold_ok(c, k);
     if (m.qfold)
@@ -997,6 +1020,7 @@ int ltx2_dit_set_weight(ltx2_dit* c, const char* name, const void* ptr, int dtyp
     LTX2_CHECK_ARG(dtype == LTX2_DTYPE_BF16 || dtype == LTX2_DTYPE_F32 || dtype == LTX2_DTYPE_FP8_E4M3FN, "dit_set_weight: bad dtype %d", dtype);
     c->weights[name] = Wt{ptr, dtype, (long)numel};
     c->resolved = false;
+    c->prepared = false;        // the per-prompt caches (text K/V, the gathered AdaLN tables) were built from the weights registered before
     return LTX2_OK;
 }
 
@@ -1241,6 +1265,10 @@ int ltx2_dit_set_option(ltx2_dit* c, const char* name, int value) {
             return LTX2_E_STATE;
         }
         c->fp8_compute = value != 0;
+        return LTX2_OK;
+    }
+    if (!strcmp(name, "adaln_combine")) {       // 0: tables and embeddings reach every kernel separately (round 3's form; same results bit for bit)
+        c->adaln_combine = value != 0;
         return LTX2_OK;
     }
     ltx2_set_error("dit_set_option: unknown option '%s'", name);

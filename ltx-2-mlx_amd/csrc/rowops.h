@@ -15,6 +15,8 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
 
 // out_g[row][:] = rms_norm(x[row][:]) * (1 + scale_tab[g] + scale_emb[g]) + shift_tab[g] + shift_emb[g] for g = 0, 1 (row-invariant tables; any
 // pointer may be null): two modulations of one normalised stream from ONE read of x (the AudioVideo block's cross-modal attention inputs)
+// comb[l][i] = tab[l][i] + emb[i] for l < layers, i < n (round 4: every layer's AdaLN rows for one step in one launch)
+int adaln_combine_launch(const float* tab, const float* emb, float* out, int layers, long n, hipStream_t stream);
 int norm_mod2_launch(const float* x, long ldx, bf16* out0, bf16* out1, long ldo, int rows, int D, float eps, const float* const* scale_tab,
                      const float* const* shift_tab, const float* const* scale_emb, const float* const* shift_emb, hipStream_t stream);
 

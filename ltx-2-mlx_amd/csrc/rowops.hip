@@ -130,13 +130,14 @@ __global__ __launch_bounds__(256) void norm_mod_shared_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int d = threadIdx.x * 4 + i * 1024;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, h = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};     // 1 + (table + embedding): the same rounding whether the sum arrives combined (adaln_combine) or in two parts
         if (d < D) {
             if (scale_tab) sc += *(const f32x4*)(scale_tab + d);
             if (scale_emb) sc += *(const f32x4*)(scale_emb + d);
             if (shift_tab) h += *(const f32x4*)(shift_tab + d);
             if (shift_emb) h += *(const f32x4*)(shift_emb + d);
         }
+        sc += 1.f;
         sc1[i] = sc;
         sh[i] = h;
     }
@@ -191,13 +192,14 @@ __global__ __launch_bounds__(256) void norm_mod_shared2_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int d = threadIdx.x * 4 + i * 1024;
-            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, h = {0.f, 0.f, 0.f, 0.f};
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
             if (d < D) {
                 if (t.scale_tab[g]) sc += *(const f32x4*)(t.scale_tab[g] + d);
                 if (t.scale_emb[g]) sc += *(const f32x4*)(t.scale_emb[g] + d);
                 if (t.shift_tab[g]) h += *(const f32x4*)(t.shift_tab[g] + d);
                 if (t.shift_emb[g]) h += *(const f32x4*)(t.shift_emb[g] + d);
             }
+            sc += 1.f;
             sc1[g][i] = sc;
             sh[g][i] = h;
         }
@@ -884,6 +886,22 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
                            scale_tab, shift_tab, scale_emb, shift_emb, emb_stride, q8, ldq, qscale);
     }
     LTX2_CHECK_LAUNCH("norm_mod_kernel");
+    return LTX2_OK;
+}
+
+// comb[l][i] = tab[l][i] + emb[i]: the AdaLN rows of EVERY layer for this step in one launch (row-invariant modulation: one sigma per step).  The norm
+// kernels then read two vectors per row set instead of four and the gated-residual GEMMs take their gate as a table (no per-row gate loads).
+static __global__ __launch_bounds__(256) void adaln_combine_kernel(const float* __restrict__ tab, const float* __restrict__ emb, float* __restrict__ out, long n, long total) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 1024) {
+        const f32x4 a = *(const f32x4*)(tab + i), e = *(const f32x4*)(emb + i % n);
+        *(f32x4*)(out + i) = a + e;
+    }
+}
+int adaln_combine_launch(const float* tab, const float* emb, float* out, int layers, long n, hipStream_t stream) {
+    LTX2_CHECK_ARG(tab && emb && out && layers > 0 && n > 0 && n % 4 == 0, "adaln_combine: bad operand");
+    const long total = (long)layers * n, want = (total / 4 + 255) / 256;
+    hipLaunchKernelGGL(adaln_combine_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, stream, tab, emb, out, n, total);
+    LTX2_CHECK_LAUNCH("adaln_combine_kernel");
     return LTX2_OK;
 }
 

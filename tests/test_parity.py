@@ -137,6 +137,23 @@ def test_dit_baseline_size_block(dev):
     assert torch.equal(v, v2)
 
 
+def test_adaln_rows_combined_per_step_is_bit_identical(dev):
+    """Round 4: with one timestep per modality the engine adds the timestep embedding to EVERY layer's scale_shift_table in one launch at the top
+    of the step (norm kernels read half the vectors, the gated-residual GEMMs take their gate as a table).  Same arithmetic, same rounding order:
+    the velocity is bit-identical to the form that hands tables and embeddings to every kernel separately (option adaln_combine = 0)."""
+    from ltx_2_mlx_amd.model.transformer import Modality
+    cfg, w, m = make_dit(dev, heads=4, layers=3, cap=128, seed=5)
+    lat, ctx, pos = inputs(3, 8, 12, 128, 128, seed=6)
+    sigma = torch.tensor([0.6])
+    mod = Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev))
+    a = m(mod)
+    m.set_option("adaln_combine", 0)
+    b = m(mod)
+    m.set_option("adaln_combine", 1)
+    c = m(mod)
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_denoise_loop_and_graph(dev):
     """8 distilled steps (CLI loop, scripts/generate.py:1797-1979): API-faithful loop, fused C step
     and hipGraph replay all agree with the oracle (and the two fused forms with each other)."""
