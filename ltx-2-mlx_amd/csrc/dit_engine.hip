@@ -70,7 +70,7 @@ struct Mod {        // per-modality geometry + workspace
     int D = 0, H = 0, hd = 0, Cin = 0, Cout = 0;
     int N = 0, Npad = 0, S = 0, Spad = 0;
     float *x = nullptr, *sin_f = nullptr, *e1_f = nullptr, *e_f = nullptr, *emb = nullptr, *vel = nullptr, *x0 = nullptr,
-          *cosb = nullptr, *sinb = nullptr, *ccos = nullptr, *csin = nullptr, *aux_e = nullptr, *prompt_emb = nullptr, *sst_all = nullptr, *comb = nullptr,
+          *cosb = nullptr, *sinb = nullptr, *ccos = nullptr, *csin = nullptr, *aux_e = nullptr, *prompt_emb = nullptr, *sst_all = nullptr, *comb = nullptr, *ca_all = nullptr, *ca_comb = nullptr,
           *cross_ss = nullptr, *cross_gate = nullptr, *glog = nullptr;
     bf16 *lat = nullptr, *h = nullptr, *h2 = nullptr, *qkv = nullptr, *vt = nullptr, *att = nullptr, *ff = nullptr,
          *sin_b = nullptr, *e1_b = nullptr, *es_b = nullptr, *ctx_in = nullptr, *c1 = nullptr, *ctxp = nullptr,
@@ -169,7 +169,9 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         m.sst_all = (float*)take(4L * L * rows * D);
         m.comb = (float*)take(4L * L * rows * D);
         m.cross_ss = (float*)take(c->av ? 4L * 4 * D : 0);
-        m.cross_gate = (float*)take(c->av ? 4L * D : 0);
+        m.cross_gate = (float*)take(c->av ? 4L * D : 0);        // (directly behind cross_ss: the five cross-modal embedding rows are one block, see forward())
+        m.ca_all = (float*)take(c->av ? 4L * L * 5 * D : 0);
+        m.ca_comb = (float*)take(c->av ? 4L * L * 5 * D : 0);
         m.ts_tok = (float*)take(per_token ? 4L * n : 0);
         m.sin_b = (bf16*)take(per_token ? 2L * n * 256 : 0);
         m.e1_b = (bf16*)take(per_token ? 2L * n * D : 0);
@@ -684,7 +686,8 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st, hipStream_t sa) {
     const LayerW& w = c->layers[l];
     const int Dv = v.D, Da = a.D, H = a.H, hd = a.hd;
     const float eps = c->cfg.norm_eps;
-    const float *tv = w.ca[0], *ta = w.ca[1];
+    const bool comb = c->adaln_combine;          // table + embedding rows already summed for every layer (forward())
+    const float *tv = comb ? v.ca_comb + (long)l * 5 * Dv : w.ca[0], *ta = comb ? a.ca_comb + (long)l * 5 * Da : w.ca[1];
     const int offs[1] = {0};
     bf16* v_q = v.qkv;                              // a2v queries  [N][Da]
     bf16* v_kv = v.qkv + (long)v.N * Da;            // v2a keys | values [N][2 Da]
@@ -696,8 +699,8 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st, hipStream_t sa) {
     {
         const float* sct[2] = {tv, tv + 2 * Dv};
         const float* sht[2] = {tv + Dv, tv + 3 * Dv};
-        const float* sce[2] = {v.cross_ss, v.cross_ss + 2 * Dv};
-        const float* she[2] = {v.cross_ss + Dv, v.cross_ss + 3 * Dv};
+        const float* sce[2] = {comb ? nullptr : v.cross_ss, comb ? nullptr : v.cross_ss + 2 * Dv};
+        const float* she[2] = {comb ? nullptr : v.cross_ss + Dv, comb ? nullptr : v.cross_ss + 3 * Dv};
         TRY(norm_mod2_launch(v.x, Dv, v.h, v.h2, Dv, v.N, Dv, eps, sct, sht, sce, she, st));       // a2v query side | v2a context side
     }
     // the v2a key / value projection (the other big video-side GEMM) runs on the side stream from here, beside the main stream's a2v chain: same-box
@@ -717,8 +720,8 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st, hipStream_t sa) {
     {
         const float* sct[2] = {ta, ta + 2 * Da};
         const float* sht[2] = {ta + Da, ta + 3 * Da};
-        const float* sce[2] = {a.cross_ss, a.cross_ss + 2 * Da};
-        const float* she[2] = {a.cross_ss + Da, a.cross_ss + 3 * Da};
+        const float* sce[2] = {comb ? nullptr : a.cross_ss, comb ? nullptr : a.cross_ss + 2 * Da};
+        const float* she[2] = {comb ? nullptr : a.cross_ss + Da, comb ? nullptr : a.cross_ss + 3 * Da};
         TRY(norm_mod2_launch(a.x, Da, a.h, a.h2, Da, a.N, Da, eps, sct, sht, sce, she, sa));       // a2v context side | v2a query side
     }
     TRY(project_kv(c, a.h, a.N, Da, w.a2v, Da, H, hd, eps, a.ccos, a.csin, a_kv, a.vt, a.Npad, sa));
@@ -733,7 +736,7 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st, hipStream_t sa) {
     // ---- audio -> video attention (main): Q from video, K / V from audio ----
     TRY(event_wait(audio_kv, st));
     TRY(attend(v_q, Da, a_kv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st, c, nullptr, 0.f, nullptr, glog(c, v)));
-    TRY(dense(c, v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, v.cross_gate, 0, tv + 4 * Dv));
+    TRY(dense(c, v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, comb ? nullptr : v.cross_gate, 0, tv + 4 * Dv));
     // ---- video -> audio attention (side): Q from audio, K / V from video ----
     TRY(event_wait(video_norm, sa));
     TRY(dense(c, v.h2, Dv, w.v2a.kv_w, w.v2a.kv_b, v_kv, 2 * Da, v.N, 2 * Da, Dv, EPI_BF16, sa, nullptr, 0, nullptr, &vo, &vt_done));
@@ -743,7 +746,7 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st, hipStream_t sa) {
     }
     if (!vt_done) TRY(vt_transpose_launch(v_kv + Da, 2 * Da, v.vt, v.N, v.Npad, H, sa, hd));
     TRY(attend(a_q, Da, v_kv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, sa, nullptr, nullptr, 0.f, nullptr, glog(c, a)));     // few queries, long KV (side stream: the plain grid)
-    TRY(dense(c, a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, sa, a.cross_gate, 0, ta + 4 * Da));
+    TRY(dense(c, a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, sa, comb ? nullptr : a.cross_gate, 0, ta + 4 * Da));
     return LTX2_OK;
 }
 
@@ -784,6 +787,10 @@ int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = t
             const float* cs = in[1 - k].sigma;
             TRY(adaln_chain(c, m, w.cross_ss, cs, 0, 1, c->cfg.timestep_scale, m.cross_ss, nullptr, st));
             TRY(adaln_chain(c, m, w.cross_gate, cs, 0, 1, c->cfg.av_ca_timestep_scale, m.cross_gate, nullptr, st));
+            if (c->adaln_combine) {      // the five cross-modal rows (scale / shift x 2, gate) of every layer + their embeddings (cross_ss | cross_gate are adjacent)
+                LTX2_CHECK_ARG(m.cross_gate == m.cross_ss + 4L * m.D, "dit_forward: cross-modal embedding rows are not contiguous");
+                TRY(adaln_combine_launch(m.ca_all, m.cross_ss, m.ca_comb, c->cfg.num_layers, 5L * m.D, st));
+            }
         }
     }
     // the audio modality's block program runs on the side stream, joined around the cross-modal attention
@@ -870,6 +877,12 @@ int prepare_modality(ltx2_dit* c, int k, const float* context, int S, const floa
                 return LTX2_E_HIP;
             }
     }
+    if (c->av)
+        for (int l = 0; l < c->cfg.num_layers; ++l)
+            if (hipMemcpyAsync(m.ca_all + (long)l * 5 * D, c->layers[l].ca[k], 4L * 5 * D, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                ltx2_set_error("dit_prepare: cross-modal scale_shift_table copy failed");
+                return LTX2_E_HIP;
+            }
     m.qfold = text_qfold_ok(c, k);
     if (m.qfold)
         for (int l = 0; l < c->cfg.num_layers; ++l) {

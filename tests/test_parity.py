@@ -404,6 +404,11 @@ def test_av_dit_against_oracle_and_reference_vectors(dev, v23):
         vv, av = m(to_modality(video, dev), to_modality(audio, dev))
         ov, oa = dit_av.av_velocity_model(video, audio, wq, cfg)
         assert rel_l2(vv.cpu(), ov) < 3e-2 and rel_l2(av.cpu(), oa) < 3e-2
+        # round 4: the AdaLN rows (per-block and cross-modal) summed once per step for every layer vs handed to each kernel in two parts
+        m.set_option("adaln_combine", 0)
+        vv0, av0 = m(to_modality(video, dev), to_modality(audio, dev))
+        m.set_option("adaln_combine", 1)
+        assert torch.equal(vv, vv0) and torch.equal(av, av0), tsk
 
 
 @pytest.mark.parametrize("v23", [False, True])

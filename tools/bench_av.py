@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--v1", action="store_true", help="19B-style AV blocks (6-row AdaLN, caption projection, cached text K/V)")
 ap.add_argument("--layers", type=int, default=48)
 ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--ab-option", default=None, help="engine option to alternate 1 / 0 over the eager loop after the main measurement (e.g. adaln_combine)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 v23 = not a.v1
@@ -59,6 +60,15 @@ with torch.cuda.stream(side):
     m.replay_denoise_graph()
     side.synchronize()
     t_graph = (time.time() - t0) / 8
+if a.ab_option:
+    for r in range(3):
+        res = []
+        for v in (1, 0):
+            m.set_option(a.ab_option, v)
+            eager(2); torch.cuda.synchronize(); t0 = time.time(); eager(16); torch.cuda.synchronize()
+            res.append((time.time() - t0) / 16 * 1e3)
+        print(f"{a.ab_option}: 1 -> {res[0]:.2f} ms/step | 0 -> {res[1]:.2f} | {res[0] - res[1]:+.2f}", flush=True)
+    m.set_option(a.ab_option, 1)
 print(json.dumps({"workload": ("LTX-2.3" if v23 else "LTX-2 19B") + f" AudioVideo DiT {a.layers}L 768x512x65 (N=3456, Na=68, S=1024)",
                   "eager_ms_per_step": round(t_eager * 1e3, 2), "graph_ms_per_step": round(t_graph * 1e3, 2),
                   "prepare_ms": round(prep * 1e3, 1), "finite": bool(torch.isfinite(vlat).all() and torch.isfinite(alat).all())}))
