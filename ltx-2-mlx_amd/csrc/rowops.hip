@@ -869,8 +869,11 @@ int norm_mod_launch(const float* x, long ldx, bf16* out, long ldo, int rows, int
     LTX2_CHECK_ARG((out || q8) && (!q8 || (qscale && ldq % 4 == 0)), "norm_mod: no output / fp8 output without a scale vector");
     LTX2_CHECK_ARG(D <= 8192 && emb_stride % 4 == 0, "norm_mod: D=%d exceeds 8192 or emb_stride not a multiple of 4", D);
     const bool shared_mod = emb_stride == 0 && (scale_tab || shift_tab || scale_emb || shift_emb) && rows > 1024;
+#ifndef LTX2_NORM_BLOCKS
+#define LTX2_NORM_BLOCKS 1024       // blocks of the row-invariant form (each loads the combined tables once); A/B builds: -DLTX2_NORM_BLOCKS=512 / 2048
+#endif
     if (shared_mod) {
-        const int per_block = (rows + 1023) / 1024;
+        const int per_block = (rows + LTX2_NORM_BLOCKS - 1) / LTX2_NORM_BLOCKS;
         const int grid = (rows + per_block - 1) / per_block;
         if (D <= 4096)
             hipLaunchKernelGGL((norm_mod_shared_kernel<4>), dim3(grid), dim3(256), 0, stream, x, ldx, out, ldo, rows, D, eps, layer_norm,

@@ -15,7 +15,8 @@ N, D = 3456, 4096
 x = torch.randn(N, D, device=dev)
 st, sh, se, he = (0.1 * torch.randn(D, device=dev) for _ in range(4))
 print(f"norm_mod plain      {timeit(lambda: K.adaln_rmsnorm(x)):6.1f} us")
-print(f"norm_mod modulated  {timeit(lambda: K.adaln_rmsnorm(x, 1e-6, False, st, sh, se, he, 0)):6.1f} us")
+print(f"norm_mod modulated  {timeit(lambda: K.adaln_rmsnorm(x, 1e-6, False, st, sh, se, he, 0)):6.1f} us   (table + embedding rows in two parts: four vectors per block)")
+print(f"norm_mod modulated  {timeit(lambda: K.adaln_rmsnorm(x, 1e-6, False, st, sh)):6.1f} us   (combined rows: two vectors per block -- the engine's form since round 4)")
 emb = 0.1 * torch.randn(N, 2 * D, device=dev)
 print(f"norm_mod per-token  {timeit(lambda: K.adaln_rmsnorm(x, 1e-6, False, st, sh, emb[:, :D], emb[:, D:], 2 * D)):6.1f} us")
 qkv = torch.randn(N, 3 * D, device=dev).to(torch.bfloat16)
