@@ -937,7 +937,10 @@ int qknorm_rope_launch(bf16* buf, long ld, int rows, int D, int head_dim, int ns
         s.w[i] = weights[i];
     }
     LTX2_CHECK_ARG(D <= 4096, "qknorm_rope: inner dim %d exceeds 4096", D);
-    const int per_block = (rows + 2047) / 2048;             // up to 2048 blocks; beyond that a block takes several rows
+#ifndef LTX2_QK_BLOCKS
+#define LTX2_QK_BLOCKS 2048         // up to this many blocks; beyond that a block takes several rows (each block loads the norm weights once; 512 .. 4096 measured the same)
+#endif
+    const int per_block = (rows + LTX2_QK_BLOCKS - 1) / LTX2_QK_BLOCKS;
     const int grid = (rows + per_block - 1) / per_block;
     if (nseg == 2)
         hipLaunchKernelGGL((qknorm_rope_kernel<2>), dim3(grid), dim3(256), 0, stream, buf, ld, rows, D, head_dim, s, eps, cos, sin);
