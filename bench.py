@@ -334,13 +334,12 @@ def relaunch_under_torchrun(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20, help="the driver's value")
+    ap.add_argument("--warmup", type=int, default=5, help="the driver's value")
     ap.add_argument("--layers", type=int, default=48, help="debug only; the headline config is 48")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="no hipGraph anywhere: K eager steps are timed (rocprofv3 --pmc passes, per-dispatch traces)")
-    ap.add_argument("--eager", action="store_true", help="time K eager ltx2_dit_denoise_step calls as the headline (the graph replay is then reported beside it)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (AudioVideo step, two-stage pipeline)")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi socket-power samples taken during an extra graph replay")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (instrumented) pass that times the dominant GEMM")
@@ -388,11 +387,11 @@ def main():
     shape = VideoLatentShape.from_pixel_shape(VideoPixelShape(1, 65, 512, 768, 24.0))
     N = shape.frames * shape.height * shape.width
     S, Dm = 1024, model.inner_dim
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    gen_lat = torch.Generator(device=dev).manual_seed(1234 + rank)
     tools = VideoLatentTools(VideoLatentPatchifier(1), shape, fps=24.0)
     state = tools.create_initial_state(device=dev)
-    noise = torch.randn(N, 128, generator=g, device=dev)
-    ctx = 0.1 * torch.randn(1, S, 3840, generator=g, device=dev)
+    noise = torch.randn(N, 128, generator=gen_lat, device=dev)
+    ctx = 0.1 * torch.randn(1, S, 3840, generator=gen_lat, device=dev)
     t0 = time.time()
     model.prepare(ctx, state.positions)
     torch.cuda.synchronize()
@@ -412,13 +411,10 @@ def main():
             model.denoise_step_(lat, m, s0, s1)
 
     # The hot path has two launch forms of the SAME kernels: K calls of the fused step (ltx2_dit_denoise_step: what the pipelines run with a per-step
-    # callback or guidance) and the replay of the captured 8-step hipGraph (pipelines/common.py use_hip_graph=True: one call per 8 steps).  Both are
-    # timed over exactly K steps under the same barrier + synchronize contract, the in-order form first (the graph form when K is a multiple of 8 and
-    # neither --eager nor --no-graph is given); `value` is the faster of the two and `timed_with` names it.  Measured in round 4: with the warm-up
-    # steps directly in front of the timed regions the two forms are within 0.4 % of each other (76.24 / 76.55, 76.30 / 76.56 ms per step); a timed
-    # region that directly followed the capture's idle time read 1.0-1.7 % slow whichever form it held.  Both figures are on the line
-    # (eager_ms_per_step / hipgraph_ms_per_step).
-    use_graph = (K % 8 == 0) and not args.eager and not args.no_graph
+    # callback or guidance) and the replay of the captured 8-step hipGraph (pipelines/common.py use_hip_graph=True: one call per 8 steps).
+    # `value` is ALWAYS the first form -- it exists for every K (the driver's K = 20 is not a multiple of 8), so rounds stay comparable;
+    # the graph form is timed beside it over the nearest multiple of 8 steps and reported as hipgraph_ms_per_step.  Measured in round 4: with the
+    # warm-up steps directly in front of the timed regions the two forms are within 0.4 % of each other (76.24 / 76.55, 76.30 / 76.56 ms per step).
     side = torch.cuda.Stream()
 
     def run_graph(n_steps):
@@ -429,19 +425,19 @@ def main():
         """exactly n steps between barrier + synchronize on both sides -> (this rank's seconds, max over ranks)"""
         D.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t_start = time.perf_counter()
         fn(n)
         torch.cuda.synchronize()
-        mine = time.perf_counter() - t0                 # this rank's own steps (before the closing barrier)
+        mine = time.perf_counter() - t_start            # this rank's own steps (before the closing barrier)
         D.barrier()
-        return mine, D.max_over_ranks(time.perf_counter() - t0, dev)
+        return mine, D.max_over_ranks(time.perf_counter() - t_start, dev)
 
     # set-up first (one eager step so every lazily sized buffer exists, then the capture), the W warm-up steps LAST: the timed region starts on a socket
     # that has just been running the same kernels (a timed region that follows the capture's idle time directly reads ~1 % slow)
     run_steps(1)
     torch.cuda.synchronize()
     graph_err = None
-    if use_graph or not args.no_graph:
+    if not args.no_graph:
         try:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -450,93 +446,21 @@ def main():
                 model.replay_denoise_graph()            # warm-up replay
             side.synchronize()
         except Exception as e:  # noqa: BLE001
-            graph_err, use_graph = f"failed: {e}", False
+            graph_err = f"failed: {e}"
+    else:
+        graph_err = "skipped (--no-graph)"
     run_steps(W)
     torch.cuda.synchronize()
 
-    # ---------------- timed regions: exactly K steps each, nothing else on the stream ----------------
-    dt_rank_e, dt_e = timed(run_steps, K)
-    dt_rank_g, dt_g = None, None
-    if use_graph:
-        with torch.cuda.stream(side):
-            dt_rank_g, dt_g = timed(run_graph, K)
-        torch.cuda.current_stream().wait_stream(side)
-    timed_graph = use_graph and dt_g < dt_e             # (max-over-ranks figures: every rank picks the same form)
-    dt_rank, dt = (dt_rank_g, dt_g) if timed_graph else (dt_rank_e, dt_e)
+    # ---------------- THE timed region: exactly K steps, nothing else on the stream ----------------
+    dt_rank, dt = timed(run_steps, K)
     n_joined = D.count_ranks(dev)                       # counted through the process group (an RCCL all-reduce on device tensors)
 
-    # ---------------- second pass (not part of `value`): HIP events around every launch of the dominant GEMM ----------------
-    DOM_EPI = nv.EPI_RESID_GATE_F32     # gemm_v4_kernel<EPI_RESID_GATE_F32, 3, 224>: attn1.to_out, attn2.to_out, ff.net.2
-    k_ms, k_n, k_fl = 0.0, 0, 0.0
-    if not args.no_kernel_pass:
-        model.profile_begin(DOM_EPI)
-        run_steps(K)
-        torch.cuda.synchronize()
-        k_ms, k_n, k_fl = model.profile_end()
-
-    # ---------------- both launch forms on the line; socket power under the replayed graph ----------------
-    eager_ms = dt_e / K * 1e3
-    graph_ms = dt_g / K * 1e3 if dt_g is not None else None
-    power = None
-    try:
-        if args.no_graph or graph_err:
-            raise RuntimeError(graph_err or "skipped (--no-graph)")
-        with torch.cuda.stream(side):
-            if graph_ms is None:                        # K not a multiple of 8, or --eager: the graph form over the nearest multiple, for the record
-                reps = max(1, K // 8)
-                _, g = timed(run_graph, reps * 8)
-                graph_ms = g / (reps * 8) * 1e3
-            # socket power while the same graph keeps replaying (~3 s, outside every timed region): the step time on this part is set by the
-            # 1400 W cap, so the line carries the evidence; every rank samples ITS socket while all ranks keep replaying
-            if not args.no_power:
-                power = socket_power_during(lambda: (model.replay_denoise_graph(), side.synchronize()), seconds=3.0, smi_device=local)
-        torch.cuda.current_stream().wait_stream(side)
-    except Exception as e:  # noqa: BLE001
-        if graph_ms is None:
-            graph_ms = f"failed: {e}"
-
-    # ---------------- VAE decode: latent in HBM -> uint8 frames in HBM ----------------
-    vae_fps, vae_ms = None, None
-    if not args.no_vae:
-        dec = SimpleVideoDecoder(device=dev)
-        dec.init_random_weights(seed=7)
-        dec.generator = torch.Generator(device=dev).manual_seed(99 + rank)
-        z = torch.randn(1, 128, shape.frames, shape.height, shape.width, generator=g, device=dev)
-        frames = decode_latent(z, dec)                    # warm-up (also sizes the workspace)
-        torch.cuda.synchronize()
-        D.barrier()
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            frames = decode_latent(z, dec)
-        torch.cuda.synchronize()
-        D.barrier()
-        vdt = D.max_over_ranks((time.perf_counter() - t0) / reps, dev)
-        assert tuple(frames.shape) == (65, 512, 768, 3)
-        vae_ms = vdt * 1e3
-        vae_fps = world * 65 / vdt
-
-    per_rank = D.gather_floats([dt_rank / K * 1e3, (power or {}).get("mean_w", -1.0), (power or {}).get("max_w", -1.0)], dev)
-    if rank != 0:
-        return
+    # ---------------- the headline line exists from here on; every later leg can only ADD to it ----------------
     steps_per_s = world * K / dt
     ms_per_step = dt / K * 1e3
     alg = dit_algorithmic_flops(N, S, Dm, L)
     exe = dit_executed_flops(N, S, Dm, L)
-    # HBM/fabric traffic of the dominant kernel cannot be collected from inside the process: it comes from the committed
-    # rocprofv3 --pmc passes of THIS kernel version (the newest profiles/r*_pmc_traffic.json names the commit), null if absent.
-    traffic, traffic_src, traffic_stale = None, None, None
-    try:
-        import glob
-        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
-            tj = json.load(f)
-            traffic, traffic_src = tj.get("per_launch_avg_bytes"), tj.get("commit")
-            # stale = the kernel's sources changed since the counters were collected (files without the digest predate round 4: stale)
-            traffic_stale = tj.get("kernel_source_sha16") != kernel_source_sha()
-    except Exception:  # noqa: BLE001
-        pass
-    kern_avg_ms = k_ms / max(k_n, 1)
-    kern_tflops = (k_fl / max(k_n, 1)) / (kern_avg_ms * 1e-3) / 1e12 if k_n else None
     out = {
         "metric": "denoise_steps_per_sec", "value": round(steps_per_s, 4), "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 3),
@@ -544,68 +468,167 @@ def main():
         "config": {"workload": f"LTX-2 19B distilled DiT ({L} layers, D=4096, 32x128 heads), 768x512x65 "
                                f"(N={N} video tokens, S={S} text tokens), 8-step distilled sigmas, bf16, random-init weights",
                    "parallelism": f"prompt-parallel x{world} (independent prompt/seed per GPU, one RCCL weight broadcast)"},
-        "vae_decode_frames_per_sec": None if vae_fps is None else round(vae_fps, 2),
-        "vae_decode_ms": None if vae_ms is None else round(vae_ms, 2),
-        "timed_with": ("hipGraph replay of the captured 8-step loop (K / 8 launches): the faster of the two launch forms on this box" if timed_graph
-                       else "K ltx2_dit_denoise_step calls on the in-order stream" + (": the faster of the two launch forms on this box" if use_graph else "")),
+        "timed_with": "K ltx2_dit_denoise_step calls on the in-order stream (the headline form every round; the hipGraph replay of the same "
+                      "kernels is hipgraph_ms_per_step)",
+        "eager_ms_per_step": round(ms_per_step, 3),
         "step_algorithmic_tflop": round(alg / 1e12, 3),
         "step_mfma_roofline_frac": round(alg / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "step_executed_tflop": round(exe / 1e12, 3),
         "step_executed_mfma_frac": round(exe / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "step_executed_note": "executed = algorithmic minus the text cross-attention K / V projections (4 S D^2 per layer), which are step-invariant "
                               "and run once per prompt (prompt_setup_ms); the reference recomputes them every step",
-        "hipgraph_ms_per_step": graph_ms if not isinstance(graph_ms, float) else round(graph_ms, 3),
-        "eager_ms_per_step": eager_ms if not isinstance(eager_ms, float) else round(eager_ms, 3),
         "prompt_setup_ms": round(prep_ms, 1),
-        "socket_power": power,
         "rccl_ranks": n_joined, "rccl_ranks_how": "all_reduce(sum) of a device-resident 1 over the process group",
-        "per_rank_ms_per_step": {"min": round(min(r[0] for r in per_rank), 3), "max": round(max(r[0] for r in per_rank), 3),
-                                 "all": [round(r[0], 3) for r in per_rank]},
-        "per_rank_socket_power_w": None if args.no_power else {"mean": [r[1] for r in per_rank], "max": [r[2] for r in per_rank]},
         "collective_backend": (torch.distributed.get_backend() if world > 1 else None), "weight_bytes": w_bytes, "weight_broadcast_s": round(bcast_s, 3),
         "weight_broadcast_collectives": n_coll, "weight_broadcast_mode": bcast_mode if world > 1 else None,
         "weights_identical": weights_identical,
         "weight_broadcast_gbps": round(w_bytes / bcast_s / 1e9, 1) if world > 1 and bcast_s > 0 else None,
-        "roofline": {"kernel": "gemm_v4_kernel<EPI_RESID_GATE_F32, layout 3, 224> (224x256x64 tile, 4 waves, generated asm K loop, "
-                               "v_mfma_f32_16x16x32_bf16: attn1/attn2 to_out and ff.net.2 + bias + gate * (.) added into the fp32 residual)",
-                     "bound": "mfma", "achieved": None if kern_tflops is None else round(kern_tflops, 1), "peak": PEAK_BF16_TFLOPS,
-                     "unit": "TFLOP/s", "frac": None if kern_tflops is None else round(kern_tflops / PEAK_BF16_TFLOPS, 4),
-                     "traffic": traffic, "traffic_source_commit": traffic_src, "traffic_stale": traffic_stale,
-                     "launches": k_n, "avg_launch_us": round(kern_avg_ms * 1e3, 2),
-                     "algorithmic_flops_per_launch": round(k_fl / max(k_n, 1)),
-                     "measured": "HIP events around every launch of this kernel in a separate pass of the same K steps (not in `value`)"},
     }
-    if vae_ms is not None:
-        t = vae_ms * 1e-3 / 1.0
-        out["vae_roofline"] = {
-            "workload": "decode_latent 768x512x65 (7/2 temporal chunking, cross-fade, uint8), latent and frames in HBM",
-            "algorithmic_tflop": VAE_ALG_TFLOP, "algorithmic_gb": VAE_ALG_GB,
-            "mfma": {"achieved": round(VAE_ALG_TFLOP / t, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(VAE_ALG_TFLOP / t / PEAK_BF16_TFLOPS, 4)},
-            "hbm": {"achieved": round(VAE_ALG_GB / t, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(VAE_ALG_GB / t / PEAK_HBM_GBS, 4)},
-            "bound": "mfma", "note": "the conv stack is MFMA-bound (arithmetic intensity ~2000 F/B); the HBM fraction cannot exceed ~0.15 (SURVEY 8d)"}
-    if world == 1 and not args.no_extra:
-        # Secondary BASELINE configurations, reported beside the headline (never part of `value`): config 4 shape
-        # (LTX-2.3-style AudioVideo DiT, joint audio+video step) and config 5 (two-stage 1536x1024x65 with the
-        # spatial upscaler).  Any failure here is reported as text and cannot affect the numbers above.
+    emitted = [False]
+
+    def emit():
+        if rank == 0 and not emitted[0]:
+            emitted[0] = True
+            _REAL_STDOUT.write(json.dumps(out) + "\n")
+            _REAL_STDOUT.flush()
+
+    def leg(name, fn):
+        """One secondary leg: whatever it raises becomes `<name>_error` on the line (a failure after the timed region must never
+        cost the headline).  Legs hold NO collectives -- ranks meet only at the fixed points below -- so one rank's failure cannot hang the others."""
         try:
-            del model
-            torch.cuda.empty_cache()
-            out["extra_configs"] = extra_configs(dev, L)
+            if os.environ.get("LTX2_BENCH_FAIL_LEG") == name:       # tests/test_cli_gpu.py::test_bench_line_survives_a_failing_leg
+                raise RuntimeError(f"LTX2_BENCH_FAIL_LEG={name}")
+            return fn()
         except Exception as e:  # noqa: BLE001
-            out["extra_configs"] = {"error": str(e)}
-    if world == 1 and not args.no_loader:
+            out[f"{name}_error"] = f"{type(e).__name__}: {e}"
+            sys.stderr.write(f"[bench] leg {name} failed on rank {rank}: {type(e).__name__}: {e}\n")
+            return None
+
+    try:
+        # ---------------- second pass (not part of `value`): HIP events around every launch of the dominant GEMM ----------------
+        DOM_EPI = nv.EPI_RESID_GATE_F32     # gemm_v4_kernel<EPI_RESID_GATE_F32, 3, 224>: attn1.to_out, attn2.to_out, ff.net.2
+
+        def kernel_pass():
+            model.profile_begin(DOM_EPI)
+            run_steps(K)
+            torch.cuda.synchronize()
+            return model.profile_end()
+        k_ms, k_n, k_fl = (0.0, 0, 0.0) if args.no_kernel_pass else (leg("kernel_pass", kernel_pass) or (0.0, 0, 0.0))
+        # HBM/fabric traffic of the dominant kernel cannot be collected from inside the process: it comes from the committed
+        # rocprofv3 --pmc passes of THIS kernel version (the newest profiles/r*_pmc_traffic.json names the commit), null if absent.
+        traffic, traffic_src, traffic_stale = None, None, None
         try:
-            torch.cuda.empty_cache()
-            out["loader"] = loader_throughput(dev, args.loader_layers)
-        except Exception as e:  # noqa: BLE001
-            out["loader"] = {"error": str(e)}
-    if world == 1 and not args.no_cpu_baseline:        # the CPU leg is reported at N = 1 only (rank 0's host cores)
-        try:
-            out["cpu_baseline"] = cpu_baseline(min(CPU_THREADS, os.cpu_count() or 1))
-        except Exception as e:  # noqa: BLE001
-            out["cpu_baseline"] = {"error": str(e)}
-    _REAL_STDOUT.write(json.dumps(out) + "\n")
-    _REAL_STDOUT.flush()
+            import glob
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
+                tj = json.load(f)
+                traffic, traffic_src = tj.get("per_launch_avg_bytes"), tj.get("commit")
+                # stale = the kernel's sources changed since the counters were collected (files without the digest predate round 4: stale)
+                traffic_stale = tj.get("kernel_source_sha16") != kernel_source_sha()
+        except Exception:  # noqa: BLE001
+            pass
+        kern_avg_ms = k_ms / max(k_n, 1)
+        kern_tflops = (k_fl / max(k_n, 1)) / (kern_avg_ms * 1e-3) / 1e12 if k_n else None
+        out["roofline"] = {
+            "kernel": "gemm_v4_kernel<EPI_RESID_GATE_F32, layout 3, 224> (224x256x64 tile, 4 waves, generated asm K loop, "
+                      "v_mfma_f32_16x16x32_bf16: attn1/attn2 to_out and ff.net.2 + bias + gate * (.) added into the fp32 residual)",
+            "bound": "mfma", "achieved": None if kern_tflops is None else round(kern_tflops, 1), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": None if kern_tflops is None else round(kern_tflops / PEAK_BF16_TFLOPS, 4),
+            "traffic": traffic, "traffic_source_commit": traffic_src, "traffic_stale": traffic_stale,
+            "launches": k_n, "avg_launch_us": round(kern_avg_ms * 1e3, 2),
+            "algorithmic_flops_per_launch": round(k_fl / max(k_n, 1)),
+            "measured": "HIP events around every launch of this kernel in a separate pass of the same K steps (not in `value`)"}
+
+        # ---------------- the hipGraph form over the nearest multiple of 8 steps (this rank's own clock), then socket power under it ----------------
+        def graph_leg():
+            if graph_err:
+                raise RuntimeError(graph_err)
+            n_g = max(8, K // 8 * 8)
+            with torch.cuda.stream(side):
+                run_graph(8)
+                side.synchronize()
+                t_start = time.perf_counter()
+                run_graph(n_g)
+                side.synchronize()
+                ms = (time.perf_counter() - t_start) / n_g * 1e3
+            torch.cuda.current_stream().wait_stream(side)
+            return ms, n_g
+        graph_ms, graph_steps = leg("hipgraph", graph_leg) or (None, None)
+
+        def power_leg():
+            # socket power while the same graph keeps replaying (~3 s, outside every timed region): the step time on this part is set by the
+            # 1400 W cap (DESIGN.md section 4), so the line carries the evidence; every rank samples ITS socket while all ranks keep replaying
+            if graph_err:
+                raise RuntimeError(graph_err)
+            with torch.cuda.stream(side):
+                pw = socket_power_during(lambda: (model.replay_denoise_graph(), side.synchronize()), seconds=3.0, smi_device=local)
+            torch.cuda.current_stream().wait_stream(side)
+            return pw
+        power = None if args.no_power else leg("socket_power", power_leg)
+        out["hipgraph_ms_per_step"] = None if graph_ms is None else round(graph_ms, 3)
+        out["hipgraph_steps_timed"] = graph_steps
+        out["socket_power"] = power
+
+        # ---------------- VAE decode: latent in HBM -> uint8 frames in HBM ----------------
+        def vae_leg():
+            dec = SimpleVideoDecoder(device=dev)
+            dec.init_random_weights(seed=7)
+            dec.generator = torch.Generator(device=dev).manual_seed(99 + rank)
+            gen_vae = torch.Generator(device=dev).manual_seed(4321 + rank)
+            z = torch.randn(1, 128, shape.frames, shape.height, shape.width, generator=gen_vae, device=dev)
+            frames = decode_latent(z, dec)                    # warm-up (also sizes the workspace)
+            torch.cuda.synchronize()
+            reps = 3
+            t_start = time.perf_counter()
+            for _ in range(reps):
+                frames = decode_latent(z, dec)
+            torch.cuda.synchronize()
+            if tuple(frames.shape) != (65, 512, 768, 3):
+                raise RuntimeError(f"decode_latent returned {tuple(frames.shape)}")
+            return (time.perf_counter() - t_start) / reps
+        D.barrier()
+        vae_s = None if args.no_vae else leg("vae", vae_leg)
+
+        # ---------------- fixed meeting point of the ranks: per-rank figures of every leg ----------------
+        per_rank = D.gather_floats([dt_rank / K * 1e3, (power or {}).get("mean_w", -1.0), (power or {}).get("max_w", -1.0),
+                                    -1.0 if graph_ms is None else graph_ms, -1.0 if vae_s is None else vae_s], dev)
+        if rank != 0:
+            return
+        out["per_rank_ms_per_step"] = {"min": round(min(r[0] for r in per_rank), 3), "max": round(max(r[0] for r in per_rank), 3),
+                                       "all": [round(r[0], 3) for r in per_rank]}
+        out["per_rank_socket_power_w"] = None if args.no_power else {"mean": [r[1] for r in per_rank], "max": [r[2] for r in per_rank]}
+        if world > 1:
+            out["per_rank_hipgraph_ms_per_step"] = [None if r[3] < 0 else round(r[3], 3) for r in per_rank]
+        vae_all = [r[4] for r in per_rank]
+        if not args.no_vae and all(v > 0 for v in vae_all):
+            vdt = max(vae_all)                                  # the slowest rank's decode: whole-job frames/s = world * 65 / that
+            out["vae_decode_frames_per_sec"] = round(world * 65 / vdt, 2)
+            out["vae_decode_ms"] = round(vdt * 1e3, 2)
+            out["vae_roofline"] = {
+                "workload": "decode_latent 768x512x65 (7/2 temporal chunking, cross-fade, uint8), latent and frames in HBM",
+                "algorithmic_tflop": VAE_ALG_TFLOP, "algorithmic_gb": VAE_ALG_GB,
+                "mfma": {"achieved": round(VAE_ALG_TFLOP / vdt, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(VAE_ALG_TFLOP / vdt / PEAK_BF16_TFLOPS, 4)},
+                "hbm": {"achieved": round(VAE_ALG_GB / vdt, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(VAE_ALG_GB / vdt / PEAK_HBM_GBS, 4)},
+                "bound": "mfma", "note": "the conv stack is MFMA-bound (arithmetic intensity ~2000 F/B); the HBM fraction cannot exceed ~0.15 (SURVEY 8d)"}
+        else:
+            out["vae_decode_frames_per_sec"], out["vae_decode_ms"] = None, None
+        if world == 1 and not args.no_extra:
+            # Secondary BASELINE configurations, reported beside the headline (never part of `value`): config 3 (fp8), config 4 shape
+            # (LTX-2.3-style AudioVideo DiT, joint audio+video step) and config 5 (two-stage 1536x1024x65 with the spatial upscaler).
+            def extra_leg():
+                nonlocal model
+                model = None                                    # the 38 GB of headline weights (every later leg builds its own model)
+                torch.cuda.empty_cache()
+                return extra_configs(dev, L)
+            out["extra_configs"] = leg("extra_configs", extra_leg)
+        if world == 1 and not args.no_loader:
+            def loader_leg():
+                torch.cuda.empty_cache()
+                return loader_throughput(dev, args.loader_layers)
+            out["loader"] = leg("loader", loader_leg)
+        if world == 1 and not args.no_cpu_baseline:        # the CPU leg is reported at N = 1 only (rank 0's host cores)
+            out["cpu_baseline"] = leg("cpu_baseline", lambda: cpu_baseline(min(CPU_THREADS, os.cpu_count() or 1)))
+    finally:
+        emit()
 
 
 _REAL_STDOUT = sys.stdout

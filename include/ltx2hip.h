@@ -41,8 +41,11 @@ extern "C" {
  * 1 = round 1;  2 = round 2 added the `sigma` / `sigma_dev` argument to ltx2_dit_forward / ltx2_dit_denoise_step (in the middle of
  * the list: an old caller's arguments would shift silently), round 3 added ltx2_dit_health; round 4 added entry points only
  * (ltx2_clear_error, ltx2_adaln_rmsnorm2, ltx2_flash_attn_gated, ltx2_flash_attn_form, ltx2_dit_graph_capture_cond[_av], the
- * "adaln_combine" option): no existing signature changed, the version stays 2. */
-#define LTX2_ABI_VERSION 2
+ * "adaln_combine" option) without bumping the version -- a round-3 library then passed the check and failed later on a symbol lookup;
+ * 3 = round 5: the round-4 additions are part of the version, ltx2_flash_attn_form (the 64-rows-per-wave experiment's entry) is REMOVED, and
+ * ltx2_dit_graph_capture_cond[_av] take the element counts of the mask / clean-latent buffers they replay from.  Rule from here on: any change
+ * of the exported symbol set or of a signature bumps the version. */
+#define LTX2_ABI_VERSION 3
 
 const char* ltx2_last_error(void);
 /* forget the calling thread's message (a binding that loads several builds of the library reads every build's message after a failure and
@@ -226,14 +229,6 @@ int ltx2_flash_attn_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, c
 int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const void* gate_w, const float* gate_b,
                         float* logits, int rows, int Dq, int H, int head_dim, void* stream);
 
-/* ltx2_flash_attn / ltx2_flash_attn_rowscale (q_ss != NULL) on a NAMED kernel form (round 4; tests and same-box timing): form 1 = 32 query rows per
- * wave, two workgroups per CU (what the launcher uses); form 2 = the 64-rows-per-wave experiment (two 32-row blocks sharing every K / V^T fragment,
- * one workgroup per CU; head_dim 128, no q_ss -- measured slower, never picked: profiles/r04_attn_64row_negative.md); form 2 + flags = its
- * timing-experiment builds (1: no exponentials, 16: no row maximum; wrong results by construction); form 0 = what the launcher would pick.
- * Forms 1 and 2 agree to the bf16 rounding of the pre-scaled Q.                                                                              */
-int ltx2_flash_attn_form(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
-                         int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, int form, void* stream);
-
 /* ltx2_flash_attn with the per-head gates applied in the kernel's epilogue (round 4: the engine's form -- the gate multiplies the fp32 result
  * before it is rounded, instead of a pass over the rounded output): out[q, h*hd:(h+1)*hd] = 2*sigmoid(gate_logits[q*gate_ld + h]) * attention. */
 int ltx2_flash_attn_gated(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
@@ -380,11 +375,12 @@ int ltx2_dit_graph_capture(ltx2_dit* ctx, float* latent, const float* host_sigma
  * denoise mask (1 = free token), clean fp32 [N][C] = the clean latent of the conditioned tokens.  Step i runs with per-token timesteps
  * mask * sigma_i (formed on the device inside the captured step) and blends x0 with `clean` before the Euler update, exactly as
  * ltx2_dit_denoise_step with n_timesteps = N, mask and clean.  The workspace must be bound with per_token = 1.  A null mask (per modality in
- * the _av form) = no conditioning tokens there.  (round 4, additive)                                                             */
-int ltx2_dit_graph_capture_cond(ltx2_dit* ctx, float* latent, const float* host_sigmas, int n_steps, const float* mask, const float* clean,
-                                void* stream);
-int ltx2_dit_graph_capture_cond_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps, const float* v_mask,
-                                   const float* v_clean, const float* a_mask, const float* a_clean, void* stream);
+ * the _av form) = no conditioning tokens there.  n_mask / n_clean: ELEMENT counts of the two buffers, checked against the bound token count
+ * and N * out_channels (the replay reads exactly that much on every step).  (round 4; the counts: round 5, ABI 3)                       */
+int ltx2_dit_graph_capture_cond(ltx2_dit* ctx, float* latent, const float* host_sigmas, int n_steps, const float* mask, int64_t n_mask, const float* clean,
+                                int64_t n_clean, void* stream);
+int ltx2_dit_graph_capture_cond_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps, const float* v_mask, int64_t n_v_mask,
+                                   const float* v_clean, int64_t n_v_clean, const float* a_mask, int64_t n_a_mask, const float* a_clean, int64_t n_a_clean, void* stream);
 int ltx2_dit_graph_capture_av(ltx2_dit* ctx, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps,
                               void* stream);
 int ltx2_dit_graph_launch(ltx2_dit* ctx, void* stream);

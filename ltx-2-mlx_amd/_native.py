@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("LTX2HIP_LIB") or os.path.join(_HERE, "lib", "libltx2h
 # the same sources compiled with -DLTX2_F16: IEEE-half activations / weights (the reference's default compute dtype)
 LIB_PATH_F16 = os.environ.get("LTX2HIP_LIB_F16") or os.path.join(_HERE, "lib", "libltx2hip_f16.so")
 
-ABI_VERSION = 2         # LTX2_ABI_VERSION of include/ltx2hip.h these signatures were written against
+ABI_VERSION = 3         # LTX2_ABI_VERSION of include/ltx2hip.h these signatures were written against
 OK, E_INVALID, E_HIP, E_STATE = 0, -1, -2, -3
 DTYPE_BF16, DTYPE_F32, DTYPE_FP8_E4M3FN = 0, 1, 2
 MODEL_VIDEO_ONLY, MODEL_AUDIO_VIDEO = 0, 1
@@ -56,7 +56,6 @@ SIGNATURES = {
     "ltx2_gemm_bf16_rowss": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, C.POINTER(i32), vp]),
     "ltx2_flash_attn_keymask": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, vp, vp]),
     "ltx2_adaln_rmsnorm2": (i32, [vp, i64, vp, vp, i64, i32, i32, f32, vp, vp, vp, vp, vp]),
-    "ltx2_flash_attn_form": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, i32, f32, i32, vp]),
     "ltx2_flash_attn_gated": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, vp]),
     "ltx2_flash_attn_rowscale": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, i32, f32, vp]),
     "ltx2_gemm_route": (i32, [i32, i32, i32, i32, i32, i32]),
@@ -104,8 +103,8 @@ SIGNATURES = {
     "ltx2_dit_forward": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "ltx2_dit_denoise_step": (i32, [vp, vp, vp, i32, vp, vp, vp, f32, f32, vp, vp]),
     "ltx2_dit_graph_capture": (i32, [vp, vp, C.POINTER(f32), i32, vp]),
-    "ltx2_dit_graph_capture_cond": (i32, [vp, vp, C.POINTER(f32), i32, vp, vp, vp]),
-    "ltx2_dit_graph_capture_cond_av": (i32, [vp, vp, vp, C.POINTER(f32), i32, vp, vp, vp, vp, vp]),
+    "ltx2_dit_graph_capture_cond": (i32, [vp, vp, C.POINTER(f32), i32, vp, i64, vp, i64, vp]),
+    "ltx2_dit_graph_capture_cond_av": (i32, [vp, vp, vp, C.POINTER(f32), i32, vp, i64, vp, i64, vp, i64, vp, i64, vp]),
     "ltx2_dit_graph_launch": (i32, [vp, vp]),
     "ltx2_dit_health": (i32, [vp, vp]),
     "ltx2_dit_set_context_mask": (i32, [vp, i32, vp, i32, vp]),
@@ -154,7 +153,10 @@ def lib(dtype: Optional[torch.dtype] = None) -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             if os.environ.get(env) and not hasattr(l, name):
                 continue                # an A/B build of the SAME ABI version that predates a newly ADDED entry: it just cannot be called
-            fn = getattr(l, name)       # AttributeError if the ABI and the header drift apart
+            try:
+                fn = getattr(l, name)
+            except AttributeError:      # the ABI and the header drifted apart without a version bump: still the 'rebuild it' message
+                raise NativeLibraryMissing(f"{path} (ABI version {have}) does not export {name}: rebuild it (`make -C ltx-2-mlx_amd/csrc`)") from None
             fn.restype = res
             fn.argtypes = args
         _libs[key] = l

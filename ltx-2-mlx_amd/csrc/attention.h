@@ -33,7 +33,6 @@ struct AttnParams {
     // result before it is rounded (round 4: was a pass over the attention output).  null = none.
     const float* gate;
     int gate_ld;
-    int form;           // 0: the launcher picks; 1: the 32-rows-per-wave kernel (two workgroups per CU); 2: the 64-rows-per-wave kernel (one per CU; head_dim 128)
     int sk_force;       // 1: stream-K whenever there are more units than slots (unit tests); 0: only when the plain grid's last round is badly filled
 };
 

@@ -575,400 +575,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Round 4: the 64-rows-per-wave form -- an EXPERIMENT kept for its measurements (profiles/r04_attn_64row_negative.md), reachable only through
-// ltx2_flash_attn_form (form 2); the launcher never picks it (attn2_preferred).  Best build: 216 us against the 32-row form's 202 us on the DiT's
-// self-attention (N = 3456, same box), 2757 against 2691 us at N = 13824.
-// One workgroup per CU, ONE wave per SIMD (512 registers), every wave owns TWO 32-row query blocks that share each K / V^T fragment it reads: per KV
-// tile a wave issues 64 MFMAs against the SAME 32 fragment reads, 8 LDS-DMA pieces and one barrier that the 32-row form spends on 32 MFMAs.  With
-// one wave per SIMD the wave's instruction stream is the only thing the SIMD has: a wave issues at most one instruction per ~4 cycles whatever its
-// type, so beside an MFMA (32 cycles) there is room for ~7 others.  The first builds (hipcc-scheduled softmax: ~10 instructions per MFMA with its
-// moves, wait-state pads and the exponent fma) ran 20-40 % slower than the 32-row form for exactly that reason.  What this build does about it:
-//   * a software pipeline over KV tiles, the softmax of tile t spread evenly between the QK^T MFMAs of tile t + 1 and the PV MFMAs of tile t;
-//   * every loop instruction written out (one asm statement per MFMA pair / exponential pair / max step: hipcc allocates registers and keeps the
-//     statement order, it adds no moves between them): ~5 instructions per MFMA; scores in VGPRs, output accumulators and Q fragments in AGPRs;
-//   * the exponent's fma is gone: Q is pre-multiplied by scale * log2(e) and the first k-step of S accumulates onto -m (a 16-register block per
-//     query block holding the running maximum, in exponent units), so the MFMAs deliver s' = log2(e) * scale * (s - m) and P = 2^s' directly
-//     (the results differ from the 32-row form's by the bf16 rounding of the scaled Q);
-//   * K and V^T in three-deep LDS rings, a tile's LDS-DMA issued a whole iteration before the barrier that publishes it, unconditionally
-//     (past the last tile it re-stages the last tile into a free slot: no branches, a constant vmcnt).
-// Wait states: hipcc pads nothing it cannot see.  In front of the MFMAs of a slot stand that slot's ds_read and s_waitcnt (or s_waitcnt + s_nop):
-// the two states a compiler v_accvgpr_write / v_mov of an operand needs (under register pressure it keeps some Q fragments in VGPRs and copies
-// them in front of the statement; the first pipelined build computed its last tile from stale Q fragments exactly so).  MFMA results are read by
-// the VALU a phase (>= 11 slots) after their last MFMA, the prologue and the rescale branch use mfma_result_guard() / explicit s_nops.
-// Head dim 128, no key mask, no q_ss.
-struct Attn2Geo {
-    static constexpr int KT = Geo<128>::K_TILE;         // one K (or V^T) tile: 64 keys x 128 dims x 2 B
-    static constexpr int RING = 3;
-    static constexpr int VBASE = RING * KT;
-    static constexpr int LDS_BYTES = 2 * RING * KT;     // 96 KiB
-};
-#define AT2_MFMA "v_mfma_f32_32x32x16_" LTX2_DT " "
-
-// FL: timing experiments only (tools/attn_form_time.py; results are wrong with any of them): 1 no exponentials, 2 no LDS-DMA in the loop, 16 no row
-// maximum / rescale decision
-template <int FL = 0>
-__global__ __launch_bounds__(256, 1) void attn2_fwd_kernel(const AttnParams p) {
-    constexpr int HD = 128, NQB = 2, QB2 = 128 * NQB;
-    using G = Geo<HD>;
-    constexpr int NKS = G::NKS, ND = G::ND, NJ = G::NJ;
-    constexpr int NK = 2 * NKS, NV = 4 * ND;
-    constexpr int KT = Attn2Geo::KT, VBASE = Attn2Geo::VBASE;
-    constexpr int DK = AT_DK < NK ? AT_DK : NK, DV = AT_DV < NV ? AT_DV : NV;
-    static_assert(NK == 16 && NV == 16 && NJ == 4 && NKS == 8 && ND == 4, "the slot schedule below is written for 16 + 16 fragment slots per tile");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int nt = (p.Nkv + KVB - 1) / KVB, nfull = p.Nkv / KVB;
-    const int head = blockIdx.y, qt = blockIdx.x;
-
-    unsigned k_vo[NJ], v_vo[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int kr = (wv * NJ + j) * 4 + (lane >> 4);
-        const int kchunk = (lane & 15) ^ (kr & 15);
-        k_vo[j] = ((unsigned)kr * (unsigned)p.ldk + kchunk * 8) * 2;
-        const int vr = (wv * NJ + j) * 8 + (lane >> 3);
-        const int vchunk = (lane & 7) ^ ((vr >> 1) & 7);
-        v_vo[j] = ((unsigned)vr * (unsigned)p.Npad + vchunk * 8) * 2;
-    }
-    const unsigned k_tile_bytes = (unsigned)KVB * (unsigned)p.ldk * 2;
-    const unsigned k_bytes = ((unsigned)(p.Nkv - 1) * (unsigned)p.ldk + HD) * 2, v_bytes = (unsigned)HD * (unsigned)p.Npad * 2;
-    const int k_xor = l31 & 15, v_xor = (l31 >> 1) & 7;
-    // per-lane fragment addresses INSIDE the ring slot currently read; they move on by one slot per iteration (12 VALU adds)
-    unsigned k_lane[NKS], v_lane[4];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) k_lane[ks] = lds0 + l31 * (2 * HD) + (((2 * ks + hi) ^ k_xor) << 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v_lane[i] = lds0 + VBASE + l31 * 128 + (((2 * i + hi) ^ v_xor) << 4);
-
-    const int q0 = qt * QB2 + wv * (32 * NQB);
-    const float c = p.scale_log2e;
-    bf16x8 qf[NQB][NKS];            // scale * log2(e) * Q
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        const int qrow = min(q0 + qb * 32 + l31, p.Nq - 1);
-        const bf16* qp = p.Q + (long)qrow * p.ldq + head * HD + 8 * hi;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            bf16x8 v = *(const bf16x8*)(qp + 16 * ks);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = f2bf((float)v[e] * c);
-            qf[qb][ks] = v;
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.K + head * HD), 0, (int)k_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.VT + (long)head * p.vt_head_stride), 0, (int)v_bytes, 0x00020000);
-    f32x16 o[NQB][ND];
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb)
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[qb][d][r] = 0.f;
-    // Software pipeline over KV tiles:
-    //   iteration t:  phase A  S'(t+1) = K(t+1) (cQ)^T - m  (16 slots of 2 MFMAs)  with exponential pairs 0..15 of tile t (its first two 16-key chunks)
-    //                          and the LDS-DMA of K(t+3) / V^T(t+2)
-    //                 phase B  O += V^T(t) P(t)             (16 slots of 2 MFMAs)  with exponential pairs 16..31 (chunks 2, 3: each P fragment complete
-    //                          before the slot that multiplies it), then the row maximum of S'(t+1)
-    //                 then the (wave-uniform, rare) rescale decision for tile t+1
-    // An exponential pair is ISSUED in one slot (exp, exp) and RETIRED in the next (row sums, 16-bit pack): the transcendental's latency runs under
-    // the next slot's MFMAs instead of stalling the wave's only instruction stream.
-    f32x16 s[2][NQB][2];            // two score sets (tile parity), per query block, per 32-key block
-    f32x16 ci[NQB];                 // -m (exponent units) in all 16 registers: the C operand of a score block's first k-step
-    u32x4 pf[NQB][4];               // P fragments of the tile in phase B: per query block, per 16-key chunk
-    float psum[NQB][2][2];          // row sums (four partial sums per block: the retire statements of neighbouring pairs stay independent)
-    float pend[2][2], tmax[NQB], mc[NQB];
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        mc[qb] = 0.f;
-        psum[qb][0][0] = psum[qb][0][1] = psum[qb][1][0] = psum[qb][1][1] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ci[qb][r] = 0.f;
-    }
-    const bool ragged = nfull < nt;
-
-    auto stage_k = [&](int t, unsigned slot_off, int i) {        // piece i (of NJ) of this wave's share of K(t) -> ring slot at byte offset slot_off
-#if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(smem + slot_off + wv * (NJ * 1024) + i * 1024), 16, k_vo[i], t * k_tile_bytes, 0, 0);
-#else
-        (void)t; (void)slot_off; (void)i;
-#endif
-    };
-    auto stage_v = [&](int t, unsigned slot_off, int i) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(smem + VBASE + slot_off + wv * (NJ * 1024) + i * 1024), 16, v_vo[i], t * (KVB * 2), 0, 0);
-#else
-        (void)t; (void)slot_off; (void)i;
-#endif
-    };
-    // K fragment n (issue order: 32-key block n & 1, k-step n >> 1 -- the two blocks' accumulators alternate, a dependent MFMA is four MFMAs away)
-    u32x4 kf[NK], vf[NV];
-    auto k_read = [&](auto N) __attribute__((always_inline)) {
-        constexpr int n = decltype(N)::value;
-        kf[n] = lds_read16<(n & 1) * 32 * 2 * HD>(k_lane[n >> 1]);
-    };
-    // slot n of phase A: [read fragment n + DK] wait for fragment n, the two blocks' MFMAs into score set SP
-    auto qk_slot = [&](auto SPAR, auto N) __attribute__((always_inline)) {
-        constexpr int SP = decltype(SPAR)::value, n = decltype(N)::value, b = n & 1, ks = n >> 1, nn = n + DK;
-        (void)&s; (void)&kf; (void)&qf; (void)&ci; (void)&k_lane;
-        if constexpr (ks == 0) {
-            static_assert(nn < NK, "the first k-steps always have a read to issue");
-            asm volatile("ds_read_b128 %2, %8 offset:%9\n\ts_waitcnt lgkmcnt(%10)\n\t" AT2_MFMA "%0, %3, %4, %6\n\t" AT2_MFMA "%1, %3, %5, %7"
-                         : "=&v"(s[SP][0][b]), "=&v"(s[SP][1][b]), "=&v"(kf[nn < NK ? nn : 0])
-                         : "v"(kf[n]), "a"(qf[0][ks]), "a"(qf[1][ks]), "v"(ci[0]), "v"(ci[1]), "v"(k_lane[(nn < NK ? nn : 0) >> 1]), "n"((nn & 1) * 32 * 2 * HD), "n"(DK)
-                         : "memory");
-        } else if constexpr (nn < NK) {
-            asm volatile("ds_read_b128 %2, %6 offset:%7\n\ts_waitcnt lgkmcnt(%8)\n\t" AT2_MFMA "%0, %3, %4, %0\n\t" AT2_MFMA "%1, %3, %5, %1"
-                         : "+v"(s[SP][0][b]), "+v"(s[SP][1][b]), "=&v"(kf[nn < NK ? nn : 0])
-                         : "v"(kf[n]), "a"(qf[0][ks]), "a"(qf[1][ks]), "v"(k_lane[(nn < NK ? nn : 0) >> 1]), "n"((nn & 1) * 32 * 2 * HD), "n"(DK)
-                         : "memory");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(%5)\n\ts_nop 0\n\t" AT2_MFMA "%0, %2, %3, %0\n\t" AT2_MFMA "%1, %2, %4, %1"
-                         : "+v"(s[SP][0][b]), "+v"(s[SP][1][b])
-                         : "v"(kf[n]), "a"(qf[0][ks]), "a"(qf[1][ks]), "n"(NK - 1 - n)
-                         : "memory");
-        }
-    };
-    // V^T fragment of slot n of phase B: dim block n % 4, 16-key chunk n / 4
-    auto v_read = [&](auto N) __attribute__((always_inline)) {
-        constexpr int n = decltype(N)::value;
-        vf[n] = lds_read16<(n % ND) * 32 * 128>(v_lane[n / ND]);
-    };
-    auto pv_slot = [&](auto N) __attribute__((always_inline)) {
-        constexpr int n = decltype(N)::value, d = n % ND, ch = n / ND, nn = n + DV;
-        (void)&o; (void)&vf; (void)&pf; (void)&v_lane;
-        if constexpr (nn < NV) {
-            asm volatile("ds_read_b128 %2, %6 offset:%7\n\ts_waitcnt lgkmcnt(%8)\n\t" AT2_MFMA "%0, %3, %4, %0\n\t" AT2_MFMA "%1, %3, %5, %1"
-                         : "+a"(o[0][d]), "+a"(o[1][d]), "=&v"(vf[nn < NV ? nn : 0])
-                         : "v"(vf[n]), "v"(pf[0][ch]), "v"(pf[1][ch]), "v"(v_lane[(nn < NV ? nn : 0) / ND]), "n"((nn % ND) * 32 * 128), "n"(DV)
-                         : "memory");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(%5)\n\ts_nop 0\n\t" AT2_MFMA "%0, %2, %3, %0\n\t" AT2_MFMA "%1, %2, %4, %1"
-                         : "+a"(o[0][d]), "+a"(o[1][d])
-                         : "v"(vf[n]), "v"(pf[0][ch]), "v"(pf[1][ch]), "n"(NV - 1 - n)
-                         : "memory");
-        }
-    };
-    // exponential pair E (0..31) of the tile whose scores are in set SP: 16-key chunk E / 8, query block (E / 4) % 2, register pair E % 4
-    auto exp_issue = [&](auto SPAR, auto E) __attribute__((always_inline)) {
-        constexpr int SP = decltype(SPAR)::value, e = decltype(E)::value, j = e / 8, qb = (e / 4) % 2, b = j / 2, r = 8 * (j % 2) + 2 * (e % 4);
-        (void)&pend; (void)&s;
-        if constexpr (!(FL & 1))
-            asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(pend[e & 1][0]), "=v"(pend[e & 1][1]) : "v"(s[SP][qb][b][r]), "v"(s[SP][qb][b][r + 1]));
-    };
-    auto exp_retire = [&](auto E) __attribute__((always_inline)) {
-        constexpr int e = decltype(E)::value, j = e / 8, qb = (e / 4) % 2;
-        (void)&psum; (void)&pf; (void)&pend;
-        if constexpr (!(FL & 1))
-            asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_cvt_pk_" LTX2_DT "_f32 %2, %3, %4"
-                     : "+v"(psum[qb][e & 1][0]), "+v"(psum[qb][e & 1][1]), "=v"(pf[qb][j][e % 4]) : "v"(pend[e & 1][0]), "v"(pend[e & 1][1]));
-    };
-    // row maximum step R (0..15) of both blocks over score set SP
-    auto max_step = [&](auto SPAR, auto R) __attribute__((always_inline)) {
-        constexpr int SP = decltype(SPAR)::value, r = decltype(R)::value;
-        (void)&tmax; (void)&s;      // (a generic lambda whose only uses of a local are asm operands does not capture it with this clang)
-        asm volatile("v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %4, %5"
-                     : "+v"(tmax[0]), "+v"(tmax[1]) : "v"(s[SP][0][0][r]), "v"(s[SP][0][1][r]), "v"(s[SP][1][0][r]), "v"(s[SP][1][1][r]));
-    };
-    // keys of the ragged last tile u past Nkv, on its scores (set SP)
-    auto mask_scores = [&](auto SPAR, int u) __attribute__((always_inline)) {
-        constexpr int SP = decltype(SPAR)::value;
-        const int kv0 = u * KVB;
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kl = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (kv0 + kl >= p.Nkv) s[SP][qb][b][r] = -INFINITY;
-                }
-    };
-    // after the row maximum of the tile in flight (set SP, relative to the running maximum): other lane half; if any row of the wave gained more than
-    // RESCALE_THR exponent units, the block's running maximum moves up: accumulators, row sums and the scores already computed follow it
-    auto decide = [&](auto SPAR) __attribute__((always_inline)) {
-        constexpr int SP = decltype(SPAR)::value;
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) {
-            float t_lo, t_hi;
-            half_pair(tmax[qb], t_lo, t_hi);
-            const float tm = fmaxf(t_lo, t_hi);
-            if (!__all(tm <= RESCALE_THR)) {
-                const float up = fmaxf(tm, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-up);
-                mc[qb] += up;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    psum[qb][i][0] *= alpha;
-                    psum[qb][i][1] *= alpha;
-                }
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[SP][qb][b][r] -= up;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ci[qb][r] = -mc[qb];
-                // the accumulators live in AGPRs, which the VALU cannot touch: they are copied out and back HERE, inside the (rare) branch -- the
-                // empty asms redefine them on both sides, so hipcc cannot hoist the 64 v_accvgpr_read of a block to the top of every tile (it did)
-#pragma unroll
-                for (int d = 0; d < ND; ++d) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(o[qb][d]));       // (+ the last PV MFMAs' wait states)
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[qb][d][r] *= alpha;
-#pragma unroll
-                for (int d = 0; d < ND; ++d) asm volatile("" : "+a"(o[qb][d]));
-            }
-        }
-    };
-
-    // ---- prologue: K(0..2), V^T(0..1) on their way; S(0) with C = 0; its row maximum becomes the running maximum ----
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) stage_k(0, 0, i);
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) stage_v(0, 0, i);
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) stage_k(min(1, nt - 1), KT, i);
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) stage_v(min(1, nt - 1), KT, i);
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) stage_k(min(2, nt - 1), 2 * KT, i);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    static_for<0, DK>(k_read);
-    static_for<0, NK>([&](auto N) __attribute__((always_inline)) { qk_slot(std::integral_constant<int, 0>{}, N); });
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) tmax[qb] = -INFINITY;
-    mfma_result_guard(s[0][0][0], s[0][0][1], tmax[0]);
-    mfma_result_guard(s[0][1][0], s[0][1][1], tmax[1]);
-    if (ragged && nt == 1) mask_scores(std::integral_constant<int, 0>{}, 0);
-    static_for<0, 16>([&](auto R) __attribute__((always_inline)) { max_step(std::integral_constant<int, 0>{}, R); });
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        float t_lo, t_hi;
-        half_pair(tmax[qb], t_lo, t_hi);
-        mc[qb] = fmaxf(t_lo, t_hi);
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[0][qb][b][r] -= mc[qb];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ci[qb][r] = -mc[qb];
-    }
-    // ring positions (wave-uniform): K(t+1) is read from slot kr, V^T(t) from slot vr; K(t+3) goes to slot (t % 3), V^T(t+2) to slot ((t + 2) % 3)
-    int kr = 1, vr = 0;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) k_lane[ks] += KT;
-
-    auto iteration = [&](const int t, auto par) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;            // t & 1
-        constexpr auto CUR = std::integral_constant<int, PAR>{};
-        constexpr auto NXT = std::integral_constant<int, 1 - PAR>{};
-        // what the PREVIOUS iteration issued may still fly (two tiles = 8 pieces per wave); everything older has to have landed
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __syncthreads();
-        const int tk = min(t + 3, nt - 1), tv = min(t + 2, nt - 1);
-        const unsigned k_dst = (unsigned)(vr * KT), v_dst = (unsigned)((vr == 0 ? 2 : vr - 1) * KT);       // t % 3 == vr ; (t + 2) % 3
-        // ---- phase A ----
-        static_for<0, DK>(k_read);
-        static_for<0, NK>([&](auto N) __attribute__((always_inline)) {
-            constexpr int n = decltype(N)::value;
-            qk_slot(NXT, N);
-            if constexpr (n > 0) exp_retire(std::integral_constant<int, n - 1>{});
-            exp_issue(CUR, N);
-            if constexpr (!(FL & 2)) {
-                if constexpr ((n & 1) && n / 2 < NJ) stage_k(tk, k_dst, n / 2);
-                else if constexpr ((n & 1)) stage_v(tv, v_dst, n / 2 - NJ);
-            } else if constexpr (n == 15) {
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) stage_k(tk, k_dst, i);     // (timing experiment: the same count of pieces, all at the end)
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) stage_v(tv, v_dst, i);
-            }
-        });
-        // ---- phase B ----
-        static_for<0, DV>(v_read);
-        static_for<0, NV>([&](auto N) __attribute__((always_inline)) {
-            constexpr int n = decltype(N)::value;
-            pv_slot(N);
-            // exponential pairs 16..31: two per slot in slots 0..4, one in 5..10 (chunk 2 complete before slot 8, chunk 3 before slot 12)
-            if constexpr (n == 0) {
-                exp_retire(std::integral_constant<int, 15 + 0 * n>{});
-                exp_issue(CUR, std::integral_constant<int, 16 + 0 * n>{});
-                exp_issue(CUR, std::integral_constant<int, 17 + 0 * n>{});
-            } else if constexpr (n <= 4) {
-                exp_retire(std::integral_constant<int, 14 + 2 * n>{});
-                exp_retire(std::integral_constant<int, 15 + 2 * n>{});
-                exp_issue(CUR, std::integral_constant<int, 16 + 2 * n>{});
-                exp_issue(CUR, std::integral_constant<int, 17 + 2 * n>{});
-            } else if constexpr (n == 5) {
-                exp_retire(std::integral_constant<int, 24 + 0 * n>{});
-                exp_retire(std::integral_constant<int, 25 + 0 * n>{});
-                exp_issue(CUR, std::integral_constant<int, 26 + 0 * n>{});
-            } else if constexpr (n <= 10) {
-                exp_retire(std::integral_constant<int, 20 + n>{});
-                exp_issue(CUR, std::integral_constant<int, 21 + n>{});
-            } else if constexpr (n == 11) {
-                exp_retire(std::integral_constant<int, 31 + 0 * n>{});
-                // the row maximum of S'(t+1): its MFMAs ended eleven slots ago
-#pragma unroll
-                for (int qb = 0; qb < NQB; ++qb) tmax[qb] = -INFINITY;
-                if (ragged && t + 1 == nt - 1) mask_scores(NXT, t + 1);
-            }
-            if constexpr (n >= 11 && !(FL & 16)) {
-                constexpr int k = n - 11;         // 5 slots: 16 max3 steps
-                static_for<(k * 16) / 5, ((k + 1) * 16) / 5>([&](auto R) __attribute__((always_inline)) { max_step(NXT, R); });
-            }
-        });
-        if (t + 1 < nt && !(FL & 16)) decide(NXT);       // (the last iteration's S(nt) is computed from a stale ring slot and never looked at)
-        // the rings move on by one slot
-        const int dk = kr == 2 ? -2 * KT : KT, dv = vr == 2 ? -2 * KT : KT;
-        kr = kr == 2 ? 0 : kr + 1;
-        vr = vr == 2 ? 0 : vr + 1;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) k_lane[ks] += dk;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v_lane[i] += dv;
-    };
-
-    for (int t = 0;; t += 2) {
-        iteration(t, std::integral_constant<int, 0>{});
-        if (t + 1 >= nt) break;
-        iteration(t + 1, std::integral_constant<int, 1>{});
-        if (t + 2 >= nt) break;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // the last PV MFMAs' results (asm: the hazard recogniser does not see them) before the VALU reads the accumulators
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb)
-#pragma unroll
-        for (int d = 0; d < ND; ++d) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(o[qb][d]));
-
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        float l_lo, l_hi;
-        half_pair((psum[qb][0][0] + psum[qb][0][1]) + (psum[qb][1][0] + psum[qb][1][1]), l_lo, l_hi);
-        float inv = 1.0f / (l_lo + l_hi);
-        const int qrow = q0 + qb * 32 + l31;
-        if (p.gate && qrow < p.Nq) inv *= 2.f / (1.f + __expf(-p.gate[(long)qrow * p.gate_ld + head]));
-        if (qrow < p.Nq) {
-            bf16* op = p.O + (long)qrow * p.ldo + head * HD + 4 * hi;
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = f2bf(o[qb][d][g * 4 + e] * inv);
-                    *(bf16x4*)(op + d * 32 + g * 8) = v;
-                }
-        }
-    }
-}
-
 // V [Nkv][ld] (head h at columns h*HD) -> VT[h][HD][Npad] with the key permutation
 // pos(kv = 32b + 8g + 4hi + e) = 32b + 16(g>>1) + 8hi + 4(g&1) + e ; keys >= Nkv are zero-filled.
 template <int HD>
@@ -1052,12 +658,6 @@ long attn_sk_workspace_bytes(int head_dim) {
     return 4096 + 1024L * slot;            // the flags (one 4-KiB page, zero before first use) + up to 1024 workgroup slots
 }
 
-// when the launcher picks the 64-rows-per-wave form by itself (AttnParams::form == 0): never -- it measured slower on every DiT shape (tools/attn_form_time.py)
-static bool attn2_preferred(const AttnParams& p) {
-    (void)p;
-    return false;
-}
-
 int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.Nq > 0 && p.Nkv > 0 && p.H > 0, "attention: empty problem");
     LTX2_CHECK_ARG(p.head_dim == 0 || p.head_dim == 128 || p.head_dim == 64, "attention: head_dim=%d, only 128 and 64 are implemented", p.head_dim);
@@ -1097,20 +697,6 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
         else
             hipLaunchKernelGGL((attn_fwd_kernel<128, true>), dim3(workers), dim3(256), Geo<128>::LDS_BYTES, stream, q);
         LTX2_CHECK_LAUNCH("attn_fwd_kernel<SK>");
-        return LTX2_OK;
-    }
-    // the 64-rows-per-wave form (attn2_fwd_kernel): head_dim 128, enough query rows to fill the CUs with 256-row tiles
-    if (p.form >= 2 || (p.form == 0 && attn2_preferred(p))) {
-        LTX2_CHECK_ARG(p.head_dim != 64 && !p.q_ss && !p.kmask, "attention: the 64-rows-per-wave form needs head_dim 128, no key mask, no q_ss");
-        dim3 grid2((p.Nq + 255) / 256, p.H);
-#define AT2_LAUNCH(FLV) case FLV: { (void)hipFuncSetAttribute((const void*)attn2_fwd_kernel<FLV>, hipFuncAttributeMaxDynamicSharedMemorySize, Attn2Geo::LDS_BYTES); \
-            hipLaunchKernelGGL(attn2_fwd_kernel<FLV>, grid2, dim3(256), Attn2Geo::LDS_BYTES, stream, p); break; }
-        switch (p.form >= 2 ? p.form - 2 : 0) {
-            AT2_LAUNCH(0) AT2_LAUNCH(1) AT2_LAUNCH(16) AT2_LAUNCH(17)
-            default: LTX2_CHECK_ARG(false, "attention: unknown form %d", p.form);
-        }
-#undef AT2_LAUNCH
-        LTX2_CHECK_LAUNCH("attn2_fwd_kernel");
         return LTX2_OK;
     }
     dim3 grid((p.Nq + QB - 1) / QB, p.H);

@@ -302,34 +302,6 @@ int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const
     return head_gate_launch((bf16*)att, ld, logits, H, rows, H, head_dim, (hipStream_t)stream);
 }
 
-int ltx2_flash_attn_form(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
-                         int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, int form, void* stream) {
-    LTX2_CHECK_ARG(Q && K && VT && out, "flash_attn_form: null operand");
-    LTX2_CHECK_ARG(head_dim == 128 || head_dim == 64, "flash_attn_form: head_dim=%d, only 128 and 64 are implemented", head_dim);
-    LTX2_CHECK_ARG(form >= 0 && form < 66, "flash_attn_form: form 0 (the launcher picks), 1 (32 rows per wave), 2 (64 rows per wave), 2 + flags (timing experiments)");
-    AttnParams a{};
-    a.Q = (const bf16*)Q;
-    a.ldq = ldq;
-    a.K = (const bf16*)K;
-    a.ldk = ldk;
-    a.VT = (const bf16*)VT;
-    a.vt_head_stride = (long)head_dim * Npad;
-    a.head_dim = head_dim;
-    a.O = (bf16*)out;
-    a.ldo = ldo;
-    a.Nq = Nq;
-    a.Nkv = Nkv;
-    a.Npad = Npad;
-    a.H = H;
-    a.scale_log2e = scale * 1.4426950408889634f;
-    a.q_ss = q_ss;
-    a.q_ss_ld = q_ss_ld;
-    a.q_norm_dim = q_norm_dim;
-    a.q_eps = q_eps;
-    a.form = form;
-    return attn_launch(a, (hipStream_t)stream);
-}
-
 int ltx2_flash_attn_gated(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
                           int H, int head_dim, float scale, const float* gate_logits, int gate_ld, void* stream) {
     LTX2_CHECK_ARG(Q && K && VT && out && gate_logits && gate_ld >= H, "flash_attn_gated: null operand / gate_ld < H");

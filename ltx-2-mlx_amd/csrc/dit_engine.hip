@@ -1157,10 +1157,13 @@ int ltx2_dit_graph_capture(ltx2_dit* c, float* latent, const float* host_sigmas,
 // Conditioned loops (image-to-video: some tokens carry a denoise mask < 1): per step the timesteps are mask * sigma_i, formed on the device
 // inside the captured step, and the Euler update blends x0 with the clean latent as ltx2_dit_denoise_step does.
 namespace {
-int cond_modality(ltx2_dit* c, int k, const float* mask, const float* clean, const float* sigma_i, ModIn& in, StepIo& io, hipStream_t st) {
+int cond_modality(ltx2_dit* c, int k, const float* mask, long n_mask, const float* clean, long n_clean, const float* sigma_i, ModIn& in, StepIo& io, hipStream_t st) {
     Mod& m = c->m[k];
     if (!mask) return LTX2_OK;           // this modality has no conditioning tokens: the uniform form
     LTX2_CHECK_ARG(clean, "dit_graph_capture_cond: a denoise mask needs the clean latent");
+    // the replayed kernels read N mask elements and N * C clean-latent elements on every step: a buffer of another modality's length would be an
+    // out-of-bounds device read, not an error
+    LTX2_CHECK_ARG(n_mask == m.N && n_clean == (long)m.N * m.Cout, "dit_graph_capture_cond: modality %d has %d tokens x %d channels, got a mask of %ld and a clean latent of %ld elements", k, m.N, m.Cout, n_mask, n_clean);
     if (!c->per_token || !m.ts_tok) {
         ltx2_set_error("dit_graph_capture_cond: the workspace was not bound for per-token timesteps");
         return LTX2_E_STATE;
@@ -1175,7 +1178,8 @@ int cond_modality(ltx2_dit* c, int k, const float* mask, const float* clean, con
 }
 }  // namespace
 
-int ltx2_dit_graph_capture_cond(ltx2_dit* c, float* latent, const float* host_sigmas, int n_steps, const float* mask, const float* clean, void* stream) {
+int ltx2_dit_graph_capture_cond(ltx2_dit* c, float* latent, const float* host_sigmas, int n_steps, const float* mask, int64_t n_mask, const float* clean,
+                                int64_t n_clean, void* stream) {
     LTX2_CHECK_ARG(latent && host_sigmas && n_steps > 0 && n_steps < 64, "dit_graph_capture_cond: bad argument");
     TRY(check_ready(c, "dit_graph_capture_cond", false));
     hipStream_t st = (hipStream_t)stream;
@@ -1184,14 +1188,14 @@ int ltx2_dit_graph_capture_cond(ltx2_dit* c, float* latent, const float* host_si
     for (int i = 0; i < n_steps && rc == LTX2_OK; ++i) {
         ModIn in[1] = {{latent, c->sigmas_dev + i, 1, c->sigmas_dev + i, nullptr}};
         StepIo io[1] = {{latent, nullptr, nullptr, nullptr}};
-        rc = cond_modality(c, 0, mask, clean, c->sigmas_dev + i, in[0], io[0], st);
+        rc = cond_modality(c, 0, mask, n_mask, clean, n_clean, c->sigmas_dev + i, in[0], io[0], st);
         if (rc == LTX2_OK) rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st, i == 0);
     }
     return end_capture(c, rc, st);
 }
 
-int ltx2_dit_graph_capture_cond_av(ltx2_dit* c, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps, const float* v_mask,
-                                   const float* v_clean, const float* a_mask, const float* a_clean, void* stream) {
+int ltx2_dit_graph_capture_cond_av(ltx2_dit* c, float* v_latent, float* a_latent, const float* host_sigmas, int n_steps, const float* v_mask, int64_t n_v_mask,
+                                   const float* v_clean, int64_t n_v_clean, const float* a_mask, int64_t n_a_mask, const float* a_clean, int64_t n_a_clean, void* stream) {
     LTX2_CHECK_ARG(v_latent && a_latent && host_sigmas && n_steps > 0 && n_steps < 64, "dit_graph_capture_cond_av: bad argument");
     TRY(check_ready(c, "dit_graph_capture_cond_av", true));
     hipStream_t st = (hipStream_t)stream;
@@ -1201,8 +1205,8 @@ int ltx2_dit_graph_capture_cond_av(ltx2_dit* c, float* v_latent, float* a_latent
         const float* s = c->sigmas_dev + i;
         ModIn in[2] = {{v_latent, s, 1, s, nullptr}, {a_latent, s, 1, s, nullptr}};
         StepIo io[2] = {{v_latent, nullptr, nullptr, nullptr}, {a_latent, nullptr, nullptr, nullptr}};
-        rc = cond_modality(c, 0, v_mask, v_clean, s, in[0], io[0], st);
-        if (rc == LTX2_OK) rc = cond_modality(c, 1, a_mask, a_clean, s, in[1], io[1], st);
+        rc = cond_modality(c, 0, v_mask, n_v_mask, v_clean, n_v_clean, s, in[0], io[0], st);
+        if (rc == LTX2_OK) rc = cond_modality(c, 1, a_mask, n_a_mask, a_clean, n_a_clean, s, in[1], io[1], st);
         if (rc == LTX2_OK) rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st, i == 0);
     }
     return end_capture(c, rc, st);

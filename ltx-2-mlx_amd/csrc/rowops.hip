@@ -910,7 +910,7 @@ int adaln_combine_launch(const float* tab, const float* emb, float* out, int lay
 
 int norm_mod2_launch(const float* x, long ldx, bf16* out0, bf16* out1, long ldo, int rows, int D, float eps, const float* const* scale_tab,
                      const float* const* shift_tab, const float* const* scale_emb, const float* const* shift_emb, hipStream_t stream) {
-    LTX2_CHECK_ARG(x && out0 && out1 && rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && D <= 4096, "norm_mod2: bad operand (D <= 4096, multiples of 4)");
+    LTX2_CHECK_ARG(x && out0 && out1 && rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && D <= 8192, "norm_mod2: bad operand (D <= 8192, multiples of 4)");
     NormMod2Tabs t{};
     for (int g = 0; g < 2; ++g) {
         t.scale_tab[g] = scale_tab[g];
@@ -918,9 +918,12 @@ int norm_mod2_launch(const float* x, long ldx, bf16* out0, bf16* out1, long ldo,
         t.scale_emb[g] = scale_emb[g];
         t.shift_emb[g] = shift_emb[g];
     }
-    const int per_block = (rows + 1023) / 1024;
+    const int per_block = (rows + LTX2_NORM_BLOCKS - 1) / LTX2_NORM_BLOCKS;
     const int grid = (rows + per_block - 1) / per_block;
-    hipLaunchKernelGGL((norm_mod_shared2_kernel<4>), dim3(grid), dim3(256), 0, stream, x, ldx, out0, out1, ldo, rows, D, eps, t);
+    if (D <= 4096)
+        hipLaunchKernelGGL((norm_mod_shared2_kernel<4>), dim3(grid), dim3(256), 0, stream, x, ldx, out0, out1, ldo, rows, D, eps, t);
+    else        // the two norm_mod launches this replaced took D <= 8192
+        hipLaunchKernelGGL((norm_mod_shared2_kernel<8>), dim3(grid), dim3(256), 0, stream, x, ldx, out0, out1, ldo, rows, D, eps, t);
     LTX2_CHECK_LAUNCH("norm_mod_shared2_kernel");
     return LTX2_OK;
 }

@@ -108,20 +108,6 @@ def flash_attn_rowscale(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, head
     return out
 
 
-def flash_attn_form(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, form: int, q_ss: Optional[torch.Tensor] = None,
-                    eps: float = 1e-6, scale: Optional[float] = None) -> torch.Tensor:
-    """flash_attn (or flash_attn_rowscale when q_ss is given) on a named kernel form: 1 (32 query rows per wave: production) or 2 (the 64-rows-per-wave
-    experiment; head_dim 128, no q_ss); 2 + flags = its timing-experiment builds (tools/attn_form_time.py)."""
-    assert q.dtype in ACT16 and q.stride(1) == 1 and k.stride(1) == 1
-    nq, hd = q.shape[0], vt.shape[1]
-    out = torch.empty(nq, heads * hd, device=q.device, dtype=q.dtype)
-    if scale is None:
-        scale = 1.0 / math.sqrt(float(hd))
-    nv.check(_L(q).ltx2_flash_attn_form(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out), out.stride(0), nq, nkv,
-                                        heads, hd, scale, nv.ptr(q_ss), q_ss.shape[1] if q_ss is not None else 0, heads * hd, eps, form, nv.stream()))
-    return out
-
-
 def flash_attn_gated(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, gate_logits: torch.Tensor,
                      scale: Optional[float] = None) -> torch.Tensor:
     """flash_attn with per-head output gates 2*sigmoid(gate_logits[q, h]) applied in the epilogue (fp32, before the rounding)."""

@@ -638,16 +638,18 @@ class LTXModel:
         for mk, cl in ((denoise_mask, clean_latent), (audio_denoise_mask, audio_clean_latent)):
             if mk is not None:
                 assert cl is not None and mk.dtype == torch.float32 and cl.dtype == torch.float32 and mk.is_contiguous() and cl.is_contiguous() and mk.dim() == 1
+        n_el = lambda t: 0 if t is None else t.numel()      # element counts: the engine checks them against the bound token count (a wrong-length buffer would be an out-of-bounds replay read)
         self._graph_refs = (latent, audio_latent, denoise_mask, clean_latent, audio_denoise_mask, audio_clean_latent)
         if self.is_av:
             assert audio_latent is not None
             if cond:
-                nv.check(self._L.ltx2_dit_graph_capture_cond_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), arr, len(sigmas) - 1, nv.ptr(denoise_mask),
-                                                                nv.ptr(clean_latent), nv.ptr(audio_denoise_mask), nv.ptr(audio_clean_latent), st.cuda_stream))
+                nv.check(self._L.ltx2_dit_graph_capture_cond_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), arr, len(sigmas) - 1, nv.ptr(denoise_mask), n_el(denoise_mask),
+                                                                nv.ptr(clean_latent), n_el(clean_latent), nv.ptr(audio_denoise_mask), n_el(audio_denoise_mask),
+                                                                nv.ptr(audio_clean_latent), n_el(audio_clean_latent), st.cuda_stream))
             else:
                 nv.check(self._L.ltx2_dit_graph_capture_av(self._h, nv.ptr(latent), nv.ptr(audio_latent), arr, len(sigmas) - 1, st.cuda_stream))
         elif cond:
-            nv.check(self._L.ltx2_dit_graph_capture_cond(self._h, nv.ptr(latent), arr, len(sigmas) - 1, nv.ptr(denoise_mask), nv.ptr(clean_latent), st.cuda_stream))
+            nv.check(self._L.ltx2_dit_graph_capture_cond(self._h, nv.ptr(latent), arr, len(sigmas) - 1, nv.ptr(denoise_mask), n_el(denoise_mask), nv.ptr(clean_latent), n_el(clean_latent), st.cuda_stream))
         else:
             nv.check(self._L.ltx2_dit_graph_capture(self._h, nv.ptr(latent), arr, len(sigmas) - 1, st.cuda_stream))
 

@@ -108,6 +108,46 @@ def test_bench_single_gpu_line(dev):
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["roofline"]["frac"] is not None and out["roofline"]["traffic"] is not None
 
 
+def test_bench_driver_command(dev):
+    """The driver's exact argv (`--gpus 1 --steps 20 --warmup 5`: 20 is NOT a multiple of 8) plus only `--layers 2 --loader-layers 1`, with every leg the
+    driver's run takes: kernel pass, the hipGraph form for the record, the power probe, the VAE decode, the secondary configurations, the loader and the
+    CPU baseline.  Round 4's line was lost to an exception in a leg AFTER the timed region; this is the run that would have caught it."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--layers", "2", "--loader-layers", "1"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert not [k for k in out if k.endswith("_error")], {k: v for k, v in out.items() if k.endswith("_error")}
+    assert out["steps"] == 20 and out["warmup"] == 5 and out["n_gpus"] == 1 and out["value"] > 0
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-2 * out["value"]
+    for k in ("vae_decode_ms", "vae_decode_frames_per_sec", "hipgraph_ms_per_step", "eager_ms_per_step", "step_mfma_roofline_frac"):
+        assert isinstance(out[k], float) and out[k] > 0, (k, out[k])
+    assert isinstance(out["roofline"]["frac"], float) and out["roofline"]["launches"] > 0
+    assert isinstance(out["cpu_baseline"]["value"], float) and out["cpu_baseline"]["cores"] >= 1
+    assert isinstance(out["vae_roofline"]["mfma"]["frac"], float) and isinstance(out["vae_roofline"]["hbm"]["frac"], float)
+    assert out["hipgraph_steps_timed"] == 16
+    ex = out["extra_configs"]
+    assert "error" not in ex and ex["fp8_compute_ms_per_step"] > 0 and ex["ltx23_audiovideo_ms_per_step"] > 0
+    assert out["loader"]["first_load"]["file_to_hbm_gbps"] > 0
+
+
+def test_bench_line_survives_a_failing_leg(dev):
+    """A leg that raises after the timed region costs its own fields only: LTX2_BENCH_FAIL_LEG makes the VAE leg raise; the line still
+    carries the headline, the roofline object and `vae_error`, rc 0."""
+    import json
+    import subprocess
+    env = dict(os.environ, LTX2_BENCH_FAIL_LEG="vae")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "9", "--warmup", "1", "--layers", "2", "--no-extra", "--no-loader",
+                        "--no-cpu-baseline", "--no-power"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert out["value"] > 0 and out["roofline"]["frac"] is not None and out["hipgraph_ms_per_step"] > 0
+    assert "LTX2_BENCH_FAIL_LEG" in out["vae_error"] and out["vae_decode_ms"] is None
+
+
 def test_generate_cli_two_stage(dev, tmp_path):
     """`--two-stage-distilled` (MI355X extra) routes through the reference's DistilledPipeline class (pipelines/distilled.py:274-505),
     which the reference's own CLI never wires; `--pipeline two-stage` (dev-model CFG stage 1) is refused."""

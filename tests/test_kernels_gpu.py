@@ -775,7 +775,7 @@ def test_flash_attention_key_mask(dev, hd, H, Nq, S):
 
 
 # ------------------------------------------------------------------------------------------ round 4: the AudioVideo block's cross-modal section
-@pytest.mark.parametrize("rows,D", [(3456, 4096), (68, 2048), (5, 512)])
+@pytest.mark.parametrize("rows,D", [(3456, 4096), (68, 2048), (5, 512), (130, 6144)])
 def test_adaln_rmsnorm2_equals_two_passes(K, dev, rows, D):
     g = torch.Generator().manual_seed(rows)
     x = torch.randn(rows, D, generator=g).to(dev)
@@ -786,30 +786,6 @@ def test_adaln_rmsnorm2_equals_two_passes(K, dev, rows, D):
     assert torch.equal(o0, r0) and torch.equal(o1, r1)
     p0, p1 = K.adaln_rmsnorm2(x, None, None, t[2], None)
     assert torch.equal(p0, K.adaln_rmsnorm(x)) and torch.equal(p1, K.adaln_rmsnorm(x, 1e-6, False, t[2], None))
-
-
-@pytest.mark.parametrize("heads,Nq,Nkv", [(1, 256, 64), (2, 256, 128), (2, 512, 320), (3, 300, 1000), (2, 1000, 50), (8, 700, 1472)])
-def test_flash_attn_64row_form(K, dev, heads, Nq, Nkv):
-    """The 64-rows-per-wave attention experiment (form 2: software-pipelined, three-deep LDS rings, pre-scaled Q) against the production form
-    and fp64: one / two / odd / even / ragged KV tile counts, query tiles past Nq."""
-    hd = 128
-    g = torch.Generator().manual_seed(Nq + Nkv)
-    D = heads * hd
-    qq = (2 * torch.randn(Nq, D, generator=g)).to(BF).to(dev)
-    kk = torch.randn(Nkv, D, generator=g)
-    if Nkv == 1472:       # keys growing along the sequence: the running maximum moves up tile after tile (the rescale branch)
-        kk = kk * torch.linspace(0.2, 3.0, Nkv)[:, None]
-    kk = kk.to(BF).to(dev)
-    vv = torch.randn(Nkv, D, generator=g).to(BF).to(dev)
-    vt = K.vt_transpose(vv, heads, head_dim=hd)
-    a = K.flash_attn_form(qq, kk, vt, heads, Nkv, 1)
-    b = K.flash_attn_form(qq, kk, vt, heads, Nkv, 2)
-    assert torch.equal(b, K.flash_attn_form(qq, kk, vt, heads, Nkv, 2))
-    qh, kh, vh = [t.double().reshape(-1, heads, hd).transpose(0, 1) for t in (qq, kk, vv)]
-    exact = (torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(hd), dim=-1) @ vh).transpose(0, 1).reshape(Nq, D)
-    assert rel_l2(a.double().cpu(), exact.cpu()) < 6e-3
-    assert rel_l2(b.double().cpu(), exact.cpu()) < 6e-3
-    assert rel_l2(b.double().cpu(), a.double().cpu()) < 6e-3
 
 
 @pytest.mark.parametrize("heads,hd,Nq,Nkv", [(32, 128, 1100, 1024), (32, 64, 68, 3456), (4, 64, 300, 68)])

@@ -105,6 +105,13 @@ def test_conditioned_loop_through_the_hipgraph(dev):
     assert rel_l2(outs[1], outs[0]) < 1e-5
     # the conditioned tokens end at their clean values, the free ones moved
     assert rel_l2(outs[1][:, :24], clean[:, :24]) < 1e-5 and rel_l2(outs[1][:, 30:], lat[:, 30:]) > 0.1
+    # a mask / clean latent of another length (the audio modality's, say) is refused at capture: the replay would read past it
+    lat_d = lat[0].clone().to(dev)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        with pytest.raises(ValueError, match="tokens x"):
+            m.capture_denoise_graph(lat_d, DISTILLED_SIGMA_VALUES, denoise_mask=torch.ones(N - 8, device=dev), clean_latent=clean[0].to(dev).contiguous())
+        with pytest.raises(ValueError, match="tokens x"):
+            m.capture_denoise_graph(lat_d, DISTILLED_SIGMA_VALUES, denoise_mask=torch.ones(N, device=dev), clean_latent=clean[0, :N - 8].to(dev).contiguous())
 
 
 def test_dit_full_width_block(dev):
