@@ -58,6 +58,12 @@ struct Geo {
 #ifndef AT_MAX2
 #define AT_MAX2 0
 #endif
+#ifndef AT_DV16X
+#define AT_DV16X 4
+#endif
+#ifndef AT_PVX16
+#define AT_PVX16 2      // the 16x16x32 kernel's same-wave exp / MFMA interleave: 0 never, 1 always, 2 where the grid's last round leaves SIMDs with one wave
+#endif
 #ifndef AT_PRIO
 #define AT_PRIO 1       // 1 = s_setprio 1 over the two MFMA clusters of a tile (round 3, same-box A/B: self-attention -0.7 %, text cross-attention -2 %:
                         // the wave inside an MFMA cluster wins the issue slot, its SIMD partner's softmax VALU fills the gaps); 2 = over the softmax (no gain)
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     using G = Geo<HD>;
     constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NKS = G::NKS, ND = G::ND, NJ = G::NJ;
     constexpr int NK = 2 * NKS, NV = 4 * ND;        // K / V^T fragment reads (= MFMAs) per wave per tile
-    constexpr int DK = AT_DK < NK ? AT_DK : NK, DV = AT_DV < NV ? AT_DV : NV;
+    constexpr int DK = AT_DK < NK ? AT_DK : NK, DVW = PVX && HD == 128 ? AT_DV16X : AT_DV, DV = DVW < NV ? DVW : NV;     // (the interleaved form at head_dim 128 spills with 6 fragments in flight)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -575,6 +581,310 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
+#if AT_FORM16
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same kernel on v_mfma_f32_16x16x32 blocks.  Why: the socket runs attention at its power cap, and tools/micro/mfma_power.hip measures the
+// 16x16x32 form at 2.06-2.10 PF/s against 1.75-1.80 for 32x32x16 on random operands AT that cap (a quarter of the accumulator traffic per flop) -- the
+// reason gemm_v4 uses it.  Same workgroup (4 waves x 32 query rows, 64-key tiles, the same LDS image and staging), per wave and tile:
+//   S^T[kb][qb] (16 keys x 16 queries, kb < 4, qb < 2) += K[kb][ks] (A: 16 keys x 32 dims) . Q[qb][ks]^T (B)      4 * NKS fragment reads, 2 MFMAs each
+//   O^T[db][qb] (16 dims x 16 queries, db < HD/16)     += V^T[db][kk] (A: 16 dims x 32 keys) . P[qb][kk]^T (B)    2 * NDB fragment reads, 2 MFMAs each
+// Lane (c = lane & 15, g = lane >> 4) owns query column 16 qb + c of both query blocks; of a 16-key block it holds keys 4 g + r (r < 4), so a row's
+// statistics live in the four lanes {c, c+16, c+32, c+48}: one v_permlane32_swap + one v_permlane16_swap fold BOTH query blocks' maxima at once.
+// P never leaves registers: the B fragment of key half kk is [S[2kk][qb][0..3], S[2kk+1][qb][0..3]] = keys {32kk + 4g + r, 32kk + 16 + 4g + r} at MFMA
+// k-slots 8g + e, so V^T keeps, inside every 32-key block, key 16h + 4g + r at position 8g + 4h + r (vt_transpose_kernel / gemm_v4's fused V^T epilogue
+// under the same macro): the V^T fragment stays one conflict-free 16-byte LDS read.
+// PV order: key half kk -> dim block db -> query block qb (the V^T fragment stays put over its two MFMAs; AT_DV fragments in flight).  PVX: the
+// exponentials of key half 1 issue between the MFMAs of key half 0 (one pair per MFMA).  [key half -> query block -> dim block, which hides three
+// quarters of the exponentials, needs all 8 fragments of a key half live at once: 25 registers spilled]
+__device__ __forceinline__ void quad_fold_max(float& a, float& b) {
+    // in: a = value of query block 0, b = of query block 1 (per lane).  out: a = max over the row's four lanes for block 0, b = for block 1, in EVERY lane.
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));        // a = [a.lo | b.lo], b = [a.hi | b.hi]
+    float c = fmaxf(a, b), d = c;                                                                 // lanes 0-31: block 0 (g, g+2 folded), lanes 32-63: block 1
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));        // c = rows [c0 c0 c2 c2], d = rows [c1 c1 c3 c3]
+    float e = fmaxf(c, d);                                                                        // rows [m0 m0 m1 m1]
+    a = e;
+    b = e;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));        // a = m0 everywhere, b = m1 everywhere
+}
+__device__ __forceinline__ void quad_fold_sum(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float c = a + b, d = c;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));
+    float e = c + d;
+    a = e;
+    b = e;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void mfma16_result_guard(f32x4 (&s)[4][2], float& t0, float& t1) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[3][0]), "+v"(s[3][1]),
+                 "+v"(t0), "+v"(t1));
+}
+
+template <int HD, bool QS = false, bool KM = false, bool PVX = false>
+__global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const AttnParams p) {
+    using G = Geo<HD>;
+    constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NJ = G::NJ;
+    constexpr int NKS = HD / 32, NDB = HD / 16;
+    constexpr int NK = 4 * NKS, NV = 2 * NDB;       // K / V^T fragment reads per wave per tile (two MFMAs each)
+    constexpr int DK = AT_DK < NK ? AT_DK : NK, DVW = PVX && HD == 128 ? AT_DV16X : AT_DV, DV = DVW < NV ? DVW : NV;     // (the interleaved form at head_dim 128 spills with 6 fragments in flight)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nt = (p.Nkv + KVB - 1) / KVB, nfull = p.Nkv / KVB;
+
+    // ---- staging: exactly the 32x32 kernel's (same LDS image, same source-side swizzle) ----
+    unsigned k_vo[NJ], v_vo[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int kr = HD == 128 ? (wv * NJ + j) * 4 + (lane >> 4) : (wv * NJ + j) * 8 + (lane >> 3);
+        const int kchunk = HD == 128 ? ((lane & 15) ^ (kr & 15)) : ((lane & 7) ^ ((kr >> 1) & 7));
+        k_vo[j] = ((unsigned)kr * (unsigned)p.ldk + kchunk * 8) * 2;
+        const int vr = (wv * NJ + j) * 8 + (lane >> 3);
+        const int vchunk = (lane & 7) ^ ((vr >> 1) & 7);
+        v_vo[j] = ((unsigned)vr * (unsigned)p.Npad + vchunk * 8) * 2;
+    }
+    const unsigned k_tile_bytes = (unsigned)KVB * (unsigned)p.ldk * 2;
+    const unsigned k_bytes = ((unsigned)(p.Nkv - 1) * (unsigned)p.ldk + HD) * 2, v_bytes = (unsigned)HD * (unsigned)p.Npad * 2;
+
+    // fragment addresses: K row 16 kb + c, 16-byte chunk 4 ks + g of the row; V^T row 16 db + c, chunk 4 kk + g (swizzled as staged)
+    const int k_xor = HD == 128 ? l15 : ((l15 >> 1) & 7);
+    const int v_xor = (l15 >> 1) & 7;
+    unsigned k_lane[NKS], v_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) k_lane[ks] = lds0 + l15 * (2 * HD) + (((4 * ks + g) ^ k_xor) << 4);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) v_lane[kk] = lds0 + K_TILE + l15 * 128 + (((4 * kk + g) ^ v_xor) << 4);
+
+    const int head = blockIdx.y, qt = blockIdx.x, ta = 0, tb = nt;
+    const int q0 = qt * QB + wv * 32;
+
+    // ---- Q fragments (B operand): Q[q0 + 16 qb + c][32 ks + 8 g .. +8] ----
+    bf16x8 qf[2][NKS];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = min(q0 + 16 * qb + l15, p.Nq - 1);
+        const bf16* qp = p.Q + (long)qrow * p.ldq + head * HD + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + 32 * ks);
+    }
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.K + head * HD), 0, (int)k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.VT + (long)head * p.vt_head_stride), 0, (int)v_bytes, 0x00020000);
+    auto stage_piece = [&](int t, int buf, int i) {
+        char* dst = smem + buf * STAGE + wv * (NJ * 1024);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (i < NJ)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(dst + i * 1024), 16, k_vo[i], t * k_tile_bytes, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + K_TILE + (i - NJ) * 1024), 16, v_vo[i - NJ], t * (KVB * 2), 0, 0);
+#else
+        (void)dst; (void)t; (void)i;
+#endif
+    };
+
+    f32x4 o[NDB][2];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) o[d][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float c[2] = {p.scale_log2e, p.scale_log2e};
+    if constexpr (QS) {
+        // the four lanes of a row add a quarter of its partial sums each
+        const int quarter = p.q_ss_ld >> 2;
+        float ss[2] = {0.f, 0.f};
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float* sp = p.q_ss + (long)min(q0 + 16 * qb + l15, p.Nq - 1) * p.q_ss_ld + g * quarter;
+#pragma unroll 4
+            for (int jj = 0; jj < quarter; jj += 4) {
+                const f32x4 t = *(const f32x4*)(sp + jj);
+                ss[qb] += (t[0] + t[1]) + (t[2] + t[3]);
+            }
+        }
+        quad_fold_sum(ss[0], ss[1]);
+        c[0] *= rsqrtf(ss[0] / (float)p.q_norm_dim + p.q_eps);
+        c[1] *= rsqrtf(ss[1] / (float)p.q_norm_dim + p.q_eps);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2 * NJ; ++i) stage_piece(ta, 0, i);
+
+    auto tile = [&](const int t, auto masked, auto par) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked)::value;
+        constexpr int PAR = decltype(par)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int tn = min(t + 1, tb - 1);
+        constexpr int nbuf = 1 - PAR;
+
+#if AT_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        // ---- S^T = K . Q^T ; fragment n = 4 ks + kb feeds the two query blocks (A stays put over the pair, 8 MFMAs between dependent ones) ----
+        f32x4 s[4][2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) s[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 kf[NK];
+        auto read_k = [&](auto N) {
+            constexpr int n = decltype(N)::value, ks = n / 4, kb = n % 4;
+            kf[n] = lds_read16<PAR * STAGE + kb * 16 * 2 * HD>(k_lane[ks]);
+        };
+        static_for<0, DK>(read_k);
+        static_for<0, NK>([&](auto N) {
+            constexpr int n = decltype(N)::value, ks = n / 4, kb = n % 4;
+            if constexpr (n + DK < NK) read_k(std::integral_constant<int, n + DK>{});
+            lds_wait<(n + DK < NK ? DK : NK - 1 - n)>(kf[n]);
+            s[kb][0] = LTX2_MFMA_16x16x32(as_bf16x8(kf[n]), qf[0][ks], s[kb][0], 0, 0, 0);
+            s[kb][1] = LTX2_MFMA_16x16x32(as_bf16x8(kf[n]), qf[1][ks], s[kb][1], 0, 0, 0);
+            if constexpr ((n & 1) && n / 2 < 2 * NJ) stage_piece(tn, nbuf, n / 2);
+        });
+        static_for<NK / 2, 2 * NJ>([&](auto I) { stage_piece(tn, nbuf, decltype(I)::value); });
+
+        if constexpr (MASKED) {
+            const int kv0 = t * KVB;
+            unsigned long long km = ~0ull;
+            if constexpr (KM) km = p.kmask[t];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kl = 16 * kb + 4 * g + r;
+                    const bool oob = kv0 + kl >= p.Nkv, off = KM && !((km >> kl) & 1ull);
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        if (oob) s[kb][qb][r] = -INFINITY;
+                        else if (off) s[kb][qb][r] = AT_KEY_MASKED;
+                    }
+                }
+        }
+        // the first V^T fragments go out before the row maximum and the exponentials (which hide their latency); fragment n = NDB kk + db
+        u32x4 vf[NV];
+        auto read_v = [&](auto N) {
+            constexpr int n = decltype(N)::value, kk = n / NDB, db = n % NDB;
+            vf[n] = lds_read16<PAR * STAGE + db * 16 * 128>(v_lane[kk]);
+        };
+        static_for<0, DV>(read_v);
+
+        float tmax[2] = {-INFINITY, -INFINITY};
+        mfma16_result_guard(s, tmax[0], tmax[1]);
+#if AT_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                tmax[qb] = max3(tmax[qb], s[0][qb][r], s[1][qb][r]);
+                tmax[qb] = max3(tmax[qb], s[2][qb][r], s[3][qb][r]);
+            }
+        quad_fold_max(tmax[0], tmax[1]);
+        if (!__all((tmax[0] - m_run[0]) * c[0] <= RESCALE_THR && (tmax[1] - m_run[1]) * c[1] <= RESCALE_THR)) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float m_new = fmaxf(m_run[qb], tmax[qb]);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c[qb]);
+                m_run[qb] = m_new;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) o[d][qb] *= alpha;
+            }
+        }
+        const float nmc[2] = {-m_run[0] * c[0], -m_run[1] * c[1]};
+        bf16x8 pf[2][2];                // [qb][kk]
+        float ps[2] = {0.f, 0.f};
+        // the 4 exponential pairs Q of P[qb][kk] (pair Q: elements 2 Q, 2 Q + 1 of the fragment = rows 2 (Q & 1), +1 of key block 2 kk + (Q >> 1))
+        auto exp_pair = [&](auto KK, auto QB, auto Q) __attribute__((always_inline)) {
+            constexpr int kk = decltype(KK)::value, qb = decltype(QB)::value, q = decltype(Q)::value, kb = 2 * kk + q / 2, r = 2 * (q % 2);
+            asm volatile("" : "+v"(s[kb][qb]));
+            const float e0 = KM ? (s[kb][qb][r] - m_run[qb]) * c[qb] : __builtin_fmaf(s[kb][qb][r], c[qb], nmc[qb]);
+            const float e1 = KM ? (s[kb][qb][r + 1] - m_run[qb]) * c[qb] : __builtin_fmaf(s[kb][qb][r + 1], c[qb], nmc[qb]);
+            float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
+            asm volatile("" : "+v"(p0), "+v"(p1));
+            ps[qb] += p0 + p1;
+            pf[qb][kk][2 * q] = f2bf(p0);
+            pf[qb][kk][2 * q + 1] = f2bf(p1);
+        };
+        // pair index x < 8 of a key half: query block x / 4, pair x % 4
+        auto exp_x = [&](auto KK, auto X) __attribute__((always_inline)) {
+            constexpr int x = decltype(X)::value;
+            exp_pair(KK, std::integral_constant<int, x / 4>{}, std::integral_constant<int, x % 4>{});
+        };
+        static_for<0, 8>([&](auto X) { exp_x(std::integral_constant<int, 0>{}, X); });
+        if constexpr (!PVX) static_for<0, 8>([&](auto X) { exp_x(std::integral_constant<int, 1>{}, X); });
+#if AT_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        // ---- O^T += V^T . P^T : fragment n = NDB kk + db feeds the two query blocks; PVX: key half 1's exponentials between key half 0's MFMAs ----
+        static_for<0, NV>([&](auto N) __attribute__((always_inline)) {
+            constexpr int n = decltype(N)::value, kk = n / NDB, db = n % NDB;
+            if constexpr (n + DV < NV) read_v(std::integral_constant<int, n + DV>{});
+            lds_wait<(n + DV < NV ? DV : NV - 1 - n)>(vf[n]);
+            o[db][0] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[0][kk], o[db][0], 0, 0, 0);
+            if constexpr (PVX && kk == 0) static_for<(8 * db) / NDB, (8 * db + 4) / NDB>([&](auto X) { exp_x(std::integral_constant<int, 1>{}, X); });
+            o[db][1] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[1][kk], o[db][1], 0, 0, 0);
+            if constexpr (PVX && kk == 0) static_for<(8 * db + 4) / NDB, (8 * (db + 1)) / NDB>([&](auto X) { exp_x(std::integral_constant<int, 1>{}, X); });
+        });
+        l_run[0] += ps[0];
+        l_run[1] += ps[1];
+#if AT_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+
+    const int t_unmasked_end = KM ? ta : min(tb, nfull);
+    int t = ta;
+    for (; t + 1 < t_unmasked_end; t += 2) {
+        tile(t, std::false_type{}, std::integral_constant<int, 0>{});
+        tile(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
+    }
+    if (t < t_unmasked_end) {
+        tile(t, std::false_type{}, std::integral_constant<int, 0>{});
+        ++t;
+    }
+    if constexpr (KM) {
+        for (; t < tb; ++t) {
+            if ((t - ta) & 1) tile(t, std::true_type{}, std::integral_constant<int, 1>{});
+            else tile(t, std::true_type{}, std::integral_constant<int, 0>{});
+        }
+    } else if (nfull < tb) {
+        if ((nfull - ta) & 1) tile(nfull, std::true_type{}, std::integral_constant<int, 1>{});
+        else tile(nfull, std::true_type{}, std::integral_constant<int, 0>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- finalize: lane owns queries q0 + 16 qb + c, dims 16 db + 4 g + r.  Dim blocks 2i / 2i + 1 trade halves between lane rows (g, g ^ 1) with
+    //      v_permlane16_swap so every lane stores 16 contiguous bytes: 8 dwordx4 stores per lane instead of 16 dwordx2 (the store tail is issue-bound) ----
+    float lt[2] = {l_run[0], l_run[1]};
+    quad_fold_sum(lt[0], lt[1]);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0 + 16 * qb + l15;
+        float inv = 1.0f / lt[qb];
+        if (p.gate && qrow < p.Nq) inv *= 2.f / (1.f + __expf(-p.gate[(long)qrow * p.gate_ld + head]));
+        bf16* op = p.O + (long)min(qrow, p.Nq - 1) * p.ldo + head * HD + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+        for (int i = 0; i < NDB / 2; ++i) {
+            bf16x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = f2bf(o[2 * i][qb][e] * inv);
+                b[e] = f2bf(o[2 * i + 1][qb][e] * inv);
+            }
+            u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            // rows (g odd) of ua <-> rows (g even) of ub: g even keeps its block-2i half and gets its neighbour's -> dims [16 (2i) + 8 (g >> 1), +8);
+            // g odd gets its neighbour's block-(2i+1) half and keeps its own -> dims [16 (2i + 1) + 8 (g >> 1), +8)
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1" : "+v"(ua[0]), "+v"(ua[1]), "+v"(ub[0]), "+v"(ub[1]));
+            const u32x4 w = {ua[0], ua[1], ub[0], ub[1]};
+            if (qrow < p.Nq) *(u32x4*)(op + 32 * i) = w;
+        }
+    }
+}
+#endif  // AT_FORM16
+
 // V [Nkv][ld] (head h at columns h*HD) -> VT[h][HD][Npad] with the key permutation
 // pos(kv = 32b + 8g + 4hi + e) = 32b + 16(g>>1) + 8hi + 4(g&1) + e ; keys >= Nkv are zero-filled.
 template <int HD>
@@ -611,8 +921,12 @@ __global__ __launch_bounds__(256) void vt_transpose_kernel(const bf16* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int pos = i * 8 + e;                       // position within the 32-block
+#if AT_FORM16
+                const int kvl = 16 * ((pos >> 2) & 1) + 4 * (pos >> 3) + (pos & 3);      // position 8 g + 4 h + r holds key 16 h + 4 g + r (attn16_fwd_kernel)
+#else
                 const int ks = pos >> 4, hh = (pos >> 3) & 1, g0 = (pos >> 2) & 1, ee = pos & 3;
                 const int kvl = 8 * (2 * ks + g0) + 4 * hh + ee; // inverse of pos()
+#endif
                 v[e] = tile[p0 + kvl][d];
             }
             *(bf16x8*)(dst + i * 8) = v;
@@ -680,6 +994,43 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     bool xcd = false;
     if (p.q_ss)
         LTX2_CHECK_ARG(p.head_dim != 64 && p.q_ss_ld > 0 && p.q_ss_ld % 8 == 0 && p.q_norm_dim > 0, "attention: the per-row scale form needs head_dim 128 and q_ss_ld %% 8 == 0");
+#if AT_FORM16
+    {
+        LTX2_CHECK_ARG(!p.q_ss || p.q_ss_ld % 16 == 0, "attention: the per-row scale form needs q_ss_ld %% 16 == 0");
+        dim3 grid16((p.Nq + QB - 1) / QB, p.H);
+        static int slots16 = 0;
+        if (!slots16) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            slots16 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 2 * prop.multiProcessorCount : 512;
+        }
+        const long units16 = (long)grid16.x * grid16.y, rem16 = units16 % slots16;
+        const bool lone16 = units16 < slots16 || (rem16 != 0 && rem16 * 10 < (long)slots16 * 9);
+        const bool pvx = AT_PVX16 == 1 || (AT_PVX16 == 2 && lone16 && !p.q_ss && !p.kmask);
+#define AT16_LAUNCH(HDV, QSV, KMV, PVXV)                                                                                                                  \
+        do {                                                                                                                                              \
+            static PerDeviceOnce once_;                                                                                                                   \
+            if (once_.first())                                                                                                                            \
+                (void)hipFuncSetAttribute((const void*)attn16_fwd_kernel<HDV, QSV, KMV, PVXV>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<HDV>::LDS_BYTES); \
+            hipLaunchKernelGGL((attn16_fwd_kernel<HDV, QSV, KMV, PVXV>), grid16, dim3(256), Geo<HDV>::LDS_BYTES, stream, p);                               \
+        } while (0)
+        if (p.head_dim == 64) {
+            if (p.kmask) AT16_LAUNCH(64, false, true, false);
+            else if (pvx) AT16_LAUNCH(64, false, false, true);
+            else AT16_LAUNCH(64, false, false, false);
+        } else if (p.kmask) {
+            if (p.q_ss) AT16_LAUNCH(128, true, true, false);
+            else AT16_LAUNCH(128, false, true, false);
+        } else if (p.q_ss) {
+            if (AT_PVX16 == 1) AT16_LAUNCH(128, true, false, true);
+            else AT16_LAUNCH(128, true, false, false);
+        } else if (pvx) AT16_LAUNCH(128, false, false, true);
+        else AT16_LAUNCH(128, false, false, false);
+#undef AT16_LAUNCH
+        LTX2_CHECK_LAUNCH("attn16_fwd_kernel");
+        return LTX2_OK;
+    }
+#endif
     const int workers = (p.sk_ws && !p.kmask) ? sk_workers(p, &xcd) : 0;
     if (workers > 0) {
         LTX2_CHECK_ARG(workers < 1024 && p.sk_ws_bytes >= attn_sk_workspace_bytes(p.head_dim), "attention: stream-K workspace too small");

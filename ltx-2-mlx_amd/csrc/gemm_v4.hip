@@ -553,11 +553,17 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
 #pragma unroll
                 for (int cg = 0; cg < BM / 32; ++cg) {
                     const int ch = cg * 4 + (lane & 3);                   // 8-position chunk of the tile's key range
+#if AT_FORM16
+                    const int kbase = (ch >> 2) * 32 + (ch & 3) * 4;                              // chunk g of a 32-key block: keys 4 g + r, then 16 + 4 g + r
+                    constexpr int RUN2 = 16;
+#else
                     const int kbase = (ch >> 2) * 32 + ((ch >> 1) & 1) * 16 + (ch & 1) * 4;      // first key of the chunk's first run
+                    constexpr int RUN2 = 8;
+#endif
                     bf16x8 v;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int r = kbase + (e >> 2) * 8 + (e & 3);
+                        const int r = kbase + (e >> 2) * RUN2 + (e & 3);
                         const bf16 x = *(const bf16*)(wl + r * ROWB + ((cchunk ^ ((r >> 1) & 7)) << 4) + coff);
                         v[e] = (m0 + r < p.M) ? x : f2bf(0.f);
                     }

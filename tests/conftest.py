@@ -1,3 +1,4 @@
+import json
 import os
 import sys
 
@@ -7,16 +8,55 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# every rel_l2() a test evaluates, in call order: (test id, file:line of the call, value) -- printed as a table at the END of the run
+# (pytest_terminal_summary) so the measured parity figures land in the driver's log tail, not only pass / fail dots
+_MEASURED = []
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
 def rel_l2(a, b):
-    """||a-b|| / ||b|| in fp64."""
+    """||a-b|| / ||b|| in fp64 (recorded for the end-of-run parity table)."""
     a = a.double().flatten()
     b = b.double().flatten()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    v = float((a - b).norm() / b.norm().clamp_min(1e-30))
+    f = sys._getframe(1)
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    _MEASURED.append((test, f"{os.path.basename(f.f_code.co_filename)}:{f.f_lineno}", v))
+    return v
+
+
+def measure(tag, value):
+    """Record any other measured parity figure (uint8 mean |diff|, ...) for the end-of-run table; returns the value."""
+    v = float(value)
+    f = sys._getframe(1)
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    _MEASURED.append((test, f"{os.path.basename(f.f_code.co_filename)}:{f.f_lineno} [{tag}]", v))
+    return v
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not _MEASURED:
+        return
+    per_test = {}
+    for test, where, v in _MEASURED:
+        d = per_test.setdefault(test, {"n": 0, "max": 0.0, "where": where})
+        d["n"] += 1
+        if v >= d["max"]:
+            d["max"], d["where"] = v, where
+    tr = terminalreporter
+    tr.write_sep("=", "measured parity (max rel-L2 per test; gates sit at <= 5x these)")
+    for test, d in per_test.items():
+        tr.write_line(f"{d['max']:.3e}  n={d['n']:<3d} {d['where']:<32s} {test.split('::', 1)[-1]}")
+    out = os.environ.get("LTX2_PARITY_JSON")
+    if out:
+        per_line = {}
+        for test, where, v in _MEASURED:
+            per_line[where] = max(per_line.get(where, 0.0), v)
+        with open(out, "w") as f:
+            json.dump({"per_line_max": per_line, "per_test": per_test}, f, indent=1)
 
 
 @pytest.fixture(scope="session")

@@ -37,10 +37,10 @@ def test_leaf_kernels_in_float16(dev):
     b = torch.randn(N, generator=g).to(dev)
     ref = a.double() @ w.double().t() + b.double()
     out = K.gemm(a, w, b)
-    assert out.dtype == F16 and rel_l2(out.cpu().float(), ref.cpu()) < 1e-3
+    assert out.dtype == F16 and rel_l2(out.cpu().float(), ref.cpu()) < 0.0008
     assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_F32).cpu(), ref.cpu()) < 1e-5
     og = K.gemm(a, w, b, epilogue=nv.EPI_GELU_BF16)
-    assert rel_l2(og.cpu().float(), torch.nn.functional.gelu(ref.float(), approximate="tanh").cpu()) < 2e-3
+    assert rel_l2(og.cpu().float(), torch.nn.functional.gelu(ref.float(), approximate="tanh").cpu()) < 0.0008
     x = torch.randn(M, N, generator=g).to(dev)
     x2 = x.clone()
     gt = torch.randn(N, generator=g).to(dev)
@@ -54,11 +54,11 @@ def test_leaf_kernels_in_float16(dev):
     o = K.flash_attn(q, k, vt, H, Nq)
     qh, kh, vh = [t.float().reshape(Nq, H, hd).transpose(0, 1) for t in (q, k, v)]
     ro = torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(hd), dim=-1) @ vh
-    assert o.dtype == F16 and rel_l2(o.cpu().float(), ro.transpose(0, 1).reshape(Nq, D).cpu()) < 2e-3
+    assert o.dtype == F16 and rel_l2(o.cpu().float(), ro.transpose(0, 1).reshape(Nq, D).cpu()) < 0.0012
     ws = K.flash_attn_workspace(hd, dev)
     q2, k2, v2 = [torch.randn(3456, D, generator=g).to(F16).to(dev) for _ in range(3)]
     vt2 = K.vt_transpose(v2, H)
-    assert rel_l2(K.flash_attn(q2, k2, vt2, H, 3456, workspace=ws).float(), K.flash_attn(q2, k2, vt2, H, 3456).float()) < 1e-3
+    assert rel_l2(K.flash_attn(q2, k2, vt2, H, 3456, workspace=ws).float(), K.flash_attn(q2, k2, vt2, H, 3456).float()) < 1e-05
     # fused QKV with the V^T epilogue == GEMM + transpose pass
     wq = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(F16).to(dev)
     xin = torch.randn(3456, D, generator=g).to(F16).to(dev)
@@ -70,7 +70,7 @@ def test_leaf_kernels_in_float16(dev):
     tab = (0.1 * torch.randn(2, 1024, generator=g)).to(dev)
     y = K.adaln_rmsnorm(xf, scale_tab=tab[1], shift_tab=tab[0], dtype=F16)
     ry = xf * torch.rsqrt((xf * xf).mean(-1, keepdim=True) + 1e-6) * (1 + tab[1]) + tab[0]
-    assert y.dtype == F16 and rel_l2(y.float(), ry) < 1e-3
+    assert y.dtype == F16 and rel_l2(y.float(), ry) < 0.0008
 
 
 def test_dit_step_and_loop_in_float16(dev):
@@ -84,7 +84,7 @@ def test_dit_step_and_loop_in_float16(dev):
     for ts in (torch.tensor([0.725]), (torch.rand(1, f * h * wd, 1, generator=torch.Generator().manual_seed(5)) > 0.3).float() * 0.909375):
         ref = dit.x0_model(lat, ctx, ts, pos, wq, cfg)
         x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=pos.to(dev)))
-        assert rel_l2(x0.cpu(), ref) < 5e-3 and pearson(x0.cpu(), ref) > 0.9999
+        assert rel_l2(x0.cpu(), ref) < 0.0003 and pearson(x0.cpu(), ref) > 0.9999
     sig = loop.DISTILLED_SIGMA_VALUES
     ref = loop.denoise_loop_cli(loop.unpatchify(lat, f, h, wd), lambda tok, s: dit.x0_model(tok, ctx, torch.tensor([s]), pos, wq, cfg), sig)
     m.prepare(ctx.to(dev), pos.to(dev))
@@ -96,7 +96,7 @@ def test_dit_step_and_loop_in_float16(dev):
         m.replay_denoise_graph()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    assert rel_l2(z.cpu(), loop.patchify(ref)[0]) < 1e-2
+    assert rel_l2(z.cpu(), loop.patchify(ref)[0]) < 0.0002
 
 
 def test_vae_decode_in_float16(dev):
@@ -112,7 +112,7 @@ def test_vae_decode_in_float16(dev):
     z, nz = torch.randn(1, 128, 2, 3, 4, generator=g), torch.randn(1, 128, 2, 3, 4, generator=g)
     ref = vae.decoder_forward(z, vwq, vcfg, 0.05, noise=nz)
     out = d(z.to(dev), timestep=0.05, noise=nz.to(dev)).cpu()
-    assert out.shape == ref.shape and rel_l2(out, ref) < 1e-2
+    assert out.shape == ref.shape and rel_l2(out, ref) < 0.0025
 
 
 def test_dit_48_layer_step_in_float16(dev):
@@ -134,7 +134,7 @@ def test_dit_48_layer_step_in_float16(dev):
         x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=pos.to(dev)))
         e, r = rel_l2(x0.cpu(), ref), pearson(x0.cpu(), ref)
         print(f"float16, 48 layers, sigma {sigma}: rel-L2 {e:.5f}, Pearson {r:.6f}")
-        assert e < 1e-2 and r > 0.9999, (sigma, e, r)
+        assert e < 2e-3 and r > 0.9999, (sigma, e, r)       # measured 4.0e-4 (round 5)
     del w, m
     torch.cuda.empty_cache()
 
@@ -156,7 +156,7 @@ def test_text_cross_attention_forms_in_float16(dev):
     qh, kh, vh = [t.double().cpu().reshape(-1, H, hd).transpose(0, 1) for t in (q, k, v)]
     s = (qh @ kh.transpose(1, 2)) / math.sqrt(hd) + (1 - mk.double()) * -3.4e38
     ref = (torch.softmax(s, dim=-1) @ vh).transpose(0, 1).reshape(Nq, D)
-    assert out.dtype == F16 and rel_l2(out.double().cpu(), ref) < 2e-3
+    assert out.dtype == F16 and rel_l2(out.double().cpu(), ref) < 0.0012
     # q_norm fold: projection with row partial sums, keys carrying k_norm.weight * q_norm.weight
     x = torch.randn(Nq, D, generator=g).to(F16).to(dev)
     wq = (torch.randn(D, D, generator=g) / math.sqrt(D)).to(F16).to(dev)
@@ -172,4 +172,4 @@ def test_text_cross_attention_forms_in_float16(dev):
     kf = kf * torch.rsqrt((kf * kf).mean(-1, keepdim=True) + 1e-6) * kn.double().cpu()
     qh2, kh2 = [t.reshape(-1, H, hd).transpose(0, 1) for t in (qf, kf)]
     ref2 = (torch.softmax(qh2 @ kh2.transpose(1, 2) / math.sqrt(hd), dim=-1) @ vh).transpose(0, 1).reshape(Nq, D)
-    assert o2.dtype == F16 and rel_l2(o2.double().cpu(), ref2) < 2e-3
+    assert o2.dtype == F16 and rel_l2(o2.double().cpu(), ref2) < 0.0015

@@ -32,7 +32,7 @@ def test_gemm_bias(K, dev, M, N, Kd):
     b = torch.randn(N, generator=g)
     ref = a @ w.t() + b
     out = K.gemm(a.to(dev, BF), w.to(dev, BF), b.to(dev), epilogue=3)   # fp32 out
-    assert rel_l2(out.cpu(), ref) < 2e-3
+    assert rel_l2(out.cpu(), ref) < 1e-05
     # asymmetric-operand transpose check: distinct row/col patterns
     out_bf = K.gemm(a.to(dev, BF), w.to(dev, BF), b.to(dev), epilogue=0)
     assert rel_l2(out_bf.float().cpu(), ref) < 6e-3
@@ -55,13 +55,13 @@ def test_gemm_epilogues(K, dev):
     tab = torch.randn(N, generator=g)
     x = x0.clone().to(dev)
     K.gemm(A, W, B, epilogue=nv.EPI_RESID_GATE_F32, out=x, gate=gate.to(dev), gate_table=tab.to(dev))
-    assert rel_l2(x.cpu(), x0 + (gate + tab) * lin) < 3e-3
+    assert rel_l2(x.cpu(), x0 + (gate + tab) * lin) < 1e-05
     x = x0.clone().to(dev)
     K.gemm(A, W, B, epilogue=nv.EPI_RESID_GATE_F32, out=x, gate=gate[:1].contiguous().to(dev), gate_table=tab.to(dev))
-    assert rel_l2(x.cpu(), x0 + (gate[:1] + tab) * lin) < 3e-3
+    assert rel_l2(x.cpu(), x0 + (gate[:1] + tab) * lin) < 1e-05
     x = x0.clone().to(dev)
     K.gemm(A, W, B, epilogue=nv.EPI_RESID_GATE_F32, out=x)
-    assert rel_l2(x.cpu(), x0 + lin) < 3e-3
+    assert rel_l2(x.cpu(), x0 + lin) < 1e-05
     res = q(torch.randn(M, N, generator=g))
     o = K.gemm(A, W, B, epilogue=nv.EPI_ADD_BF16, res=res.to(dev, BF))
     assert rel_l2(o.float().cpu(), lin + res) < 8e-3
@@ -85,13 +85,13 @@ def test_gemm_v4_ragged_last_row_tile(K, dev, M):
     canary = torch.full((M + 300, N), 7.0, device=dev, dtype=BF)
     out = K.gemm(a, w, b, out=canary[:M])
     assert rel_l2(out.float(), lin) < 6e-3 and bool((canary[M:] == 7.0).all())
-    assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_F32), lin) < 2e-3
+    assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_F32), lin) < 1e-05
     assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_GELU_BF16).float(), F.gelu(lin, approximate="tanh")) < 8e-3
     gate = torch.randn(N, generator=g, device=dev)
     x0 = torch.randn(M + 300, N, generator=g, device=dev)
     x = x0.clone()
     K.gemm(a, w, b, epilogue=nv.EPI_RESID_GATE_F32, out=x[:M], gate_table=gate)
-    assert rel_l2(x[:M], x0[:M] + gate * lin) < 3e-3 and torch.equal(x[M:], x0[M:])
+    assert rel_l2(x[:M], x0[:M] + gate * lin) < 1e-05 and torch.equal(x[M:], x0[M:])
     assert torch.equal(K.gemm_w8a16(a, codes.view(torch.uint8), scale, b), out)
     x8 = x0.clone()
     K.gemm_w8a16(a, codes.view(torch.uint8), scale, b, epilogue=nv.EPI_RESID_GATE_F32, out=x8[:M], gate_table=gate)
@@ -115,7 +115,7 @@ def test_gemm_skinny_m(K, dev, M, N, Kd):
     assert rel_l2(out.float(), lin) < 6e-3 and bool((canary[M:] == 7.0).all())
     for _ in range(3):
         assert torch.equal(K.gemm(a, w, b), out)
-    assert rel_l2(K.gemm(a, w, None, epilogue=nv.EPI_F32), lin - b) < 2e-3
+    assert rel_l2(K.gemm(a, w, None, epilogue=nv.EPI_F32), lin - b) < 1e-05
     assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_GELU_BF16).float(), F.gelu(lin, approximate="tanh")) < 8e-3
     assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_SILU_BF16).float(), F.silu(lin)) < 8e-3
     gate = torch.randn(M, N, generator=g, device=dev)
@@ -123,10 +123,10 @@ def test_gemm_skinny_m(K, dev, M, N, Kd):
     x0 = torch.randn(M + 40, N, generator=g, device=dev)
     x = x0.clone()
     K.gemm(a, w, b, epilogue=nv.EPI_RESID_GATE_F32, out=x[:M], gate=gate, gate_table=tab)
-    assert rel_l2(x[:M], x0[:M] + (gate + tab) * lin) < 3e-3 and torch.equal(x[M:], x0[M:])
+    assert rel_l2(x[:M], x0[:M] + (gate + tab) * lin) < 1e-05 and torch.equal(x[M:], x0[M:])
     x = x0.clone()
     K.gemm(a, w, b, epilogue=nv.EPI_RESID_GATE_F32, out=x[:M], gate=gate[:1].contiguous(), gate_table=tab)
-    assert rel_l2(x[:M], x0[:M] + (gate[:1] + tab) * lin) < 3e-3
+    assert rel_l2(x[:M], x0[:M] + (gate[:1] + tab) * lin) < 1e-05
     res = torch.randn(M, N, generator=g, device=dev).to(BF)
     assert rel_l2(K.gemm(a, w, b, epilogue=nv.EPI_ADD_BF16, res=res).float(), lin + res.float()) < 8e-3
     # fp8-resident weights on the same kernel: bit-identical to the bf16 run on the dequantised weights
@@ -160,7 +160,7 @@ def test_gemv(K, dev, M):
     b = torch.randn(300, generator=g)
     ref = F.silu(F.silu(a) @ w.t() + b)
     out = K.gemv(a.to(dev), w.to(dev, BF), b.to(dev), act_in=1, act_out=1)
-    assert rel_l2(out.cpu(), ref) < 1e-4
+    assert rel_l2(out.cpu(), ref) < 1e-05
 
 
 @pytest.mark.parametrize("rows,D", [(5, 256), (288, 4096)])
@@ -275,7 +275,7 @@ def test_flash_attn_forced_rescale(K, dev):
     ref = dit.sdpa(qq[None], kk[None], vv[None], heads)[0]
     vt = K.vt_transpose(vv.to(dev, BF), heads)
     out = K.flash_attn(qq.to(dev, BF), kk.to(dev, BF), vt, heads, Nkv)
-    assert rel_l2(out.float().cpu(), ref) < 1e-2
+    assert rel_l2(out.float().cpu(), ref) < 0.006
     assert (out.float().cpu() - ref).abs().max() < 5e-2
 
 
@@ -435,7 +435,7 @@ def test_conv3d_decoder_stage_sizes(K, dev, T, H, W, C):
     ref = ref.reshape(T, H, W, C)
     assert rel_l2(out.float().cpu(), ref.cpu()) < 6e-3
     for sl in ((0, 0, 0), (T - 1, H - 1, W - 1), (T // 2, 0, W - 1)):               # corners / edges: the padding rules
-        assert rel_l2(out[sl].float().cpu(), ref[sl].cpu()) < 2e-2
+        assert rel_l2(out[sl].float().cpu(), ref[sl].cpu()) < 0.008
 
 
 @pytest.mark.parametrize("stride,mult,residual", [((2, 2, 2), 2, True), ((2, 2, 2), 1, False), ((1, 2, 2), 2, True), ((2, 1, 1), 2, True)])
@@ -771,7 +771,7 @@ def test_flash_attention_key_mask(dev, hd, H, Nq, S):
         assert torch.isfinite(out).all(), tag
         assert rel_l2(out.double().cpu(), ref) < 6e-3, (tag, rel_l2(out.double().cpu(), ref))
     # an all-ones mask is the unmasked kernel up to the exponent's rounding
-    assert rel_l2(KK.flash_attn_keymask(q, k, vt, H, S, masks["all"]).float().cpu(), KK.flash_attn(q, k, vt, H, S).float().cpu()) < 2e-3
+    assert rel_l2(KK.flash_attn_keymask(q, k, vt, H, S, masks["all"]).float().cpu(), KK.flash_attn(q, k, vt, H, S).float().cpu()) < 0.00025
 
 
 # ------------------------------------------------------------------------------------------ round 4: the AudioVideo block's cross-modal section

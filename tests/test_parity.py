@@ -12,7 +12,7 @@ Tolerance (bf16 operands, fp32 accumulation and fp32 residual stream, vs an fp32
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import measure, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -55,7 +55,7 @@ def test_dit_x0_tiny(dev, grid, S):
     ref = dit.x0_model(lat, ctx, sigma, pos, w, cfg)
     x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
     assert x0.shape == ref.shape and x0.dtype == torch.float32
-    assert rel_l2(x0.cpu(), ref) < 2e-2 and pearson(x0.cpu(), ref) > 0.999
+    assert rel_l2(x0.cpu(), ref) < 0.0025 and pearson(x0.cpu(), ref) > 0.999
 
 
 def test_dit_per_token_timesteps(dev):
@@ -70,14 +70,14 @@ def test_dit_per_token_timesteps(dev):
     ts = mask * 0.725
     ref = dit.x0_model(lat, ctx, ts, pos, w, cfg)
     x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=pos.to(dev)))
-    assert rel_l2(x0.cpu(), ref) < 2e-2
+    assert rel_l2(x0.cpu(), ref) < 0.002
     # uniform per-token timesteps stay on the per-token path (no host sync to find out that they are equal -- the pipelines
     # pass a 1-element tensor when they KNOW the mask is uniform): same arithmetic through the per-token AdaLN GEMMs
     uni = torch.full((1, N, 1), 0.725)
     a = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=uni.to(dev), positions=pos.to(dev)))
     b = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=torch.tensor([0.725], device=dev), positions=pos.to(dev)))
-    assert rel_l2(a.cpu(), b.cpu()) < 2e-3
-    assert rel_l2(a.cpu(), dit.x0_model(lat, ctx, uni, pos, w, cfg)) < 2e-2
+    assert rel_l2(a.cpu(), b.cpu()) < 0.0008
+    assert rel_l2(a.cpu(), dit.x0_model(lat, ctx, uni, pos, w, cfg)) < 0.002
 
 
 def test_conditioned_loop_through_the_hipgraph(dev):
@@ -123,7 +123,7 @@ def test_dit_full_width_block(dev):
     sigma = torch.tensor([0.975])
     ref = dit.velocity_model(lat, ctx, sigma, pos, w, cfg)
     v = m(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
-    assert rel_l2(v.cpu(), ref) < 2e-2 and pearson(v.cpu(), ref) > 0.999
+    assert rel_l2(v.cpu(), ref) < 0.012 and pearson(v.cpu(), ref) > 0.999
 
 
 def test_dit_baseline_size_block(dev):
@@ -138,7 +138,7 @@ def test_dit_baseline_size_block(dev):
     ref = dit.velocity_model(lat, ctx, sigma, pos, w, cfg)
     v = m(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
     assert v.shape == (1, 3456, 128)
-    assert rel_l2(v.cpu(), ref) < 2e-2 and pearson(v.cpu(), ref) > 0.999
+    assert rel_l2(v.cpu(), ref) < 0.012 and pearson(v.cpu(), ref) > 0.999
     # determinism: the video path has no atomics -- a second call is bit-identical
     v2 = m(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
     assert torch.equal(v, v2)
@@ -181,7 +181,7 @@ def test_denoise_loop_and_graph(dev):
     for i in range(8):
         x0 = x0m(Modality(latent=x, context=C, context_mask=None, timesteps=torch.tensor([sig[i]], device=dev), positions=P))
         x = stepper.step(x, x0, sig, i)
-    assert rel_l2(x.cpu(), ref) < 3e-2 and pearson(x.cpu(), ref) > 0.999
+    assert rel_l2(x.cpu(), ref) < 0.002 and pearson(x.cpu(), ref) > 0.999
     # (b) fused step
     y = lat[0].to(dev).contiguous()
     for i in range(8):
@@ -226,7 +226,7 @@ def test_vae_decoder_forward(dev, tcond):
     ref = vae.decoder_forward(z, w, cfg, timestep=0.05, noise=noise)
     out = d(z.to(dev), timestep=0.05, noise=noise.to(dev))
     assert out.shape == ref.shape == (1, 3, 17, 128, 160)
-    assert rel_l2(out.cpu(), ref) < 4e-2 and pearson(out.cpu(), ref) > 0.999
+    assert rel_l2(out.cpu(), ref) < 0.03 and pearson(out.cpu(), ref) > 0.999
 
 
 def test_vae_decode_latent_chunked(dev):
@@ -242,7 +242,7 @@ def test_vae_decode_latent_chunked(dev):
     out = decode_latent(z.to(dev), d, noise=noise.to(dev))
     assert out.shape == ref.shape == (65, 64, 96, 3) and out.dtype == torch.uint8
     diff = (out.cpu().int() - ref.int()).abs().float()
-    assert diff.mean() < 2.0 and pearson(out.cpu().float(), ref.float()) > 0.999
+    assert measure("uint8 mean |diff|", diff.mean()) < 1.2 and pearson(out.cpu().float(), ref.float()) > 0.999
 
 
 def test_vae_decode_tiled(dev):
@@ -255,7 +255,7 @@ def test_vae_decode_tiled(dev):
     ref = vae.decode_tiled(z, lambda t: vae.decoder_forward(t, w, cfg, timestep=None), spatial=(96, 32), temporal=(16, 8))
     out = next(decode_tiled(z.to(dev), lambda t, timestep=None: d(t, timestep=None), tc))
     assert out.shape == ref.shape
-    assert rel_l2(out.cpu(), ref) < 4e-2
+    assert rel_l2(out.cpu(), ref) < 0.025
 
 
 def test_distilled_pipeline_api(dev):
@@ -278,7 +278,7 @@ def test_distilled_pipeline_api(dev):
     ref_lat = loop.unpatchify(ref_tok, f, h, wd)
     pipe = DistilledPipeline(m, None, None)
     lat = pipe(ctx.to(dev), None, conf, initial_noise=noise.to(dev))
-    assert rel_l2(lat.cpu(), ref_lat) < 3e-2
+    assert rel_l2(lat.cpu(), ref_lat) < 0.0015
     conf_g = DistilledConfig(height=256, width=384, num_frames=17, seed=1, use_hip_graph=True)
     lat_g = pipe(ctx.to(dev), None, conf_g, initial_noise=noise.to(dev))
     assert rel_l2(lat_g.cpu(), lat.cpu()) < 1e-5
@@ -378,8 +378,8 @@ def test_video_dit_against_reference_vectors(dev):
         vel = m(mod).cpu()
         x0 = X0Model(m)(mod).cpu()
         rv, rx = torch.from_numpy(z[f"velocity_{tag}"]), torch.from_numpy(z[f"x0_{tag}"])
-        assert rel_l2(vel, rv) < 3e-2 and pearson(vel, rv) > 0.999, tag
-        assert rel_l2(x0, rx) < 3e-2 and pearson(x0, rx) > 0.999, tag
+        assert rel_l2(vel, rv) < 0.012 and pearson(vel, rv) > 0.999, tag
+        assert rel_l2(x0, rx) < 0.003 and pearson(x0, rx) > 0.999, tag
 
 
 def to_modality(d, dev):
@@ -404,13 +404,13 @@ def test_av_dit_against_oracle_and_reference_vectors(dev, v23):
     for tsk, (video, audio) in cases.items():
         vx0, ax0 = X0Model(m)(to_modality(video, dev), to_modality(audio, dev))
         rv, ra = dit_av.av_x0_model(video, audio, wq, cfg)
-        assert rel_l2(vx0.cpu(), rv) < 2e-2 and pearson(vx0.cpu(), rv) > 0.999, tsk
-        assert rel_l2(ax0.cpu(), ra) < 2e-2 and pearson(ax0.cpu(), ra) > 0.999, tsk
-        assert rel_l2(vx0.cpu(), torch.from_numpy(z[f"{tag}_{tsk}_video_x0"])) < 3e-2
-        assert rel_l2(ax0.cpu(), torch.from_numpy(z[f"{tag}_{tsk}_audio_x0"])) < 3e-2
+        assert rel_l2(vx0.cpu(), rv) < 0.003 and pearson(vx0.cpu(), rv) > 0.999, tsk
+        assert rel_l2(ax0.cpu(), ra) < 0.0025 and pearson(ax0.cpu(), ra) > 0.999, tsk
+        assert rel_l2(vx0.cpu(), torch.from_numpy(z[f"{tag}_{tsk}_video_x0"])) < 0.004
+        assert rel_l2(ax0.cpu(), torch.from_numpy(z[f"{tag}_{tsk}_audio_x0"])) < 0.003
         vv, av = m(to_modality(video, dev), to_modality(audio, dev))
         ov, oa = dit_av.av_velocity_model(video, audio, wq, cfg)
-        assert rel_l2(vv.cpu(), ov) < 3e-2 and rel_l2(av.cpu(), oa) < 3e-2
+        assert rel_l2(vv.cpu(), ov) < 1e-2 and rel_l2(av.cpu(), oa) < 1e-2
         # round 4: the AdaLN rows (per-block and cross-modal) summed once per step for every layer vs handed to each kernel in two parts
         m.set_option("adaln_combine", 0)
         vv0, av0 = m(to_modality(video, dev), to_modality(audio, dev))
@@ -450,7 +450,7 @@ def test_av_denoise_loop_and_graph(dev, v23):
         mv = Modality(latent=lv[None], context=vc, context_mask=None, timesteps=s, positions=vp, sigma=s)
         ma = Modality(latent=la[None], context=ac, context_mask=None, timesteps=s, positions=ap, sigma=s)
         m.denoise_step_(lv, mv, sigmas[i], sigmas[i + 1], audio_latent=la, audio=ma)
-    assert rel_l2(lv.cpu(), rv[0]) < 3e-2 and rel_l2(la.cpu(), ra[0]) < 3e-2
+    assert rel_l2(lv.cpu(), rv[0]) < 2.5e-3 and rel_l2(la.cpu(), ra[0]) < 2.5e-3
     # hipGraph replay
     gv, ga = vlat[0].to(dev).contiguous(), alat[0].to(dev).contiguous()
     m.prepare(vc, vp, audio_context=ac, audio_positions=ap)
@@ -499,7 +499,7 @@ def test_fp8_checkpoint_loader(dev, tmp_path):
     sigma = torch.tensor([0.725])
     ref = dit.x0_model(lat, ctx, sigma, pos, wq, cfg)
     x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
-    assert rel_l2(x0.cpu(), ref) < 2e-2 and pearson(x0.cpu(), ref) > 0.999
+    assert rel_l2(x0.cpu(), ref) < 0.002 and pearson(x0.cpu(), ref) > 0.999
 
 
 def test_spatial_upscaler(dev):
@@ -519,12 +519,12 @@ def test_spatial_upscaler(dev):
     ref = oup.spatial_upscaler(x, wq, num_blocks=2)
     assert rel_l2(out.cpu(), ref) < 4e-2 and pearson(out.cpu(), ref) > 0.999
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "upscaler_tiny.npz"))
-    assert rel_l2(out.cpu(), torch.from_numpy(z["upscaled"])) < 5e-2
+    assert rel_l2(out.cpu(), torch.from_numpy(z["upscaled"])) < 0.04
     g = torch.Generator().manual_seed(5)
     mean, std = torch.randn(64, generator=g), 0.5 + torch.rand(64, generator=g)
     out2 = upscale_latent(x.to(dev), up, mean, std)
     ref2 = oup.upscale_latent(x, wq, mean, std, num_blocks=2)
-    assert rel_l2(out2.cpu(), ref2) < 4e-2
+    assert rel_l2(out2.cpu(), ref2) < 0.02
 
 
 def test_two_stage_pipeline_with_upscaler(dev):
@@ -551,7 +551,7 @@ def test_two_stage_pipeline_with_upscaler(dev):
         lat = pipe(ctx.to(dev), None, conf, initial_noise=noise.to(dev))
         assert lat.shape == (1, 128, 3, 8, 12) and bool(torch.isfinite(lat).all())
         outs.append(lat)
-    assert rel_l2(outs[1], outs[0]) < 1e-4
+    assert rel_l2(outs[1], outs[0]) < 1e-05
 
 
 @pytest.mark.parametrize("v23", [False, True])
@@ -602,8 +602,8 @@ def test_vae_encoder_and_image_conditioning(dev, tmp_path):
         out = enc(x.to(dev))
         ref = oenc.encoder_forward(x, wq)
         assert out.shape == ref.shape and out.dtype == torch.float32
-        assert rel_l2(out.cpu(), ref) < 5e-2 and pearson(out.cpu(), ref) > 0.998, name
-        assert rel_l2(out.cpu(), torch.from_numpy(z[name])) < 6e-2, name
+        assert rel_l2(out.cpu(), ref) < 0.04 and pearson(out.cpu(), ref) > 0.998, name
+        assert rel_l2(out.cpu(), torch.from_numpy(z[name])) < 0.05, name
     # image-to-video: 256x384x17 -> stage-1 128x192 image, latent 3x4x6
     cfg, wd, m = make_dit(dev, heads=2, layers=2, cap=128)
     g = torch.Generator().manual_seed(2)
@@ -666,7 +666,7 @@ def test_lora_fusion_at_load(dev, tmp_path):
     base = dit.x0_model(lat, ctx, sigma, pos, {k: (v.to(torch.bfloat16).float() if v.dim() == 2 else v) for k, v in w.items()}, cfg)
     x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
     err = rel_l2(x0.cpu(), ref)
-    assert err < 2e-2 and rel_l2(base, ref) > 5 * err        # the adapters matter and are applied
+    assert err < 2.5e-3 and rel_l2(base, ref) > 5 * err        # the adapters matter and are applied (measured 5.3e-4)
 
 
 def test_text_connector_and_feature_extractors(dev, tmp_path):
@@ -698,9 +698,9 @@ def test_text_connector_and_feature_extractors(dev, tmp_path):
         ref, _ = tc.encode_projected(x, am, qw(w), cfg)
         y = out.video_encoding.cpu()
         assert y.shape == (1, 1024, 256) and y.dtype == torch.float32 and int(out.attention_mask.sum()) == 1024
-        assert rel_l2(y, ref) < 2e-2 and pearson(y, ref) > 0.999, tag
-        assert rel_l2(y[:, :56], torch.from_numpy(z[f"connector_{tag}_head"])) < 3e-2, tag
-        assert rel_l2(y[:, 992:], torch.from_numpy(z[f"connector_{tag}_tail"])) < 3e-2, tag
+        assert rel_l2(y, ref) < 0.008 and pearson(y, ref) > 0.999, tag
+        assert rel_l2(y[:, :56], torch.from_numpy(z[f"connector_{tag}_head"])) < 0.008, tag
+        assert rel_l2(y[:, 992:], torch.from_numpy(z[f"connector_{tag}_tail"])) < 0.008, tag
     # production width: 30 heads x 128 = 3840, one block, a 100-token prompt
     cfg = tc.ConnectorConfig(num_layers=1)
     w = tc.make_connector_weights(cfg, seed=64)
@@ -710,7 +710,7 @@ def test_text_connector_and_feature_extractors(dev, tmp_path):
     y, m = conn(x.to(dev))
     ref = tc.embeddings_connector(x, qw(w), cfg)
     assert y.shape == (1, 1024, 3840) and float(m.abs().max()) == 0.0
-    assert rel_l2(y.cpu(), ref) < 2e-2 and pearson(y.cpu(), ref) > 0.999
+    assert rel_l2(y.cpu(), ref) < 0.012 and pearson(y.cpu(), ref) > 0.999
 
     # feature extractors: D = 64, L = 5 layers, left-padded batch of 2
     gen = torch.Generator().manual_seed(66)
@@ -722,7 +722,7 @@ def test_text_connector_and_feature_extractors(dev, tmp_path):
     fe1.load_state_dict({"aggregate_embed.weight": w1})
     o1 = fe1.extract_from_hidden_states([h.to(dev) for h in hs], am.to(dev), padding_side="left").cpu()
     r1 = tc.feature_extractor_v1(hs, am, {"aggregate_embed.weight": w1.to(torch.bfloat16).float()}, "left")
-    assert o1.shape == (2, 12, 64) and rel_l2(o1, r1) < 1e-2
+    assert o1.shape == (2, 12, 64) and rel_l2(o1, r1) < 0.006
     assert float(o1[1, :5].abs().max()) == 0.0                     # pad rows: no bias in V1
     wv, bv = 0.05 * torch.randn(128, 320, generator=gen), 0.1 * torch.randn(128, generator=gen)
     wa, ba = 0.05 * torch.randn(64, 320, generator=gen), 0.1 * torch.randn(64, generator=gen)
@@ -773,7 +773,7 @@ def test_vae_full_size_decode(dev):
         ref = vae.decode_latent(z.to(dev), wq, cfg, noise=nz.to(dev))
     assert ref.shape == a.shape
     diff = (a.int() - ref.int()).abs().float()
-    assert diff.mean() < 2.0 and pearson(a.float().cpu(), ref.float().cpu()) > 0.999
+    assert measure("uint8 mean |diff|", diff.mean()) < 1.2 and pearson(a.float().cpu(), ref.float().cpu()) > 0.999
 
 
 def test_dit_full_size_denoise_loop(dev):
@@ -802,7 +802,7 @@ def test_dit_full_size_denoise_loop(dev):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert z.shape == (3456, 128)
-    assert rel_l2(z.cpu(), ref[0]) < 3e-2 and pearson(z.cpu(), ref[0]) > 0.999
+    assert rel_l2(z.cpu(), ref[0]) < 0.008 and pearson(z.cpu(), ref[0]) > 0.999
 
 
 @pytest.mark.parametrize("v23", [False, True])
@@ -831,8 +831,8 @@ def test_av_full_size_step(dev, v23):
     with torch.device(dev), torch.no_grad():
         rv, ra = dit_av.av_x0_model({k: t.to(dev) for k, t in video.items()}, {k: t.to(dev) for k, t in audio.items()}, wg, cfg)
     assert vx0.shape == (1, 3456, 128) and ax0.shape == (1, 68, 128)
-    assert rel_l2(vx0.cpu(), rv.cpu()) < 2e-2 and pearson(vx0.cpu(), rv.cpu()) > 0.999
-    assert rel_l2(ax0.cpu(), ra.cpu()) < 2e-2 and pearson(ax0.cpu(), ra.cpu()) > 0.999
+    assert rel_l2(vx0.cpu(), rv.cpu()) < 0.01 and pearson(vx0.cpu(), rv.cpu()) > 0.999
+    assert rel_l2(ax0.cpu(), ra.cpu()) < 0.006 and pearson(ax0.cpu(), ra.cpu()) > 0.999
 
 
 def test_upscaler_and_encoder_full_size(dev):
@@ -862,7 +862,7 @@ def test_upscaler_and_encoder_full_size(dev):
     with torch.device(dev), torch.no_grad():
         rlat = oenc.encoder_forward(img.to(dev), weg)
     assert lat.shape == rlat.shape == (1, 128, 1, 16, 24)
-    assert rel_l2(lat.cpu(), rlat.cpu()) < 5e-2 and pearson(lat.cpu(), rlat.cpu()) > 0.998
+    assert rel_l2(lat.cpu(), rlat.cpu()) < 0.04 and pearson(lat.cpu(), rlat.cpu()) > 0.998
 
 
 def test_dit_full_size_per_token_timesteps(dev):
@@ -882,7 +882,7 @@ def test_dit_full_size_per_token_timesteps(dev):
     with torch.device(dev), torch.no_grad():
         ref = dit.x0_model(lat.to(dev), ctx.to(dev), ts.to(dev), pos.to(dev), wg, cfg).cpu()
     assert x0.shape == (1, 3456, 128)
-    assert rel_l2(x0.cpu(), ref) < 2e-2 and pearson(x0.cpu(), ref) > 0.999
+    assert rel_l2(x0.cpu(), ref) < 0.012 and pearson(x0.cpu(), ref) > 0.999
 
 
 @pytest.mark.parametrize("family", ["video", "av_v1", "av_v23"])
@@ -911,7 +911,7 @@ def test_one_stage_pipeline_against_oracle_loop(dev, family):
             rv = loop.euler_step(rv, dit.x0_model(rv, ctx, torch.tensor([s]), vpos, wq, cfg), s, float(sig[i + 1]))
         pipe = OneStagePipeline(m, None, None)
         lat, aud = pipe(ctx.to(dev), None, OneStageCFGConfig(**kw), initial_noise=noise.to(dev))
-        assert aud is None and rel_l2(lat.cpu(), loop.unpatchify(rv, f, h, wd)) < 3e-2
+        assert aud is None and rel_l2(lat.cpu(), loop.unpatchify(rv, f, h, wd)) < 0.002
         lat_g, _ = pipe(ctx.to(dev), None, OneStageCFGConfig(use_hip_graph=True, **kw), initial_noise=noise.to(dev))
         assert rel_l2(lat_g.cpu(), lat.cpu()) < 1e-5
         # classifier-free guidance (one_stage.py:224-330): two evaluations per step, CFGStarRescalingGuider for rescale_scale > 0 else CFGGuider
@@ -926,8 +926,8 @@ def test_one_stage_pipeline_against_oracle_loop(dev, family):
                 rv = loop.euler_step(rv, guider.guide(pos, ngt), s, float(sig[i + 1]))
             lat_c, _ = pipe(ctx.to(dev), nctx.to(dev), OneStageCFGConfig(**dict(kw, cfg_scale=SC, rescale_scale=rescale)), initial_noise=noise.to(dev))
             ref_c = loop.unpatchify(rv, f, h, wd)
-            assert rel_l2(lat_c.cpu(), ref_c) < 3e-2, rescale
-            assert rel_l2(ref_c, lat.cpu()) > 2e-2 and rel_l2(lat_c.cpu(), ref_c) < 0.5 * rel_l2(lat_c.cpu(), lat.cpu())      # the guided trajectory, not the plain one
+            assert rel_l2(lat_c.cpu(), ref_c) < 0.02, rescale
+            assert rel_l2(ref_c, lat.cpu()) > 2e-2 and rel_l2(lat_c.cpu(), ref_c) < 0.15 * rel_l2(lat_c.cpu(), lat.cpu())      # the guided trajectory, not the plain one
         with pytest.raises(ValueError, match="negative"):
             pipe(ctx.to(dev), None, OneStageCFGConfig(**dict(kw, cfg_scale=3.0)))
         return
@@ -949,9 +949,9 @@ def test_one_stage_pipeline_against_oracle_loop(dev, family):
         pipe(vctx.to(dev), None, OneStageCFGConfig(**kw))
     lat, aud = pipe(vctx.to(dev), None, OneStageCFGConfig(audio_enabled=True, **kw), positive_audio_encoding=actx.to(dev),
                     initial_noise=noise.to(dev), initial_audio_noise=anoise.to(dev))
-    assert rel_l2(lat.cpu(), loop.unpatchify(rv, f, h, wd)) < 3e-2
+    assert rel_l2(lat.cpu(), loop.unpatchify(rv, f, h, wd)) < 0.0025
     ref_aud = AudioPatchifier(patch_size=1).unpatchify(ra, AudioLatentShape(1, 8, Ta, 16))
-    assert aud.shape == (1, 8, Ta, 16) and rel_l2(aud.cpu(), ref_aud) < 3e-2
+    assert aud.shape == (1, 8, Ta, 16) and rel_l2(aud.cpu(), ref_aud) < 0.0015
     # silent video from an AV checkpoint (audio_enabled=False): the internal audio branch still runs (use_internal_audio_branch),
     # only the audio output is dropped; hipGraph replay of the joint loop agrees with the eager per-step API
     lat_g, aud_g = pipe(vctx.to(dev), None, OneStageCFGConfig(use_hip_graph=True, **kw), positive_audio_encoding=actx.to(dev),
@@ -972,8 +972,8 @@ def test_one_stage_pipeline_against_oracle_loop(dev, family):
         ra = loop.euler_step(ra, ga.guide(pa, na_), float(sig[i]), float(sig[i + 1]))
     lat_c, aud_c = pipe(vctx.to(dev), nvctx.to(dev), OneStageCFGConfig(audio_enabled=True, **dict(kw, cfg_scale=3.0, audio_cfg_scale=7.0, rescale_scale=0.7)),
                         positive_audio_encoding=actx.to(dev), negative_audio_encoding=nactx.to(dev), initial_noise=noise.to(dev), initial_audio_noise=anoise.to(dev))
-    assert rel_l2(lat_c.cpu(), loop.unpatchify(rv, f, h, wd)) < 3e-2
-    assert rel_l2(aud_c.cpu(), AudioPatchifier(patch_size=1).unpatchify(ra, AudioLatentShape(1, 8, Ta, 16))) < 5e-2
+    assert rel_l2(lat_c.cpu(), loop.unpatchify(rv, f, h, wd)) < 0.006
+    assert rel_l2(aud_c.cpu(), AudioPatchifier(patch_size=1).unpatchify(ra, AudioLatentShape(1, 8, Ta, 16))) < 0.008
     # use_internal_audio_branch=False on an AV model: the video half alone (reference model.py:829-840), no audio encoding needed
     lat_v, _ = pipe(vctx.to(dev), None, OneStageCFGConfig(use_internal_audio_branch=False, **kw), initial_noise=noise.to(dev))
     assert lat_v.shape == lat.shape and torch.isfinite(lat_v).all() and rel_l2(lat_v.cpu(), lat.cpu()) > 1e-3
@@ -1007,7 +1007,7 @@ def test_video_only_v23_conditioned_token0_against_oracle(dev):
     mod = Modality(latent=video["latent"].to(dev), context=video["context"].to(dev), context_mask=None, timesteps=ts.to(dev),
                    positions=video["positions"].to(dev), sigma=video["sigma"].to(dev))
     x0 = X0Model(vo)(mod).cpu()
-    assert rel_l2(x0, rv) < 2e-2 and pearson(x0, rv) > 0.999
+    assert rel_l2(x0, rv) < 0.003 and pearson(x0, rv) > 0.999
     # (that the oracle itself follows Modality.sigma, not timesteps[0], is pinned with the reference's own vector and a negative
     # control in tests/test_oracle_golden.py::test_video_only_inference_matches_reference)
 
@@ -1025,7 +1025,7 @@ def test_video_only_inference_against_reference_vectors(dev, v23):
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_av_tiny.npz"))
     x0, empty = X0Model(m)(to_modality(video, dev), None)
     ref = torch.from_numpy(z[f"{'v23' if v23 else 'v1'}_videoonly_x0"])
-    assert empty.shape == (1, 0, 128) and rel_l2(x0.cpu(), ref) < 3e-2 and pearson(x0.cpu(), ref) > 0.999
+    assert empty.shape == (1, 0, 128) and rel_l2(x0.cpu(), ref) < 0.004 and pearson(x0.cpu(), ref) > 0.999
 
 
 def test_stream_k_timeout_is_reported_at_the_next_health_check(dev):
@@ -1077,11 +1077,11 @@ def test_masked_text_cross_attention_against_oracle_and_reference_vectors(dev):
     rm, rc = torch.from_numpy(z["x0_masked"]), torch.from_numpy(z["x0_masked_control"])
     for mk in (cmask, cmask.bool(), cmask.to(torch.int64)):
         got = run(mk)
-        assert rel_l2(got, rm) < 3e-2 and pearson(got, rm) > 0.999
-        assert rel_l2(got, rm) < 0.5 * rel_l2(got, rc)            # ... and it is the masked vector, not the control
+        assert rel_l2(got, rm) < 0.003 and pearson(got, rm) > 0.999
+        assert rel_l2(got, rm) < 0.025 * rel_l2(got, rc)            # ... and it is the masked vector, not the control
     ctl = run(None)                                                 # the mask does not outlive the call that carried it
     assert rel_l2(ctl, rc) < 3e-2 and rel_l2(ctl, rc) < 0.5 * rel_l2(ctl, rm)
-    assert rel_l2(run(cmask), rm) < 3e-2
+    assert rel_l2(run(cmask), rm) < 0.003
     # float (additive) masks and wrong shapes are refused, not reinterpreted
     with pytest.raises(NotImplementedError):
         run(cmask.float())
@@ -1124,11 +1124,11 @@ def test_av_masked_text_cross_attention_against_reference_vectors(dev, v23):
     gv, ga = [torch.from_numpy(z[f"{tag}_masked_{k}_x0"]) for k in ("video", "audio")]
     cv, ca = [torch.from_numpy(z[f"{tag}_masked_control_{k}_x0"]) for k in ("video", "audio")]
     vx0, ax0 = run(vm, am.bool())
-    assert rel_l2(vx0, gv) < 3e-2 and rel_l2(ax0, ga) < 3e-2
-    assert rel_l2(vx0, gv) < 0.5 * rel_l2(vx0, cv)                  # the masked vector, not the control
+    assert rel_l2(vx0, gv) < 5e-3 and rel_l2(ax0, ga) < 5e-3
+    assert rel_l2(vx0, gv) < 0.2 * rel_l2(vx0, cv)                  # the masked vector, not the control
     if v23:
-        assert rel_l2(ax0, ga) < 0.5 * rel_l2(ax0, ca)              # (v1's audio vectors differ by 5e-3 only: inside the 16-bit tolerance)
+        assert rel_l2(ax0, ga) < 0.08 * rel_l2(ax0, ca)              # (v1's audio vectors differ by 5e-3 only: inside the 16-bit tolerance)
     vx0, ax0 = run(None, None)                                      # no mask outlives its call
     assert rel_l2(vx0, cv) < 3e-2 and rel_l2(vx0, cv) < 0.5 * rel_l2(vx0, gv)
     vx0, ax0 = run(vm, None)                                        # one modality masked, the other not
-    assert rel_l2(vx0, gv) < 0.5 * rel_l2(vx0, cv)
+    assert rel_l2(vx0, gv) < 0.2 * rel_l2(vx0, cv)

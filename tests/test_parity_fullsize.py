@@ -57,7 +57,7 @@ def test_dit_48_layer_step(dev):
             ref = dit.x0_model(lat.to(dev), ctx.to(dev), ts.to(dev), pos.to(dev), w, cfg).cpu()
         x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=ts.to(dev), positions=pos.to(dev)))
         assert x0.shape == (1, 3456, 128)
-        assert rel_l2(x0.cpu(), ref) < 3e-2 and pearson(x0.cpu(), ref) > 0.999, sigma
+        assert rel_l2(x0.cpu(), ref) < 0.012 and pearson(x0.cpu(), ref) > 0.999, sigma
         refs[sigma] = ref
     # BASELINE config 3 as an opt-in fp8-COMPUTE step (fp8 MFMA, e4m3fn weights per output channel + per-token e4m3fn activations in the
     # six projections of every block): same weights, same inputs, against the same fp32 oracle.  Tolerance of THIS mode (stated in
@@ -103,7 +103,7 @@ def test_dit_stage2_size_step(dev):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert z.shape == (13824, 128)
-    assert rel_l2(z.cpu(), ref[0]) < 3e-2 and pearson(z.cpu(), ref[0]) > 0.999
+    assert rel_l2(z.cpu(), ref[0]) < 0.008 and pearson(z.cpu(), ref[0]) > 0.999
 
 
 def test_decode_tiled_full_width(dev):
@@ -131,7 +131,7 @@ def test_decode_tiled_full_width(dev):
     with torch.device(dev), torch.no_grad():
         ref = vae.decode_tiled(z.to(dev), lambda t: vae.decoder_forward(t, wq, cfg, timestep=0.05, noise=None))
     assert out.shape == ref.shape == (1, 3, 65, 512, 1280)
-    assert rel_l2(out.cpu(), ref.cpu()) < 4e-2 and pearson(out.cpu(), ref.cpu()) > 0.999
+    assert rel_l2(out.cpu(), ref.cpu()) < 0.03 and pearson(out.cpu(), ref.cpu()) > 0.999
 
 
 def test_two_stage_pipeline_against_oracle_loop(dev):
@@ -172,7 +172,7 @@ def test_two_stage_pipeline_against_oracle_loop(dev):
         conf = DistilledConfig(height=256, width=384, num_frames=17, seed=1, use_hip_graph=graph)
         lat = pipe(ctx.to(dev), None, conf, initial_noise=noise1.to(dev), stage2_noise=noise2.to(dev))
         assert lat.shape == ref.shape == (1, 128, 3, 8, 12)
-        assert rel_l2(lat.cpu(), ref) < 4e-2 and pearson(lat.cpu(), ref) > 0.999, graph
+        assert rel_l2(lat.cpu(), ref) < 0.005 and pearson(lat.cpu(), ref) > 0.999, graph
 
 
 def test_gemm_w8a16_is_bit_identical_to_dequantise_at_load(dev):
@@ -309,7 +309,7 @@ def test_fp8_compute_trajectory_and_outlier_channels(dev):
             torch.cuda.empty_cache()
         print(f"8-step trajectory, 48 layers, outlier channels {outliers}: bf16 rel-L2 {res[False][0]:.4f} Pearson {res[False][1]:.5f} | "
               f"fp8 compute rel-L2 {res[True][0]:.4f} Pearson {res[True][1]:.5f}")
-        assert res[False][0] < 3e-2 and res[False][1] > 0.999, res
+        assert res[False][0] < 1e-2 and res[False][1] > 0.999, res            # measured 2.2e-3
         assert res[True][0] < FP8_COMPUTE_REL_L2 and res[True][1] > FP8_COMPUTE_PEARSON, res
         del w
         torch.cuda.empty_cache()
@@ -370,7 +370,7 @@ def test_av_48_layer_step_v23(dev):
     with torch.device(dev), torch.no_grad():
         rv, ra = dit_av.av_x0_model({k: t.to(dev) for k, t in video.items()}, {k: t.to(dev) for k, t in audio.items()}, w, cfg)
     assert vx0.shape == (1, 3456, 128) and ax0.shape == (1, 68, 128)
-    assert rel_l2(vx0.cpu(), rv.cpu()) < 3e-2 and pearson(vx0.cpu(), rv.cpu()) > 0.999
-    assert rel_l2(ax0.cpu(), ra.cpu()) < 3e-2 and pearson(ax0.cpu(), ra.cpu()) > 0.999
+    assert rel_l2(vx0.cpu(), rv.cpu()) < 0.012 and pearson(vx0.cpu(), rv.cpu()) > 0.999
+    assert rel_l2(ax0.cpu(), ra.cpu()) < 0.008 and pearson(ax0.cpu(), ra.cpu()) > 0.999
     del w, m
     torch.cuda.empty_cache()
