@@ -42,7 +42,8 @@ extern "C" {
  * the list: an old caller's arguments would shift silently), round 3 added ltx2_dit_health; round 4 added entry points only
  * (ltx2_clear_error, ltx2_adaln_rmsnorm2, ltx2_flash_attn_gated, ltx2_flash_attn_form, ltx2_dit_graph_capture_cond[_av], the
  * "adaln_combine" option) without bumping the version -- a round-3 library then passed the check and failed later on a symbol lookup;
- * 3 = round 5: the round-4 additions are part of the version, ltx2_flash_attn_form (the 64-rows-per-wave experiment's entry) is REMOVED, and
+ * 3 = round 5: the round-4 additions are part of the version, ltx2_flash_attn_form (the 64-rows-per-wave experiment's entry), ltx2_flash_attn_ws /
+ * ltx2_flash_attn_workspace_bytes (the stream-K launch form) and ltx2_dit_health (its timeout flag) are REMOVED with their kernels, and
  * ltx2_dit_graph_capture_cond[_av] take the element counts of the mask / clean-latent buffers they replay from.  Rule from here on: any change
  * of the exported symbol set or of a signature bumps the version. */
 #define LTX2_ABI_VERSION 3
@@ -213,16 +214,7 @@ int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, in
  * Replaces _compiled_attention_core_no_mask (attention.py:12-34).                             */
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
                     int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream);
-/* The same with a scratch buffer: when ceil(Nq/128) * H exceeds the chip's 2-per-CU workgroup slots (3456 tokens x 32 heads =
- * 864 units on 512 slots) the launch becomes stream-K -- one persistent workgroup per slot, each with an equal range of
- * (unit, KV-tile) items; units cut by a range boundary are computed in two pieces and merged in a fixed order (bit-reproducible;
- * equal to ltx2_flash_attn within fp32 rounding of the merge).  workspace: ltx2_flash_attn_workspace_bytes(head_dim) bytes, its
- * FIRST 4096 bytes zero before the first launch (every launch leaves them zero); launches sharing it must be stream-ordered.
- * workspace == NULL is ltx2_flash_attn.                                                                        */
-int64_t ltx2_flash_attn_workspace_bytes(int head_dim);
-int ltx2_flash_attn_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
-                       int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* workspace,
-                       int64_t workspace_bytes, void* stream);
+
 
 /* Per-head attention gates (V2.3, attention.py:241-249): logits[rows][H] (fp32 scratch, also returned)
  * = x[rows][Dq] @ gate_w[H][Dq]^T + gate_b ; att[:, h*hd:(h+1)*hd] *= 2*sigmoid(logits[:, h]).  H <= 32. */
@@ -400,12 +392,6 @@ int ltx2_dit_set_context_mask(ltx2_dit* ctx, int modality, const float* mask, in
  *   timestep per modality the sums of all layers are formed by one launch at the top of the step (bit-identical results).              */
 int ltx2_dit_set_option(ltx2_dit* ctx, const char* name, int value);
 
-
-/* Health check at a host synchronisation point (per prompt / after a sampling loop): synchronises `stream`, reads the sticky error
- * word of the stream-K attention hand-off (a consumer that waited ~0.2 s for a partial result gives up instead of hanging the GPU,
- * ltx2_flash_attn_ws) and, if it is set, resets the flag page and returns LTX2_E_STATE: everything computed since the last check is
- * invalid.  LTX2_OK otherwise.                                                                                         */
-int ltx2_dit_health(ltx2_dit* ctx, void* stream);
 
 /* Measurement aid: bracket every launch of one GEMM kernel instantiation (epilogue id, or -1 for
  * every GEMM) issued by this thread's ltx2_dit_* calls with HIP events on the launch stream;

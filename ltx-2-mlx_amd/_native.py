@@ -72,8 +72,7 @@ SIGNATURES = {
     "ltx2_qknorm_rope": (i32, [vp, i64, i32, i32, i32, i32, vp, i32, vp, f32, vp, vp, vp]),
     "ltx2_vt_transpose": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
     "ltx2_flash_attn": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp]),
-    "ltx2_flash_attn_workspace_bytes": (i64, [i32]),
-    "ltx2_flash_attn_ws": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i64, vp]),
+    "ltx2_flash_attn": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp]),
     "ltx2_attn_head_gate": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ltx2_rope_tables": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "ltx2_timestep_sinusoid": (i32, [vp, i64, f32, i32, i32, vp, vp, vp]),
@@ -106,7 +105,6 @@ SIGNATURES = {
     "ltx2_dit_graph_capture_cond": (i32, [vp, vp, C.POINTER(f32), i32, vp, i64, vp, i64, vp]),
     "ltx2_dit_graph_capture_cond_av": (i32, [vp, vp, vp, C.POINTER(f32), i32, vp, i64, vp, i64, vp, i64, vp, i64, vp]),
     "ltx2_dit_graph_launch": (i32, [vp, vp]),
-    "ltx2_dit_health": (i32, [vp, vp]),
     "ltx2_dit_set_context_mask": (i32, [vp, i32, vp, i32, vp]),
     "ltx2_dit_set_option": (i32, [vp, C.c_char_p, i32]),
     "ltx2_dit_profile_begin": (i32, [vp, i32]),

@@ -11,31 +11,22 @@ struct AttnParams {
     int Nq, Nkv, Npad, H;
     int head_dim;       // 128 (default when 0) or 64
     float scale_log2e;  // (1/sqrt(d)) * log2(e)
-    // stream-K (attention.hip): scratch for the partial (O, m, l) of units cut by a work-range boundary, attn_sk_workspace_bytes()
-    // bytes, its last 4 KiB (the flags) ZERO before the first launch; null = plain one-workgroup-per-unit grid.  Launches that
-    // share a workspace must be ordered on one stream.  sk_xcd / sk_flags are filled by the launcher.
-    void* sk_ws;
-    long sk_ws_bytes;
-    unsigned* sk_flags;
-    int sk_xcd;
     // Per-query-row softmax scale (text cross-attention with q_norm folded in, round 3): q_ss[q * q_ss_ld + j], j < q_ss_ld, are partial sums
     // of the row's squared norm over the FULL inner dim q_norm_dim; row q then uses scale_log2e * rsqrt(sum / q_norm_dim + q_eps) -- the
     // RMS normalisation of q as a positive per-row factor on its scores (the row maximum is taken on the raw scores: order-preserving).
-    // null = one scale for every row.  Plain grid only.
+    // null = one scale for every row.
     const float* q_ss;
     int q_ss_ld, q_norm_dim;
     float q_eps;
     // Key mask (reference attention.py:38-70 with the boolean (B, S) context mask of model.py:163-201): bit i of kmask[t] = key 64 t + i may be
     // attended; a masked key's score is replaced by -1e30 (the reference ADDS -3.4e38 to it: the same softmax, including the uniform
-    // result over the masked keys of a row whose keys are all masked).  null = no mask.  Plain grid only.
+    // result over the masked keys of a row whose keys are all masked).  null = no mask.
     const unsigned long long* kmask;
     // Per-head output gates (V2.3 apply_gated_attention, attention.py:241-249): out[q, h] *= 2 * sigmoid(gate[q * gate_ld + h]), applied to the fp32
     // result before it is rounded (round 4: was a pass over the attention output).  null = none.
     const float* gate;
     int gate_ld;
-    int sk_force;       // 1: stream-K whenever there are more units than slots (unit tests); 0: only when the plain grid's last round is badly filled
 };
 
 int attn_launch(const AttnParams& p, hipStream_t stream);
-long attn_sk_workspace_bytes(int head_dim);
 int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream, int head_dim = 128);

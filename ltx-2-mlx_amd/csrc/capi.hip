@@ -326,18 +326,9 @@ int ltx2_flash_attn_gated(const void* Q, int64_t ldq, const void* K, int64_t ldk
     return attn_launch(a, (hipStream_t)stream);
 }
 
-int64_t ltx2_flash_attn_workspace_bytes(int head_dim) { return attn_sk_workspace_bytes(head_dim); }
-
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
                     int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream) {
-    return ltx2_flash_attn_ws(Q, ldq, K, ldk, VT, Npad, out, ldo, Nq, Nkv, H, head_dim, scale, nullptr, 0, stream);
-}
-
-int ltx2_flash_attn_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
-                       int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* workspace,
-                       int64_t workspace_bytes, void* stream) {
     LTX2_CHECK_ARG(Q && K && VT && out, "flash_attn: null operand");
-    LTX2_CHECK_ARG(!workspace || workspace_bytes >= attn_sk_workspace_bytes(head_dim), "flash_attn: workspace smaller than ltx2_flash_attn_workspace_bytes()");
     LTX2_CHECK_ARG(head_dim == 128 || head_dim == 64, "flash_attn: head_dim=%d, only 128 and 64 are implemented", head_dim);
     AttnParams a{};
     a.Q = (const bf16*)Q;
@@ -354,9 +345,6 @@ int ltx2_flash_attn_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, c
     a.Npad = Npad;
     a.H = H;
     a.scale_log2e = scale * 1.4426950408889634f;
-    a.sk_ws = workspace;
-    a.sk_ws_bytes = workspace_bytes;
-    a.sk_force = 1;
     return attn_launch(a, (hipStream_t)stream);
 }
 

@@ -19,14 +19,6 @@ typedef __bf16 bf16;
 #define LTX2_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define LTX2_DT "bf16"
 #endif
-// Which MFMA block shape the attention kernel runs on -- it fixes the key order inside every 32-key block of V^T, so the three places that
-// know that order (attn*_fwd_kernel, vt_transpose_kernel, gemm_v4's fused V^T epilogue) switch together:
-//   0: v_mfma_f32_32x32x16 (rounds 1-4): position 16 (g >> 1) + 8 hi + 4 (g & 1) + e holds key 8 g + 4 hi + e
-//   1: v_mfma_f32_16x16x32 (round 5):    position 8 g + 4 h + r holds key 16 h + 4 g + r
-#ifndef AT_FORM16
-#define AT_FORM16 0
-#endif
-
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));

@@ -108,8 +108,6 @@ struct ltx2_dit {
     std::unordered_map<const void*, const float*> fp8_scale;
     bool adaln_combine = true;         // ltx2_dit_set_option("adaln_combine"): round 4, see forward()
     bool fp8_compute = false;          // ltx2_dit_set_option("fp8_compute"): fp8-resident weights x per-token fp8 activations on the fp8 MFMA
-    void* sk_ws = nullptr;             // stream-K attention scratch (attention.h); main-stream launches only
-    long sk_bytes = 0;
     bool prepared = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -137,8 +135,6 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         return p;
     };
     c->sigmas_dev = (float*)take(4L * 64);
-    c->sk_bytes = attn_sk_workspace_bytes(128);
-    c->sk_ws = take(c->sk_bytes);
     for (int k = 0; k < (c->av ? 2 : 1); ++k) {
         Mod& m = c->m[k];
         const long n = k ? Na : N, s = k ? Sa : S;
@@ -488,10 +484,8 @@ int adaln_chain(ltx2_dit* c, Mod& m, const AdaW& a, const float* ts, long t_stri
     return LTX2_OK;
 }
 
-// sk: the context's stream-K scratch -- only for launches on the MAIN stream (they are ordered; the audio modality's
-// attention runs beside them on the side stream and keeps the plain grid).
 int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int npad, bf16* out, long ldo, int nq,
-           int nkv, int H, int hd, hipStream_t st, ltx2_dit* sk = nullptr, const float* q_ss = nullptr, float q_eps = 0.f,
+           int nkv, int H, int hd, hipStream_t st, const float* q_ss = nullptr, float q_eps = 0.f,
            const unsigned long long* kmask = nullptr, const float* gate = nullptr) {
     AttnParams a{};
     a.kmask = kmask;
@@ -502,10 +496,6 @@ int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int
         a.q_ss_ld = H * hd / 64;
         a.q_norm_dim = H * hd;
         a.q_eps = q_eps;
-    }
-    if (sk) {
-        a.sk_ws = sk->sk_ws;
-        a.sk_ws_bytes = sk->sk_bytes;
     }
     a.Q = q;
     a.ldq = ldq;
@@ -611,7 +601,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
         TRY(qknorm_rope_launch(m.qkv, 3 * D, N, D, hd, 2, offs, wts, eps, m.cosb, m.sinb, st));
     }
     if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
-    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, k == 0 ? c : nullptr, nullptr, 0.f, nullptr, glog(c, m)));
+    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, nullptr, 0.f, nullptr, glog(c, m)));
     TRY(dense(c, m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(2), es, tab + 2 * D));
 
     // text cross-attention: no RoPE, no mask.  V1: plain RMSNorm on x, K/V cached per prompt.
@@ -643,7 +633,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
         const float* wts[1] = {w.text.qn};
         TRY(qknorm_rope_launch(m.qkv, D, N, D, hd, 1, offs, wts, eps, nullptr, nullptr, st));
     }
-    TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st, k == 0 ? c : nullptr, m.qfold ? m.qss : nullptr, eps,
+    TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st, m.qfold ? m.qss : nullptr, eps,
                m.has_kmask ? m.kmask : nullptr, glog(c, m)));
     if (c->v2)
         TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(8), es, tab + 8 * D));
@@ -735,7 +725,7 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st, hipStream_t sa) {
     }
     // ---- audio -> video attention (main): Q from video, K / V from audio ----
     TRY(event_wait(audio_kv, st));
-    TRY(attend(v_q, Da, a_kv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st, c, nullptr, 0.f, nullptr, glog(c, v)));
+    TRY(attend(v_q, Da, a_kv, 2 * Da, a.vt, a.Npad, v.att, Da, v.N, a.N, H, hd, st, nullptr, 0.f, nullptr, glog(c, v)));
     TRY(dense(c, v.att, Da, w.a2v.o_w, w.a2v.o_b, v.x, Dv, v.N, Dv, Da, EPI_RESID_GATE_F32, st, comb ? nullptr : v.cross_gate, 0, tv + 4 * Dv));
     // ---- video -> audio attention (side): Q from audio, K / V from video ----
     TRY(event_wait(video_norm, sa));
@@ -745,7 +735,7 @@ int block_cross_modal(ltx2_dit* c, int l, hipStream_t st, hipStream_t sa) {
         TRY(qknorm_rope_launch(v_kv, 2 * Da, v.N, Da, hd, 1, offs, wts, eps, v.ccos, v.csin, sa));
     }
     if (!vt_done) TRY(vt_transpose_launch(v_kv + Da, 2 * Da, v.vt, v.N, v.Npad, H, sa, hd));
-    TRY(attend(a_q, Da, v_kv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, sa, nullptr, nullptr, 0.f, nullptr, glog(c, a)));     // few queries, long KV (side stream: the plain grid)
+    TRY(attend(a_q, Da, v_kv, 2 * Da, v.vt, v.Npad, a.att, Da, a.N, v.N, H, hd, sa, nullptr, 0.f, nullptr, glog(c, a)));     // few queries, long KV (side stream)
     TRY(dense(c, a.att, Da, w.v2a.o_w, w.v2a.o_b, a.x, Da, a.N, Da, Da, EPI_RESID_GATE_F32, sa, comb ? nullptr : a.cross_gate, 0, ta + 4 * Da));
     return LTX2_OK;
 }
@@ -1076,7 +1066,6 @@ int ltx2_dit_prepare(ltx2_dit* c, const float* context, int S, const float* rope
         return LTX2_E_STATE;
     }
     TRY(resolve(c));
-    if (hipMemsetAsync(c->sk_ws, 0, 4096, (hipStream_t)stream) != hipSuccess) return LTX2_E_HIP;   // stream-K flags start at zero
     TRY(prepare_modality(c, 0, context, S, rope_cos, rope_sin, nullptr, nullptr, (hipStream_t)stream));
     c->prepared = true;
     return LTX2_OK;
@@ -1093,7 +1082,6 @@ int ltx2_dit_prepare_av(ltx2_dit* c, const float* v_context, int S, const float*
         return LTX2_E_STATE;
     }
     TRY(resolve(c));
-    if (hipMemsetAsync(c->sk_ws, 0, 4096, (hipStream_t)stream) != hipSuccess) return LTX2_E_HIP;   // stream-K flags start at zero
     TRY(prepare_modality(c, 0, v_context, S, v_cos, v_sin, v_cross_cos, v_cross_sin, (hipStream_t)stream));
     TRY(prepare_modality(c, 1, a_context, Sa, a_cos, a_sin, a_cross_cos, a_cross_sin, (hipStream_t)stream));
     c->prepared = true;
@@ -1292,27 +1280,6 @@ int ltx2_dit_set_option(ltx2_dit* c, const char* name, int value) {
     return LTX2_E_INVALID;
 }
 
-int ltx2_dit_health(ltx2_dit* c, void* stream) {
-    LTX2_CHECK_ARG(c, "dit_health: null context");
-    if (!c->sk_ws) return LTX2_OK;
-    hipStream_t st = (hipStream_t)stream;
-    unsigned sticky = 0;
-    if (hipMemcpyAsync(&sticky, (const char*)c->sk_ws + 4 * 1023, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) {
-        ltx2_set_error("dit_health: %s", hipGetErrorString(hipGetLastError()));
-        return LTX2_E_HIP;
-    }
-    if (sticky) {
-        // a stream-K consumer gave up waiting for a producer's partial result (attention.hip): that launch's output and possibly
-        // later ones are wrong, and producer flags may be stale -- the whole flag page is reset so the NEXT launch is clean
-        (void)hipMemsetAsync(c->sk_ws, 0, 4096, st);
-        (void)hipStreamSynchronize(st);
-        ltx2_set_error("dit_health: a stream-K attention launch timed out waiting for a partial result since the last check; the results "
-                       "computed since then are invalid (flag page reset)");
-        return LTX2_E_STATE;
-    }
-    return LTX2_OK;
-}
 
 int ltx2_dit_graph_launch(ltx2_dit* c, void* stream) {
     LTX2_CHECK_ARG(c, "dit_graph_launch: null context");

@@ -540,8 +540,8 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
         }
         if ((LAYOUT == 3 || LAYOUT == 5 || LAYOUT == 6) && EPI == EPI_BF16 && !CONV && p.vt && n0 >= p.vt_col0) {
             // V tile of a fused QKV projection: this wave's 64 columns are 64 dims of ONE head; leave as V^T rows
-            // vt[head][d][.] with attention's key order inside every 32-key block: position 16 ks + 8 hh + 4 g0 + e holds
-            // key 8 (2 ks + g0) + 4 hh + e.  One instruction stores 16 dims x 64 bytes (4 chunks of 8 positions); every chunk is
+            // vt[head][d][.] with attention's key order inside every 32-key block: position 8 g + 4 h + r holds
+            // key 16 h + 4 g + r.  One instruction stores 16 dims x 64 bytes (4 chunks of 8 positions); every chunk is
             // two runs of 4 consecutive keys gathered from the slab with 2-byte LDS reads.  Keys >= M are zeros (up to Npad).
             const int cw = n0 + wc * WN - p.vt_col0;
             const int head = cw / p.vt_hd, d0 = cw - head * p.vt_hd;
@@ -553,13 +553,8 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
 #pragma unroll
                 for (int cg = 0; cg < BM / 32; ++cg) {
                     const int ch = cg * 4 + (lane & 3);                   // 8-position chunk of the tile's key range
-#if AT_FORM16
                     const int kbase = (ch >> 2) * 32 + (ch & 3) * 4;                              // chunk g of a 32-key block: keys 4 g + r, then 16 + 4 g + r
                     constexpr int RUN2 = 16;
-#else
-                    const int kbase = (ch >> 2) * 32 + ((ch >> 1) & 1) * 16 + (ch & 1) * 4;      // first key of the chunk's first run
-                    constexpr int RUN2 = 8;
-#endif
                     bf16x8 v;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {

@@ -365,25 +365,16 @@ def vt_transpose(v: torch.Tensor, heads: int, head_dim: int = 128) -> torch.Tens
     return vt
 
 
-def flash_attn_workspace(head_dim: int, device) -> torch.Tensor:
-    """Scratch for the stream-K launch form of flash_attn (flags zeroed here; every launch leaves them zero)."""
-    ws = torch.empty(int(nv.lib().ltx2_flash_attn_workspace_bytes(head_dim)), device=device, dtype=torch.uint8)
-    ws[:4096].zero_()
-    return ws
-
-
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int,
-               scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q [Nq, H*hd], k [Nkv, H*hd] bf16 (row-strided views allowed), vt [H,hd,Npad] from vt_transpose (hd 128 or 64).
-    workspace (flash_attn_workspace): lets grids of more than one round of workgroup slots run stream-K."""
+               scale: Optional[float] = None) -> torch.Tensor:
+    """q [Nq, H*hd], k [Nkv, H*hd] bf16 (row-strided views allowed), vt [H,hd,Npad] from vt_transpose (hd 128 or 64)."""
     assert q.dtype in ACT16 and k.dtype == q.dtype and vt.dtype == q.dtype and q.stride(1) == 1 and k.stride(1) == 1
     nq, hd = q.shape[0], vt.shape[1]
     out = torch.empty(nq, heads * hd, device=q.device, dtype=q.dtype)
     if scale is None:
         scale = 1.0 / math.sqrt(float(hd))
-    nv.check(_L(q).ltx2_flash_attn_ws(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out),
-                                         out.stride(0), nq, nkv, heads, hd, scale, nv.ptr(workspace),
-                                         workspace.numel() if workspace is not None else 0, nv.stream()))
+    nv.check(_L(q).ltx2_flash_attn(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out),
+                                      out.stride(0), nq, nkv, heads, hd, scale, nv.stream()))
     return out
 
 

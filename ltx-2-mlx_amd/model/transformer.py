@@ -588,15 +588,6 @@ class LTXModel:
             t = self._sigma_dev[float(sigma)] = torch.tensor([float(sigma)], device=self.device, dtype=torch.float32)
         return t
 
-    def check_health(self) -> None:
-        """Host sync point (per prompt / after a sampling loop): raises RuntimeError if a stream-K attention launch gave up waiting
-        for a partial result since the last check (ltx2_dit_health; the results since then are invalid)."""
-        nv.check(self._L.ltx2_dit_health(self._h, nv.stream()))
-        if self._twin is not None:
-            self._twin.check_health()
-        if self._clone is not None:
-            self._clone.check_health()
-
     # ------------------------------------------------------------------ fused sampling step / graph
     def denoise_step_(self, latent: torch.Tensor, video: Modality, sigma: float, sigma_next: float,
                       denoise_mask: Optional[torch.Tensor] = None, clean_latent: Optional[torch.Tensor] = None,

@@ -162,7 +162,6 @@ def joint_denoise_loop(transformer, is_av_model: bool, video_state: LatentState,
             model.capture_denoise_graph(lat, sig, audio_latent=alat, **cond)
             model.replay_denoise_graph()
         torch.cuda.current_stream().wait_stream(side)
-        model.check_health()            # host sync at the end of the loop: a stream-K hand-off that timed out raises here
         video_state = video_state.replace(latent=lat[None].to(video_state.latent.dtype))
         if joint:
             audio_state = audio_state.replace(latent=alat[None].to(audio_state.latent.dtype))
@@ -189,5 +188,4 @@ def joint_denoise_loop(transformer, is_av_model: bool, video_state: LatentState,
             audio_state = audio_state.replace(latent=stepper.step(sample=audio_state.latent, denoised_sample=ax0, sigmas=sig, step_index=i))
         if callback:
             callback(i + 1, n)
-    model.check_health()
     return video_state, audio_state

@@ -600,7 +600,6 @@ def generate_video(
             vm.capture_denoise_graph(lat2d, sigmas)
             vm.replay_denoise_graph()
         torch.cuda.current_stream().wait_stream(side)
-        vm.check_health()
         tok = lat2d[None]
     else:
         for i in range(len(sigmas) - 1):

@@ -55,10 +55,13 @@ def test_leaf_kernels_in_float16(dev):
     qh, kh, vh = [t.float().reshape(Nq, H, hd).transpose(0, 1) for t in (q, k, v)]
     ro = torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(hd), dim=-1) @ vh
     assert o.dtype == F16 and rel_l2(o.cpu().float(), ro.transpose(0, 1).reshape(Nq, D).cpu()) < 0.0012
-    ws = K.flash_attn_workspace(hd, dev)
     q2, k2, v2 = [torch.randn(3456, D, generator=g).to(F16).to(dev) for _ in range(3)]
     vt2 = K.vt_transpose(v2, H)
-    assert rel_l2(K.flash_attn(q2, k2, vt2, H, 3456, workspace=ws).float(), K.flash_attn(q2, k2, vt2, H, 3456).float()) < 1e-05
+    o2 = K.flash_attn(q2, k2, vt2, H, 3456)
+    assert torch.equal(o2, K.flash_attn(q2, k2, vt2, H, 3456))
+    q2h, k2h, v2h = [t.float().reshape(3456, H, hd).transpose(0, 1) for t in (q2, k2, v2)]
+    r2 = (torch.softmax(q2h @ k2h.transpose(1, 2) / math.sqrt(hd), dim=-1) @ v2h).transpose(0, 1).reshape(3456, D)
+    assert rel_l2(o2.cpu().float(), r2.cpu()) < 2e-3          # a 54-tile row in IEEE half (P <= 2^12 by the kernel's sum check)
     # fused QKV with the V^T epilogue == GEMM + transpose pass
     wq = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(F16).to(dev)
     xin = torch.randn(3456, D, generator=g).to(F16).to(dev)

@@ -1,4 +1,4 @@
-"""Stream-K attention beside the plain grid on the DiT shapes (same box, alternating), with the max |difference|."""
+"""The attention kernel on the DiT shapes (same box, best of 3): us and TF/s.  Same-box A/B of two builds: tools/ab_run.sh 2 "base NAME" python tools/attn_time.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ltx_2_mlx_amd.kernels as K
@@ -17,12 +17,6 @@ for (Nq, Nkv, H, hd) in [(3456, 3456, 32, 128), (3456, 1024, 32, 128), (13824, 1
     k = torch.randn(Nkv, D, device=dev).to(torch.bfloat16)
     v = torch.randn(Nkv, D, device=dev).to(torch.bfloat16)
     vt = K.vt_transpose(v, H, head_dim=hd)
-    ws = K.flash_attn_workspace(hd, dev)
-    a = K.flash_attn(q, k, vt, H, Nkv); b = K.flash_attn(q, k, vt, H, Nkv, workspace=ws)
-    diff = (a.float() - b.float()).abs().max().item()
-    best = [1e9, 1e9]
-    for _ in range(3):
-        best[0] = min(best[0], timeit(lambda: K.flash_attn(q, k, vt, H, Nkv)))
-        best[1] = min(best[1], timeit(lambda: K.flash_attn(q, k, vt, H, Nkv, workspace=ws)))
+    best = min(timeit(lambda: K.flash_attn(q, k, vt, H, Nkv)) for _ in range(3))
     fl = 4.0 * Nq * Nkv * D
-    print(f"Nq={Nq} Nkv={Nkv} H={H} hd={hd}: plain {best[0]*1e6:8.1f} us {fl/best[0]/1e12:7.1f} TF/s | stream-K {best[1]*1e6:8.1f} us {fl/best[1]/1e12:7.1f} TF/s | max diff {diff:.3g}", flush=True)
+    print(f"Nq={Nq} Nkv={Nkv} H={H} hd={hd}: {best*1e6:8.1f} us {fl/best/1e12:7.1f} TF/s", flush=True)

@@ -11,8 +11,7 @@ if which.startswith("attn"):
     nkv = 1024 if which == "attn_cross" else N
     q = torch.randn(N, D, device=dev).to(torch.bfloat16); k = torch.randn(nkv, D, device=dev).to(torch.bfloat16)
     vt = K.vt_transpose(torch.randn(nkv, D, device=dev).to(torch.bfloat16), H)
-    ws = K.flash_attn_workspace(128, dev)
-    fn = lambda: K.flash_attn(q, k, vt, H, nkv, workspace=ws if which == "attn" else None)
+    fn = lambda: K.flash_attn(q, k, vt, H, nkv)
     flop = 4.0 * N * nkv * D
 elif which == "vae":
     from ltx_2_mlx_amd.model.video_vae import SimpleVideoDecoder, decode_latent
