@@ -44,6 +44,9 @@ struct Geo {
 #ifndef AT_DV
 #define AT_DV 6
 #endif
+#ifndef AT_WAIT2
+#define AT_WAIT2 0      // 1: one counted LDS wait per PAIR of fragments (A/B)
+#endif
 #ifndef AT_PRIO
 #define AT_PRIO 1       // s_setprio 1 over the two MFMA clusters of a tile (round 3, same-box A/B: self-attention -0.7 %, text cross-attention -2 %:
                         // the wave inside an MFMA cluster wins the issue slot, its SIMD partner's softmax VALU fills the gaps)
@@ -56,6 +59,12 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
+}
+
+// one counted wait for TWO fragments (AT_WAIT2): "at most N younger reads outstanding" proves the younger of the pair has landed, hence both
+template <int N>
+__device__ __forceinline__ void lds_wait2(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
 // score of a masked key: far below any real score and small enough that (score - max) stays finite
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 s[kb][qb] = f32x4{init, init, init, init};
             }
         bf16x8 pf[2][2];                // [qb][kk]
-        float ps[2] = {0.f, 0.f};
+        float ps[2] = {0.f, 0.f};       // this tile's exponential sums per query block
         // exponential pair Q4 (< 4) of key block KB: query block Q4 / 2, rows 2 (Q4 % 2), +1 -> elements 4 (KB % 2) + row of P[qb][KB / 2]
         auto exp_pair = [&](auto KB, auto Q4) __attribute__((always_inline)) {
             constexpr int kb = decltype(KB)::value, q4 = decltype(Q4)::value, qb = q4 / 2, r = 2 * (q4 % 2), kk = kb / 2, e = 4 * (kb % 2) + r;
@@ -241,8 +250,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         static_for<0, DK>(read_k);
         static_for<0, NK>([&](auto N) __attribute__((always_inline)) {
             constexpr int n = decltype(N)::value, kb = n / NKS, ks = n % NKS;
+#if AT_WAIT2
+            // reads run TWO fragments ahead in pairs: at even n the pair (n + DK, n + DK + 1) is requested and ONE wait covers fragments n and n + 1
+            if constexpr (n % 2 == 0) {
+                if constexpr (n + DK < NK) read_k(std::integral_constant<int, n + DK>{});
+                if constexpr (n + DK + 1 < NK) read_k(std::integral_constant<int, n + DK + 1>{});
+                constexpr int issued = (n + DK + 2 < NK ? n + DK + 2 : NK);        // reads requested so far
+                lds_wait2<issued - (n + 2)>(kf[n], kf[n + 1]);
+            }
+#else
             if constexpr (n + DK < NK) read_k(std::integral_constant<int, n + DK>{});
             lds_wait<(n + DK < NK ? DK : NK - 1 - n)>(kf[n]);
+#endif
             s[kb][0] = LTX2_MFMA_16x16x32(as_bf16x8(kf[n]), qf[0][ks], s[kb][0], 0, 0, 0);
             if constexpr (FAST && kb > 0) static_for<(4 * ks) / NKS, (4 * ks + 2) / NKS>([&](auto Q4) { exp_pair(std::integral_constant<int, kb - 1>{}, Q4); });
             s[kb][1] = LTX2_MFMA_16x16x32(as_bf16x8(kf[n]), qf[1][ks], s[kb][1], 0, 0, 0);
@@ -260,6 +279,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #if AT_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #endif
+        // O^T += V^T . P^T over the fragments [N0, N1) (fragment n = NDB kk + db feeds the two query blocks)
+        auto pv = [&](auto N0, auto N1) __attribute__((always_inline)) {
+            constexpr int n0 = decltype(N0)::value, n1 = decltype(N1)::value;
+#if AT_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);
+#endif
+            static_for<n0, n1>([&](auto N) __attribute__((always_inline)) {
+                constexpr int n = decltype(N)::value, kk = n / NDB, db = n % NDB;
+#if AT_WAIT2
+                if constexpr (n % 2 == 0) {
+                    if constexpr (n + DV < NV) read_v(std::integral_constant<int, n + DV>{});
+                    if constexpr (n + DV + 1 < NV) read_v(std::integral_constant<int, n + DV + 1>{});
+                    constexpr int issued = (n + DV + 2 < NV ? n + DV + 2 : NV);
+                    lds_wait2<issued - (n + 2)>(vf[n], vf[n + 1]);
+                }
+#else
+                if constexpr (n + DV < NV) read_v(std::integral_constant<int, n + DV>{});
+                lds_wait<(n + DV < NV ? DV : NV - 1 - n)>(vf[n]);
+#endif
+                o[db][0] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[0][kk], o[db][0], 0, 0, 0);
+                o[db][1] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[1][kk], o[db][1], 0, 0, 0);
+            });
+#if AT_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using IN = std::integral_constant<int, NV>;
         bool classic = !FAST;
         if constexpr (FAST) {
             static_for<0, 4>([&](auto Q4) { exp_pair(std::integral_constant<int, 3>{}, Q4); });
@@ -334,20 +381,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         }
         l_run[0] += ps[0];
         l_run[1] += ps[1];
-#if AT_PRIO == 1
-        __builtin_amdgcn_s_setprio(1);
-#endif
-        // ---- O^T += V^T . P^T : fragment n = NDB kk + db feeds the two query blocks ----
-        static_for<0, NV>([&](auto N) __attribute__((always_inline)) {
-            constexpr int n = decltype(N)::value, kk = n / NDB, db = n % NDB;
-            if constexpr (n + DV < NV) read_v(std::integral_constant<int, n + DV>{});
-            lds_wait<(n + DV < NV ? DV : NV - 1 - n)>(vf[n]);
-            o[db][0] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[0][kk], o[db][0], 0, 0, 0);
-            o[db][1] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[1][kk], o[db][1], 0, 0, 0);
-        });
-#if AT_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        pv(I0{}, IN{});
     };
 
     using T_ = std::true_type;
