@@ -44,9 +44,6 @@ struct Geo {
 #ifndef AT_DV
 #define AT_DV 6
 #endif
-#ifndef AT_WAIT2
-#define AT_WAIT2 0      // 1: one counted LDS wait per PAIR of fragments (A/B)
-#endif
 #ifndef AT_PRIO
 #define AT_PRIO 1       // s_setprio 1 over the two MFMA clusters of a tile (round 3, same-box A/B: self-attention -0.7 %, text cross-attention -2 %:
                         // the wave inside an MFMA cluster wins the issue slot, its SIMD partner's softmax VALU fills the gaps)
@@ -59,12 +56,6 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
-}
-
-// one counted wait for TWO fragments (AT_WAIT2): "at most N younger reads outstanding" proves the younger of the pair has landed, hence both
-template <int N>
-__device__ __forceinline__ void lds_wait2(u32x4& a, u32x4& b) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
 // score of a masked key: far below any real score and small enough that (score - max) stays finite
@@ -250,18 +241,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         static_for<0, DK>(read_k);
         static_for<0, NK>([&](auto N) __attribute__((always_inline)) {
             constexpr int n = decltype(N)::value, kb = n / NKS, ks = n % NKS;
-#if AT_WAIT2
-            // reads run TWO fragments ahead in pairs: at even n the pair (n + DK, n + DK + 1) is requested and ONE wait covers fragments n and n + 1
-            if constexpr (n % 2 == 0) {
-                if constexpr (n + DK < NK) read_k(std::integral_constant<int, n + DK>{});
-                if constexpr (n + DK + 1 < NK) read_k(std::integral_constant<int, n + DK + 1>{});
-                constexpr int issued = (n + DK + 2 < NK ? n + DK + 2 : NK);        // reads requested so far
-                lds_wait2<issued - (n + 2)>(kf[n], kf[n + 1]);
-            }
-#else
             if constexpr (n + DK < NK) read_k(std::integral_constant<int, n + DK>{});
             lds_wait<(n + DK < NK ? DK : NK - 1 - n)>(kf[n]);
-#endif
             s[kb][0] = LTX2_MFMA_16x16x32(as_bf16x8(kf[n]), qf[0][ks], s[kb][0], 0, 0, 0);
             if constexpr (FAST && kb > 0) static_for<(4 * ks) / NKS, (4 * ks + 2) / NKS>([&](auto Q4) { exp_pair(std::integral_constant<int, kb - 1>{}, Q4); });
             s[kb][1] = LTX2_MFMA_16x16x32(as_bf16x8(kf[n]), qf[1][ks], s[kb][1], 0, 0, 0);
@@ -287,17 +268,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #endif
             static_for<n0, n1>([&](auto N) __attribute__((always_inline)) {
                 constexpr int n = decltype(N)::value, kk = n / NDB, db = n % NDB;
-#if AT_WAIT2
-                if constexpr (n % 2 == 0) {
-                    if constexpr (n + DV < NV) read_v(std::integral_constant<int, n + DV>{});
-                    if constexpr (n + DV + 1 < NV) read_v(std::integral_constant<int, n + DV + 1>{});
-                    constexpr int issued = (n + DV + 2 < NV ? n + DV + 2 : NV);
-                    lds_wait2<issued - (n + 2)>(vf[n], vf[n + 1]);
-                }
-#else
                 if constexpr (n + DV < NV) read_v(std::integral_constant<int, n + DV>{});
                 lds_wait<(n + DV < NV ? DV : NV - 1 - n)>(vf[n]);
-#endif
                 o[db][0] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[0][kk], o[db][0], 0, 0, 0);
                 o[db][1] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[1][kk], o[db][1], 0, 0, 0);
             });
