@@ -44,6 +44,23 @@ struct Geo {
 #ifndef AT_DV
 #define AT_DV 6
 #endif
+#ifndef AT_XCD
+#define AT_XCD 1        // whole heads dealt to the XCDs (same-box A/B: self-attention N = 3456 187.1 -> 182.2 us, with the priorities above 194.9 -> 179-181; 0 = the plain (q-tile, head) grid order)
+#endif
+#ifndef AT_DMA
+#define AT_DMA 0        // where the next tile's 2 NJ LDS-DMA pieces issue: 0 = between the QK^T MFMAs, 1 = all behind them (in the softmax's VALU stretch), 2 = K in, V^T behind
+#endif
+#ifndef AT_PQK
+#define AT_PQK 2        // s_setprio level inside the QK^T cluster / the P.V cluster / between them (softmax tail, barrier).  Round 5, same-box A/B
+                        // (tools/attn_time.py, self-attention N = 3456): no priorities 212 us, 1 / 1 / 0 (rounds 3-4) 187, 1 / 0 / 0 182.5, 2 / 1 / 0 179-181, 3 / 3 / 0 186:
+                        // the wave inside QK^T (which carries the exponentials of the previous key block) must win over a partner inside P.V
+#endif
+#ifndef AT_PPV
+#define AT_PPV 1
+#endif
+#ifndef AT_PGAP
+#define AT_PGAP 0
+#endif
 #ifndef AT_PRIO
 #define AT_PRIO 1       // s_setprio 1 over the two MFMA clusters of a tile (round 3, same-box A/B: self-attention -0.7 %, text cross-attention -2 %:
                         // the wave inside an MFMA cluster wins the issue slot, its SIMD partner's softmax VALU fills the gaps)
@@ -142,7 +159,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) v_lane[kk] = lds0 + K_TILE + l15 * 128 + (((4 * kk + g) ^ v_xor) << 4);
 
-    const int head = blockIdx.y, qt = blockIdx.x, tb = nt;
+    int head = blockIdx.y, qt = blockIdx.x;
+#if AT_XCD
+    // workgroup b runs on XCD b % 8 (observed placement): deal whole heads to the XCDs, so a head's K / V^T tiles are fetched by ONE L2 instead of all eight
+    if ((gridDim.y & 7) == 0) {
+        const int b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7, idx = b >> 3;
+        head = xcd + 8 * (idx / (int)gridDim.x);
+        qt = idx % (int)gridDim.x;
+    }
+#endif
+    const int tb = nt;
     const int q0 = qt * QB + wv * 32;
 
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.K + head * HD), 0, (int)k_bytes, 0x00020000);
@@ -209,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         __syncthreads();
         const int tn = min(t + 1, tb - 1);
         constexpr int nbuf = 1 - PAR;
-#if AT_PRIO == 1
-        __builtin_amdgcn_s_setprio(1);
+#if AT_PRIO
+        __builtin_amdgcn_s_setprio(AT_PQK);
 #endif
         // ---- S^T = K . (c Q)^T - M ; fragment n = NKS kb + ks feeds the two query blocks ----
         f32x4 s[4][2];
@@ -247,9 +273,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             if constexpr (FAST && kb > 0) static_for<(4 * ks) / NKS, (4 * ks + 2) / NKS>([&](auto Q4) { exp_pair(std::integral_constant<int, kb - 1>{}, Q4); });
             s[kb][1] = LTX2_MFMA_16x16x32(as_bf16x8(kf[n]), qf[1][ks], s[kb][1], 0, 0, 0);
             if constexpr (FAST && kb > 0) static_for<(4 * ks + 2) / NKS, (4 * (ks + 1)) / NKS>([&](auto Q4) { exp_pair(std::integral_constant<int, kb - 1>{}, Q4); });
+#if AT_DMA == 0
             if constexpr ((n & 1) && n / 2 < 2 * NJ) stage_piece(tn, nbuf, n / 2);
+#elif AT_DMA == 2
+            if constexpr ((n & 1) && n / 2 < NJ) stage_piece(tn, nbuf, n / 2);        // the K pieces here, the V^T pieces in the VALU gap below
+#endif
         });
+#if AT_DMA == 0
         static_for<NK / 2, 2 * NJ>([&](auto I) { stage_piece(tn, nbuf, decltype(I)::value); });
+#elif AT_DMA == 1
+        static_for<0, 2 * NJ>([&](auto I) { stage_piece(tn, nbuf, decltype(I)::value); });
+#else
+        static_for<(NK / 2 < NJ ? NK / 2 : NJ), 2 * NJ>([&](auto I) { stage_piece(tn, nbuf, decltype(I)::value); });
+#endif
         // the first V^T fragments go out now: the remaining softmax work hides their latency
         u32x4 vf[NV];
         auto read_v = [&](auto N) {
@@ -257,14 +293,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             vf[n] = lds_read16<PAR * STAGE + db * 16 * 128>(v_lane[kk]);
         };
         static_for<0, DV>(read_v);
-#if AT_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
+#if AT_PRIO
+        __builtin_amdgcn_s_setprio(AT_PGAP);
 #endif
         // O^T += V^T . P^T over the fragments [N0, N1) (fragment n = NDB kk + db feeds the two query blocks)
         auto pv = [&](auto N0, auto N1) __attribute__((always_inline)) {
             constexpr int n0 = decltype(N0)::value, n1 = decltype(N1)::value;
-#if AT_PRIO == 1
-            __builtin_amdgcn_s_setprio(1);
+#if AT_PRIO
+            __builtin_amdgcn_s_setprio(AT_PPV);
 #endif
             static_for<n0, n1>([&](auto N) __attribute__((always_inline)) {
                 constexpr int n = decltype(N)::value, kk = n / NDB, db = n % NDB;
@@ -273,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 o[db][0] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[0][kk], o[db][0], 0, 0, 0);
                 o[db][1] = LTX2_MFMA_16x16x32(as_bf16x8(vf[n]), pf[1][kk], o[db][1], 0, 0, 0);
             });
-#if AT_PRIO == 1
-            __builtin_amdgcn_s_setprio(0);
+#if AT_PRIO
+            __builtin_amdgcn_s_setprio(AT_PGAP);
 #endif
         };
         using I0 = std::integral_constant<int, 0>;

@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# the ORACLE's fp32 convolutions run through torch (MIOpen) when a test executes the oracle on the GPU: the fast find mode picks a solver without the
+# exhaustive per-shape search (a fresh box has no MIOpen cache: test_vae_full_size_decode spent ~100 of its 121 s there).  Checker-side only.
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

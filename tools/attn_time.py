@@ -11,7 +11,8 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e-3
-for (Nq, Nkv, H, hd) in [(3456, 3456, 32, 128), (3456, 1024, 32, 128), (13824, 13824, 32, 128), (13824, 1024, 32, 128), (3456, 68, 32, 64), (68, 3456, 32, 64)]:
+SHAPES = [(3456, 3456, 32, 128), (3456, 1024, 32, 128), (13824, 13824, 32, 128), (13824, 1024, 32, 128), (3456, 68, 32, 64), (68, 3456, 32, 64)]
+for (Nq, Nkv, H, hd) in SHAPES[:int(sys.argv[1]) if len(sys.argv) > 1 else None]:        # optional argument: only the first n shapes
     D = H * hd
     q = torch.randn(Nq, D, device=dev).to(torch.bfloat16)
     k = torch.randn(Nkv, D, device=dev).to(torch.bfloat16)
