@@ -44,9 +44,6 @@ struct Geo {
 #ifndef AT_DV
 #define AT_DV 6
 #endif
-#ifndef AT_PROBE
-#define AT_PROBE 0
-#endif
 #ifndef AT_XCD
 #define AT_XCD 1        // whole heads dealt to the XCDs (same-box A/B: self-attention N = 3456 187.1 -> 182.2 us, with the priorities above 194.9 -> 179-181; 0 = the plain (q-tile, head) grid order)
 #endif
@@ -320,12 +317,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         using IN = std::integral_constant<int, NV>;
         bool classic = !FAST;
         if constexpr (FAST) {
-#if !(AT_PROBE & 1)         // AT_PROBE: timing experiments through tools/ab_build.py, WRONG results by construction (1: no exponentials of key block 3, 2: no sum check)
             static_for<0, 4>([&](auto Q4) { exp_pair(std::integral_constant<int, 3>{}, Q4); });
-#endif
-#if !(AT_PROBE & 2)
             classic = __any(!(ps[0] <= AT_P_BIG && ps[1] <= AT_P_BIG));          // (also catches a NaN sum)
-#endif
         }
         if (classic) {
             if constexpr (MASKED) {
