@@ -26,6 +26,9 @@ struct AttnParams {
     // result before it is rounded (round 4: was a pass over the attention output).  null = none.
     const float* gate;
     int gate_ld;
+    // gate_parts > 1: `gate` holds that many partial logit arrays of [Nq][gate_ld] each (gate_logits_parts_launch) and gate_bias[H] is added to their sum
+    int gate_parts;
+    const float* gate_bias;
 };
 
 int attn_launch(const AttnParams& p, hipStream_t stream);

@@ -429,7 +429,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int qb = 0; qb < 2; ++qb) {
         const int qrow = q0 + 16 * qb + l15;
         float inv = 1.0f / lt[qb];
-        if (p.gate && qrow < p.Nq) inv *= 2.f / (1.f + __expf(-p.gate[(long)qrow * p.gate_ld + head]));
+        if (p.gate && qrow < p.Nq) {
+            float gl = p.gate[(long)qrow * p.gate_ld + head];
+            if (p.gate_parts > 1) {         // partial sums over K slices + bias, in slice order
+                for (int pt = 1; pt < p.gate_parts; ++pt) gl += p.gate[((long)pt * p.Nq + qrow) * p.gate_ld + head];
+                gl += p.gate_bias[head];
+            }
+            inv *= 2.f / (1.f + __expf(-gl));
+        }
         bf16* op = p.O + (long)min(qrow, p.Nq - 1) * p.ldo + head * HD + 16 * (g & 1) + 8 * (g >> 1);
 #pragma unroll
         for (int i = 0; i < NDB / 2; ++i) {

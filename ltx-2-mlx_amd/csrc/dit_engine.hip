@@ -72,6 +72,8 @@ struct Mod {        // per-modality geometry + workspace
     float *x = nullptr, *sin_f = nullptr, *e1_f = nullptr, *e_f = nullptr, *emb = nullptr, *vel = nullptr, *x0 = nullptr,
           *cosb = nullptr, *sinb = nullptr, *ccos = nullptr, *csin = nullptr, *aux_e = nullptr, *prompt_emb = nullptr, *sst_all = nullptr, *comb = nullptr, *ca_all = nullptr, *ca_comb = nullptr,
           *cross_ss = nullptr, *cross_gate = nullptr, *glog = nullptr;
+    int glog_parts = 1;                 // how the last gate_logits() call left m.glog: one array, or GATE_LOGIT_PARTS partial sums + glog_bias
+    const float* glog_bias = nullptr;
     bf16 *lat = nullptr, *h = nullptr, *h2 = nullptr, *qkv = nullptr, *vt = nullptr, *att = nullptr, *ff = nullptr,
          *sin_b = nullptr, *e1_b = nullptr, *es_b = nullptr, *ctx_in = nullptr, *c1 = nullptr, *ctxp = nullptr,
          *ctxm = nullptr, *kv2 = nullptr, *vt2 = nullptr;
@@ -149,7 +151,7 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         m.vt = (bf16*)take(2L * D * npad);
         m.att = (bf16*)take(2L * n * D);
         m.ff = (bf16*)take(2L * n * 4 * D);
-        m.glog = (float*)take(c->gated ? 4L * n * m.H : 0);
+        m.glog = (float*)take(c->gated ? 4L * n * m.H * GATE_LOGIT_PARTS : 0);       // (room for the K-slice partial sums of gate_logits_parts_launch)
         m.kmask = (unsigned long long*)take(8L * (spad / 64));
         m.qss = (float*)take(4L * n * (D / 64));
         m.knq = (float*)take(4L * L * D);
@@ -484,13 +486,21 @@ int adaln_chain(ltx2_dit* c, Mod& m, const AdaW& a, const float* ts, long t_stri
     return LTX2_OK;
 }
 
+// per-head gate logits as gate_logits() left them: one [rows][H] array, or GATE_LOGIT_PARTS partial sums + the bias (summed in the attention kernel's epilogue)
+struct GateRef {
+    const float* p = nullptr;
+    int parts = 1;
+    const float* bias = nullptr;
+};
 int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int npad, bf16* out, long ldo, int nq,
            int nkv, int H, int hd, hipStream_t st, const float* q_ss = nullptr, float q_eps = 0.f,
-           const unsigned long long* kmask = nullptr, const float* gate = nullptr) {
+           const unsigned long long* kmask = nullptr, GateRef gate = GateRef{}) {
     AttnParams a{};
     a.kmask = kmask;
-    a.gate = gate;          // per-head gate logits [nq][H] (V2.3): out *= 2 sigmoid(.) in the kernel's epilogue
+    a.gate = gate.p;        // per-head gate logits [nq][H] (V2.3): out *= 2 sigmoid(.) in the kernel's epilogue
     a.gate_ld = H;
+    a.gate_parts = gate.parts;
+    a.gate_bias = gate.bias;
     if (q_ss) {         // q_norm as a per-row softmax scale from the projection's partial sums (text cross-attention)
         a.q_ss = q_ss;
         a.q_ss_ld = H * hd / 64;
@@ -555,13 +565,18 @@ int event_wait(hipEvent_t e, hipStream_t to) {
 }
 
 // Per-head gates (attention.py:241-249): att[:, h*hd:(h+1)*hd] *= 2*sigmoid(x @ Wg^T + bg)[:, h]
+// many rows: K-slice partial sums, added (with the bias) by the attention kernel's epilogue; few rows (the audio stream): the one-launch form
+inline bool gate_in_parts(int rows, int Dq) { return rows >= 1024 && Dq % (GATE_LOGIT_PARTS * 32) == 0 && Dq <= 8192; }
 int gate_logits(ltx2_dit* c, Mod& m, const AttnW& w, const bf16* xin, int Dq, int rows, int H, hipStream_t st) {
     if (!c->gated) return LTX2_OK;
+    m.glog_parts = gate_in_parts(rows, Dq) ? GATE_LOGIT_PARTS : 1;
+    m.glog_bias = w.g_b;
+    if (m.glog_parts > 1) return gate_logits_parts_launch(xin, Dq, w.g_w, m.glog, rows, Dq, H, st);
     return gate_logits_launch(xin, Dq, w.g_w, w.g_b, m.glog, H, rows, Dq, H, st);
 }
 
 // the gate logits gate_logits() left for the attention that follows (null for ungated models): the kernel's epilogue applies 2 sigmoid(.) per head
-const float* glog(ltx2_dit* c, const Mod& m) { return c->gated ? m.glog : nullptr; }
+GateRef glog(ltx2_dit* c, const Mod& m) { return c->gated ? GateRef{m.glog, m.glog_parts, m.glog_bias} : GateRef{}; }
 
 // K (k_norm applied, optional RoPE) and V^T of a text / cross-modal context
 int project_kv(ltx2_dit* c, const bf16* ctx, int rows, int Dc, const AttnW& w, int Di, int H, int hd, float eps, const float* cosb,

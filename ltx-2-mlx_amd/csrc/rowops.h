@@ -34,6 +34,10 @@ int ctx_mod_launch(const bf16* ctx, bf16* out, int rows, int D, const float* sca
 // logits_f32[M][H] = X_bf16[M][K] @ Wg_bf16[H][K]^T + bg   (to_gate_logits, H <= 32 heads)
 int gate_logits_launch(const bf16* X, long ldx, const bf16* Wg, const float* bg, float* out, long ldo, int M, int K, int H,
                        hipStream_t stream);
+// the same for many rows, as GATE_LOGIT_PARTS partial sums over K slices: parts[ks][M][H] fp32, NO bias; the attention kernel's epilogue adds the parts and
+// the bias in a fixed order (AttnParams::gate_parts)
+constexpr int GATE_LOGIT_PARTS = 8;
+int gate_logits_parts_launch(const bf16* X, long ldx, const bf16* Wg, float* parts, int M, int K, int H, hipStream_t stream);
 
 // att[row][h*hd + j] *= 2 * sigmoid(logits[row*ldl + h])   (per-head attention gates, attention.py:241-249)
 int head_gate_launch(bf16* att, long ld, const float* logits, long ldl, int rows, int H, int hd, hipStream_t stream);

@@ -382,6 +382,55 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16* __restrict
     }
 }
 
+// The same product for many rows (round 5): the kernel above re-reads the whole 32 x K gate weight (256 KiB at K = 4096) from L2 in every 16-row block -- 55 MB of
+// weight traffic beside 28 MB of activations at 3456 x 4096, 14-20 us.  Here a block takes 64 rows x ONE K slice (K / KS columns): the slice of the weight
+// (32 x K/KS, 64 KiB at K = 4096, KS = 4) is staged in LDS once and shared by the block's four waves (16 rows each); X streams from global memory.  The KS partial
+// sums are NOT reduced here: parts[ks][M][H] (fp32, no bias) -- the consumer (the attention kernel's epilogue) adds the KS values and the bias in a fixed order.
+template <int KS>
+__global__ __launch_bounds__(256) void gate_logits_parts_kernel(const bf16* __restrict__ X, long ldx, const bf16* __restrict__ Wg, float* __restrict__ parts,
+                                                                int M, int K, int H) {
+    extern __shared__ __attribute__((aligned(16))) char gl_smem[];
+    const int Kc = K / KS, ks = blockIdx.y, ROWB = (Kc + 8) * 2;       // padded LDS row: 16 rows x 16 B land on 16 different bank groups
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    // stage the weight slice: 32 rows x Kc columns as 16-byte pieces (rows >= H repeat row H - 1: their products are never stored)
+    const int pieces_per_row = Kc / 8;
+    for (int i = tid; i < 32 * pieces_per_row; i += 256) {
+        const int h = i / pieces_per_row, c = i - h * pieces_per_row;
+        const bf16x8 v = *(const bf16x8*)(Wg + (long)min(h, H - 1) * K + (long)ks * Kc + c * 8);
+        *(bf16x8*)(gl_smem + h * ROWB + c * 16) = v;
+    }
+    __syncthreads();
+    const int row0 = blockIdx.x * 64 + wv * 16;
+    const bf16* xp = X + (long)min(row0 + r16, M - 1) * ldx + (long)ks * Kc + kq * 8;
+    const char* w0 = gl_smem + r16 * ROWB + kq * 16;
+    const char* w1 = gl_smem + (16 + r16) * ROWB + kq * 16;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int DEPTH = 16;
+    for (int k = 0; k < Kc; k += 32 * DEPTH) {
+        bf16x8 a[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) a[j] = (k + 32 * j < Kc) ? *(const bf16x8*)(xp + k + 32 * j) : bf16x8{};
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            if (k + 32 * j < Kc) {
+                const bf16x8 b0 = *(const bf16x8*)(w0 + (k + 32 * j) * 2), b1 = *(const bf16x8*)(w1 + (k + 32 * j) * 2);
+                acc0 = LTX2_MFMA_16x16x32(a[j], b0, acc0, 0, 0, 0);
+                acc1 = LTX2_MFMA_16x16x32(a[j], b1, acc1, 0, 0, 0);
+            }
+        }
+    }
+    float* out = parts + (long)ks * M * H;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 4 * kq + r;
+        if (row < M) {
+            if (r16 < H) out[(long)row * H + r16] = acc0[r];
+            if (16 + r16 < H) out[(long)row * H + 16 + r16] = acc1[r];
+        }
+    }
+}
+
 __global__ void head_gate_kernel(bf16* __restrict__ att, long ld, const float* __restrict__ logits, long ldl, long n8,
                                  int per_row8, int hd) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -969,6 +1018,17 @@ int gate_logits_launch(const bf16* X, long ldx, const bf16* Wg, const float* bg,
     LTX2_CHECK_ARG(M > 0 && H > 0 && H <= 32 && K % 128 == 0 && ldx % 8 == 0, "gate_logits: need H <= 32, K %% 128 == 0, ldx %% 8 == 0");
     hipLaunchKernelGGL(gate_logits_kernel, dim3((M + 15) / 16), dim3(256), 0, stream, X, ldx, Wg, bg, out, ldo, M, K, H);
     LTX2_CHECK_LAUNCH("gate_logits_kernel");
+    return LTX2_OK;
+}
+
+int gate_logits_parts_launch(const bf16* X, long ldx, const bf16* Wg, float* parts, int M, int K, int H, hipStream_t stream) {
+    LTX2_CHECK_ARG(M > 0 && H > 0 && H <= 32 && K % (GATE_LOGIT_PARTS * 32) == 0 && ldx % 8 == 0, "gate_logits_parts: need H <= 32, K %% %d == 0, ldx %% 8 == 0", GATE_LOGIT_PARTS * 32);
+    const int lds = 32 * (K / GATE_LOGIT_PARTS + 8) * 2;
+    LTX2_CHECK_ARG(lds <= 160 * 1024, "gate_logits_parts: K=%d too wide for the LDS-resident weight slice", K);
+    static PerDeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)gate_logits_parts_kernel<GATE_LOGIT_PARTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(gate_logits_parts_kernel<GATE_LOGIT_PARTS>, dim3((M + 63) / 64, GATE_LOGIT_PARTS), dim3(256), lds, stream, X, ldx, Wg, parts, M, K, H);
+    LTX2_CHECK_LAUNCH("gate_logits_parts_kernel");
     return LTX2_OK;
 }
 
