@@ -389,7 +389,11 @@ int ltx2_dit_set_context_mask(ltx2_dit* ctx, int modality, const float* mask, in
  *   (ltx2_quantize_rows_fp8).  Default 0: fp8-resident weights are expanded to bf16 inside the GEMM (bit-identical to the
  *   reference's dequantise-at-load).
  *   "adaln_combine" = 0 (any time): tables and timestep embeddings reach every kernel separately, as in round 3.  Default 1: with one
- *   timestep per modality the sums of all layers are formed by one launch at the top of the step (bit-identical results).              */
+ *   timestep per modality the sums of all layers are formed by one launch at the top of the step (bit-identical results).
+ *   "text_kv_ahead" = 0 (any time; AudioVideo models with cross_attention_adaln only): the video stream projects its sigma-modulated text K / V
+ *   inline, in front of its text cross-attention (round 4's schedule).  Default 1 (round 5): they are a function of the prompt and sigma only,
+ *   so layer l's are projected on the side stream at the top of layer l, beside the main stream's norm / QKV projection (bit-identical
+ *   results; -1.4 ... -1.8 ms per LTX-2.3 step).  Ignored with fp8_compute (that projection shares the video stream's activation scratch).  */
 int ltx2_dit_set_option(ltx2_dit* ctx, const char* name, int value);
 
 

@@ -109,6 +109,8 @@ struct ltx2_dit {
     // -- the video twin of an AudioVideo model -- keeps its own entries); rebuilt whenever the weights are resolved again.
     std::unordered_map<const void*, const float*> fp8_scale;
     bool adaln_combine = true;         // ltx2_dit_set_option("adaln_combine"): round 4, see forward()
+    bool text_kv_ahead = true;         // ltx2_dit_set_option("text_kv_ahead"): round 5, AudioVideo V2.3 -- the video stream's sigma-modulated text K / V of layer l are projected on the SIDE stream at the top of the layer
+    hipEvent_t text_kv_ev = nullptr;   //   (they depend on the prompt and sigma only); the main stream waits on this event in front of its text cross-attention
     bool fp8_compute = false;          // ltx2_dit_set_option("fp8_compute"): fp8-resident weights x per-token fp8 activations on the fp8 MFMA
     bool prepared = false;
     hipGraph_t graph = nullptr;
@@ -591,6 +593,15 @@ int project_kv(ltx2_dit* c, const bf16* ctx, int rows, int Dc, const AttnW& w, i
     return vt_transpose_launch(kv + Di, 2 * Di, vt, rows, npad, H, st, hd);
 }
 
+// V2.3: the prompt-AdaLN-modulated text context of layer l and its K / V^T (transformer.py:427-455) -- a function of the prompt and sigma only
+int text_kv(ltx2_dit* c, int k, int l, hipStream_t st) {
+    Mod& m = c->m[k];
+    const BlockW& w = c->layers[l].m[k];
+    const int D = m.D;
+    TRY(ctx_mod_launch(m.ctx, m.ctxm, m.S, D, w.prompt_sst + D, w.prompt_sst, m.prompt_emb + D, m.prompt_emb, st));
+    return project_kv(c, m.ctxm, m.S, D, w.text, D, m.H, m.hd, c->cfg.norm_eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st, m.qfold ? m.knq + (long)l * D : nullptr);
+}
+
 // Self-attention, text cross-attention of one modality (transformer.py:503-554 / 191-226)
 int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     Mod& m = c->m[k];
@@ -630,8 +641,12 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     float* a8sq = q2 ? m.a8s : nullptr;
     if (c->v2) {
         TRY(norm_mod_launch(m.x, D, h2, D, N, D, eps, 0, tab + 7 * D, tab + 6 * D, E(7), E(6), es, st, a8q, D, a8sq));
-        TRY(ctx_mod_launch(m.ctx, m.ctxm, m.S, D, w.prompt_sst + D, w.prompt_sst, m.prompt_emb + D, m.prompt_emb, st));
-        TRY(project_kv(c, m.ctxm, m.S, D, w.text, D, H, hd, eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st, m.qfold ? m.knq + (long)l * D : nullptr));
+        if (k == 0 && c->text_kv_ev) {      // projected ahead on the side stream (forward()): wait for it here
+            TRY(event_wait(c->text_kv_ev, st));
+            c->text_kv_ev = nullptr;
+        } else {
+            TRY(text_kv(c, k, l, st));
+        }
         kk = m.kv2;
         vt = m.vt2;
     } else {
@@ -800,9 +815,18 @@ int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = t
     }
     // the audio modality's block program runs on the side stream, joined around the cross-modal attention
     hipStream_t sa = (c->av && c->side) ? c->side : st;
+    c->text_kv_ev = nullptr;
     for (int l = 0; l < c->cfg.num_layers; ++l) {
         if (c->av) {
             TRY(stream_after(c, st, sa));
+            // the side stream has just waited for everything of layer l - 1 (its text cross-attention read kv2 / vt2: free now); the video stream's
+            // text K / V of THIS layer go first on it, beside the main stream's norm / gate / QKV projection
+            // (not with fp8 compute: that projection quantises its input into the video modality's ONE activation scratch, which the main stream is using)
+            if (c->v2 && c->text_kv_ahead && sa != st && !c->fp8_compute) {
+                TRY(text_kv(c, 0, l, sa));
+                c->text_kv_ev = event_record(c, sa);
+                if (!c->text_kv_ev) return LTX2_E_HIP;
+            }
             TRY(block_attention(c, 1, l, es[1], sa));
         }
         TRY(block_attention(c, 0, l, es[0], st));
@@ -1285,6 +1309,10 @@ int ltx2_dit_set_option(ltx2_dit* c, const char* name, int value) {
             return LTX2_E_STATE;
         }
         c->fp8_compute = value != 0;
+        return LTX2_OK;
+    }
+    if (!strcmp(name, "text_kv_ahead")) {       // 0: the video stream projects its sigma-modulated text K / V inline (round 4's schedule; same results bit for bit)
+        c->text_kv_ahead = value != 0;
         return LTX2_OK;
     }
     if (!strcmp(name, "adaln_combine")) {       // 0: tables and embeddings reach every kernel separately (round 3's form; same results bit for bit)

@@ -464,6 +464,42 @@ def test_av_denoise_loop_and_graph(dev, v23):
     assert rel_l2(gv, lv) < 1e-5 and rel_l2(ga, la) < 1e-5
 
 
+def test_av_text_kv_ahead_is_bit_identical(dev):
+    """V2.3 AudioVideo: the video stream's sigma-modulated text K / V projected on the side stream at the top of the layer (option text_kv_ahead = 1,
+    the default) against the inline schedule (0): the same kernels on the same operands, only their stream differs -- bit-identical velocities, eager and
+    through the captured graph."""
+    from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES
+    from ltx_2_mlx_amd.model.transformer import Modality
+    from oracle import dit_av, loop
+    cfg, w, wq, m = make_av(dev, True, seed=15)
+    g = torch.Generator().manual_seed(13)
+    f, h, wd, Ta, S = 2, 6, 8, 21, 40
+    vlat, alat = torch.randn(1, f * h * wd, 128, generator=g), torch.randn(1, Ta, 128, generator=g)
+    vctx = 0.1 * torch.randn(1, S, cfg.caption_channels or cfg.inner_dim, generator=g)
+    actx = 0.1 * torch.randn(1, S, cfg.caption_channels or cfg.audio_inner_dim, generator=g)
+    vpos, apos = loop.video_positions(1, f, h, wd, 24.0), dit_av.audio_positions(1, Ta)
+    s = torch.tensor([0.725], device=dev)
+    mv = Modality(latent=vlat.to(dev), context=vctx.to(dev), context_mask=None, timesteps=s, positions=vpos.to(dev), sigma=s)
+    ma = Modality(latent=alat.to(dev), context=actx.to(dev), context_mask=None, timesteps=s, positions=apos.to(dev), sigma=s)
+    outs = {}
+    for opt in (1, 0, 1):
+        m.set_option("text_kv_ahead", opt)
+        v, a = m(mv, ma)
+        lv, la = vlat[0].to(dev).contiguous(), alat[0].to(dev).contiguous()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m.capture_denoise_graph(lv, DISTILLED_SIGMA_VALUES[5:], audio_latent=la)
+            m.replay_denoise_graph()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        outs.setdefault(opt, []).append((v.clone(), a.clone(), lv.clone(), la.clone()))
+    ref = outs[0][0]
+    for got in outs[1]:
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y)
+
+
 def test_fp8_checkpoint_loader(dev, tmp_path):
     """BASELINE config 3 plumbing: an fp8 (e4m3fn + weight_scale) safetensors checkpoint with the reference's
     key scheme goes through load_transformer_weights(use_fp8=True) (GPU dequantisation) and the model matches
