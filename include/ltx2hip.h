@@ -206,11 +206,12 @@ int ltx2_qknorm_rope(void* buf, int64_t ld, int rows, int D, int head_dim, int q
                      int k_off, const float* k_weight, float eps, const float* cos, const float* sin, void* stream);
 
 /* V[Nkv][ld] (head h at columns h*hd) -> VT[H][hd][Npad], keys permuted inside each block of 32
- * to match the MFMA accumulator layout of the attention kernel; padded keys are zero.
+ * to match the MFMA accumulator layout of the attention kernel (ABI 3: position 8g + 4h + r of a block holds key 16h + 4g + r -- the
+ * 16x16x32 kernel's order; a V^T written by an ABI-2 library is NOT valid for this one); padded keys are zero.
  * head_dim hd = 128 (video streams) or 64 (audio streams, audio<->video attention).          */
 int ltx2_vt_transpose(const void* V, int64_t ld, void* VT, int Nkv, int Npad, int H, int head_dim, void* stream);
 
-/* out[q][h*hd..] = softmax(Q_h K_h^T * scale) V_h, non-causal, no mask, head_dim 128 or 64.
+/* out[q][h*hd..] = softmax(Q_h K_h^T * scale) V_h, non-causal, no mask, head_dim 128 or 64; ldq, ldk, ldo multiples of 8 (16-byte rows).
  * Replaces _compiled_attention_core_no_mask (attention.py:12-34).                             */
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
                     int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream);
