@@ -57,15 +57,18 @@ def _bcast_flat(flat: torch.Tensor, src: int, mode: str) -> None:
     if mode == "ring" or world == 1 or flat.numel() < world:
         dist.broadcast(flat, src=src)
         return
+    # scatter + all-gather straight into the bucket: the only extra memory is this rank's 1 / world chunk (round 4 padded a copy of the bucket and
+    # gathered into a second one: three buckets in flight); the < world elements that do not divide go by one small broadcast
     n = flat.numel()
-    per = (n + world - 1) // world
-    padded = flat if per * world == n else torch.cat([flat, flat.new_zeros(per * world - n)])
+    per = n // world
+    main = per * world
+    body = flat[:main]
     mine = torch.empty(per, dtype=flat.dtype, device=flat.device)
-    chunks = list(padded.view(world, per).unbind(0)) if dist.get_rank() == src else None
+    chunks = list(body.view(world, per).unbind(0)) if dist.get_rank() == src else None
     dist.scatter(mine, chunks, src=src)
-    gathered = torch.empty(per * world, dtype=flat.dtype, device=flat.device)
-    dist.all_gather_into_tensor(gathered, mine)
-    flat.copy_(gathered[:n])
+    dist.all_gather_into_tensor(body, mine)
+    if main < n:
+        dist.broadcast(flat[main:], src=src)
 
 
 def broadcast_tensors(tensors: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 256 << 20, mode: Optional[str] = None) -> int:
