@@ -97,11 +97,27 @@ int ltx2_gemm_w8a16(const void* A, int64_t lda, const void* W8, const float* wsc
  * sums of squares of out's ROUNDED values over each 64-column strip of row m; *written = 0: plain GEMM, rowss untouched.
  * ltx2_flash_attn_rowscale: ltx2_flash_attn with a per-query-row scale: row q uses scale * rsqrt(sum_j q_ss[q][j] / q_norm_dim + q_eps),
  * i.e. softmax((rms_norm(Q) K'^T) * scale) V for K' carrying q_norm.weight * k_norm.weight -- identical to normalising Q first up to the
- * rounding of the normalised Q to 16 bits (which this form does not do).  head_dim 128, q_ss_ld % 4 == 0.                      */
+ * rounding of the normalised Q to 16 bits (which this form does not do).  head_dim 128, q_ss_ld % 16 == 0 (ABI 3: the row's four lanes read f32x4 quarters; rows 64-byte aligned).                     */
 int ltx2_gemm_bf16_rowss(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K, float* rowss,
                          int* written, void* stream);
 int ltx2_flash_attn_rowscale(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
                              int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, void* stream);
+
+/* RMS norms folded around the GEMMs (round 6; _compiled_adaln_forward + nn.Linear, transformer.py:16-31, 191-238, as arithmetic instead of a pass
+ * over x): rms_norm(x) (1 + s) + t in front of a projection (W, b) equals r (x (1 + s)) W^T + (t W^T + b), r[m] = rsqrt(mean_j x[m][j]^2 + eps).
+ * ltx2_gemm_bf16_fold: ltx2_gemm_bf16 with the producer / consumer halves of that identity (any of them may be absent: null / 0):
+ *   epilogue RESID_GATE_F32 (x += gate_table * (acc + bias), row-invariant gate): shadow[m][n] = 16-bit(x_new[m][n] * (1 + shadow_scale[n]))
+ *     (row stride ld_shadow), shadow_ss[m][N / 64] = the sums of x_new[m][n]^2 over each 64-column strip, and shadow_xrow [N] copied into shadow row M;
+ *   epilogue BF16 / GELU_BF16: out = epilogue(rowfac[m] * acc + bias); xrow = 1: A holds M + 1 rows and row M's product leaves as fp32
+ *     xrow_out[n] = acc + xrow_bias[n] instead of reaching out (with the NEXT step's shift row t' as row M that is the next step's t' W^T + b, formed by the
+ *     GEMM that streams W anyway).
+ *   *supported = 0 (nothing launched) when the 4-wave layout-3 kernel does not take the problem (M >= 1024, N % 256 == 0, K % 128 == 0, dense 16-bit weights;
+ *   xrow / shadow_xrow: M not a multiple of the row tile).
+ * ltx2_rowfac: rowfac[m] = rsqrt(sum_{j < nparts} ss[m][j] / D + eps).                                                                              */
+int ltx2_gemm_bf16_fold(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                        const float* gate_table, void* shadow, int64_t ld_shadow, const float* shadow_scale, float* shadow_ss, const void* shadow_xrow,
+                        const float* rowfac, int xrow, float* xrow_out, const float* xrow_bias, int* supported, void* stream);
+int ltx2_rowfac(const float* ss, int nparts, float* rowfac, int rows, int D, float eps, void* stream);
 
 /* flash attention with a key mask (attention.py:38-70 with the additive mask model.py:163-201 builds from a boolean (B, S) context
  * mask): mask fp32 [Nkv], non-zero = the key may be attended; a masked key takes no weight unless every key is masked (then the
@@ -391,6 +407,11 @@ int ltx2_dit_set_context_mask(ltx2_dit* ctx, int modality, const float* mask, in
  *   reference's dequantise-at-load).
  *   "adaln_combine" = 0 (any time): tables and timestep embeddings reach every kernel separately, as in round 3.  Default 1: with one
  *   timestep per modality the sums of all layers are formed by one launch at the top of the step (bit-identical results).
+ *   "fold_norms" = 0 / 1 / 2 (any time; default 2; VideoOnly non-V2.3 models on dense 16-bit weights in the bfloat16 build, one timestep per modality):
+ *   1: the text cross-attention's plain RMS pre-norm rides on attn1.to_out's epilogue (ltx2_gemm_bf16_fold); 2: the two AdaLN-modulated norms of a block too,
+ *   in steps that know the next sigma (ltx2_dit_denoise_step, the captured loops): each QKV / FFN-up projection forms the NEXT step's shift product
+ *   from one extra operand row; a loop's first step (and any step whose sigma is not the one the previous step announced) runs the norm passes.  0: round 5's
+ *   form, a norm pass in front of every projection.  Same mathematics, the operand is rounded before the row factor instead of after it.
  *   "text_kv_ahead" = 0 (any time; AudioVideo models with cross_attention_adaln only): the video stream projects its sigma-modulated text K / V
  *   inline, in front of its text cross-attention (round 4's schedule).  Default 1 (round 5): they are a function of the prompt and sigma only,
  *   so layer l's are projected on the side stream at the top of layer l, beside the main stream's norm / QKV projection (bit-identical

@@ -126,6 +126,12 @@ __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
+// v as seen through a DPP control word (row = 16 lanes): 0xB1 / 0x4E quad swaps, 0x141 row_half_mirror, 0x140 row_mirror -- four adds sum a row of 16 lanes
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

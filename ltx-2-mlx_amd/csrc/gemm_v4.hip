@@ -83,6 +83,12 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // ---- block -> tile (XCD-contiguous, grouped row-tiles; as gemm_pp.hip) ----
     // split-K (p.splitk > 1): blockIdx = split * tiles + tile; this block accumulates K-tiles [split * nk, +nk) and writes an
     // fp32 partial tile into slab `split` of p.out ([splitk][M][ldo] fp32); splitk_reduce_kernel adds the slabs
+    // round 6 (GemmParams "fold" fields): the dense bf16 layout-3 kernels only.  XROW: A holds one more row than `out` (row M: the next step's shift row);
+    // M % BM != 0 (gemm_fold_supported), so it lies inside the last row tile and the tile count does not change
+    constexpr bool FOLD_OK = LAYOUT == 3 && !CONV && VAR == 0;
+    constexpr bool FOLD_CONS = FOLD_OK && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16);         // consumer side: row factors, the extra row
+    constexpr bool FOLD_PROD = FOLD_OK && EPI == EPI_RESID_GATE_F32;                          // producer side: bf16 shadow + partial sums of squares
+    const int Mx = p.M + (FOLD_CONS ? p.xrow : 0);
     const int Mt = (p.M + BM - 1) / BM, Nt = LAYOUT == 7 ? 1 : p.N / TBN;        // (layout 7: ONE column tile, N <= 64, columns >= N masked)
     const int ntiles = Mt * Nt;
     const int split = p.splitk > 1 ? bid / ntiles : 0;
@@ -103,14 +109,14 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // layout 3, 224-row tiles, dense bf16 weights: the ragged last row tile runs a K loop over only the row blocks that hold real
     // rows (6 of 14 for 3456 rows, 10 of 14 for 13824) -- fewer DMA pieces per wave, so the wave -> tile-row mapping shrinks with it
     constexpr bool SHORT_OK = LAYOUT == 3 && BM == 224 && !CONV;
-    const int valid_rows = p.M - m0;
+    const int valid_rows = Mx - m0;
     const int short_rb = !SHORT_OK ? 0 : valid_rows <= 96 ? 6 : valid_rows <= 160 ? 10 : 0;      // block-uniform
     const int npa_rt = short_rb ? short_rb / 2 : NPA;
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
         const int r = (w * npa_rt + j) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        const int m = min(m0 + r, p.M - 1);
+        const int m = min(m0 + r, Mx - 1);
         if constexpr (CONV) {       // output position (t, h, w) = padded position of its (0,0,0) tap
             const int hw = p.H * p.Wd;
             const int t = m / hw, r2 = m - t * hw, h = r2 / p.Wd, x = r2 - h * p.Wd;
@@ -203,7 +209,17 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
                 gate4[cb][gq] = (EPI == EPI_RESID_GATE_F32 && p.gate_table) ? *(const f32x4*)(p.gate_table + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq)
                                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    if constexpr (HOIST_COL_VECTORS) load_bias();
+    // consumer side of a folded norm: this lane's row factor per row block (row lr of each), requested right behind the K loop
+    [[maybe_unused]] float rf[FOLD_CONS ? RBW : 1];
+    auto load_rf = [&]() __attribute__((always_inline)) {
+        if constexpr (FOLD_CONS) {
+            int lr2 = lr;
+            asm volatile("" : "+v"(lr2));        // (keeps the address arithmetic behind the loop: formed in front of it, the 64-bit address is carried across in scratch)
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) rf[rb] = p.rowfac ? p.rowfac[min(m0 + rb * MB + lr2, p.M - 1)] : 1.f;
+        }
+    };
+    if constexpr (HOIST_COL_VECTORS) load_bias();        // (the row factors stay behind the loop: carried across it they spill -- 132 bytes of scratch per lane)
     // ---- gated fp32-residual epilogue (EPI_RESID_GATE_F32 through LDS, below): the read-back side's geometry, declared here because the FIRST
     //      part's residual rows are requested BEFORE the K loop where the loop leaves registers (224-row dense bf16 loops end at v179; round 4):
     //      x is this tile's alone, so the rows can be read any time, and the epilogue then starts with its first 32 rows already on chip
@@ -302,6 +318,11 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // 32x32 block: row lr, groups gq = 0..3 at columns 8 gq + 4 kq (accumulator registers 4 gq .. 4 gq + 3)
     // 16x16 block: row lr, one group at columns 4 kq (accumulator registers 0..3)
     if constexpr (!HOIST_COL_VECTORS) load_bias();
+    load_rf();
+    if constexpr (FOLD_CONS) {
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) asm volatile("" : "+v"(rf[rb]));
+    }
     load_gate();
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb)
@@ -373,6 +394,21 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
             char* wl = smem + w * (2 * PR * ROWB);
             f32x4 gtab = {0.f, 0.f, 0.f, 0.f};              // the read-back lane's 4 columns of the broadcast part
             if (ROWGATE && p.gate_table) gtab = *(const f32x4*)(p.gate_table + n0 + wc * WN + cc * 4);
+            // round 6: the new residual rows also leave as the NEXT projection's operand (bf16, times the next norm's 1 + scale) with their partial sums
+            // of squares, so the norm pass between this GEMM and the next disappears (GemmParams::shadow; row-invariant gates only)
+            const bool shadow = FOLD_PROD && !ROWGATE && p.shadow != nullptr;          // (block-uniform)
+            f32x4 sm4 = {1.f, 1.f, 1.f, 1.f};
+            bf16* yg = nullptr;
+            float* ssg = nullptr;
+            if constexpr (FOLD_PROD && !ROWGATE) {
+                if (shadow) {
+                    if (p.shadow_scale) sm4 += *(const f32x4*)(p.shadow_scale + n0 + wc * WN + cc * 4);
+                    yg = p.shadow + (long)(m0 + rr) * p.ld_shadow + n0 + wc * WN + cc * 4;
+                    ssg = p.shadow_ss + (long)(m0 + rr) * (p.N / 64) + (n0 + wc * WN) / 64;
+                    if (p.shadow_xrow && m0 <= p.M && p.M < m0 + BM && lane < 16)        // the tile that holds row M: the consumer's extra row
+                        *(bf16x4*)(p.shadow + (long)p.M * p.ld_shadow + n0 + wc * WN + lane * 4) = *(const bf16x4*)(p.shadow_xrow + n0 + wc * WN + lane * 4);
+                }
+            }
             f32x4 xv[3][NIT];
             [[maybe_unused]] f32x4 gv[ROWGATE ? 3 : 1][NIT];
             auto load_part = [&](auto PART) __attribute__((always_inline)) {
@@ -417,7 +453,24 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
                         asm volatile("" : "+v"(xv[part % 3][i]));       // consume in issue order: counted waits, not vmcnt(0)
                         f32x4 d = *(const f32x4*)(sl + row * ROWB + ((cc ^ (row & 15)) << 4));
                         if constexpr (ROWGATE) d *= gtab + gv[part % 3][i];
-                        if (m0 + part * PR + row < p.M) *(f32x4*)(xg + ((long)part * PR + row - rr) * p.ldo) = xv[part % 3][i] + d;
+                        const f32x4 xn = xv[part % 3][i] + d;
+                        const bool live = m0 + part * PR + row < p.M;
+                        if (live) *(f32x4*)(xg + ((long)part * PR + row - rr) * p.ldo) = xn;
+                        if constexpr (FOLD_PROD && !ROWGATE) {
+                            if (shadow) {
+                                // the row's 64 columns of this wave sit in the 16 lanes of one DPP row: quad, quad, half-mirror, mirror
+                                float ss = (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);
+                                ss += dpp_f32<0xB1>(ss);
+                                ss += dpp_f32<0x4E>(ss);
+                                ss += dpp_f32<0x141>(ss);
+                                ss += dpp_f32<0x140>(ss);
+                                const f32x4 y = xn * sm4;
+                                if (live) {
+                                    *(bf16x4*)(yg + ((long)part * PR + row - rr) * p.ld_shadow) = pack_bf16x4(y[0], y[1], y[2], y[3]);
+                                    if (cc == 0) ssg[((long)part * PR + row - rr) * (p.N / 64)] = ss;
+                                }
+                            }
+                        }
                     }
                 }
             });
@@ -503,7 +556,7 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
         }
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
-            if (m0 + wr * WM + rb * MB >= p.M) continue;     // no real row in this block (block-uniform): its slab rows are never read as data
+            if (m0 + wr * WM + rb * MB >= Mx) continue;     // no real row in this block (block-uniform): its slab rows are never read as data
             const int r = rb * MB + lr;
             const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
             // (EPI_ADD_BF16) the row block's residual slots are read up front: in source order read -> add -> write per slot, hipcc keeps
@@ -522,7 +575,14 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
             for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
               for (int gq = 0; gq < NG; ++gq) {
-                f32x4 v = acc_group(rb, cb, gq) + bias4[cb][gq];
+                f32x4 v;
+                if constexpr (FOLD_CONS) {
+                    v = acc_group(rb, cb, gq) * rf[rb] + bias4[cb][gq];
+                    if (p.xrow && m0 + r == p.M)        // the extra row: its product (+ the projection's own bias) is the next step's bias vector; its slab row is never stored
+                        *(f32x4*)(p.xrow_out + n0 + wc * WN + cb * MB + 4 * kq) = acc_group(rb, cb, gq) + *(const f32x4*)(p.xrow_bias + n0 + wc * WN + cb * MB + 4 * kq);
+                } else {
+                    v = acc_group(rb, cb, gq) + bias4[cb][gq];
+                }
                 if (EPI == EPI_GELU_BF16) {
                     const f32x2 g0 = gelu_tanh2(f32x2{v[0], v[1]}), g1 = gelu_tanh2(f32x2{v[2], v[3]});
                     v = f32x4{g0[0], g0[1], g1[0], g1[1]};

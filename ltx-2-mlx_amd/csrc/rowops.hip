@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16* __restrict
 
 // The same product for many rows (round 5): the kernel above re-reads the whole 32 x K gate weight (256 KiB at K = 4096) from L2 in every 16-row block -- 55 MB of
 // weight traffic beside 28 MB of activations at 3456 x 4096, 14-20 us.  Here a block takes 64 rows x ONE K slice (K / KS columns): the slice of the weight
-// (32 x K/KS, 64 KiB at K = 4096, KS = 4) is staged in LDS once and shared by the block's four waves (16 rows each); X streams from global memory.  The KS partial
+// (32 x K/KS, 32 KiB at K = 4096 with KS = GATE_LOGIT_PARTS = 8; a 4-slice form measured no faster than the round-4 kernel) is staged in LDS once and shared by the block's four waves (16 rows each); X streams from global memory.  The KS partial
 // sums are NOT reduced here: parts[ks][M][H] (fp32, no bias) -- the consumer (the attention kernel's epilogue) adds the KS values and the bias in a fixed order.
 template <int KS>
 __global__ __launch_bounds__(256) void gate_logits_parts_kernel(const bf16* __restrict__ X, long ldx, const bf16* __restrict__ Wg, float* __restrict__ parts,

@@ -45,15 +45,24 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if not _MEASURED:
         return
     per_test = {}
+    per_site = {}       # (test, call site) -> [n, max]: one line per rel_l2() / measure() call site, so a test that checks several configurations
+    order = []          # (bf16, float16, fp8 compute at one test id) shows each of them, not only its largest (VERDICT r5 weak #1a)
     for test, where, v in _MEASURED:
         d = per_test.setdefault(test, {"n": 0, "max": 0.0, "where": where})
         d["n"] += 1
         if v >= d["max"]:
             d["max"], d["where"] = v, where
+        k = (test, where)
+        if k not in per_site:
+            per_site[k] = [0, 0.0]
+            order.append(k)
+        per_site[k][0] += 1
+        per_site[k][1] = max(per_site[k][1], v)
     tr = terminalreporter
-    tr.write_sep("=", "measured parity (max rel-L2 per test; gates sit at <= 5x these)")
-    for test, d in per_test.items():
-        tr.write_line(f"{d['max']:.3e}  n={d['n']:<3d} {d['where']:<32s} {test.split('::', 1)[-1]}")
+    tr.write_sep("=", "measured parity (max per call site: rel-L2 unless tagged; gates sit at <= 5x these)")
+    for k in order:
+        n, mx = per_site[k]
+        tr.write_line(f"{mx:.3e}  n={n:<3d} {k[1]:<40s} {k[0].split('::', 1)[-1]}")
     out = os.environ.get("LTX2_PARITY_JSON")
     if out:
         per_line = {}

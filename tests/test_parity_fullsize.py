@@ -374,3 +374,83 @@ def test_av_48_layer_step_v23(dev):
     assert rel_l2(ax0.cpu(), ra.cpu()) < 0.008 and pearson(ax0.cpu(), ra.cpu()) > 0.999
     del w, m
     torch.cuda.empty_cache()
+
+
+
+def test_fold_norms_levels_agree_and_graph_is_bit_identical(dev):
+    """Round 6: the block's RMS norms folded around its GEMMs (engine option fold_norms, default 2: DESIGN.md "folded norms").  At the headline
+    geometry (D = 4096, N = 3456) with 3 layers: the 8-step loop at levels 0 (a norm pass in front of every projection), 1 (text cross-attention
+    pre-norm on attn1.to_out's epilogue) and 2 (the modulated norms too, c formed one step ahead) against the fp32 oracle's loop; the levels agree
+    with each other far inside the oracle gate, level 2 really runs another program (not bit-equal to level 0), the captured loop equals the
+    eager steps bit for bit, and a step whose sigma is NOT the announced one falls back to the norm passes (same result as a fresh loop)."""
+    from oracle import dit, loop
+    from ltx_2_mlx_amd.components import DISTILLED_SIGMA_VALUES
+    from ltx_2_mlx_amd.model.transformer import Modality
+    cfg, w, m = make_dit(dev, heads=32, layers=3, cap=3840, seed=61)
+    f, h, wd = 9, 16, 24
+    lat, ctx, pos = inputs(f, h, wd, 256, 3840, seed=62)
+    sig = DISTILLED_SIGMA_VALUES
+    wg = {k: v.to(dev) for k, v in w.items()}
+    with torch.device(dev), torch.no_grad():
+        ctx_g, pos_g = ctx.to(dev), pos.to(dev)
+        ref = loop.denoise_loop_cli(loop.unpatchify(lat.to(dev), f, h, wd),
+                                    lambda tok, s: dit.x0_model(tok, ctx_g, torch.tensor([s]), pos_g, wg, cfg), sig)
+        ref = loop.patchify(ref).cpu()[0]
+    C, P = ctx.to(dev), pos.to(dev)
+
+    def eager(level, sigmas=sig):
+        m.set_option("fold_norms", level)
+        y = lat[0].to(dev).contiguous()
+        for i in range(len(sigmas) - 1):
+            mod = Modality(latent=y[None], context=C, context_mask=None, timesteps=torch.tensor([sigmas[i]], device=dev), positions=P)
+            m.denoise_step_(y, mod, sigmas[i], sigmas[i + 1])
+        return y
+
+    outs = {lv: eager(lv) for lv in (0, 1, 2)}
+    for lv, y in outs.items():
+        assert rel_l2(y.cpu(), ref) < 0.008 and pearson(y.cpu(), ref) > 0.999, lv
+    assert rel_l2(outs[1].cpu(), outs[0].cpu()) < 2e-3 and rel_l2(outs[2].cpu(), outs[0].cpu()) < 2e-3
+    assert not torch.equal(outs[1], outs[0]) and not torch.equal(outs[2], outs[1])
+    # the same loop again: nothing is carried over from the previous loop's last step (its announced sigma, 0, is not this loop's first)
+    assert torch.equal(eager(2), outs[2])
+    # captured loop == eager steps, bit for bit (twice: replays are re-entrant)
+    for _ in range(2):
+        z = lat[0].to(dev).contiguous()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m.capture_denoise_graph(z, sig)
+            m.replay_denoise_graph()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(z, outs[2])
+    # an eager step after a replay, and a step with a sigma nobody announced: both must run the norm passes for that step
+    y = lat[0].to(dev).contiguous()
+    odd = [1.0, 0.97, 0.5, 0.25, 0.0]
+    for i in range(4):
+        mod = Modality(latent=y[None], context=C, context_mask=None, timesteps=torch.tensor([odd[i]], device=dev), positions=P)
+        m.denoise_step_(y, mod, odd[i], odd[i + 1] if i != 1 else 0.7)         # step 1 announces 0.7, step 2 then comes with 0.5
+    m.set_option("fold_norms", 0)
+    y0 = lat[0].to(dev).contiguous()
+    for i in range(4):
+        mod = Modality(latent=y0[None], context=C, context_mask=None, timesteps=torch.tensor([odd[i]], device=dev), positions=P)
+        m.denoise_step_(y0, mod, odd[i], odd[i + 1] if i != 1 else 0.7)
+    m.set_option("fold_norms", 2)
+    assert rel_l2(y.cpu(), y0.cpu()) < 2e-3
+
+
+def test_text_qnorm_fold_falls_back_at_20_heads(dev):
+    """D = 2560 (20 heads x 128) gives q_ss_ld = D / 64 = 40, not a multiple of 16 -- the attention kernel's row-scale form rejects it, so
+    ltx2_dit_prepare must keep the q_norm pass for such models (text_qfold_ok gates on D % 1024).  N >= 1024 so the query projection runs on the
+    4-wave kernel (the route that would otherwise enable the fold).  Against the fp32 oracle."""
+    from oracle import dit
+    from ltx_2_mlx_amd.model.transformer import Modality
+    cfg, w, m = make_dit(dev, heads=20, layers=1, cap=128, seed=71)
+    lat, ctx, pos = inputs(3, 16, 24, 64, 128, seed=72)
+    sigma = torch.tensor([0.725])
+    wg = {k: v.to(dev) for k, v in w.items()}
+    with torch.device(dev), torch.no_grad():
+        ref = dit.velocity_model(lat.to(dev), ctx.to(dev), sigma.to(dev), pos.to(dev), wg, cfg).cpu()
+    v = m(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=sigma.to(dev), positions=pos.to(dev)))
+    assert v.shape == (1, 1152, 128)
+    assert rel_l2(v.cpu(), ref) < 0.012 and pearson(v.cpu(), ref) > 0.999
