@@ -107,17 +107,18 @@ int ltx2_flash_attn_rowscale(const void* Q, int64_t ldq, const void* K, int64_t 
  * over x): rms_norm(x) (1 + s) + t in front of a projection (W, b) equals r (x (1 + s)) W^T + (t W^T + b), r[m] = rsqrt(mean_j x[m][j]^2 + eps).
  * ltx2_gemm_bf16_fold: ltx2_gemm_bf16 with the producer / consumer halves of that identity (any of them may be absent: null / 0):
  *   epilogue RESID_GATE_F32 (x += gate_table * (acc + bias), row-invariant gate): shadow[m][n] = 16-bit(x_new[m][n] * (1 + shadow_scale[n]))
- *     (row stride ld_shadow), shadow_ss[m][N / 64] = the sums of x_new[m][n]^2 over each 64-column strip, and shadow_xrow [N] copied into shadow row M;
- *   epilogue BF16 / GELU_BF16: out = epilogue(rowfac[m] * acc + bias); xrow = 1: A holds M + 1 rows and row M's product leaves as fp32
- *     xrow_out[n] = acc + xrow_bias[n] instead of reaching out (with the NEXT step's shift row t' as row M that is the next step's t' W^T + b, formed by the
- *     GEMM that streams W anyway).
- *   *supported = 0 (nothing launched) when the 4-wave layout-3 kernel does not take the problem (M >= 1024, N % 256 == 0, K % 128 == 0, dense 16-bit weights;
- *   xrow / shadow_xrow: M not a multiple of the row tile).
- * ltx2_rowfac: rowfac[m] = rsqrt(sum_{j < nparts} ss[m][j] / D + eps).                                                                              */
+ *     (row stride ld_shadow), shadow_ss[(n / 256) * ld_ss + m] = the sum of x_new[m][n]^2 over each 256-column tile (ld_ss >= the row tiles' extent:
+ *     M rounded up to a multiple of 256 is always enough; % 4 == 0), and shadow_xrow [N] copied into shadow row M;
+ *   epilogue BF16 / GELU_BF16: out = epilogue(r[m] * acc + bias) with r[m] = rsqrt(sum_{j < rf_nparts} rf_parts[j * rf_ld + m] / rf_dim + rf_eps)
+ *     formed inside the kernel (rf_parts = a producer's shadow_ss, rf_nparts <= 24; null: r = 1); xrow = 1: A holds M + 1 rows and row M's
+ *     product leaves as fp32 xrow_out[n] = acc + xrow_bias[n] instead of reaching out (with the NEXT step's shift row t' as row M that is the next
+ *     step's t' W^T + b, formed by the GEMM that streams W anyway).
+ *   *supported = 0 (nothing launched) when the 4-wave layout-3 kernel does not take the problem (M >= 1024, N % 256 == 0, K % 128 == 0, dense 16-bit
+ *   weights; xrow / shadow_xrow: M not a multiple of the row tile).                                                                               */
 int ltx2_gemm_bf16_fold(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue,
-                        const float* gate_table, void* shadow, int64_t ld_shadow, const float* shadow_scale, float* shadow_ss, const void* shadow_xrow,
-                        const float* rowfac, int xrow, float* xrow_out, const float* xrow_bias, int* supported, void* stream);
-int ltx2_rowfac(const float* ss, int nparts, float* rowfac, int rows, int D, float eps, void* stream);
+                        const float* gate_table, void* shadow, int64_t ld_shadow, const float* shadow_scale, float* shadow_ss, int64_t ld_ss, const void* shadow_xrow,
+                        const float* rf_parts, int64_t rf_ld, int rf_nparts, int rf_dim, float rf_eps, int xrow, float* xrow_out, const float* xrow_bias,
+                        int* supported, void* stream);
 
 /* flash attention with a key mask (attention.py:38-70 with the additive mask model.py:163-201 builds from a boolean (B, S) context
  * mask): mask fp32 [Nkv], non-zero = the key may be attended; a masked key takes no weight unless every key is masked (then the

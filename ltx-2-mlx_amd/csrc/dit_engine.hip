@@ -85,9 +85,9 @@ struct Mod {        // per-modality geometry + workspace
     float* qss = nullptr;           // text cross-attention with q_norm folded in: partial row sums of squares of the projected queries [N][D/64]
     float* knq = nullptr;           //   and k_norm.weight * q_norm.weight per layer [L][D] (the per-dim q weight moves onto the cached keys)
     bool qfold = false;             //   decided per prepare: the query projection runs on a kernel that writes the partial sums
-    // round 6, norms folded around the GEMMs (GemmParams::shadow / rowfac / xrow; fold_level()): h doubles as the bf16 shadow of the residual stream
-    float* rss = nullptr;           //   partial sums of squares of the new residual rows [N][D/64], left by the producing gated-residual epilogue
-    float* rfac = nullptr;          //   row factors rsqrt(mean x^2 + eps) [N] (rowfac_launch)
+    // round 6, norms folded around the GEMMs (GemmParams::shadow / rf_parts / xrow; fold_supported()): h doubles as the bf16 shadow of the residual stream
+    float* rss = nullptr;           //   partial sums of squares of the new residual rows, one per 256-column tile [D/256][rss_ld], left by the producing gated-residual epilogue
+    long rss_ld = 0;                //   (the consuming projection turns them into its rows' RMS factors itself)
     float* cvec[2] = {nullptr, nullptr};   //   per layer [3D | 4D]: c = shift W^T + bias of the QKV / FFN-up projections for this step's sigma, and the set the GEMMs of this step leave for the next sigma
     float* embn = nullptr;          //   the next sigma's AdaLN shift rows (shift_msa, shift_mlp) [2][D]
     bf16* tnext = nullptr;          //   the next step's shift rows per layer, bf16 [L][2][D]: the extra row of the QKV / FFN-up operands
@@ -171,8 +171,8 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         m.qss = (float*)take(4L * n * (D / 64));
         m.knq = (float*)take(4L * L * D);
         const bool fold_bufs = k == 0 && !c->av;
-        m.rss = (float*)take(fold_bufs ? 4L * n * (D / 64) : 0);
-        m.rfac = (float*)take(fold_bufs ? 4L * n : 0);
+        m.rss_ld = align_up(n, 256) + 256;
+        m.rss = (float*)take(fold_bufs ? 4L * (D / 256 + 1) * m.rss_ld : 0);
         m.cvec[0] = (float*)take(fold_bufs ? 4L * L * 7 * D : 0);
         m.cvec[1] = (float*)take(fold_bufs ? 4L * L * 7 * D : 0);
         m.embn = (float*)take(fold_bufs ? 4L * 2 * D : 0);
@@ -415,7 +415,7 @@ int fold_supported(ltx2_dit* c, int k) {
 #else
     if (c->av || c->v2 || c->gated || c->fp8_compute || !c->fp8_scale.empty() || k != 0) return 0;
     const Mod& m = c->m[k];
-    if (!m.rss || m.D % 64 != 0) return 0;
+    if (!m.rss || m.D % 256 != 0 || m.D / 256 > GEMM_RF_MAX_PARTS) return 0;
     const BlockW& w = c->layers[0].m[k];
     GemmParams q{};
     q.A = m.h;
@@ -430,6 +430,7 @@ int fold_supported(ltx2_dit* c, int k) {
     q.shadow = m.h;
     q.ld_shadow = m.D;
     q.shadow_ss = m.rss;
+    q.ld_ss = m.rss_ld;
     if (!gemm_fold_supported(q, EPI_RESID_GATE_F32)) return 0;
     GemmParams r{};
     r.A = m.h;
@@ -440,7 +441,10 @@ int fold_supported(ltx2_dit* c, int k) {
     r.ldo = m.D;
     r.out = m.qkv;
     r.W = w.text.q_w;
-    r.rowfac = m.rfac;
+    r.rf_parts = m.rss;
+    r.rf_ld = m.rss_ld;
+    r.rf_nparts = m.D / 256;
+    r.rf_dim = m.D;
     if (!gemm_fold_supported(r, EPI_BF16)) return 0;
     // level 2
     q.shadow_xrow = m.tnext;
@@ -476,7 +480,10 @@ struct Fold {
     float* shadow_ss = nullptr;
     const bf16* shadow_xrow = nullptr;
     long ld_shadow = 0;
-    const float* rowfac = nullptr;
+    const float* rf_parts = nullptr;
+    long ld_ss = 0;         // row stride of shadow_ss / rf_parts
+    int rf_nparts = 0, rf_dim = 0;
+    float rf_eps = 0.f;
     int xrow = 0;
     float* xrow_out = nullptr;
     const float* xrow_bias = nullptr;
@@ -494,7 +501,12 @@ int dense(ltx2_dit* c, const bf16* A, long lda, const bf16* W, const float* bias
         p.shadow_ss = fold->shadow_ss;
         p.shadow_xrow = fold->shadow_xrow;
         p.ld_shadow = fold->ld_shadow;
-        p.rowfac = fold->rowfac;
+        p.ld_ss = fold->ld_ss;
+        p.rf_parts = fold->rf_parts;
+        p.rf_ld = fold->ld_ss;
+        p.rf_nparts = fold->rf_nparts;
+        p.rf_dim = fold->rf_dim;
+        p.rf_eps = fold->rf_eps;
         p.xrow = fold->xrow;
         p.xrow_out = fold->xrow_out;
         p.xrow_bias = fold->xrow_bias;
@@ -709,13 +721,30 @@ int text_kv(ltx2_dit* c, int k, int l, hipStream_t st) {
 // ---- round 6: the three RMS norms of a block folded around its GEMMs -------------------------------------------------------------------------
 // rms_norm(x) (1 + s) + t in front of a projection W, b equals r (x (1 + s)) W^T + (t W^T + b) with the row factor r = rsqrt(mean x^2 + eps).  The gated-residual
 // GEMM that forms x (attn1.to_out, attn2.to_out, ff.net.2) therefore also leaves y = bf16(x (1 + s)) in `h` with the partial sums of squares of x (GemmParams::shadow),
-// rowfac_launch turns the sums into r, and the projection takes (y, r, c = t W^T + b) -- the norm pass between the two GEMMs (85 MB per launch) is gone.
+// and the projection takes (y, the partial sums -> r inside the kernel, c = t W^T + b) -- the norm pass between the two GEMMs (85 MB per launch) is gone.
 //   * text cross-attention: plain RMS norm (s = 0, t = 0, c = to_q.bias): nothing else is needed                                              -> level 1
 //   * self-attention / feed-forward: c depends on sigma through t, and forming it costs a pass over W -- so the GEMM that streams W anyway forms it ONE STEP
 //     AHEAD: its operand carries one more row, the NEXT step's shift row t' (bf16), and that row's product leaves as the next step's c (GemmParams::xrow).
 //     A step whose c was not left by the step before it (the first of a loop, a sigma other than the announced one) runs the norm passes and only leaves c. -> level 2
 // Row-invariant modulation only (one timestep per modality), VideoOnly non-V2.3 models on dense bf16 weights, the bfloat16 build (x (1 + s) un-normalised is not
 // safe in IEEE half).  Same mathematics, another rounding order: y is rounded before the row factor instead of after it (both relative 2^-9).
+// the two halves on a Fold: the producer writes x's shadow into h and its partial sums into rss; the consumer reads them back
+inline void fold_produce(Fold& f, Mod& m, const float* scale, const bf16* xrow) {
+    f.shadow = m.h;
+    f.ld_shadow = m.D;
+    f.shadow_ss = m.rss;
+    f.ld_ss = m.rss_ld;
+    f.shadow_scale = scale;
+    f.shadow_xrow = xrow;
+}
+inline void fold_consume(Fold& f, const Mod& m, float eps) {
+    f.rf_parts = m.rss;
+    f.ld_ss = m.rss_ld;
+    f.rf_nparts = m.D / 256;
+    f.rf_dim = m.D;
+    f.rf_eps = eps;
+}
+
 struct FoldStep {
     int level = 0;            // for this forward: 0 / 1 / 2
     bool valid = false;       // level 2: cvec[c_cur] is this step's c
@@ -759,7 +788,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, const Fo
         fq.xrow_bias = w.self.qkv_b;
     }
     if (fold_in) {
-        fq.rowfac = m.rfac;
+        fold_consume(fq, m, eps);
     } else {
         TRY(norm_mod_launch(m.x, D, (q1 && !c->gated) ? nullptr : m.h, D, N, D, eps, 0, tab + D, tab, E(1), E(0), es, st, q1 ? m.a8 : nullptr, D,
                             q1 ? m.a8s : nullptr));
@@ -781,11 +810,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, const Fo
     if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
     TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, nullptr, 0.f, nullptr, glog(c, m)));
     Fold fo{};
-    if (fl >= 1) {          // the new residual rows also leave as the cross-attention query projection's operand (plain RMS norm: no scale, no shift)
-        fo.shadow = m.h;
-        fo.ld_shadow = D;
-        fo.shadow_ss = m.rss;
-    }
+    if (fl >= 1) fold_produce(fo, m, nullptr, nullptr);          // the new residual rows also leave as the cross-attention query projection's operand (plain RMS norm: no scale, no shift)
     TRY(dense(c, m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(2), es, tab + 2 * D, nullptr, nullptr, false, nullptr, fl >= 1 ? &fo : nullptr));
 
     // text cross-attention: no RoPE, no mask.  V1: plain RMSNorm on x, K/V cached per prompt.
@@ -808,8 +833,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, const Fo
         kk = m.kv2;
         vt = m.vt2;
     } else {
-        if (fl >= 1) TRY(rowfac_launch(m.rss, D / 64, m.rfac, N, D, eps, st));
-        else TRY(norm_mod_launch(m.x, D, h2, D, N, D, eps, 0, nullptr, nullptr, nullptr, nullptr, 0, st, a8q, D, a8sq));
+        if (fl < 1) TRY(norm_mod_launch(m.x, D, h2, D, N, D, eps, 0, nullptr, nullptr, nullptr, nullptr, 0, st, a8q, D, a8sq));
         kk = m.kv2 + (long)l * m.S * 2 * D;
         vt = m.vt2 + (long)l * D * m.Spad;
     }
@@ -817,7 +841,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, const Fo
     // q_norm folded (m.qfold): the projection's epilogue leaves the partial sums of squares of its rows; q_norm.weight already sits on the keys
     // (k_norm.weight * q_norm.weight, prepare) and the row's RMS factor becomes its softmax scale -- no pass over q between GEMM and attention
     Fold fc{};
-    fc.rowfac = m.rfac;
+    fold_consume(fc, m, eps);
     TRY(dense(c, m.h, D, w.text.q_w, w.text.q_b, m.qkv, D, N, D, D, EPI_BF16, st, nullptr, 0, nullptr, nullptr, nullptr, q2, m.qfold ? m.qss : nullptr, fl >= 1 ? &fc : nullptr));
     if (!m.qfold) {
         const int offs[1] = {0};
@@ -830,13 +854,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, const Fo
         TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(8), es, tab + 8 * D));
     else {
         Fold ft{};
-        if (fl == 2 && fs.valid) {      // the feed-forward's operand: y = bf16(x (1 + scale_mlp)) + the next step's shift_mlp row
-            ft.shadow = m.h;
-            ft.ld_shadow = D;
-            ft.shadow_ss = m.rss;
-            ft.shadow_scale = tab + 4 * D;
-            ft.shadow_xrow = m.tnext + ((long)l * 2 + 1) * D;
-        }
+        if (fl == 2 && fs.valid) fold_produce(ft, m, tab + 4 * D, m.tnext + ((long)l * 2 + 1) * D);      // the feed-forward's operand: y = bf16(x (1 + scale_mlp)) + the next step's shift_mlp row
         TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, nullptr, 0, nullptr, nullptr, nullptr, false, nullptr, ft.shadow ? &ft : nullptr));
     }
     return LTX2_OK;
@@ -860,8 +878,7 @@ int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st, const FoldStep
         fu.xrow_bias = w.ff1_b;
     }
     if (fold_in) {
-        TRY(rowfac_launch(m.rss, D / 64, m.rfac, N, D, c->cfg.norm_eps, st));
-        fu.rowfac = m.rfac;
+        fold_consume(fu, m, c->cfg.norm_eps);
     } else {
         TRY(norm_mod_launch(m.x, D, q3 ? nullptr : m.h, D, N, D, c->cfg.norm_eps, 0, tab + 4 * D, tab + 3 * D, E(4), E(3), es, st,
                             q3 ? m.a8 : nullptr, D, q3 ? m.a8s : nullptr));
@@ -873,15 +890,9 @@ int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st, const FoldStep
     TRY(dense(c, m.h, D, w.ff1_w, fold_in ? fs.c_now + ((long)l * 7 + 3) * D : w.ff1_b, m.ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st, nullptr, 0, nullptr, nullptr, nullptr, q3, nullptr,
               fl == 2 ? &fu : nullptr));
     Fold fd{};
-    if (fold_in && l + 1 < c->cfg.num_layers) {     // the next layer's self-attention operand: y = bf16(x (1 + scale_msa[l + 1])) + its next shift_msa row
-        fd.shadow = m.h;
-        fd.ld_shadow = D;
-        fd.shadow_ss = m.rss;
-        fd.shadow_scale = tab + (long)(c->v2 ? 9 : 6) * D + D;
-        fd.shadow_xrow = m.tnext + (long)(l + 1) * 2 * D;
-    }
+    if (fold_in && l + 1 < c->cfg.num_layers)       // the next layer's self-attention operand: y = bf16(x (1 + scale_msa[l + 1])) + its next shift_msa row
+        fold_produce(fd, m, tab + (long)(c->v2 ? 9 : 6) * D + D, m.tnext + (long)(l + 1) * 2 * D);
     TRY(dense(c, m.ff, 4 * D, w.ff2_w, w.ff2_b, m.x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, E(5), es, tab + 5 * D, nullptr, nullptr, false, nullptr, fd.shadow ? &fd : nullptr));
-    if (fd.shadow) TRY(rowfac_launch(m.rss, D / 64, m.rfac, N, D, c->cfg.norm_eps, st));
     return LTX2_OK;
 }
 

@@ -110,7 +110,7 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // rows (6 of 14 for 3456 rows, 10 of 14 for 13824) -- fewer DMA pieces per wave, so the wave -> tile-row mapping shrinks with it
     constexpr bool SHORT_OK = LAYOUT == 3 && BM == 224 && !CONV;
     const int valid_rows = Mx - m0;
-    const int short_rb = !SHORT_OK ? 0 : valid_rows <= 96 ? 6 : valid_rows <= 160 ? 10 : 0;      // block-uniform
+    const int short_rb = !SHORT_OK ? 0 : valid_rows <= 96 ? 6 : (valid_rows <= 128 && !W8) ? 8 : valid_rows <= 160 ? 10 : 0;      // block-uniform (8: 96 rows + a folded norm's extra row)
     const int npa_rt = short_rb ? short_rb / 2 : NPA;
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
@@ -209,17 +209,29 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
                 gate4[cb][gq] = (EPI == EPI_RESID_GATE_F32 && p.gate_table) ? *(const f32x4*)(p.gate_table + n0 + wc * WN + cb * MB + 8 * gq + 4 * kq)
                                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // consumer side of a folded norm: this lane's row factor per row block (row lr of each), requested right behind the K loop
-    [[maybe_unused]] float rf[FOLD_CONS ? RBW : 1];
-    auto load_rf = [&]() __attribute__((always_inline)) {
-        if constexpr (FOLD_CONS) {
-            int lr2 = lr;
-            asm volatile("" : "+v"(lr2));        // (keeps the address arithmetic behind the loop: formed in front of it, the 64-bit address is carried across in scratch)
-#pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) rf[rb] = p.rowfac ? p.rowfac[min(m0 + rb * MB + lr2, p.M - 1)] : 1.f;
+    // consumer side of a folded norm: the producer's partial sums of squares of this tile's rows ([rf_nparts][BM] floats) arrive by LDS-DMA in the LDS above
+    // the stage buffers while the K loop runs (no register carries them: the loop owns the file); behind the loop BM threads turn them into row factors
+    constexpr int RF_OFF = G::LOOP_BYTES, RF_FAC = RF_OFF + GEMM_RF_MAX_PARTS * BM * 4;
+    if constexpr (FOLD_CONS) {
+        if (p.rf_parts) {       // (block-uniform)
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.rf_parts, 0, 0x7fffffff, 0x00020000);
+            const int total = p.rf_nparts * (BM / 4);          // 16-byte pieces, part-major
+            for (int it = 0; it * 256 < total; ++it) {
+                const int idx = it * 256 + tid;
+                if (idx < total) {
+                    const int part = idx / (BM / 4), c4 = idx - part * (BM / 4);
+                    const unsigned voff = (unsigned)(((long)part * p.rf_ld + m0 + 4 * c4) * 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr_t)(smem + RF_OFF + it * 4096 + w * 1024), 16, voff, 0, 0, 0);
+#else
+                    (void)voff;
+#endif
+                }
+            }
         }
-    };
-    if constexpr (HOIST_COL_VECTORS) load_bias();        // (the row factors stay behind the loop: carried across it they spill -- 132 bytes of scratch per lane)
+    }
+    [[maybe_unused]] float rf[FOLD_CONS ? RBW : 1];
+    if constexpr (HOIST_COL_VECTORS) load_bias();
     // ---- gated fp32-residual epilogue (EPI_RESID_GATE_F32 through LDS, below): the read-back side's geometry, declared here because the FIRST
     //      part's residual rows are requested BEFORE the K loop where the loop leaves registers (224-row dense bf16 loops end at v179; round 4):
     //      x is this tile's alone, so the rows can be read any time, and the epilogue then starts with its first 32 rows already on chip
@@ -284,6 +296,7 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     } else if constexpr (LAYOUT == 3) {
         if constexpr (BM == 224) {
             if (short_rb == 6) V4_ASM(LTX2_V4_L14_M16_RB6);
+            else if (short_rb == 8) V4_ASM(LTX2_V4_L14_M16_RB8);
             else if (short_rb == 10) V4_ASM(LTX2_V4_L14_M16_RB10);
             else V4_ASM(LTX2_V4_L14_M16_RB14);
         } else {
@@ -318,10 +331,13 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // 32x32 block: row lr, groups gq = 0..3 at columns 8 gq + 4 kq (accumulator registers 4 gq .. 4 gq + 3)
     // 16x16 block: row lr, one group at columns 4 kq (accumulator registers 0..3)
     if constexpr (!HOIST_COL_VECTORS) load_bias();
-    load_rf();
     if constexpr (FOLD_CONS) {
-#pragma unroll
-        for (int rb = 0; rb < RBW; ++rb) asm volatile("" : "+v"(rf[rb]));
+        if (p.rf_parts && tid < BM) {       // row tid of the tile: the partials in part order (deterministic), then the RMS factor
+            const float* pl = (const float*)(smem + RF_OFF);
+            float sq = 0.f;
+            for (int j = 0; j < p.rf_nparts; ++j) sq += pl[j * BM + tid];
+            *(float*)(smem + RF_FAC + tid * 4) = rsqrtf(sq / (float)p.rf_dim + p.rf_eps);
+        }
     }
     load_gate();
 #pragma unroll
@@ -399,12 +415,11 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
             const bool shadow = FOLD_PROD && !ROWGATE && p.shadow != nullptr;          // (block-uniform)
             f32x4 sm4 = {1.f, 1.f, 1.f, 1.f};
             bf16* yg = nullptr;
-            float* ssg = nullptr;
+            float* sspart = (float*)(smem + 4 * (2 * PR * ROWB)) + w * BM;       // this wave's strip sums per tile row, behind the four waves' slabs
             if constexpr (FOLD_PROD && !ROWGATE) {
                 if (shadow) {
                     if (p.shadow_scale) sm4 += *(const f32x4*)(p.shadow_scale + n0 + wc * WN + cc * 4);
                     yg = p.shadow + (long)(m0 + rr) * p.ld_shadow + n0 + wc * WN + cc * 4;
-                    ssg = p.shadow_ss + (long)(m0 + rr) * (p.N / 64) + (n0 + wc * WN) / 64;
                     if (p.shadow_xrow && m0 <= p.M && p.M < m0 + BM && lane < 16)        // the tile that holds row M: the consumer's extra row
                         *(bf16x4*)(p.shadow + (long)p.M * p.ld_shadow + n0 + wc * WN + lane * 4) = *(const bf16x4*)(p.shadow_xrow + n0 + wc * WN + lane * 4);
                 }
@@ -467,13 +482,20 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
                                 const f32x4 y = xn * sm4;
                                 if (live) {
                                     *(bf16x4*)(yg + ((long)part * PR + row - rr) * p.ld_shadow) = pack_bf16x4(y[0], y[1], y[2], y[3]);
-                                    if (cc == 0) ssg[((long)part * PR + row - rr) * (p.N / 64)] = ss;
                                 }
+                                if (cc == 0) sspart[part * PR + row] = ss;
                             }
                         }
                     }
                 }
             });
+            if constexpr (FOLD_PROD && !ROWGATE) {
+                if (shadow) {       // the tile's four 64-column strip sums, added in wave order: one partial per (row, 256-column tile), stored tile-major (coalesced)
+                    __syncthreads();
+                    const float* sp = (const float*)(smem + 4 * (2 * PR * ROWB));
+                    if (tid < BM && m0 + tid < p.M) p.shadow_ss[(long)(n0 / TBN) * p.ld_ss + m0 + tid] = (sp[tid] + sp[BM + tid]) + (sp[2 * BM + tid] + sp[3 * BM + tid]);
+                }
+            }
         };
         if (rowgate) run(std::true_type{});
         else run(std::false_type{});
@@ -531,6 +553,10 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
         // (16 rows x one column group per lane group) and for the 16-byte row reads.
         constexpr int ROWB = WN * 2, CPR = ROWB / 16, RPI = 64 / CPR;          // bytes per row, chunks per row, rows per instruction
         __syncthreads();                                    // every wave has finished its fragment reads
+        if constexpr (FOLD_CONS) {
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) rf[rb] = p.rf_parts ? *(const float*)(smem + RF_FAC + (rb * MB + lr) * 4) : 1.f;
+        }
         char* wl = smem + w * (WM * ROWB);
         if constexpr (EPI == EPI_ADD_BF16) {
             // out = bf16(acc + bias + res): the residual tile comes in through the same slab with whole-row loads; each lane then
@@ -738,7 +764,9 @@ int launch_v4(const GemmParams& p, hipStream_t stream) {
     using G = V4Geo<LAYOUT, BM, VAR == 20>;
     // the gated-residual kernel of the 224-row dense bf16 loop parks the first 32 residual rows of every wave above the stage buffers
     // (RESID_PRELOAD in the kernel): + 32 KiB = the CU's whole 160 KiB
-    constexpr int LDS = G::LDS_BYTES + ((EPI == EPI_RESID_GATE_F32 && LAYOUT == 3 && BM == 224 && !CONV && VAR != 20 && VAR != 9) ? 32768 : 0);
+    // (round 6) the bf16 / GELU kernels of the dense bf16 loop stage a folded norm's partial sums + row factors above the stage buffers: (GEMM_RF_MAX_PARTS + 1) x BM floats
+    constexpr int LDS = G::LDS_BYTES + ((EPI == EPI_RESID_GATE_F32 && LAYOUT == 3 && BM == 224 && !CONV && VAR != 20 && VAR != 9) ? 32768 : 0) +
+                        ((LAYOUT == 3 && !CONV && VAR == 0 && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16)) ? (GEMM_RF_MAX_PARTS + 1) * BM * 4 : 0);
     static_assert(LDS <= 160 * 1024, "LDS");
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {

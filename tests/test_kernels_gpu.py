@@ -838,7 +838,7 @@ def test_flash_attn_gated_epilogue(K, dev, heads, hd, Nq, Nkv):
 
 @pytest.mark.parametrize("M,D,NO,must", [(3456, 4096, 12288, True), (13824, 4096, 4096, True), (1300, 1024, 4096, False), (600, 512, 512, False)])
 def test_norm_folded_around_the_gemms(dev, M, D, NO, must):
-    """Round 6 (GemmParams::shadow / rowfac / xrow): rms_norm(x) (1 + s) + t in front of a projection (W, b) as
+    """Round 6 (GemmParams::shadow / rf_parts / xrow): rms_norm(x) (1 + s) + t in front of a projection (W, b) as
     r (x (1 + s)) W^T + (t W^T + b).  Producer = a gated-residual GEMM that also leaves y = bf16(x_new (1 + s)), the partial sums of squares of
     x_new and the extra row t'; consumer = the projection with row factors, c as its bias and the extra row's product as the NEXT c.
     Checked against the unfolded kernels (norm pass + plain GEMMs) and fp64."""
@@ -871,18 +871,19 @@ def test_norm_folded_around_the_gemms(dev, M, D, NO, must):
         return
     _, ss = r
     assert torch.equal(xa, xb)                                              # the residual stream itself is untouched by the extra outputs
-    assert rel_l2(ss.sum(-1).cpu(), (xa.double() ** 2).sum(-1).cpu()) < 1e-6
+    assert rel_l2(ss[:, :M].sum(0).cpu(), (xa.double() ** 2).sum(-1).cpu()) < 1e-6
     assert torch.equal(y[:M], (xa * (1.0 + sc)).to(torch.bfloat16))         # the shadow: one rounding of x (1 + s)
     assert torch.equal(y[M], tn)
-    rf = KK.rowfac(ss, D, eps)
-    assert rel_l2(rf.cpu(), torch.rsqrt((xa.double() ** 2).mean(-1) + eps).cpu()) < 1e-6
     # this step's c = t W^T + b (fp64 here; in the engine the previous step's extra row leaves it)
     c_now = (sh.to(torch.bfloat16).double() @ wp.double().T + bp.double()).float()
-    out, c_next = KK.gemm_fold(y, wp, c_now, nv.EPI_BF16, rowfac=rf, xrow=True, xrow_bias=bp)
+    out, c_next = KK.gemm_fold(y, wp, c_now, nv.EPI_BF16, rf_parts=ss, rf_dim=D, eps=eps, xrow=True, xrow_bias=bp)
     exact = ((xa.double() * torch.rsqrt((xa.double() ** 2).mean(-1, keepdim=True) + eps)) * (1 + sc.double()) + sh.double()) @ wp.double().T + bp.double()
     e_fold, e_ref = rel_l2(out.double().cpu(), exact.cpu()), rel_l2(ref.double().cpu(), exact.cpu())
     assert e_fold < 6e-3 and e_fold < 1.5 * e_ref + 1e-4                     # the same accuracy class as norm-then-GEMM
     assert rel_l2(c_next.cpu(), (tn.double() @ wp.double().T + bp.double()).cpu()) < 1e-5
+    # the row factors alone: consumer with unit weights would be overkill -- check them through a second consumer call without the extra row
+    o3 = KK.gemm_fold(y[:M], wp, c_now, nv.EPI_BF16, rf_parts=ss, rf_dim=D, eps=eps)[0]
+    assert torch.equal(o3, out)
     # GELU consumer, no extra row, no row factors given (= 1): plain GEMM + bias
     o2 = KK.gemm_fold(y[:M], wp, bp, nv.EPI_GELU_BF16)[0]
     assert torch.equal(o2, KK.gemm(y[:M].contiguous(), wp, bp, nv.EPI_GELU_BF16))

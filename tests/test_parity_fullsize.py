@@ -409,7 +409,7 @@ def test_fold_norms_levels_agree_and_graph_is_bit_identical(dev):
     outs = {lv: eager(lv) for lv in (0, 1, 2)}
     for lv, y in outs.items():
         assert rel_l2(y.cpu(), ref) < 0.008 and pearson(y.cpu(), ref) > 0.999, lv
-    assert rel_l2(outs[1].cpu(), outs[0].cpu()) < 2e-3 and rel_l2(outs[2].cpu(), outs[0].cpu()) < 2e-3
+    assert rel_l2(outs[1].cpu(), outs[0].cpu()) < 5e-3 and rel_l2(outs[2].cpu(), outs[0].cpu()) < 5e-3
     assert not torch.equal(outs[1], outs[0]) and not torch.equal(outs[2], outs[1])
     # the same loop again: nothing is carried over from the previous loop's last step (its announced sigma, 0, is not this loop's first)
     assert torch.equal(eager(2), outs[2])
@@ -436,7 +436,7 @@ def test_fold_norms_levels_agree_and_graph_is_bit_identical(dev):
         mod = Modality(latent=y0[None], context=C, context_mask=None, timesteps=torch.tensor([odd[i]], device=dev), positions=P)
         m.denoise_step_(y0, mod, odd[i], odd[i + 1] if i != 1 else 0.7)
     m.set_option("fold_norms", 2)
-    assert rel_l2(y.cpu(), y0.cpu()) < 2e-3
+    assert rel_l2(y.cpu(), y0.cpu()) < 5e-3
 
 
 def test_text_qnorm_fold_falls_back_at_20_heads(dev):
