@@ -232,6 +232,48 @@ def extra_configs(dev, layers):
     torch.cuda.current_stream().wait_stream(side)
     del m
     torch.cuda.empty_cache()
+    # --- the headline step at the reference's DEFAULT precision (scripts/generate.py:1006 computes in float16): libltx2hip_f16.so, same geometry
+    m = LTXModel(num_layers=layers, device=dev, compute_dtype=torch.float16)
+    m.init_random_weights(seed=0)
+    m.prepare(ctx3, pos3)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.capture_denoise_graph(lat3, DISTILLED_SIGMA_VALUES)
+        res["fp16_ms_per_step"], res["fp16_runs"] = _median_replay_ms(m, side)
+    torch.cuda.current_stream().wait_stream(side)
+    res["fp16_note"] = "float16 operands (IEEE half MFMA), fp32 accumulation and residual stream; the folded norms (bf16 build only) are off in this build"
+    del m
+    torch.cuda.empty_cache()
+    # --- one external anchor (context, not a target): upstream's LTX-2 19 B audio+video model is quoted at 1.22 s/step on H100 for 121 frames
+    #     at 720p, Euler, CFG = 1 (docs/LTX_2_Technical_Report_compressed.pdf section 6.3).  The 19B-style AudioVideo engine at the nearest valid latent grid:
+    #     121 frames -> 16 latent frames, 1280 x 704 px -> 22 x 40 latent positions (720 is not a multiple of 32), 121 audio latents (4.84 s at 25 per second)
+    m = LTXModel(model_type=LTXModelType.AudioVideo, num_layers=layers, device=dev)
+    m.init_random_weights(seed=0)
+    gh = torch.Generator(device=dev).manual_seed(5)
+    Nh, Nah, Sh = 16 * 22 * 40, 121, 1024
+    vlh, alh = torch.randn(Nh, 128, generator=gh, device=dev), torch.randn(Nah, 128, generator=gh, device=dev)
+    vch, ach = 0.1 * torch.randn(1, Sh, 3840, generator=gh, device=dev), 0.1 * torch.randn(1, Sh, 3840, generator=gh, device=dev)
+    vph = VideoLatentTools(VideoLatentPatchifier(1), VideoLatentShape(1, 128, 16, 22, 40), fps=25.0).create_initial_state(device=dev).positions
+    aph = AudioLatentTools(AudioPatchifier(1), AudioLatentShape(1, 8, Nah, 16)).create_initial_state(device=dev).positions
+    m.prepare(vch, vph, audio_context=ach, audio_positions=aph)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.capture_denoise_graph(vlh, DISTILLED_SIGMA_VALUES, audio_latent=alh)
+        ms, runs = _median_replay_ms(m, side)
+    torch.cuda.current_stream().wait_stream(side)
+    res["h100_table_geometry_av_ms_per_step"] = ms
+    res["h100_table_geometry_av_runs"] = runs
+    res["h100_table_geometry_av"] = {
+        "geometry": "121 frames, 1280x704 px -> 16 x 22 x 40 = 14080 video tokens + 121 audio tokens, S = 1024, LTX-2 19B-style AudioVideo DiT, "
+                    f"{layers} layers, bf16, Euler, CFG = 1 (one model evaluation per step), random-init weights",
+        "video_stream_algorithmic_tflop": round(dit_algorithmic_flops(Nh, Sh, 4096, layers) / 1e12, 1),
+        "published_h100_s_per_step": 1.22,
+        "note": "context, not a target: upstream PyTorch on H100 (720p exactly, their kernels, their attention); here the same model family on one MI355X",
+    }
+    del m
+    torch.cuda.empty_cache()
     # --- config 4 shape: 48-layer AudioVideo DiT with 9-row AdaLN, prompt-modulated text K/V, per-head gates
     m = LTXModel(model_type=LTXModelType.AudioVideo, num_layers=layers, caption_channels=None, cross_attention_adaln=True,
                  apply_gated_attention=True, av_ca_timestep_scale_multiplier=1000, device=dev)
@@ -276,7 +318,21 @@ def extra_configs(dev, layers):
     res["two_stage_1536x1024x65_decode_tiled_runs_s"] = [round(r, 3) for r in runs]
     res["two_stage_decode_note"] = ("`decode_tiled` is what DistilledPipeline runs at this size (reference default tiling: overlapping tiles decode "
                                     "~3.6x the volume); the whole-volume `decode_latent` figure is the same decoder without tiling")
-    del m, dec, up, pipe
+    # --- one whole generation at the headline size with everything resident (the reference's docs/USAGE.md:310-314 quotes ~2 min end to end
+    #     for 512 x 768 x 65, 8 steps, on an M3 Max): prompt setup + the 8-step loop + VAE decode to uint8 frames through DistilledPipeline; the text encoder
+    #     (Gemma, not built) and the mp4 writer are outside it
+    pipe1 = DistilledPipeline(m, dec, None)
+    conf1 = DistilledConfig(height=512, width=768, num_frames=65, seed=0, use_hip_graph=True)
+
+    def one_generation():
+        lat1 = pipe1(ctx, None, conf1)
+        return decode_latent(lat1, dec)
+    med, runs, fr = _median_s(one_generation)
+    res["e2e_generate_s"] = round(med, 3)
+    res["e2e_generate_runs_s"] = [round(r, 3) for r in runs]
+    res["e2e_generate_note"] = (f"768x512x65, 8 distilled steps + VAE decode -> {tuple(fr.shape)} uint8 frames, weights resident, text features given; "
+                                "the reference quotes ~2 min on an M3 Max for the same size (incl. its text encoder)")
+    del m, dec, up, pipe, pipe1
     torch.cuda.empty_cache()
     return res
 
@@ -346,6 +402,7 @@ def main():
     ap.add_argument("--loader-layers", type=int, default=8, help="layers of the synthetic checkpoint the loader-throughput leg writes and loads "
                     "(8 = 4.3 GB, bounded for the default run; 48 = the full 25.8 GB file)")
     ap.add_argument("--no-loader", action="store_true", help="skip the checkpoint-loader throughput leg")
+    ap.add_argument("--fold", type=int, default=None, help="engine option fold_norms for the headline model (0 = round 5's norm passes; default: the engine's, 2)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args.gpus))
@@ -369,6 +426,11 @@ def main():
     # ---------------- model (random init of the 19B architecture; rank 0 -> RCCL broadcast) ----------------
     L = args.layers
     model = LTXModel(num_layers=L, device=dev)
+    if args.fold is not None:
+        try:
+            model.set_option("fold_norms", args.fold)
+        except Exception as e:  # noqa: BLE001  (an A/B library of an earlier round has no such option)
+            print(f"bench: fold_norms not set: {e}", file=sys.stderr)
     model.init_random_weights(seed=0, fill=(rank == 0))         # ranks > 0 only ALLOCATE (whatever the allocator hands back): their weights arrive by the broadcast
     wt = model.weight_tensors()
     w_bytes = sum(t.numel() * t.element_size() for t in wt.values())
@@ -514,6 +576,24 @@ def main():
             torch.cuda.synchronize()
             return model.profile_end()
         k_ms, k_n, k_fl = (0.0, 0, 0.0) if args.no_kernel_pass else (leg("kernel_pass", kernel_pass) or (0.0, 0, 0.0))
+        # ---------------- same-box A/B of round 6's folded norms (engine option fold_norms; not part of `value`): the same K eager steps with a norm pass in
+        #                  front of every projection (round 5's form), on this box, right behind the headline ----------------
+        def fold_ab():
+            lvl = 2 if args.fold is None else args.fold
+            try:
+                model.set_option("fold_norms", 0)
+                run_steps(max(W, 2))
+                torch.cuda.synchronize()
+                t_start = time.perf_counter()
+                run_steps(K)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t_start) / K * 1e3
+            finally:
+                model.set_option("fold_norms", lvl)
+                run_steps(1)
+        f0 = None if args.no_kernel_pass else leg("fold_ab", fold_ab)
+        out["fold_norms"] = {"level": 2 if args.fold is None else args.fold, "unfolded_ms_per_step": None if f0 is None else round(f0, 3),
+                             "note": "level 2 (default): the block's three RMS norms ride on the GEMM epilogues around them (DESIGN.md); unfolded = option 0, the same K eager steps on this box"}
         # HBM/fabric traffic of the dominant kernel cannot be collected from inside the process: it comes from the committed
         # rocprofv3 --pmc passes of THIS kernel version (the newest profiles/r*_pmc_traffic.json names the commit), null if absent.
         traffic, traffic_src, traffic_stale = None, None, None

@@ -119,10 +119,17 @@ __device__ __forceinline__ void mfma16_result_guard(f32x4 (&s)[4][2], float& t0,
 // keys so far are all masked has M = -1e30, which a relative accumulator start would swallow the real scores in).
 #ifndef AT_P_BIG
 #ifdef LTX2_F16
-#define AT_P_BIG 4096.0f            // P is IEEE half in this build: every P <= the lane's tile sum <= 2^12
+#define AT_P_BIG 32768.0f           // P is IEEE half in this build (max 65504): every P <= the lane's 16-key tile sum <= 2^15 (round 5: 2^12; round 6 measured
+                                    // how often real-shaped scores cross either bound: profiles/r06_attn_data_dependence.md)
 #else
 #define AT_P_BIG 1073741824.0f      // 2^30: l and O have 2^90 of fp32 headroom left over 3456 keys
 #endif
+#endif
+
+#ifdef AT_COUNT_FALLBACK
+// measurement build only (tools/ab_build.py ... attention.hip=-DAT_COUNT_FALLBACK; never shipped): [0] = wave-tiles that entered the stale-maximum path,
+// [1] = those that fell back to the classic path because a lane's exponential sum crossed AT_P_BIG
+__device__ unsigned long long ltx2_at_counts[2];
 #endif
 
 template <int HD, bool QS = false, bool KM = false>
@@ -319,6 +326,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         if constexpr (FAST) {
             static_for<0, 4>([&](auto Q4) { exp_pair(std::integral_constant<int, 3>{}, Q4); });
             classic = __any(!(ps[0] <= AT_P_BIG && ps[1] <= AT_P_BIG));          // (also catches a NaN sum)
+#ifdef AT_COUNT_FALLBACK
+            if (lane == 0) {
+                atomicAdd(&ltx2_at_counts[0], 1ull);
+                if (classic) atomicAdd(&ltx2_at_counts[1], 1ull);
+            }
+#endif
         }
         if (classic) {
             if constexpr (MASKED) {
@@ -529,6 +542,17 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_LAUNCH("attn_fwd_kernel");
     return LTX2_OK;
 }
+
+#ifdef AT_COUNT_FALLBACK
+extern "C" int ltx2_attn_fallback_counts(unsigned long long* out2, int reset) {
+    if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(ltx2_at_counts), 16) != hipSuccess) return LTX2_E_HIP;
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ltx2_at_counts), z, 16) != hipSuccess) return LTX2_E_HIP;
+    }
+    return LTX2_OK;
+}
+#endif
 
 int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream, int head_dim) {
     LTX2_CHECK_ARG(Npad % 64 == 0 && Npad >= Nkv && ld % 8 == 0, "vt_transpose: bad strides");

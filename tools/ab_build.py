@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Build a VARIANT of libltx2hip.so for same-box A/B timing: `python tools/ab_build.py NAME file.hip='-DX=1 -fno-slp-vectorize' ...`
 recompiles the named translation units with extra flags, links them with the standard objects (make first) and writes
-ltx-2-mlx_amd/lib/ab/NAME.so (git-ignored; it travels to the GPU box).  Use with LTX2HIP_LIB=ltx-2-mlx_amd/lib/ab/NAME.so."""
+ltx-2-mlx_amd/lib/ab/NAME.so (git-ignored; it travels to the GPU box).  Use with LTX2HIP_LIB=ltx-2-mlx_amd/lib/ab/NAME.so.
+`--f16` as the first argument: the float16 build (-DLTX2_F16, objects of build/f16) -> lib/ab/NAME.so for LTX2HIP_LIB_F16."""
 import os
 import subprocess
 import sys
@@ -12,7 +13,11 @@ FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-inlin
 
 
 def main():
-    name, specs = sys.argv[1], dict(a.split("=", 1) for a in sys.argv[2:])
+    argv = sys.argv[1:]
+    f16 = bool(argv) and argv[0] == "--f16"
+    if f16:
+        argv = argv[1:]
+    name, specs = argv[0], dict(a.split("=", 1) for a in argv[1:])
     subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
     bdir = os.path.join(CSRC, "build", "ab", name)
     os.makedirs(bdir, exist_ok=True)
@@ -21,9 +26,10 @@ def main():
     for s in srcs:
         if s in specs:
             o = os.path.join(bdir, s.replace(".hip", ".o"))
-            procs.append(subprocess.Popen(["hipcc", *FLAGS, *specs[s].split(), "-c", os.path.join(CSRC, s), "-o", o], cwd=CSRC))
+            std = ["-fno-slp-vectorize"] if s == "attention.hip" else []       # (the Makefile's per-file flag)
+            procs.append(subprocess.Popen(["hipcc", *FLAGS, *(["-DLTX2_F16"] if f16 else []), *std, *specs[s].split(), "-c", os.path.join(CSRC, s), "-o", o], cwd=CSRC))
         else:
-            o = os.path.join(CSRC, "build", s.replace(".hip", ".o"))
+            o = os.path.join(CSRC, "build", *(["f16"] if f16 else []), s.replace(".hip", ".o"))
         objs.append(o)
     if any(p.wait() for p in procs):
         raise SystemExit("compile failed")
