@@ -85,7 +85,9 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // fp32 partial tile into slab `split` of p.out ([splitk][M][ldo] fp32); splitk_reduce_kernel adds the slabs
     // round 6 (GemmParams "fold" fields): the dense bf16 layout-3 kernels only.  XROW: A holds one more row than `out` (row M: the next step's shift row);
     // M % BM != 0 (gemm_fold_supported), so it lies inside the last row tile and the tile count does not change
-    constexpr bool FOLD_OK = LAYOUT == 3 && !CONV && VAR == 0;
+    // (VAR == 30: its own instantiations -- compiled into the plain kernels the extra parameters and LDS cost them 2-4 % with nothing folded: same-box layer
+    //  traces, profiles/r06_layer_trace_*.txt)
+    constexpr bool FOLD_OK = LAYOUT == 3 && !CONV && VAR == 30;
     constexpr bool FOLD_CONS = FOLD_OK && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16);         // consumer side: row factors, the extra row
     constexpr bool FOLD_PROD = FOLD_OK && EPI == EPI_RESID_GATE_F32;                          // producer side: bf16 shadow + partial sums of squares
     const int Mx = p.M + (FOLD_CONS ? p.xrow : 0);
@@ -331,12 +333,15 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // 32x32 block: row lr, groups gq = 0..3 at columns 8 gq + 4 kq (accumulator registers 4 gq .. 4 gq + 3)
     // 16x16 block: row lr, one group at columns 4 kq (accumulator registers 0..3)
     if constexpr (!HOIST_COL_VECTORS) load_bias();
+    // (fold-specific addresses are formed from these copies: built from lr / kq directly hipcc forms them in FRONT of the loop and carries them across it in scratch)
+    [[maybe_unused]] int lr_e = lr, kq_e = kq, tid_e = tid;
+    if constexpr (FOLD_OK) asm volatile("" : "+v"(lr_e), "+v"(kq_e), "+v"(tid_e));
     if constexpr (FOLD_CONS) {
-        if (p.rf_parts && tid < BM) {       // row tid of the tile: the partials in part order (deterministic), then the RMS factor
+        if (p.rf_parts && tid_e < BM) {       // row tid of the tile: the partials in part order (deterministic), then the RMS factor
             const float* pl = (const float*)(smem + RF_OFF);
             float sq = 0.f;
-            for (int j = 0; j < p.rf_nparts; ++j) sq += pl[j * BM + tid];
-            *(float*)(smem + RF_FAC + tid * 4) = rsqrtf(sq / (float)p.rf_dim + p.rf_eps);
+            for (int j = 0; j < p.rf_nparts; ++j) sq += pl[j * BM + tid_e];
+            *(float*)(smem + RF_FAC + tid_e * 4) = rsqrtf(sq / (float)p.rf_dim + p.rf_eps);
         }
     }
     load_gate();
@@ -555,7 +560,7 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
         __syncthreads();                                    // every wave has finished its fragment reads
         if constexpr (FOLD_CONS) {
 #pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) rf[rb] = p.rf_parts ? *(const float*)(smem + RF_FAC + (rb * MB + lr) * 4) : 1.f;
+            for (int rb = 0; rb < RBW; ++rb) rf[rb] = p.rf_parts ? *(const float*)(smem + RF_FAC + (rb * MB + lr_e) * 4) : 1.f;
         }
         char* wl = smem + w * (WM * ROWB);
         if constexpr (EPI == EPI_ADD_BF16) {
@@ -605,7 +610,7 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
                 if constexpr (FOLD_CONS) {
                     v = acc_group(rb, cb, gq) * rf[rb] + bias4[cb][gq];
                     if (p.xrow && m0 + r == p.M)        // the extra row: its product (+ the projection's own bias) is the next step's bias vector; its slab row is never stored
-                        *(f32x4*)(p.xrow_out + n0 + wc * WN + cb * MB + 4 * kq) = acc_group(rb, cb, gq) + *(const f32x4*)(p.xrow_bias + n0 + wc * WN + cb * MB + 4 * kq);
+                        *(f32x4*)(p.xrow_out + n0 + wc * WN + cb * MB + 4 * kq_e) = acc_group(rb, cb, gq) + *(const f32x4*)(p.xrow_bias + n0 + wc * WN + cb * MB + 4 * kq_e);
                 } else {
                     v = acc_group(rb, cb, gq) + bias4[cb][gq];
                 }
@@ -766,7 +771,7 @@ int launch_v4(const GemmParams& p, hipStream_t stream) {
     // (RESID_PRELOAD in the kernel): + 32 KiB = the CU's whole 160 KiB
     // (round 6) the bf16 / GELU kernels of the dense bf16 loop stage a folded norm's partial sums + row factors above the stage buffers: (GEMM_RF_MAX_PARTS + 1) x BM floats
     constexpr int LDS = G::LDS_BYTES + ((EPI == EPI_RESID_GATE_F32 && LAYOUT == 3 && BM == 224 && !CONV && VAR != 20 && VAR != 9) ? 32768 : 0) +
-                        ((LAYOUT == 3 && !CONV && VAR == 0 && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16)) ? (GEMM_RF_MAX_PARTS + 1) * BM * 4 : 0);
+                        ((LAYOUT == 3 && !CONV && VAR == 30 && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16)) ? (GEMM_RF_MAX_PARTS + 1) * BM * 4 : 0);
     static_assert(LDS <= 160 * 1024, "LDS");
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
@@ -889,6 +894,16 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
     }
     const bool b224 = bm ? bm == 224 : gemm_v4_prefer_224(p);
     LTX2_CHECK_ARG(layout == 3, "gemm_v4: wave layout %d (3 = bf16 dense, 4 = 128-column convs, 5 = fp8 compute)", layout);
+    if (p.shadow || p.rf_parts || p.xrow) {      // a folded norm's producer / consumer half: the VAR = 30 instantiations
+        switch (epilogue) {
+            case EPI_BF16: return b224 ? launch_v4<EPI_BF16, 3, 224, false, 30>(p, stream) : launch_v4<EPI_BF16, 3, 256, false, 30>(p, stream);
+            case EPI_GELU_BF16: return b224 ? launch_v4<EPI_GELU_BF16, 3, 224, false, 30>(p, stream) : launch_v4<EPI_GELU_BF16, 3, 256, false, 30>(p, stream);
+            case EPI_RESID_GATE_F32: return b224 ? launch_v4<EPI_RESID_GATE_F32, 3, 224, false, 30>(p, stream) : launch_v4<EPI_RESID_GATE_F32, 3, 256, false, 30>(p, stream);
+            default:
+                ltx2_set_error("gemm_v4: a folded norm on epilogue %d", epilogue);
+                return LTX2_E_INVALID;
+        }
+    }
 #define CASE(E) \
     case E:     \
         return b224 ? launch_v4<E, 3, 224>(p, stream) : launch_v4<E, 3, 256>(p, stream);
