@@ -242,7 +242,7 @@ def extra_configs(dev, layers):
         m.capture_denoise_graph(lat3, DISTILLED_SIGMA_VALUES)
         res["fp16_ms_per_step"], res["fp16_runs"] = _median_replay_ms(m, side)
     torch.cuda.current_stream().wait_stream(side)
-    res["fp16_note"] = "float16 operands (IEEE half MFMA), fp32 accumulation and residual stream; the folded norms (bf16 build only) are off in this build"
+    res["fp16_note"] = "float16 operands (IEEE half MFMA), fp32 accumulation and residual stream; the folded pre-norm (bf16 build only) is off in this build"
     del m
     torch.cuda.empty_cache()
     # --- one external anchor (context, not a target): upstream's LTX-2 19 B audio+video model is quoted at 1.22 s/step on H100 for 121 frames
@@ -402,7 +402,7 @@ def main():
     ap.add_argument("--loader-layers", type=int, default=8, help="layers of the synthetic checkpoint the loader-throughput leg writes and loads "
                     "(8 = 4.3 GB, bounded for the default run; 48 = the full 25.8 GB file)")
     ap.add_argument("--no-loader", action="store_true", help="skip the checkpoint-loader throughput leg")
-    ap.add_argument("--fold", type=int, default=None, help="engine option fold_norms for the headline model (0 = round 5's norm passes; default: the engine's, 2)")
+    ap.add_argument("--fold", type=int, default=None, help="engine option fold_norms for the headline model (0 = round 5's norm passes; default: the engine's, 1)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args.gpus))
@@ -579,7 +579,7 @@ def main():
         # ---------------- same-box A/B of round 6's folded norms (engine option fold_norms; not part of `value`): the same K eager steps with a norm pass in
         #                  front of every projection (round 5's form), on this box, right behind the headline ----------------
         def fold_ab():
-            lvl = 2 if args.fold is None else args.fold
+            lvl = 1 if args.fold is None else args.fold
             try:
                 model.set_option("fold_norms", 0)
                 run_steps(max(W, 2))
@@ -592,8 +592,9 @@ def main():
                 model.set_option("fold_norms", lvl)
                 run_steps(1)
         f0 = None if args.no_kernel_pass else leg("fold_ab", fold_ab)
-        out["fold_norms"] = {"level": 2 if args.fold is None else args.fold, "unfolded_ms_per_step": None if f0 is None else round(f0, 3),
-                             "note": "level 2 (default): the block's three RMS norms ride on the GEMM epilogues around them (DESIGN.md); unfolded = option 0, the same K eager steps on this box"}
+        out["fold_norms"] = {"level": 1 if args.fold is None else args.fold, "unfolded_ms_per_step": None if f0 is None else round(f0, 3),
+                             "note": "level 1 (default): the text cross-attention's RMS pre-norm rides on attn1.to_out's epilogue and attn2.to_q's accumulators (DESIGN.md); "
+                                     "unfolded = option 0, the same K eager steps on this box"}
         # HBM/fabric traffic of the dominant kernel cannot be collected from inside the process: it comes from the committed
         # rocprofv3 --pmc passes of THIS kernel version (the newest profiles/r*_pmc_traffic.json names the commit), null if absent.
         traffic, traffic_src, traffic_stale = None, None, None

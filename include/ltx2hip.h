@@ -103,22 +103,19 @@ int ltx2_gemm_bf16_rowss(const void* A, int64_t lda, const void* W, const float*
 int ltx2_flash_attn_rowscale(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
                              int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, void* stream);
 
-/* RMS norms folded around the GEMMs (round 6; _compiled_adaln_forward + nn.Linear, transformer.py:16-31, 191-238, as arithmetic instead of a pass
- * over x): rms_norm(x) (1 + s) + t in front of a projection (W, b) equals r (x (1 + s)) W^T + (t W^T + b), r[m] = rsqrt(mean_j x[m][j]^2 + eps).
- * ltx2_gemm_bf16_fold: ltx2_gemm_bf16 with the producer / consumer halves of that identity (any of them may be absent: null / 0):
+/* An RMS norm folded around two GEMMs (round 6; rms_norm + nn.Linear, transformer.py:217-226, as arithmetic instead of a pass over x):
+ * rms_norm(x) (1 + s) in front of a projection (W, b) equals r (x (1 + s)) W^T + b, r[m] = rsqrt(mean_j x[m][j]^2 + eps).
+ * ltx2_gemm_bf16_fold: ltx2_gemm_bf16 with the producer / consumer half of that identity:
  *   epilogue RESID_GATE_F32 (x += gate_table * (acc + bias), row-invariant gate): shadow[m][n] = 16-bit(x_new[m][n] * (1 + shadow_scale[n]))
- *     (row stride ld_shadow), shadow_ss[(n / 256) * ld_ss + m] = the sum of x_new[m][n]^2 over each 256-column tile (ld_ss >= the row tiles' extent:
- *     M rounded up to a multiple of 256 is always enough; % 4 == 0), and shadow_xrow [N] copied into shadow row M;
+ *     (row stride ld_shadow; shadow_scale null: * 1) and shadow_ss[(n / 256) * ld_ss + m] = the sum of x_new[m][n]^2 over each 256-column tile
+ *     (ld_ss >= the row tiles' extent: M rounded up to a multiple of 256 is always enough; % 4 == 0);
  *   epilogue BF16 / GELU_BF16: out = epilogue(r[m] * acc + bias) with r[m] = rsqrt(sum_{j < rf_nparts} rf_parts[j * rf_ld + m] / rf_dim + rf_eps)
- *     formed inside the kernel (rf_parts = a producer's shadow_ss, rf_nparts <= 24; null: r = 1); xrow = 1: A holds M + 1 rows and row M's
- *     product leaves as fp32 xrow_out[n] = acc + xrow_bias[n] instead of reaching out (with the NEXT step's shift row t' as row M that is the next
- *     step's t' W^T + b, formed by the GEMM that streams W anyway).
+ *     formed inside the kernel (rf_parts = a producer's shadow_ss, rf_nparts <= 24).
  *   *supported = 0 (nothing launched) when the 4-wave layout-3 kernel does not take the problem (M >= 1024, N % 256 == 0, K % 128 == 0, dense 16-bit
- *   weights; xrow / shadow_xrow: M not a multiple of the row tile).                                                                               */
+ *   weights) or neither half is asked for.                                                                                                         */
 int ltx2_gemm_bf16_fold(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue,
-                        const float* gate_table, void* shadow, int64_t ld_shadow, const float* shadow_scale, float* shadow_ss, int64_t ld_ss, const void* shadow_xrow,
-                        const float* rf_parts, int64_t rf_ld, int rf_nparts, int rf_dim, float rf_eps, int xrow, float* xrow_out, const float* xrow_bias,
-                        int* supported, void* stream);
+                        const float* gate_table, void* shadow, int64_t ld_shadow, const float* shadow_scale, float* shadow_ss, int64_t ld_ss,
+                        const float* rf_parts, int64_t rf_ld, int rf_nparts, int rf_dim, float rf_eps, int* supported, void* stream);
 
 /* flash attention with a key mask (attention.py:38-70 with the additive mask model.py:163-201 builds from a boolean (B, S) context
  * mask): mask fp32 [Nkv], non-zero = the key may be attended; a masked key takes no weight unless every key is masked (then the
@@ -408,11 +405,9 @@ int ltx2_dit_set_context_mask(ltx2_dit* ctx, int modality, const float* mask, in
  *   reference's dequantise-at-load).
  *   "adaln_combine" = 0 (any time): tables and timestep embeddings reach every kernel separately, as in round 3.  Default 1: with one
  *   timestep per modality the sums of all layers are formed by one launch at the top of the step (bit-identical results).
- *   "fold_norms" = 0 / 1 / 2 (any time; default 2; VideoOnly non-V2.3 models on dense 16-bit weights in the bfloat16 build, one timestep per modality):
- *   1: the text cross-attention's plain RMS pre-norm rides on attn1.to_out's epilogue (ltx2_gemm_bf16_fold); 2: the two AdaLN-modulated norms of a block too,
- *   in steps that know the next sigma (ltx2_dit_denoise_step, the captured loops): each QKV / FFN-up projection forms the NEXT step's shift product
- *   from one extra operand row; a loop's first step (and any step whose sigma is not the one the previous step announced) runs the norm passes.  0: round 5's
- *   form, a norm pass in front of every projection.  Same mathematics, the operand is rounded before the row factor instead of after it.
+ *   "fold_norms" = 0 / 1 (any time; default 1; VideoOnly non-V2.3 models on dense 16-bit weights in the bfloat16 build, one timestep per modality):
+ *   1: the text cross-attention's plain RMS pre-norm rides on attn1.to_out's epilogue and attn2.to_q's accumulators (ltx2_gemm_bf16_fold) instead of
+ *   running as a pass over the residual stream; 0: round 5's form.  Same mathematics; the operand is rounded before the row factor instead of after it.
  *   "text_kv_ahead" = 0 (any time; AudioVideo models with cross_attention_adaln only): the video stream projects its sigma-modulated text K / V
  *   inline, in front of its text cross-attention (round 4's schedule).  Default 1 (round 5): they are a function of the prompt and sigma only,
  *   so layer l's are projected on the side stream at the top of layer l, beside the main stream's norm / QKV projection (bit-identical

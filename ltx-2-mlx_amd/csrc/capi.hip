@@ -74,9 +74,8 @@ int ltx2_gemm_bf16_rowss(const void* A, int64_t lda, const void* W, const float*
 }
 
 int ltx2_gemm_bf16_fold(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N, int K, int epilogue,
-                        const float* gate_table, void* shadow, int64_t ld_shadow, const float* shadow_scale, float* shadow_ss, int64_t ld_ss, const void* shadow_xrow,
-                        const float* rf_parts, int64_t rf_ld, int rf_nparts, int rf_dim, float rf_eps, int xrow, float* xrow_out, const float* xrow_bias,
-                        int* supported, void* stream) {
+                        const float* gate_table, void* shadow, int64_t ld_shadow, const float* shadow_scale, float* shadow_ss, int64_t ld_ss,
+                        const float* rf_parts, int64_t rf_ld, int rf_nparts, int rf_dim, float rf_eps, int* supported, void* stream) {
     LTX2_CHECK_ARG(A && W && out && supported, "gemm_bf16_fold: null argument");
     LTX2_CHECK_ARG(epilogue == LTX2_EPI_BF16 || epilogue == LTX2_EPI_GELU_BF16 || epilogue == LTX2_EPI_RESID_GATE_F32, "gemm_bf16_fold: epilogue %d (BF16, GELU_BF16 or RESID_GATE_F32)", epilogue);
     GemmParams p{};
@@ -95,16 +94,12 @@ int ltx2_gemm_bf16_fold(const void* A, int64_t lda, const void* W, const float* 
     p.shadow_scale = shadow_scale;
     p.shadow_ss = shadow_ss;
     p.ld_ss = ld_ss;
-    p.shadow_xrow = (const bf16*)shadow_xrow;
     p.rf_parts = rf_parts;
     p.rf_ld = rf_ld;
     p.rf_nparts = rf_nparts;
     p.rf_dim = rf_dim;
     p.rf_eps = rf_eps;
-    p.xrow = xrow;
-    p.xrow_out = xrow_out;
-    p.xrow_bias = xrow_bias;
-    *supported = gemm_fold_supported(p, epilogue) ? 1 : 0;
+    *supported = ((p.shadow || p.rf_parts) && gemm_fold_supported(p, epilogue)) ? 1 : 0;
     if (!*supported) return LTX2_OK;
     return gemm_launch(p, epilogue, false, (hipStream_t)stream);
 }

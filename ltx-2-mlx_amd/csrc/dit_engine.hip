@@ -85,14 +85,10 @@ struct Mod {        // per-modality geometry + workspace
     float* qss = nullptr;           // text cross-attention with q_norm folded in: partial row sums of squares of the projected queries [N][D/64]
     float* knq = nullptr;           //   and k_norm.weight * q_norm.weight per layer [L][D] (the per-dim q weight moves onto the cached keys)
     bool qfold = false;             //   decided per prepare: the query projection runs on a kernel that writes the partial sums
-    // round 6, norms folded around the GEMMs (GemmParams::shadow / rf_parts / xrow; fold_supported()): h doubles as the bf16 shadow of the residual stream
-    float* rss = nullptr;           //   partial sums of squares of the new residual rows, one per 256-column tile [D/256][rss_ld], left by the producing gated-residual epilogue
-    long rss_ld = 0;                //   (the consuming projection turns them into its rows' RMS factors itself)
-    float* cvec[2] = {nullptr, nullptr};   //   per layer [3D | 4D]: c = shift W^T + bias of the QKV / FFN-up projections for this step's sigma, and the set the GEMMs of this step leave for the next sigma
-    float* embn = nullptr;          //   the next sigma's AdaLN shift rows (shift_msa, shift_mlp) [2][D]
-    bf16* tnext = nullptr;          //   the next step's shift rows per layer, bf16 [L][2][D]: the extra row of the QKV / FFN-up operands
-    float* sig_next = nullptr;      //   the next sigma as a device scalar (eager steps)
-    int fold_max = 0;               //   what this geometry / model supports (prepare): 0 none, 1 the plain text-cross-attention pre-norm, 2 also the two modulated norms
+    // round 6, the text cross-attention's pre-norm folded around the GEMMs (GemmParams::shadow / rf_parts; fold_supported()): h doubles as the bf16 shadow of the residual stream
+    float* rss = nullptr;           //   partial sums of squares of the new residual rows, one per 256-column tile [D/256][rss_ld], left by attn1.to_out's epilogue
+    long rss_ld = 0;                //   (the query projection turns them into its rows' RMS factors itself)
+    int fold_max = 0;               //   what this geometry / model supports (prepare): 0 none, 1 the fold
     unsigned char* a8 = nullptr;    // fp8 compute: per-token e4m3fn codes of the current GEMM's activation operand [N][<= 4D]
     float* a8s = nullptr;           //              and their row scales [N]
 };
@@ -119,11 +115,8 @@ struct ltx2_dit {
     bool adaln_combine = true;         // ltx2_dit_set_option("adaln_combine"): round 4, see forward()
     bool text_kv_ahead = true;         // ltx2_dit_set_option("text_kv_ahead"): round 5, AudioVideo V2.3 -- the video stream's sigma-modulated text K / V of layer l are projected on the SIDE stream at the top of the layer
     hipEvent_t text_kv_ev = nullptr;   //   (they depend on the prompt and sigma only); the main stream waits on this event in front of its text cross-attention
-    int fold_norms = 2;                // ltx2_dit_set_option("fold_norms"): round 6, see block_attention() / FoldStep: 0 = every norm a pass of its own (round 5), 1 = the text cross-attention's
-                                       //   plain RMS pre-norm rides on attn1.to_out's epilogue, 2 = the two AdaLN-modulated norms too (steps that know the next sigma: denoise_step / the captured loop)
-    bool c_valid = false;              //   m[0].cvec[c_cur] holds the projections' shift products for sigma == c_sigma (left by the previous step)
-    float c_sigma = 0.f;
-    int c_cur = 0;
+    int fold_norms = 1;                // ltx2_dit_set_option("fold_norms"): round 6, see block_attention(): 0 = every norm a pass of its own (round 5), 1 = the text cross-attention's
+                                       //   plain RMS pre-norm rides on attn1.to_out's epilogue
     bool fp8_compute = false;          // ltx2_dit_set_option("fp8_compute"): fp8-resident weights x per-token fp8 activations on the fp8 MFMA
     bool prepared = false;
     hipGraph_t graph = nullptr;
@@ -160,7 +153,7 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         const long T = per_token ? n : 1, rows = c->v2 ? 9 : 6;
         m.x = (float*)take(4L * n * D);
         m.lat = (bf16*)take(2L * n * m.Cin);
-        m.h = (bf16*)take(2L * (n + 1) * D);        // (+ 1 row: the extra operand row of a folded norm, GemmParams::xrow)
+        m.h = (bf16*)take(2L * n * D);
         m.h2 = (bf16*)take(c->av ? 2L * n * D : 0);
         m.qkv = (bf16*)take(2L * n * 3 * D);      // also the cross-modal Q / K,V projected from this modality's tokens
         m.vt = (bf16*)take(2L * D * npad);
@@ -173,11 +166,6 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         const bool fold_bufs = k == 0 && !c->av;
         m.rss_ld = align_up(n, 256) + 256;
         m.rss = (float*)take(fold_bufs ? 4L * (D / 256 + 1) * m.rss_ld : 0);
-        m.cvec[0] = (float*)take(fold_bufs ? 4L * L * 7 * D : 0);
-        m.cvec[1] = (float*)take(fold_bufs ? 4L * L * 7 * D : 0);
-        m.embn = (float*)take(fold_bufs ? 4L * 2 * D : 0);
-        m.tnext = (bf16*)take(fold_bufs ? 2L * L * 2 * D : 0);
-        m.sig_next = (float*)take(fold_bufs ? 256 : 0);
         m.a8 = (unsigned char*)take((c->fp8_compute && k == 0) ? n * 4 * D : 0);
         m.a8s = (float*)take((c->fp8_compute && k == 0) ? 4L * n : 0);
         m.sin_f = (float*)take(4L * 256);
@@ -406,8 +394,8 @@ bool text_qfold_ok(ltx2_dit* c, int k) {
     return gemm_rowss_supported(q, EPI_BF16);
 }
 
-// round 6: how far the norms of this modality's blocks can be folded around their GEMMs (FoldStep below): VideoOnly non-V2.3 ungated models on dense bf16
-// weights in the bfloat16 build, every GEMM involved on the 4-wave layout-3 kernel; level 2 also needs a row tile with room for the extra operand row
+// round 6: can the text cross-attention's pre-norm of this modality's blocks be folded around attn1.to_out / attn2.to_q (block_attention())?  VideoOnly non-V2.3
+// ungated models on dense bf16 weights in the bfloat16 build (the un-normalised shadow is not safe in IEEE half), both GEMMs on the 4-wave layout-3 kernel
 int fold_supported(ltx2_dit* c, int k) {
 #ifdef LTX2_F16
     (void)c; (void)k;
@@ -423,7 +411,7 @@ int fold_supported(ltx2_dit* c, int k) {
     q.M = m.N;
     q.K = m.D;
     q.out = m.x;
-    // producers: attn1.to_out / attn2.to_out (K = D), ff.net.2 (K = 4D); consumers: attn2.to_q, attn1.to_qkv, ff.net.0
+    // producer: attn1.to_out; consumer: attn2.to_q
     q.W = w.self.o_w;
     q.N = m.D;
     q.ldo = m.D;
@@ -446,25 +434,7 @@ int fold_supported(ltx2_dit* c, int k) {
     r.rf_nparts = m.D / 256;
     r.rf_dim = m.D;
     if (!gemm_fold_supported(r, EPI_BF16)) return 0;
-    // level 2
-    q.shadow_xrow = m.tnext;
-    GemmParams q2 = q;
-    q2.K = 4 * m.D;
-    q2.lda = 4 * m.D;
-    q2.W = w.ff2_w;
-    r.xrow = 1;
-    r.xrow_out = m.cvec[0];
-    r.xrow_bias = w.self.qkv_b;
-    GemmParams r1 = r, r2 = r;
-    r1.N = 3 * m.D;
-    r1.ldo = 3 * m.D;
-    r1.W = w.self.qkv_w;
-    r2.N = 4 * m.D;
-    r2.ldo = 4 * m.D;
-    r2.W = w.ff1_w;
-    r2.out = m.ff;
-    if (!gemm_fold_supported(q, EPI_RESID_GATE_F32) || !gemm_fold_supported(q2, EPI_RESID_GATE_F32) || !gemm_fold_supported(r1, EPI_BF16) || !gemm_fold_supported(r2, EPI_GELU_BF16)) return 1;
-    return 2;
+    return 1;
 #endif
 }
 
@@ -478,15 +448,11 @@ struct Fold {
     bf16* shadow = nullptr;
     const float* shadow_scale = nullptr;
     float* shadow_ss = nullptr;
-    const bf16* shadow_xrow = nullptr;
     long ld_shadow = 0;
     const float* rf_parts = nullptr;
     long ld_ss = 0;         // row stride of shadow_ss / rf_parts
     int rf_nparts = 0, rf_dim = 0;
     float rf_eps = 0.f;
-    int xrow = 0;
-    float* xrow_out = nullptr;
-    const float* xrow_bias = nullptr;
 };
 
 // preq: the kernel that produced A already left its per-token e4m3fn codes + scales in m[0].a8 / a8s (norm_mod_launch's q8 output);
@@ -499,7 +465,6 @@ int dense(ltx2_dit* c, const bf16* A, long lda, const bf16* W, const float* bias
         p.shadow = fold->shadow;
         p.shadow_scale = fold->shadow_scale;
         p.shadow_ss = fold->shadow_ss;
-        p.shadow_xrow = fold->shadow_xrow;
         p.ld_shadow = fold->ld_shadow;
         p.ld_ss = fold->ld_ss;
         p.rf_parts = fold->rf_parts;
@@ -507,9 +472,6 @@ int dense(ltx2_dit* c, const bf16* A, long lda, const bf16* W, const float* bias
         p.rf_nparts = fold->rf_nparts;
         p.rf_dim = fold->rf_dim;
         p.rf_eps = fold->rf_eps;
-        p.xrow = fold->xrow;
-        p.xrow_out = fold->xrow_out;
-        p.xrow_bias = fold->xrow_bias;
     }
     p.A = A;
     p.lda = lda;
@@ -718,24 +680,22 @@ int text_kv(ltx2_dit* c, int k, int l, hipStream_t st) {
     return project_kv(c, m.ctxm, m.S, D, w.text, D, m.H, m.hd, c->cfg.norm_eps, nullptr, nullptr, m.kv2, m.vt2, m.Spad, st, m.qfold ? m.knq + (long)l * D : nullptr);
 }
 
-// ---- round 6: the three RMS norms of a block folded around its GEMMs -------------------------------------------------------------------------
-// rms_norm(x) (1 + s) + t in front of a projection W, b equals r (x (1 + s)) W^T + (t W^T + b) with the row factor r = rsqrt(mean x^2 + eps).  The gated-residual
-// GEMM that forms x (attn1.to_out, attn2.to_out, ff.net.2) therefore also leaves y = bf16(x (1 + s)) in `h` with the partial sums of squares of x (GemmParams::shadow),
-// and the projection takes (y, the partial sums -> r inside the kernel, c = t W^T + b) -- the norm pass between the two GEMMs (85 MB per launch) is gone.
-//   * text cross-attention: plain RMS norm (s = 0, t = 0, c = to_q.bias): nothing else is needed                                              -> level 1
-//   * self-attention / feed-forward: c depends on sigma through t, and forming it costs a pass over W -- so the GEMM that streams W anyway forms it ONE STEP
-//     AHEAD: its operand carries one more row, the NEXT step's shift row t' (bf16), and that row's product leaves as the next step's c (GemmParams::xrow).
-//     A step whose c was not left by the step before it (the first of a loop, a sigma other than the announced one) runs the norm passes and only leaves c. -> level 2
-// Row-invariant modulation only (one timestep per modality), VideoOnly non-V2.3 models on dense bf16 weights, the bfloat16 build (x (1 + s) un-normalised is not
-// safe in IEEE half).  Same mathematics, another rounding order: y is rounded before the row factor instead of after it (both relative 2^-9).
+// ---- round 6: the text cross-attention's plain RMS pre-norm folded around the two GEMMs beside it ----------------------------------------------------
+// rms_norm(x) in front of attn2.to_q (W, b) equals r (x W^T) + b with the row factor r = rsqrt(mean x^2 + eps).  attn1.to_out's gated-residual epilogue, which
+// forms x, also leaves y = bf16(x) in `h` with the partial sums of squares of x (GemmParams::shadow), and the query projection takes (y, the partial sums -> r
+// inside the kernel): the norm pass between the two GEMMs (15 us, 85 MB) is gone.  Same mathematics, another rounding order: y is rounded before the row factor
+// instead of after it (both relative 2^-9).  Row-invariant gates only (one timestep per modality).
+// The same algebra covers the two AdaLN-modulated norms (self-attention, feed-forward): the scale rides on the shadow, and the shift's product t W^T can be formed
+// one step ahead by the projection itself from an extra operand row.  That was built and measured in this round (git history: "fold: its own kernel
+// instantiations"): every kernel-level figure favoured it (three norm passes, 52 us per layer, for ~20 us of epilogue work), the step did not -- +0.3 ... +0.5 ms:
+// the GEMMs on both sides run 4-5 % slower inside the step than their stand-alone A/B says (profiles/r06_fold_norms.md).  Only this one stayed.
 // the two halves on a Fold: the producer writes x's shadow into h and its partial sums into rss; the consumer reads them back
-inline void fold_produce(Fold& f, Mod& m, const float* scale, const bf16* xrow) {
+inline void fold_produce(Fold& f, Mod& m, const float* scale) {
     f.shadow = m.h;
     f.ld_shadow = m.D;
     f.shadow_ss = m.rss;
     f.ld_ss = m.rss_ld;
     f.shadow_scale = scale;
-    f.shadow_xrow = xrow;
 }
 inline void fold_consume(Fold& f, const Mod& m, float eps) {
     f.rf_parts = m.rss;
@@ -745,28 +705,8 @@ inline void fold_consume(Fold& f, const Mod& m, float eps) {
     f.rf_eps = eps;
 }
 
-struct FoldStep {
-    int level = 0;            // for this forward: 0 / 1 / 2
-    bool valid = false;       // level 2: cvec[c_cur] is this step's c
-    const float* c_now = nullptr;     // [L][7D]
-    float* c_next = nullptr;
-};
-
-__global__ void tnext_kernel(const float* __restrict__ sst_all, const float* __restrict__ embn, bf16* __restrict__ out, int L, int D, int rows) {
-    // out[l][j][d] = bf16(sst[l][row_j][d] + embn[j][d]), rows (shift_msa, shift_mlp) = table rows (0, 3): the sum the norm kernels form, rounded to the operand type
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)L * 2 * D) return;
-    const int d = (int)(i % D), j = (int)((i / D) % 2), l = (int)(i / (2L * D));
-    out[i] = f2bf(sst_all[((long)l * rows + 3 * j) * D + d] + embn[(long)j * D + d]);
-}
-__global__ void copy_row_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[i];
-}
-__global__ void set_scalar_kernel(float* p, float v) { *p = v; }
-
 // Self-attention, text cross-attention of one modality (transformer.py:503-554 / 191-226)
-int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, const FoldStep& fs = FoldStep{}) {
+int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, int fold = 0) {
     Mod& m = c->m[k];
     const BlockW& w = c->layers[l].m[k];
     const int N = m.N, D = m.D, H = m.H, hd = m.hd;
@@ -778,30 +718,13 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, const Fo
     // self-attention: AdaLN rows (shift, scale, gate) = sst[0:3] + emb[0:3]
     // fp8 compute: the norm kernels hand the following GEMM per-token e4m3fn codes directly (and skip the bf16 copy nobody else reads)
     const bool q1 = k == 0 && f8_route(c, w.self.qkv_w, N, 3 * D, D, EPI_BF16);
-    const int fl = k == 0 ? fs.level : 0;
-    // folded (level 2, c valid, l > 0): h already holds y = bf16(x (1 + scale_msa)) + the next shift row, left by the previous layer's ff.net.2 epilogue; rfac its row factors
-    const bool fold_in = fl == 2 && fs.valid && l > 0;
-    Fold fq{};
-    if (fl == 2) {          // the QKV projection leaves the NEXT step's c from its extra operand row
-        fq.xrow = 1;
-        fq.xrow_out = fs.c_next + (long)l * 7 * D;
-        fq.xrow_bias = w.self.qkv_b;
-    }
-    if (fold_in) {
-        fold_consume(fq, m, eps);
-    } else {
-        TRY(norm_mod_launch(m.x, D, (q1 && !c->gated) ? nullptr : m.h, D, N, D, eps, 0, tab + D, tab, E(1), E(0), es, st, q1 ? m.a8 : nullptr, D,
-                            q1 ? m.a8s : nullptr));
-        if (fl == 2) {
-            hipLaunchKernelGGL(copy_row_kernel, dim3((D + 255) / 256), dim3(256), 0, st, m.tnext + (long)l * 2 * D, m.h + (long)N * D, D);
-            LTX2_CHECK_LAUNCH("copy_row_kernel");
-        }
-    }
+    const int fl = k == 0 ? fold : 0;
+    TRY(norm_mod_launch(m.x, D, (q1 && !c->gated) ? nullptr : m.h, D, N, D, eps, 0, tab + D, tab, E(1), E(0), es, st, q1 ? m.a8 : nullptr, D,
+                        q1 ? m.a8s : nullptr));
     TRY(gate_logits(c, m, w.self, m.h, D, N, H, st));
     const VtOut vo{m.vt, 2 * D, m.Npad, hd};
     bool vt_done = false;           // the QKV GEMM's epilogue writes V^T itself where it can (gemm_v4.hip)
-    TRY(dense(c, m.h, D, w.self.qkv_w, fold_in ? fs.c_now + (long)l * 7 * D : w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done, q1,
-              nullptr, fl == 2 ? &fq : nullptr));
+    TRY(dense(c, m.h, D, w.self.qkv_w, w.self.qkv_b, m.qkv, 3 * D, N, 3 * D, D, EPI_BF16, st, nullptr, 0, nullptr, &vo, &vt_done, q1));
     {
         const int offs[2] = {0, D};
         const float* wts[2] = {w.self.qn, w.self.kn};
@@ -810,7 +733,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, const Fo
     if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
     TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, nullptr, 0.f, nullptr, glog(c, m)));
     Fold fo{};
-    if (fl >= 1) fold_produce(fo, m, nullptr, nullptr);          // the new residual rows also leave as the cross-attention query projection's operand (plain RMS norm: no scale, no shift)
+    if (fl >= 1) fold_produce(fo, m, nullptr);          // the new residual rows also leave as the cross-attention query projection's operand (plain RMS norm: no scale, no shift)
     TRY(dense(c, m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(2), es, tab + 2 * D, nullptr, nullptr, false, nullptr, fl >= 1 ? &fo : nullptr));
 
     // text cross-attention: no RoPE, no mask.  V1: plain RMSNorm on x, K/V cached per prompt.
@@ -852,16 +775,13 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, const Fo
                m.has_kmask ? m.kmask : nullptr, glog(c, m)));
     if (c->v2)
         TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(8), es, tab + 8 * D));
-    else {
-        Fold ft{};
-        if (fl == 2 && fs.valid) fold_produce(ft, m, tab + 4 * D, m.tnext + ((long)l * 2 + 1) * D);      // the feed-forward's operand: y = bf16(x (1 + scale_mlp)) + the next step's shift_mlp row
-        TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, nullptr, 0, nullptr, nullptr, nullptr, false, nullptr, ft.shadow ? &ft : nullptr));
-    }
+    else
+        TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st));
     return LTX2_OK;
 }
 
 // Feed-forward: AdaLN rows 3..5 (transformer.py:229-236,622-642); Linear -> GELU(tanh) -> Linear
-int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st, const FoldStep& fs = FoldStep{}) {
+int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st) {
     Mod& m = c->m[k];
     const BlockW& w = c->layers[l].m[k];
     const int N = m.N, D = m.D;
@@ -869,30 +789,10 @@ int block_ffn(ltx2_dit* c, int k, int l, long es, hipStream_t st, const FoldStep
     const float* const emb0 = m.use_comb ? nullptr : m.emb;
     auto E = [&](int r) { return emb0 ? emb0 + (long)r * D : nullptr; };
     const bool q3 = k == 0 && f8_route(c, w.ff1_w, N, 4 * D, D, EPI_GELU_BF16);
-    const int fl = k == 0 ? fs.level : 0;
-    const bool fold_in = fl == 2 && fs.valid;      // h = bf16(x (1 + scale_mlp)) + the next shift row, from attn2.to_out's epilogue
-    Fold fu{};
-    if (fl == 2) {
-        fu.xrow = 1;
-        fu.xrow_out = fs.c_next + ((long)l * 7 + 3) * D;
-        fu.xrow_bias = w.ff1_b;
-    }
-    if (fold_in) {
-        fold_consume(fu, m, c->cfg.norm_eps);
-    } else {
-        TRY(norm_mod_launch(m.x, D, q3 ? nullptr : m.h, D, N, D, c->cfg.norm_eps, 0, tab + 4 * D, tab + 3 * D, E(4), E(3), es, st,
-                            q3 ? m.a8 : nullptr, D, q3 ? m.a8s : nullptr));
-        if (fl == 2) {
-            hipLaunchKernelGGL(copy_row_kernel, dim3((D + 255) / 256), dim3(256), 0, st, m.tnext + ((long)l * 2 + 1) * D, m.h + (long)N * D, D);
-            LTX2_CHECK_LAUNCH("copy_row_kernel");
-        }
-    }
-    TRY(dense(c, m.h, D, w.ff1_w, fold_in ? fs.c_now + ((long)l * 7 + 3) * D : w.ff1_b, m.ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st, nullptr, 0, nullptr, nullptr, nullptr, q3, nullptr,
-              fl == 2 ? &fu : nullptr));
-    Fold fd{};
-    if (fold_in && l + 1 < c->cfg.num_layers)       // the next layer's self-attention operand: y = bf16(x (1 + scale_msa[l + 1])) + its next shift_msa row
-        fold_produce(fd, m, tab + (long)(c->v2 ? 9 : 6) * D + D, m.tnext + (long)(l + 1) * 2 * D);
-    TRY(dense(c, m.ff, 4 * D, w.ff2_w, w.ff2_b, m.x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, E(5), es, tab + 5 * D, nullptr, nullptr, false, nullptr, fd.shadow ? &fd : nullptr));
+    TRY(norm_mod_launch(m.x, D, q3 ? nullptr : m.h, D, N, D, c->cfg.norm_eps, 0, tab + 4 * D, tab + 3 * D, E(4), E(3), es, st,
+                        q3 ? m.a8 : nullptr, D, q3 ? m.a8s : nullptr));
+    TRY(dense(c, m.h, D, w.ff1_w, w.ff1_b, m.ff, 4 * D, N, 4 * D, D, EPI_GELU_BF16, st, nullptr, 0, nullptr, nullptr, nullptr, q3));
+    TRY(dense(c, m.ff, 4 * D, w.ff2_w, w.ff2_b, m.x, D, N, D, 4 * D, EPI_RESID_GATE_F32, st, E(5), es, tab + 5 * D));
     return LTX2_OK;
 }
 
@@ -986,13 +886,7 @@ struct ModIn {
     float* velocity;
 };
 
-// what a step knows beyond its own inputs (denoise_step / the captured loop): its sigma and the NEXT one (host values + the next as a device scalar)
-struct StepHint {
-    float sigma, sigma_next;
-    const float* next_dev;
-};
-
-int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = true, const StepHint* hint = nullptr) {
+int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = true) {
     const int nm = c->av ? 2 : 1;
     if (rewind_events) c->sync_next = 0;
     long es[2] = {0, 0}, ee[2] = {0, 0};
@@ -1027,29 +921,8 @@ int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = t
             }
         }
     }
-    // round 6: norms folded around the GEMMs (FoldStep above)
-    FoldStep fs{};
-    if (!c->av && c->m[0].use_comb) {
-        Mod& m = c->m[0];
-        fs.level = c->fold_norms < m.fold_max ? c->fold_norms : m.fold_max;
-        if (fs.level == 2 && !hint) fs.level = 1;          // a lone forward does not know the next sigma
-        if (fs.level == 2) {
-            const ModW& w = c->mw[0];
-            const int D = m.D;
-            // the next sigma's shift rows: the AdaLN chain up to the embedded timestep, then only rows 0 and 3 of the linear layer
-            TRY(timestep_sinusoid_launch(hint->next_dev, 0, 0.f, c->cfg.timestep_scale, 1, 256, m.sin_f, nullptr, st));
-            TRY(gemv_launch(m.sin_f, 256, w.ada.t1_w, w.ada.t1_b, m.e1_f, D, 1, D, 256, 0, 1, st));
-            TRY(gemv_launch(m.e1_f, D, w.ada.t2_w, w.ada.t2_b, m.aux_e, D, 1, D, D, 0, 0, st));
-            TRY(gemv_launch(m.aux_e, D, w.ada.lin_w, w.ada.lin_b, m.embn, D, 1, D, D, 1, 0, st));
-            TRY(gemv_launch(m.aux_e, D, w.ada.lin_w + 3L * D * D, w.ada.lin_b + 3L * D, m.embn + D, D, 1, D, D, 1, 0, st));
-            const long n = (long)c->cfg.num_layers * 2 * D;
-            hipLaunchKernelGGL(tnext_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.sst_all, m.embn, m.tnext, c->cfg.num_layers, D, w.ada.rows);
-            LTX2_CHECK_LAUNCH("tnext_kernel");
-            fs.valid = c->c_valid && c->c_sigma == hint->sigma;
-            fs.c_now = m.cvec[c->c_cur];
-            fs.c_next = m.cvec[c->c_cur ^ 1];
-        }
-    }
+    // round 6: the text cross-attention's pre-norm folded around its GEMMs (block_attention()): row-invariant gates only
+    const int fold = (!c->av && c->m[0].use_comb && c->fold_norms >= 1 && c->m[0].fold_max >= 1) ? 1 : 0;
     // the audio modality's block program runs on the side stream, joined around the cross-modal attention
     hipStream_t sa = (c->av && c->side) ? c->side : st;
     c->text_kv_ev = nullptr;
@@ -1066,18 +939,13 @@ int forward(ltx2_dit* c, const ModIn* in, hipStream_t st, bool rewind_events = t
             }
             TRY(block_attention(c, 1, l, es[1], sa));
         }
-        TRY(block_attention(c, 0, l, es[0], st, fs));
+        TRY(block_attention(c, 0, l, es[0], st, fold));
         if (c->av) {
             TRY(block_cross_modal(c, l, st, sa));      // main: the video side; side: the audio side (events inside)
             TRY(block_ffn(c, 1, l, es[1], sa));
         }
-        TRY(block_ffn(c, 0, l, es[0], st, fs));
+        TRY(block_ffn(c, 0, l, es[0], st));
         if (c->av) TRY(stream_after(c, sa, st));
-    }
-    if (fs.level == 2) {        // this step's projections left the next sigma's c in the other buffer
-        c->c_cur ^= 1;
-        c->c_valid = true;
-        c->c_sigma = hint->sigma_next;
     }
     // output heads (model.py:744-774): LayerNorm(no affine) * (1 + scale) + shift, rows (shift, scale)
     for (int k = 0; k < nm; ++k) {
@@ -1097,21 +965,13 @@ struct StepIo {
 };
 
 int denoise_step(ltx2_dit* c, ModIn* in, const StepIo* io, float sigma, float sigma_next, hipStream_t st,
-                 bool rewind_events = true, const float* sigma_next_dev = nullptr) {
+                 bool rewind_events = true) {
     const int nm = c->av ? 2 : 1;
     for (int k = 0; k < nm; ++k) {
         in[k].latent = io[k].latent;
         in[k].velocity = c->m[k].vel;
     }
-    StepHint hint{sigma, sigma_next, sigma_next_dev};
-    const bool want_hint = !c->av && in[0].n_ts == 1 && c->adaln_combine && c->fold_norms >= 2 && c->m[0].fold_max >= 2;
-    if (want_hint && !sigma_next_dev) {        // eager step: the next sigma as a device scalar
-        hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, c->m[0].sig_next, sigma_next);
-        LTX2_CHECK_LAUNCH("set_scalar_kernel");
-        hint.next_dev = c->m[0].sig_next;
-    }
-    if (!want_hint) c->c_valid = false;       // (a step outside the folded form leaves no c for the next one)
-    TRY(forward(c, in, st, rewind_events, want_hint ? &hint : nullptr));
+    TRY(forward(c, in, st, rewind_events));
     for (int k = 0; k < nm; ++k) {
         Mod& m = c->m[k];
         float* x0 = io[k].x0_out ? io[k].x0_out : m.x0;
@@ -1192,7 +1052,6 @@ int begin_capture(ltx2_dit* c, const float* host_sigmas, int n_steps, hipStream_
         (void)hipGraphDestroy(c->graph);
         c->graph = nullptr;
     }
-    c->c_valid = false;         // a captured loop is self-contained: its first step runs the norm passes, steps 1.. take the c the step before them leaves
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         ltx2_set_error("dit_graph_capture: hipStreamBeginCapture failed");
         return LTX2_E_HIP;
@@ -1203,7 +1062,6 @@ int begin_capture(ltx2_dit* c, const float* host_sigmas, int n_steps, hipStream_
 int end_capture(ltx2_dit* c, int rc, hipStream_t st) {
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(st, &g);
-    c->c_valid = false;         // (what the bookkeeping recorded during capture never ran)
     if (rc != LTX2_OK) {
         if (g) (void)hipGraphDestroy(g);
         return rc;
@@ -1248,7 +1106,6 @@ int bind(ltx2_dit* c, void* ptr, int64_t bytes, int N, int S, int Na, int Sa, in
     }
     c->per_token = per_token;
     c->prepared = false;
-    c->c_valid = false;
     c->m[0].has_kmask = c->m[1].has_kmask = false;
     return LTX2_OK;
 }
@@ -1316,7 +1173,6 @@ int ltx2_dit_set_weight(ltx2_dit* c, const char* name, const void* ptr, int dtyp
     LTX2_CHECK_ARG(dtype == LTX2_DTYPE_BF16 || dtype == LTX2_DTYPE_F32 || dtype == LTX2_DTYPE_FP8_E4M3FN, "dit_set_weight: bad dtype %d", dtype);
     c->weights[name] = Wt{ptr, dtype, (long)numel};
     c->resolved = false;
-    c->c_valid = false;
     c->prepared = false;        // the per-prompt caches (text K/V, the gathered AdaLN tables) were built from the weights registered before
     return LTX2_OK;
 }
@@ -1431,7 +1287,7 @@ int ltx2_dit_graph_capture(ltx2_dit* c, float* latent, const float* host_sigmas,
     for (int i = 0; i < n_steps && rc == LTX2_OK; ++i) {
         ModIn in[1] = {{latent, c->sigmas_dev + i, 1, c->sigmas_dev + i, nullptr}};
         const StepIo io[1] = {{latent, nullptr, nullptr, nullptr}};
-        rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st, i == 0, c->sigmas_dev + i + 1);
+        rc = denoise_step(c, in, io, host_sigmas[i], host_sigmas[i + 1], st, i == 0);
     }
     return end_capture(c, rc, st);
 }
@@ -1570,10 +1426,9 @@ int ltx2_dit_set_option(ltx2_dit* c, const char* name, int value) {
         c->text_kv_ahead = value != 0;
         return LTX2_OK;
     }
-    if (!strcmp(name, "fold_norms")) {          // 0 / 1 / 2: see FoldStep (dit_engine.hip); 0 restores round 5's norm passes
-        LTX2_CHECK_ARG(value >= 0 && value <= 2, "dit_set_option: fold_norms is 0, 1 or 2");
+    if (!strcmp(name, "fold_norms")) {          // 0 / 1: see block_attention(); 0 restores round 5's norm pass in front of the text cross-attention
+        LTX2_CHECK_ARG(value == 0 || value == 1, "dit_set_option: fold_norms is 0 or 1");
         c->fold_norms = value;
-        c->c_valid = false;
         return LTX2_OK;
     }
     if (!strcmp(name, "adaln_combine")) {       // 0: tables and embeddings reach every kernel separately (round 3's form; same results bit for bit)
@@ -1591,7 +1446,6 @@ int ltx2_dit_graph_launch(ltx2_dit* c, void* stream) {
         ltx2_set_error("dit_graph_launch: no captured graph");
         return LTX2_E_STATE;
     }
-    c->c_valid = false;         // the replay overwrites the per-sigma vectors an eager step may have left
     if (hipGraphLaunch(c->exec, (hipStream_t)stream) != hipSuccess) {
         ltx2_set_error("dit_graph_launch: hipGraphLaunch failed");
         return LTX2_E_HIP;

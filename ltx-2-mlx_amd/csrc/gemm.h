@@ -44,26 +44,21 @@ struct GemmParams {
     // ROUNDED outputs): the partial sums of a row's squared norm, for a consumer that folds an RMS normalisation of `out` into its own
     // arithmetic (text cross-attention: q_norm as a per-row softmax scale).  null = off.  gemm_rowss_supported() says when.
     float* rowss;
-    // ---- round 6: the RMS normalisation in front of a projection folded around the GEMMs (gemm_v4.hip layout 3, dense bf16 weights; gemm_fold_supported()) ----
-    // norm(x) * (1 + s) + t in front of `W` is r[m] * ((x * (1 + s)) W^T) + (t W^T + b): the PRODUCER of x (the gated-residual epilogue that forms the new
-    // residual row) also leaves y = bf16(x_new * (1 + s)) and the partial sums of squares of x_new (one per 256-column tile); the CONSUMER forms the row factor
-    // r[m] = rsqrt(mean x_new^2 + eps) of its tile's rows from those partials (fetched into LDS in front of its K loop), multiplies its accumulators by it and
-    // adds c = t W^T + b as its bias -- the stand-alone norm pass (85 MB per launch at 3456 x 4096) is gone, and nothing runs between the two GEMMs.
+    // ---- round 6: the plain RMS normalisation in front of a projection folded around the GEMMs (gemm_v4.hip layout 3, dense bf16 weights; gemm_fold_supported()) ----
+    // rms_norm(x) W^T + b equals r[m] (x W^T) + b with r[m] = rsqrt(mean x[m]^2 + eps): the PRODUCER of x (the gated-residual epilogue that forms the new
+    // residual row) also leaves y = bf16(x_new) and the partial sums of squares of x_new (one per 256-column tile); the CONSUMER forms the row factors of its
+    // tile's rows from those partials (fetched into LDS in front of its K loop) and multiplies its accumulators by them -- the stand-alone norm pass and the
+    // fp32 re-read of x between the two GEMMs are gone.  (A scale (1 + s) rides on the shadow; a shift t would need t W^T per step: measured, not kept -- DESIGN.md.)
     // Producer (EPI_RESID_GATE_F32, row-invariant gate):
     bf16* shadow;              //   shadow[m][n] = bf16(x_new[m][n] * (1 + shadow_scale[n])), row stride ld_shadow; null = off
     const float* shadow_scale; //   [N] or null (plain RMS norm: * 1)
     float* shadow_ss;          //   shadow_ss[(n / 256) * ld_ss + m] = sum of x_new[m][n]^2 over the 256-column tile (fp32, before the scale; the tile's four waves added in wave order)
-    long ld_ss;                //   >= the row tiles' extent (ceil(M / tile rows) * tile rows), % 4 == 0
-    const bf16* shadow_xrow;   //   optional [N]: copied into shadow row M by the last row tile (the consumer's extra row, below)
-    long ld_shadow;
+    long ld_shadow, ld_ss;     //   ld_ss >= the row tiles' extent (ceil(M / tile rows) * tile rows), % 4 == 0
     // Consumer (EPI_BF16 / EPI_GELU_BF16): out = epilogue(r[m] * acc + bias), r[m] = rsqrt(sum_{j < rf_nparts} rf_parts[j * rf_ld + m] / rf_dim + rf_eps)
     const float* rf_parts;     //   a producer's shadow_ss (rf_ld = its ld_ss); null: r = 1
     long rf_ld;
     int rf_nparts, rf_dim;     //   rf_nparts <= GEMM_RF_MAX_PARTS
     float rf_eps;
-    int xrow;                  //   1: A holds M + 1 rows; row M's product leaves as fp32 xrow_out[n] = acc + xrow_bias[n] (nothing of it reaches `out`):
-    float* xrow_out;           //      with t (the NEXT step's shift row) as row M this is the next step's c = t W^T + b, computed by the GEMM that streams W anyway
-    const float* xrow_bias;
     int splitk;          // gemm_v4.hip: K split over this many blocks per tile (fp32 slabs + reduce); 0 / 1 = off
     void* dbg;           // ping-pong kernel: optional device buffer for interval timestamps (debug)      // ping-pong kernel: which wave bit selects the staggered group (tuning knob)
 };
@@ -96,8 +91,8 @@ int gemm_route(const GemmParams& p, int epilogue, bool conv);
 bool gemm_vt_fused(const GemmParams& p, int epilogue);
 // p.rowss set: will gemm_launch route this problem to a kernel that writes the row partial sums?  (false: the caller must not set it)
 bool gemm_rowss_supported(const GemmParams& p, int epilogue);
-// p.shadow / p.rf_parts / p.xrow set: will gemm_launch route this problem to the kernel that implements them (the 4-wave layout-3 kernel on dense bf16 weights;
-// an extra row additionally needs M % tile rows != 0, so that row M lies inside the last row tile)?  gemm_launch rejects what it cannot honour.
+// p.shadow / p.rf_parts set: will gemm_launch route this problem to the kernel that implements them (the 4-wave layout-3 kernel on dense bf16 weights)?
+// gemm_launch rejects what it cannot honour.
 bool gemm_fold_supported(const GemmParams& p, int epilogue);
 constexpr int GEMM_RF_MAX_PARTS = 24;      // partial sums per row the consumer stages in LDS (a producer of up to 6144 columns)
 // fp8 compute (p.A8 / p.ascale / p.W8 / p.wscale set): can the fp8-MFMA kernel (gemm_v4.hip layout 5) take this problem?

@@ -345,13 +345,11 @@ bool gemm_fold_supported(const GemmParams& p, int epilogue) {
     if (p.shadow) {         // producer: the gated-residual epilogue with a row-invariant gate
         if (epilogue != EPI_RESID_GATE_F32 || (p.gate && p.gate_stride != 0) || !p.shadow_ss || p.ld_shadow % 4 != 0 || ((uintptr_t)p.shadow & 7)) return false;
         if (p.ld_ss % 4 != 0 || p.ld_ss < (long)((p.M + bm - 1) / bm) * bm || ((uintptr_t)p.shadow_ss & 15)) return false;
-        if (p.shadow_xrow && p.M % bm == 0) return false;
     }
-    if (p.rf_parts || p.xrow) {
+    if (p.rf_parts) {
         if (epilogue != EPI_BF16 && epilogue != EPI_GELU_BF16) return false;
-        if (p.rf_parts && (p.rf_nparts < 1 || p.rf_nparts > GEMM_RF_MAX_PARTS || p.rf_dim < 1 || p.rf_ld % 4 != 0 || p.rf_ld < (long)((p.M + bm - 1) / bm) * bm ||
+        if ((p.rf_nparts < 1 || p.rf_nparts > GEMM_RF_MAX_PARTS || p.rf_dim < 1 || p.rf_ld % 4 != 0 || p.rf_ld < (long)((p.M + bm - 1) / bm) * bm ||
                            ((uintptr_t)p.rf_parts & 15) || (long)p.rf_nparts * p.rf_ld * 4 >= (1L << 31))) return false;
-        if (p.xrow && (p.xrow != 1 || !p.xrow_out || !p.xrow_bias || p.M % bm == 0 || (long)(p.M + 1) * p.lda * 2 >= (1L << 31))) return false;
     }
     return true;
 }
@@ -363,7 +361,7 @@ int gemm_launch(const GemmParams& p, int epilogue, bool conv, hipStream_t stream
     LTX2_CHECK_ARG(!p.vt || (!conv && gemm_vt_fused(p, epilogue)), "gemm: a fused V^T output needs the 4-wave layout-3 / layout-5 kernel (ask gemm_vt_fused first)");
     LTX2_CHECK_ARG(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
     LTX2_CHECK_ARG(!p.rowss || (!conv && gemm_rowss_supported(p, epilogue)), "gemm: row partial sums need the 4-wave kernel's bf16 epilogue (ask gemm_rowss_supported first)");
-    LTX2_CHECK_ARG(!(p.shadow || p.rf_parts || p.xrow) || (!conv && gemm_fold_supported(p, epilogue)), "gemm: a folded norm (shadow / rf_parts / xrow) needs the 4-wave layout-3 kernel on dense bf16 weights (ask gemm_fold_supported first)");
+    LTX2_CHECK_ARG(!(p.shadow || p.rf_parts) || (!conv && gemm_fold_supported(p, epilogue)), "gemm: a folded norm (shadow / rf_parts) needs the 4-wave layout-3 kernel on dense bf16 weights (ask gemm_fold_supported first)");
     if (p.A8) {     // fp8 compute: both operands e4m3fn codes + scales, fp8 MFMA (gemm_v4.hip layout 5)
         LTX2_CHECK_ARG(!conv && p.out, "gemm: fp8 compute is dense-only");
         return gemm_v4_launch(p, epilogue, stream, 0, 0);        // layout 6 (16x16x128 blocks) for 224-row tiles, 5 (32x32x64) for 256-row ones

@@ -83,14 +83,12 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // ---- block -> tile (XCD-contiguous, grouped row-tiles; as gemm_pp.hip) ----
     // split-K (p.splitk > 1): blockIdx = split * tiles + tile; this block accumulates K-tiles [split * nk, +nk) and writes an
     // fp32 partial tile into slab `split` of p.out ([splitk][M][ldo] fp32); splitk_reduce_kernel adds the slabs
-    // round 6 (GemmParams "fold" fields): the dense bf16 layout-3 kernels only.  XROW: A holds one more row than `out` (row M: the next step's shift row);
-    // M % BM != 0 (gemm_fold_supported), so it lies inside the last row tile and the tile count does not change
+    // round 6 (GemmParams "fold" fields): the dense bf16 layout-3 kernels only
     // (VAR == 30: its own instantiations -- compiled into the plain kernels the extra parameters and LDS cost them 2-4 % with nothing folded: same-box layer
     //  traces, profiles/r06_layer_trace_*.txt)
     constexpr bool FOLD_OK = LAYOUT == 3 && !CONV && VAR == 30;
-    constexpr bool FOLD_CONS = FOLD_OK && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16);         // consumer side: row factors, the extra row
+    constexpr bool FOLD_CONS = FOLD_OK && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16);         // consumer side: row factors
     constexpr bool FOLD_PROD = FOLD_OK && EPI == EPI_RESID_GATE_F32;                          // producer side: bf16 shadow + partial sums of squares
-    const int Mx = p.M + (FOLD_CONS ? p.xrow : 0);
     const int Mt = (p.M + BM - 1) / BM, Nt = LAYOUT == 7 ? 1 : p.N / TBN;        // (layout 7: ONE column tile, N <= 64, columns >= N masked)
     const int ntiles = Mt * Nt;
     const int split = p.splitk > 1 ? bid / ntiles : 0;
@@ -111,14 +109,14 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // layout 3, 224-row tiles, dense bf16 weights: the ragged last row tile runs a K loop over only the row blocks that hold real
     // rows (6 of 14 for 3456 rows, 10 of 14 for 13824) -- fewer DMA pieces per wave, so the wave -> tile-row mapping shrinks with it
     constexpr bool SHORT_OK = LAYOUT == 3 && BM == 224 && !CONV;
-    const int valid_rows = Mx - m0;
-    const int short_rb = !SHORT_OK ? 0 : valid_rows <= 96 ? 6 : (valid_rows <= 128 && !W8) ? 8 : valid_rows <= 160 ? 10 : 0;      // block-uniform (8: 96 rows + a folded norm's extra row)
+    const int valid_rows = p.M - m0;
+    const int short_rb = !SHORT_OK ? 0 : valid_rows <= 96 ? 6 : valid_rows <= 160 ? 10 : 0;      // block-uniform
     const int npa_rt = short_rb ? short_rb / 2 : NPA;
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
         const int r = (w * npa_rt + j) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        const int m = min(m0 + r, Mx - 1);
+        const int m = min(m0 + r, p.M - 1);
         if constexpr (CONV) {       // output position (t, h, w) = padded position of its (0,0,0) tap
             const int hw = p.H * p.Wd;
             const int t = m / hw, r2 = m - t * hw, h = r2 / p.Wd, x = r2 - h * p.Wd;
@@ -298,7 +296,6 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     } else if constexpr (LAYOUT == 3) {
         if constexpr (BM == 224) {
             if (short_rb == 6) V4_ASM(LTX2_V4_L14_M16_RB6);
-            else if (short_rb == 8) V4_ASM(LTX2_V4_L14_M16_RB8);
             else if (short_rb == 10) V4_ASM(LTX2_V4_L14_M16_RB10);
             else V4_ASM(LTX2_V4_L14_M16_RB14);
         } else {
@@ -334,8 +331,8 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
     // 16x16 block: row lr, one group at columns 4 kq (accumulator registers 0..3)
     if constexpr (!HOIST_COL_VECTORS) load_bias();
     // (fold-specific addresses are formed from these copies: built from lr / kq directly hipcc forms them in FRONT of the loop and carries them across it in scratch)
-    [[maybe_unused]] int lr_e = lr, kq_e = kq, tid_e = tid;
-    if constexpr (FOLD_OK) asm volatile("" : "+v"(lr_e), "+v"(kq_e), "+v"(tid_e));
+    [[maybe_unused]] int lr_e = lr, tid_e = tid;
+    if constexpr (FOLD_OK) asm volatile("" : "+v"(lr_e), "+v"(tid_e));
     if constexpr (FOLD_CONS) {
         if (p.rf_parts && tid_e < BM) {       // row tid of the tile: the partials in part order (deterministic), then the RMS factor
             const float* pl = (const float*)(smem + RF_OFF);
@@ -425,8 +422,6 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
                 if (shadow) {
                     if (p.shadow_scale) sm4 += *(const f32x4*)(p.shadow_scale + n0 + wc * WN + cc * 4);
                     yg = p.shadow + (long)(m0 + rr) * p.ld_shadow + n0 + wc * WN + cc * 4;
-                    if (p.shadow_xrow && m0 <= p.M && p.M < m0 + BM && lane < 16)        // the tile that holds row M: the consumer's extra row
-                        *(bf16x4*)(p.shadow + (long)p.M * p.ld_shadow + n0 + wc * WN + lane * 4) = *(const bf16x4*)(p.shadow_xrow + n0 + wc * WN + lane * 4);
                 }
             }
             f32x4 xv[3][NIT];
@@ -587,7 +582,7 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
         }
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
-            if (m0 + wr * WM + rb * MB >= Mx) continue;     // no real row in this block (block-uniform): its slab rows are never read as data
+            if (m0 + wr * WM + rb * MB >= p.M) continue;     // no real row in this block (block-uniform): its slab rows are never read as data
             const int r = rb * MB + lr;
             const int sw = CPR == 8 ? ((r >> 1) & 7) : (r & 15);
             // (EPI_ADD_BF16) the row block's residual slots are read up front: in source order read -> add -> write per slot, hipcc keeps
@@ -609,8 +604,6 @@ __device__ __forceinline__ void gemm_v4_tile(const GemmParams& p, const int bid)
                 f32x4 v;
                 if constexpr (FOLD_CONS) {
                     v = acc_group(rb, cb, gq) * rf[rb] + bias4[cb][gq];
-                    if (p.xrow && m0 + r == p.M)        // the extra row: its product (+ the projection's own bias) is the next step's bias vector; its slab row is never stored
-                        *(f32x4*)(p.xrow_out + n0 + wc * WN + cb * MB + 4 * kq_e) = acc_group(rb, cb, gq) + *(const f32x4*)(p.xrow_bias + n0 + wc * WN + cb * MB + 4 * kq_e);
                 } else {
                     v = acc_group(rb, cb, gq) + bias4[cb][gq];
                 }
@@ -894,7 +887,7 @@ int gemm_v4_launch(const GemmParams& p, int epilogue, hipStream_t stream, int la
     }
     const bool b224 = bm ? bm == 224 : gemm_v4_prefer_224(p);
     LTX2_CHECK_ARG(layout == 3, "gemm_v4: wave layout %d (3 = bf16 dense, 4 = 128-column convs, 5 = fp8 compute)", layout);
-    if (p.shadow || p.rf_parts || p.xrow) {      // a folded norm's producer / consumer half: the VAR = 30 instantiations
+    if (p.shadow || p.rf_parts) {      // a folded norm's producer / consumer half: the VAR = 30 instantiations
         switch (epilogue) {
             case EPI_BF16: return b224 ? launch_v4<EPI_BF16, 3, 224, false, 30>(p, stream) : launch_v4<EPI_BF16, 3, 256, false, 30>(p, stream);
             case EPI_GELU_BF16: return b224 ? launch_v4<EPI_GELU_BF16, 3, 224, false, 30>(p, stream) : launch_v4<EPI_GELU_BF16, 3, 256, false, 30>(p, stream);

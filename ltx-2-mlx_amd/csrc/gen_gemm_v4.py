@@ -631,8 +631,6 @@ def main():
             # rows cost real time elsewhere
             out.append(variant("LTX2_V4_L14_M16_RB6", 6, 4, mb=16, npa=3, dma_last=list(range(1, 23, 2)), dma_ks0=[], m0_early=True))
             out.append(variant("LTX2_V4_L14_M16_RB10", 10, 4, mb=16, npa=5, dma_last=list(range(1, 40, 3)), dma_ks0=[], m0_early=True))
-            # round 6: a last row tile of 97..128 rows -- 3456 rows + the one extra operand row of a folded norm (GemmParams::xrow)
-            out.append(variant("LTX2_V4_L14_M16_RB8", 8, 4, mb=16, npa=4, dma_last=[1, 3, 6, 8, 11, 13, 16, 18, 21, 23, 26, 28], dma_ks0=[], m0_early=True))
         # layout 4: BN = 128, 4x1 waves, 16x16x32: 7|8 x 8 blocks per wave (tile 448|512 x 128)
         out.append(variant("LTX2_V4_L41_M16_RB7" + sfx, 7, 8, mb=16, npa=14, npw=4, a_stage=57344, w_base=114688, w_stage=16384,
                            dma_last=list(range(0, 54, 3)), dma_ks0=[], m0_early=True, conv=conv))

@@ -97,33 +97,30 @@ def gemm_rowss(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
 
 def gemm_fold(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int, out: Optional[torch.Tensor] = None,
               gate_table: Optional[torch.Tensor] = None, shadow: Optional[torch.Tensor] = None, shadow_scale: Optional[torch.Tensor] = None,
-              shadow_xrow: Optional[torch.Tensor] = None, rf_parts: Optional[torch.Tensor] = None, rf_dim: int = 0, eps: float = 1e-6, xrow: bool = False,
-              xrow_bias: Optional[torch.Tensor] = None):
-    """ltx2_gemm_bf16_fold (include/ltx2hip.h): the producer / consumer halves of an RMS norm folded around two GEMMs.
-    Producer (epilogue RESID_GATE_F32, `out` = the fp32 residual stream, updated in place; shadow = 16-bit [M (+1), N]): returns (out, shadow_ss [N/256, ld]),
+              rf_parts: Optional[torch.Tensor] = None, rf_dim: int = 0, eps: float = 1e-6):
+    """ltx2_gemm_bf16_fold (include/ltx2hip.h): the producer / consumer half of an RMS norm folded around two GEMMs.
+    Producer (epilogue RESID_GATE_F32, `out` = the fp32 residual stream, updated in place; shadow = 16-bit [M, N]): returns (out, shadow_ss [N/256, ld]),
     the partial sums of squares of the new rows per 256-column tile, tile-major.
-    Consumer (BF16 / GELU_BF16; a holds M + 1 rows when xrow; rf_parts = a producer's shadow_ss over rf_dim columns): returns (out [M, N], xrow_out [N] fp32 or None).
+    Consumer (BF16 / GELU_BF16; rf_parts = a producer's shadow_ss over rf_dim columns): returns out [M, N].
     None when the 4-wave kernel does not take the problem."""
     import ctypes
     assert a.dtype in ACT16 and w.dtype == a.dtype
     a, w = _c(a), _c(w)
-    K = a.shape[1]
-    M = a.shape[0] - (1 if xrow else 0)
+    M, K = a.shape
     N = w.shape[0]
     prod = epilogue == nv.EPI_RESID_GATE_F32
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=a.dtype)
     ss = torch.zeros(max(N // 256, 1), (M + 255) // 256 * 256 + 256, device=a.device, dtype=torch.float32) if (prod and shadow is not None) else None
-    xo = torch.zeros(N, device=a.device, dtype=torch.float32) if xrow else None
     sup = ctypes.c_int(0)
     nv.check(_L(a).ltx2_gemm_bf16_fold(nv.ptr(a), a.stride(0), nv.ptr(w), nv.ptr(bias), nv.ptr(out), out.stride(0), M, N, K, epilogue, nv.ptr(gate_table),
                                        nv.ptr(shadow), shadow.stride(0) if shadow is not None else 0, nv.ptr(shadow_scale), nv.ptr(ss),
-                                       ss.stride(0) if ss is not None else 0, nv.ptr(shadow_xrow),
+                                       ss.stride(0) if ss is not None else 0,
                                        nv.ptr(rf_parts), rf_parts.stride(0) if rf_parts is not None else 0, rf_parts.shape[0] if rf_parts is not None else 0,
-                                       rf_dim, eps, 1 if xrow else 0, nv.ptr(xo), nv.ptr(xrow_bias), ctypes.byref(sup), nv.stream()))
+                                       rf_dim, eps, ctypes.byref(sup), nv.stream()))
     if not sup.value:
         return None
-    return (out, ss) if prod else (out, xo)
+    return (out, ss) if prod else out
 
 
 def flash_attn_rowscale(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, q_ss: torch.Tensor, eps: float = 1e-6,

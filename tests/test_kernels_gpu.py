@@ -836,12 +836,11 @@ def test_flash_attn_gated_epilogue(K, dev, heads, hd, Nq, Nkv):
 
 
 
-@pytest.mark.parametrize("M,D,NO,must", [(3456, 4096, 12288, True), (13824, 4096, 4096, True), (1300, 1024, 4096, False), (600, 512, 512, False)])
+@pytest.mark.parametrize("M,D,NO,must", [(3456, 4096, 4096, True), (13824, 4096, 4096, True), (1300, 1024, 4096, False), (600, 512, 512, False)])
 def test_norm_folded_around_the_gemms(dev, M, D, NO, must):
-    """Round 6 (GemmParams::shadow / rf_parts / xrow): rms_norm(x) (1 + s) + t in front of a projection (W, b) as
-    r (x (1 + s)) W^T + (t W^T + b).  Producer = a gated-residual GEMM that also leaves y = bf16(x_new (1 + s)), the partial sums of squares of
-    x_new and the extra row t'; consumer = the projection with row factors, c as its bias and the extra row's product as the NEXT c.
-    Checked against the unfolded kernels (norm pass + plain GEMMs) and fp64."""
+    """Round 6 (GemmParams::shadow / rf_parts): rms_norm(x) (1 + s) in front of a projection (W, b) as r (x (1 + s)) W^T + b.  Producer = a gated-residual
+    GEMM that also leaves y = bf16(x_new (1 + s)) and the partial sums of squares of x_new per 256-column tile; consumer = the projection that forms the row
+    factors from those partials inside the kernel.  Checked against the unfolded kernels (norm pass + plain GEMMs) and fp64."""
     import ltx_2_mlx_amd.kernels as KK
     from ltx_2_mlx_amd import _native as nv
     g = torch.Generator().manual_seed(606)
@@ -852,38 +851,31 @@ def test_norm_folded_around_the_gemms(dev, M, D, NO, must):
     gate = (1.0 + 0.2 * torch.randn(D, generator=g)).to(dev)
     x0 = (3.0 * torch.randn(M, D, generator=g)).to(dev)
     sc = (0.3 * torch.randn(D, generator=g)).to(dev)
-    sh = (0.5 * torch.randn(D, generator=g)).to(dev)
-    sh_next = (0.5 * torch.randn(D, generator=g)).to(dev)
     wp = (torch.randn(NO, D, generator=g) / math.sqrt(D)).to(torch.bfloat16).to(dev)
     bp = (0.1 * torch.randn(NO, generator=g)).to(dev)
-    # ---- unfolded: x += gate (att Wo^T + bo); h = norm(x)(1 + sc) + sh; out = h Wp^T + bp
-    xa = x0.clone()
-    KK.gemm(att, wo, bo, nv.EPI_RESID_GATE_F32, out=xa, gate_table=gate)
-    h = KK.adaln_rmsnorm(xa, eps, scale_tab=sc, shift_tab=sh)
-    ref = KK.gemm(h, wp, bp)
-    # ---- folded
-    xb = x0.clone()
-    y = torch.zeros(M + 1, D, device=dev, dtype=torch.bfloat16)
-    tn = sh_next.to(torch.bfloat16)
-    r = KK.gemm_fold(att, wo, bo, nv.EPI_RESID_GATE_F32, out=xb, gate_table=gate, shadow=y, shadow_scale=sc, shadow_xrow=tn)
-    if r is None:           # the dispatch keeps this shape off the 4-wave kernel: the engine then runs the norm pass (fold_supported())
-        assert not must
-        return
-    _, ss = r
-    assert torch.equal(xa, xb)                                              # the residual stream itself is untouched by the extra outputs
-    assert rel_l2(ss[:, :M].sum(0).cpu(), (xa.double() ** 2).sum(-1).cpu()) < 1e-6
-    assert torch.equal(y[:M], (xa * (1.0 + sc)).to(torch.bfloat16))         # the shadow: one rounding of x (1 + s)
-    assert torch.equal(y[M], tn)
-    # this step's c = t W^T + b (fp64 here; in the engine the previous step's extra row leaves it)
-    c_now = (sh.to(torch.bfloat16).double() @ wp.double().T + bp.double()).float()
-    out, c_next = KK.gemm_fold(y, wp, c_now, nv.EPI_BF16, rf_parts=ss, rf_dim=D, eps=eps, xrow=True, xrow_bias=bp)
-    exact = ((xa.double() * torch.rsqrt((xa.double() ** 2).mean(-1, keepdim=True) + eps)) * (1 + sc.double()) + sh.double()) @ wp.double().T + bp.double()
-    e_fold, e_ref = rel_l2(out.double().cpu(), exact.cpu()), rel_l2(ref.double().cpu(), exact.cpu())
-    assert e_fold < 6e-3 and e_fold < 1.5 * e_ref + 1e-4                     # the same accuracy class as norm-then-GEMM
-    assert rel_l2(c_next.cpu(), (tn.double() @ wp.double().T + bp.double()).cpu()) < 1e-5
-    # the row factors alone: consumer with unit weights would be overkill -- check them through a second consumer call without the extra row
-    o3 = KK.gemm_fold(y[:M], wp, c_now, nv.EPI_BF16, rf_parts=ss, rf_dim=D, eps=eps)[0]
-    assert torch.equal(o3, out)
-    # GELU consumer, no extra row, no row factors given (= 1): plain GEMM + bias
-    o2 = KK.gemm_fold(y[:M], wp, bp, nv.EPI_GELU_BF16)[0]
-    assert torch.equal(o2, KK.gemm(y[:M].contiguous(), wp, bp, nv.EPI_GELU_BF16))
+    for scale in (None, sc):
+        # ---- unfolded: x += gate (att Wo^T + bo); h = norm(x)(1 + scale); out = h Wp^T + bp
+        xa = x0.clone()
+        KK.gemm(att, wo, bo, nv.EPI_RESID_GATE_F32, out=xa, gate_table=gate)
+        h = KK.adaln_rmsnorm(xa, eps, scale_tab=scale)
+        ref = KK.gemm(h, wp, bp)
+        # ---- folded
+        xb = x0.clone()
+        y = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+        r = KK.gemm_fold(att, wo, bo, nv.EPI_RESID_GATE_F32, out=xb, gate_table=gate, shadow=y, shadow_scale=scale)
+        if r is None:           # the dispatch keeps this shape off the 4-wave kernel: the engine then runs the norm pass (fold_supported())
+            assert not must
+            return
+        _, ss = r
+        assert torch.equal(xa, xb)                                              # the residual stream itself is untouched by the extra outputs
+        assert rel_l2(ss[:, :M].sum(0).cpu(), (xa.double() ** 2).sum(-1).cpu()) < 1e-6
+        s1 = 1.0 if scale is None else (1.0 + scale)
+        assert torch.equal(y, (xa * s1).to(torch.bfloat16))                     # the shadow: one rounding of x (1 + s)
+        out = KK.gemm_fold(y, wp, bp, nv.EPI_BF16, rf_parts=ss, rf_dim=D, eps=eps)
+        exact = ((xa.double() * torch.rsqrt((xa.double() ** 2).mean(-1, keepdim=True) + eps)) * (1 if scale is None else (1 + scale.double()))) @ wp.double().T + bp.double()
+        e_fold, e_ref = rel_l2(out.double().cpu(), exact.cpu()), rel_l2(ref.double().cpu(), exact.cpu())
+        assert e_fold < 6e-3 and e_fold < 1.5 * e_ref + 1e-4                     # the same accuracy class as norm-then-GEMM
+        # the GELU consumer with the same row factors: against gelu of the fp64 product
+        og = KK.gemm_fold(y, wp, bp, nv.EPI_GELU_BF16, rf_parts=ss, rf_dim=D, eps=eps)
+        eg = torch.nn.functional.gelu(exact.float(), approximate="tanh")
+        assert rel_l2(og.float().cpu(), eg.cpu()) < 8e-3
