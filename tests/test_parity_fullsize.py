@@ -229,6 +229,7 @@ def test_fp8_resident_model_matches_dequantised_model(dev, tmp_path):
     for resident in (False, True):
         m = LTXModel(num_layers=2, device=dev)
         load_transformer_weights(m, path, strict=True, use_fp8=True, fp8_resident=resident)
+        m.set_option("fold_norms", 0)       # the same PROGRAM on both: the folded pre-norm (round 6) has kernels for dense 16-bit weights only, the fp8-resident model keeps the norm pass
         nbytes.append(sum(t.numel() * t.element_size() for t in m.weight_tensors().values()))
         x0 = X0Model(m)(Modality(latent=lat.to(dev), context=ctx.to(dev), context_mask=None, timesteps=torch.tensor([0.725], device=dev), positions=pos.to(dev)))
         outs.append(x0.clone())
