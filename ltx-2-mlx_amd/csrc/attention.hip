@@ -144,6 +144,9 @@ __device__ unsigned long long ltx2_at_counts[2];
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int SK_PART_VEC = 17;          // f32x4 per lane and piece: 16 accumulator groups (O^T[db][qb]) + {M0, M1, l0, l1}
 constexpr long SK_PART_BYTES = SK_PART_VEC * 256L * 16;
+#ifndef AT_SK_AUX
+#define AT_SK_AUX 16        // cache policy of the piece stores / loads: 16 = sc1 (agent scope: through the XCD's L2)
+#endif
 constexpr long SK_CNT_BYTES = 65536;     // the unit counters sit in FRONT of the pieces (one place whatever the geometry: two launch shapes may share a workspace; zero at rest)
 
 template <int HD, bool QS = false, bool KM = false, bool SK = false>
@@ -511,9 +514,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 for (int d = 0; d < NDB; ++d)
 #pragma unroll
                     for (int qb = 0; qb < 2; ++qb)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[d][qb]), rs, sb + (d * 2 + qb) * 4096, 0, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[d][qb]), rs, sb + (d * 2 + qb) * 4096, 0, AT_SK_AUX);
                 const f32x4 ml = {M[0], M[1], l_run[0], l_run[1]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ml), rs, sb + 16 * 4096, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ml), rs, sb + 16 * 4096, 0, AT_SK_AUX);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -523,9 +526,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             __syncthreads();
             const bool merge = *flag == P - 1;
             __syncthreads();                // (the flag word is staged over by the next item)
+#ifdef AT_SK_NOMERGE
+            return;
+#endif
             if (!merge) return;
+#ifndef AT_SK_NOFENCE
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            auto ld = [&](int kk, int j) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, slot0 + (unsigned)(kk * SK_PART_BYTES) + j * 4096, 0, 16)); };
+#endif
+            auto ld = [&](int kk, int j) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, slot0 + (unsigned)(kk * SK_PART_BYTES) + j * 4096, 0, AT_SK_AUX)); };
             {       // piece 0 as the running value, pieces 1 .. P - 1 folded in order
 #pragma unroll
                 for (int d = 0; d < NDB; ++d)
