@@ -103,17 +103,6 @@ int ltx2_gemm_bf16_rowss(const void* A, int64_t lda, const void* W, const float*
 int ltx2_flash_attn_rowscale(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
                              int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, void* stream);
 
-/* Balanced launch form of ltx2_flash_attn / _rowscale / _keymask (round 6): the same kernel body on ONE persistent workgroup per slot (two per CU) -- whole
- * (q-tile, head) units first, then the leftover units' KV tiles in equal shares, the pieces of a unit folded in piece order by whichever workgroup finishes it last
- * (deterministic; nobody waits).  For grids whose last round of the plain form would be badly filled: N = 3456 video tokens are 864 units on 512 slots.
- * workspace: ltx2_flash_attn_balanced_workspace_bytes(Nq, Nkv, H, head_dim) bytes (0: this geometry keeps the plain grid -- the call then runs it), 256-byte
- * aligned, its first 64 KiB ZERO before the first launch (the kernel leaves them zero); one launch at a time per workspace.  q_ss / kmask_words: null or as in
- * ltx2_flash_attn_rowscale / the 64-bit words ltx2_flash_attn_keymask builds.                                                                               */
-int64_t ltx2_flash_attn_balanced_workspace_bytes(int Nq, int Nkv, int H, int head_dim);
-int ltx2_flash_attn_balanced(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
-                             int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, const void* kmask_words,
-                             void* workspace, int64_t workspace_bytes, void* stream);
-
 /* An RMS norm folded around two GEMMs (round 6; rms_norm + nn.Linear, transformer.py:217-226, as arithmetic instead of a pass over x):
  * rms_norm(x) (1 + s) in front of a projection (W, b) equals r (x (1 + s)) W^T + b, r[m] = rsqrt(mean_j x[m][j]^2 + eps).
  * ltx2_gemm_bf16_fold: ltx2_gemm_bf16 with the producer / consumer half of that identity:
@@ -416,8 +405,6 @@ int ltx2_dit_set_context_mask(ltx2_dit* ctx, int modality, const float* mask, in
  *   reference's dequantise-at-load).
  *   "adaln_combine" = 0 (any time): tables and timestep embeddings reach every kernel separately, as in round 3.  Default 1: with one
  *   timestep per modality the sums of all layers are formed by one launch at the top of the step (bit-identical results).
- *   "attn_balanced" = 0 (any time): self-attention and text cross-attention on the plain (q-tile, head) grid, as in round 5.  Default 1: the balanced launch
- *   form (ltx2_flash_attn_balanced) where the plain grid's last round would be badly filled.  Same mathematics; a split unit's pieces are summed in piece order.
  *   "fold_norms" = 0 / 1 (any time; default 1; VideoOnly non-V2.3 models on dense 16-bit weights in the bfloat16 build, one timestep per modality):
  *   1: the text cross-attention's plain RMS pre-norm rides on attn1.to_out's epilogue and attn2.to_q's accumulators (ltx2_gemm_bf16_fold) instead of
  *   running as a pass over the residual stream; 0: round 5's form.  Same mathematics; the operand is rounded before the row factor instead of after it.

@@ -55,8 +55,6 @@ SIGNATURES = {
     "ltx2_gemm_w8a16": (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp]),
     "ltx2_gemm_bf16_rowss": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, C.POINTER(i32), vp]),
     "ltx2_gemm_bf16_fold": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, i64, i32, i32, f32, C.POINTER(i32), vp]),
-    "ltx2_flash_attn_balanced_workspace_bytes": (i64, [i32, i32, i32, i32]),
-    "ltx2_flash_attn_balanced": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, i32, f32, vp, vp, i64, vp]),
     "ltx2_flash_attn_keymask": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, vp, vp]),
     "ltx2_adaln_rmsnorm2": (i32, [vp, i64, vp, vp, i64, i32, i32, f32, vp, vp, vp, vp, vp]),
     "ltx2_flash_attn_gated": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, vp]),

@@ -29,15 +29,7 @@ struct AttnParams {
     // gate_parts > 1: `gate` holds that many partial logit arrays of [Nq][gate_ld] each (gate_logits_parts_launch) and gate_bias[H] is added to their sum
     int gate_parts;
     const float* gate_bias;
-    // Balanced launch form (round 6, attention.hip "SK"): a workspace of attn_sk_workspace_bytes() whose first 64 KiB (the unit counters) are ZERO before the first launch (the kernel
-    // leaves them zero); attn_launch takes the form when the plain grid's last round would be badly filled (N = 3456: 864 units on 512 slots).  null = plain grid.
-    // One launch at a time per workspace (launches on ONE stream are fine).
-    void* sk_ws;
-    long sk_ws_bytes;
-    int sk_pmax;            // (filled by attn_launch)
 };
 
 int attn_launch(const AttnParams& p, hipStream_t stream);
-// bytes of AttnParams::sk_ws for this problem (0: the balanced form would not be taken, pass null)
-long attn_sk_workspace_bytes(int Nq, int Nkv, int H, int head_dim);
 int vt_transpose_launch(const bf16* V, long ld, bf16* VT, int Nkv, int Npad, int H, hipStream_t stream, int head_dim = 128);

@@ -132,24 +132,7 @@ __device__ __forceinline__ void mfma16_result_guard(f32x4 (&s)[4][2], float& t0,
 __device__ unsigned long long ltx2_at_counts[2];
 #endif
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// The balanced launch form (SK; round 6).  N = 3456 is 27 q-tiles x 32 heads = 864 units on 512 workgroup slots: 1.69 rounds, and the plain grid takes the time
-// of two (N = 13 824, 6.75 rounds, runs 8-10 % faster per flop).  Here the grid is ONE persistent workgroup per slot.  Per XCD group x = b % 8 (whole heads stay
-// on one XCD: their K / V^T in one L2) with GL = G / 8 workgroups and UX = (H / 8) * QT units: workgroup bl takes the whole units bl, bl + GL, .. (all of them start
-// at KV tile 0 together: the lock step that lets an XCD's workgroups share K / V^T tiles through its L2) and then its 1 / GL share of the LEFTOVER units' KV tiles
-// -- [bl SX / GL, (bl + 1) SX / GL) of the SX = LX nt tiles, i.e. at most two pieces of two consecutive units.  A piece leaves (O, M, l) in fp32 in the workspace
-// (write-through sc1 stores: the bytes leave the XCD's L2), drains, and raises the unit's counter; the workgroup that finds the counter complete -- whichever
-// finished LAST; nobody waits for anybody, so there is no progress assumption and no time-out -- reads the unit's pieces back in piece order (fixed: the result
-// does not depend on who merges), folds them and writes the output rows.  The merger puts the counter back to 0 for the next launch.
-// ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int SK_PART_VEC = 17;          // f32x4 per lane and piece: 16 accumulator groups (O^T[db][qb]) + {M0, M1, l0, l1}
-constexpr long SK_PART_BYTES = SK_PART_VEC * 256L * 16;
-#ifndef AT_SK_AUX
-#define AT_SK_AUX 16        // cache policy of the piece stores / loads: 16 = sc1 (agent scope: through the XCD's L2)
-#endif
-constexpr long SK_CNT_BYTES = 65536;     // the unit counters sit in FRONT of the pieces (one place whatever the geometry: two launch shapes may share a workspace; zero at rest)
-
-template <int HD, bool QS = false, bool KM = false, bool SK = false>
+template <int HD, bool QS = false, bool KM = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     using G = Geo<HD>;
     constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NJ = G::NJ;
@@ -183,27 +166,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) v_lane[kk] = lds0 + K_TILE + l15 * 128 + (((4 * kk + g) ^ v_xor) << 4);
 
-    // ---- work items of this workgroup: (unit, KV tile range) ----
-    const int QT = (p.Nq + QB - 1) / QB;
-    int n_items = 1;
-    [[maybe_unused]] int sk_x = 0, sk_bl = 0, sk_GL = 1, sk_W = 0, sk_LX = 0, sk_lo = 0, sk_hi = 0;
-    if constexpr (SK) {
-        const int b = blockIdx.x, G = gridDim.x;
-        sk_x = b & 7;
-        sk_bl = b >> 3;
-        sk_GL = G >> 3;
-        const int UX = (p.H >> 3) * QT;
-        sk_W = UX / sk_GL;
-        sk_LX = UX - sk_W * sk_GL;
-        const long SX = (long)sk_LX * nt;
-        sk_lo = (int)(SX * sk_bl / sk_GL);
-        sk_hi = (int)(SX * (sk_bl + 1) / sk_GL);
-        n_items = sk_W + (sk_hi > sk_lo ? ((sk_hi - 1) / nt != sk_lo / nt ? 2 : 1) : 0);
+    int head = blockIdx.y, qt = blockIdx.x;
+#if AT_XCD
+    // workgroup b runs on XCD b % 8 (observed placement): deal whole heads to the XCDs, so a head's K / V^T tiles are fetched by ONE L2 instead of all eight
+    if ((gridDim.y & 7) == 0) {
+        const int b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7, idx = b >> 3;
+        head = xcd + 8 * (idx / (int)gridDim.x);
+        qt = idx % (int)gridDim.x;
     }
-    // One work item: unit (head, qt), KV tiles [ta, tb); sk_u >= 0: a piece of leftover unit sk_u (balanced form).  Inlined once per kernel: the plain kernels call it
-    // with (0, nt, -1) and are, instruction for instruction, round 5's kernel.
-    auto run_item = [&](const int head, const int qt, const int ta, const int tb, [[maybe_unused]] const int sk_u) __attribute__((always_inline)) {
+#endif
+    const int tb = nt;
     const int q0 = qt * QB + wv * 32;
+
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.K + head * HD), 0, (int)k_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.VT + (long)head * p.vt_head_stride), 0, (int)v_bytes, 0x00020000);
     auto stage_piece = [&](int t, int buf, int i) {
@@ -217,9 +191,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         (void)dst; (void)t; (void)i;
 #endif
     };
-    // the item's first tile is on its way while the Q fragments are loaded and scaled
+    // tile 0 is on its way while the Q fragments are loaded and scaled
 #pragma unroll
-    for (int i = 0; i < 2 * NJ; ++i) stage_piece(ta, 0, i);
+    for (int i = 0; i < 2 * NJ; ++i) stage_piece(0, 0, i);
+
     // ---- softmax scale of this lane's two query rows (exp2 domain), folded into Q ----
     float c[2] = {p.scale_log2e, p.scale_log2e};
     if constexpr (QS) {
@@ -250,12 +225,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             for (int e = 0; e < 8; ++e) qf[qb][ks][e] = f2bf(bf2f(raw[e]) * c[qb]);
         }
     }
+
     f32x4 o[NDB][2];
 #pragma unroll
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) o[d][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float M[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};     // M: reference exponent of the row (exp2 units); set by the first tile
+
     // one KV tile.  FAST: stale-maximum path with the exponentials inside the QK^T cluster; otherwise the classic path (FIRST: runtime flag)
     auto tile = [&](const int t, auto fast, auto masked, auto par, const bool first) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast)::value, MASKED = decltype(masked)::value;
@@ -427,56 +404,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         l_run[1] += ps[1];
         pv(I0{}, IN{});
     };
+
     using T_ = std::true_type;
     using F_ = std::false_type;
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-
-    // ---- normalise and store this lane's rows of the current unit (o, l_run complete) ----
-    auto finish = [&]() __attribute__((always_inline)) {
-        float lt[2] = {l_run[0], l_run[1]};
-        quad_fold_sum(lt[0], lt[1]);
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const int qrow = q0 + 16 * qb + l15;
-            float inv = 1.0f / lt[qb];
-            if (p.gate && qrow < p.Nq) {
-                float gl = p.gate[(long)qrow * p.gate_ld + head];
-                if (p.gate_parts > 1) {         // partial sums over K slices + bias, in slice order
-                    for (int pt = 1; pt < p.gate_parts; ++pt) gl += p.gate[((long)pt * p.Nq + qrow) * p.gate_ld + head];
-                    gl += p.gate_bias[head];
-                }
-                inv *= 2.f / (1.f + __expf(-gl));
-            }
-            bf16* op = p.O + (long)min(qrow, p.Nq - 1) * p.ldo + head * HD + 16 * (g & 1) + 8 * (g >> 1);
-#pragma unroll
-            for (int i = 0; i < NDB / 2; ++i) {
-                bf16x4 a, b;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[e] = f2bf(o[2 * i][qb][e] * inv);
-                    b[e] = f2bf(o[2 * i + 1][qb][e] * inv);
-                }
-                u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1" : "+v"(ua[0]), "+v"(ua[1]), "+v"(ub[0]), "+v"(ub[1]));
-                const u32x4 w = {ua[0], ua[1], ub[0], ub[1]};
-                if (qrow < p.Nq) *(u32x4*)(op + 32 * i) = w;
-            }
-        }
-    };
-
-    // ---- the item's tiles [ta, tb): stage buffer = (t - ta) & 1; the first one and the ragged last one of the unit on the classic path ----
     if constexpr (KM) {             // every tile masked, classic
-        for (int t = ta; t < tb; ++t) {
-            if ((t - ta) & 1) tile(t, F_{}, T_{}, P1{}, false);
-            else tile(t, F_{}, T_{}, P0{}, t == ta);
+        for (int t = 0; t < tb; ++t) {
+            if (t & 1) tile(t, F_{}, T_{}, P1{}, false);
+            else tile(t, F_{}, T_{}, P0{}, t == 0);
         }
     } else {
         const int t_fast_end = min(tb, nfull);
-        int t = ta;
-        if (ta < nfull) {
-            tile(ta, F_{}, F_{}, P0{}, true);
-            t = ta + 1;
+        int t = 0;
+        if (nfull > 0) {
+            tile(0, F_{}, F_{}, P0{}, true);
+            t = 1;
             for (; t + 1 < t_fast_end; t += 2) {
                 tile(t, T_{}, F_{}, P1{}, false);
                 tile(t + 1, T_{}, F_{}, P0{}, false);
@@ -486,112 +429,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 ++t;
             }
         }
-        if (nfull < tb) {           // the ragged last tile of the unit (the item's first one too when it starts there)
-            if ((nfull - ta) & 1) tile(nfull, F_{}, T_{}, P1{}, false);
-            else tile(nfull, F_{}, T_{}, P0{}, nfull == ta);
+        if (nfull < tb) {           // the ragged last tile (the first one too when Nkv < 64)
+            if (nfull & 1) tile(nfull, F_{}, T_{}, P1{}, false);
+            else tile(nfull, F_{}, T_{}, P0{}, nfull == 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    if constexpr (SK) {
-        if (sk_u >= 0 && (ta > 0 || tb < nt)) {         // a PIECE of a leftover unit: publish, count, and merge if this was the last one in
-            // the workgroups whose ranges meet unit sk_u: first .. last (ranges are [bl SX / GL, (bl + 1) SX / GL))
-            const long SX = (long)sk_LX * nt;
-            auto range_lo = [&](int w) { return (int)(SX * w / sk_GL); };
-            const int X0 = sk_u * nt, X1 = X0 + nt - 1;
-            int first = (int)((long)X0 * sk_GL / SX), last = (int)((long)X1 * sk_GL / SX);
-            while (range_lo(first + 1) <= X0) ++first;
-            while (range_lo(first) > X0) --first;
-            while (range_lo(last + 1) <= X1) ++last;
-            while (range_lo(last) > X1) --last;
-            const int k = sk_bl - first, P = last - first + 1;
-            const int ug = sk_x * sk_LX + sk_u;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, 0x7fffffff, 0x00020000);
-            const unsigned slot0 = (unsigned)(SK_CNT_BYTES + ((long)ug * p.sk_pmax) * SK_PART_BYTES) + tid * 16;        // (< 2 GiB: checked by the launcher)
-            {
-                const unsigned sb = slot0 + (unsigned)(k * SK_PART_BYTES);
+    float lt[2] = {l_run[0], l_run[1]};
+    quad_fold_sum(lt[0], lt[1]);
 #pragma unroll
-                for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                    for (int qb = 0; qb < 2; ++qb)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[d][qb]), rs, sb + (d * 2 + qb) * 4096, 0, AT_SK_AUX);
-                const f32x4 ml = {M[0], M[1], l_run[0], l_run[1]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ml), rs, sb + 16 * 4096, 0, AT_SK_AUX);
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0 + 16 * qb + l15;
+        float inv = 1.0f / lt[qb];
+        if (p.gate && qrow < p.Nq) {
+            float gl = p.gate[(long)qrow * p.gate_ld + head];
+            if (p.gate_parts > 1) {         // partial sums over K slices + bias, in slice order
+                for (int pt = 1; pt < p.gate_parts; ++pt) gl += p.gate[((long)pt * p.Nq + qrow) * p.gate_ld + head];
+                gl += p.gate_bias[head];
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            unsigned* cnt = (unsigned*)p.sk_ws + ug;
-            int* flag = (int*)smem;         // (the stage buffers are free: every wave is behind the barrier above)
-            if (tid == 0) *flag = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const bool merge = *flag == P - 1;
-            __syncthreads();                // (the flag word is staged over by the next item)
-#ifdef AT_SK_NOMERGE
-            return;
-#endif
-            if (!merge) return;
-#ifndef AT_SK_NOFENCE
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-            auto ld = [&](int kk, int j) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, slot0 + (unsigned)(kk * SK_PART_BYTES) + j * 4096, 0, AT_SK_AUX)); };
-            {       // piece 0 as the running value, pieces 1 .. P - 1 folded in order
-#pragma unroll
-                for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) o[d][qb] = ld(0, d * 2 + qb);
-                const f32x4 ml = ld(0, 16);
-                M[0] = ml[0];
-                M[1] = ml[1];
-                l_run[0] = ml[2];
-                l_run[1] = ml[3];
-            }
-            for (int kk = 1; kk < P; ++kk) {
-                const f32x4 ml = ld(kk, 16);
-                float fa[2], fb[2];
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    const float mn = fmaxf(M[qb], ml[qb]);
-                    fa[qb] = __builtin_amdgcn_exp2f(M[qb] - mn);
-                    fb[qb] = __builtin_amdgcn_exp2f(ml[qb] - mn);
-                    M[qb] = mn;
-                    l_run[qb] = l_run[qb] * fa[qb] + ml[2 + qb] * fb[qb];
-                }
-#pragma unroll
-                for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) o[d][qb] = o[d][qb] * fa[qb] + ld(kk, d * 2 + qb) * fb[qb];
-            }
-            if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (every piece of this unit is in)
+            inv *= 2.f / (1.f + __expf(-gl));
         }
-    }
-    finish();
-    };
-
-    if constexpr (SK) {
-        for (int item = 0; item < n_items; ++item) {
-            int uid, ta = 0, tb = nt, sk_u = -1;            // unit id local to the XCD group: head = x + 8 (uid / QT), q-tile uid % QT
-            if (item < sk_W) {
-                uid = item * sk_GL + sk_bl;
-            } else {
-                sk_u = sk_lo / nt + (item - sk_W);
-                ta = max(sk_lo - sk_u * nt, 0);
-                tb = min(sk_hi - sk_u * nt, nt);
-                uid = sk_W * sk_GL + sk_u;
+        bf16* op = p.O + (long)min(qrow, p.Nq - 1) * p.ldo + head * HD + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+        for (int i = 0; i < NDB / 2; ++i) {
+            bf16x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = f2bf(o[2 * i][qb][e] * inv);
+                b[e] = f2bf(o[2 * i + 1][qb][e] * inv);
             }
-            if (item > 0) __syncthreads();      // the previous item's last tile is read: stage 0 may be refilled
-            run_item(sk_x + 8 * (uid / QT), uid % QT, ta, tb, sk_u);
+            u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1" : "+v"(ua[0]), "+v"(ua[1]), "+v"(ub[0]), "+v"(ub[1]));
+            const u32x4 w = {ua[0], ua[1], ub[0], ub[1]};
+            if (qrow < p.Nq) *(u32x4*)(op + 32 * i) = w;
         }
-    } else {
-        int head = blockIdx.y, qt = blockIdx.x;
-#if AT_XCD
-        // workgroup b runs on XCD b % 8 (observed placement): deal whole heads to the XCDs, so a head's K / V^T tiles are fetched by ONE L2 instead of all eight
-        if ((gridDim.y & 7) == 0) {
-            const int b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7, idx = b >> 3;
-            head = xcd + 8 * (idx / (int)gridDim.x);
-            qt = idx % (int)gridDim.x;
-        }
-#endif
-        run_item(head, qt, 0, nt, -1);
     }
 }
 
@@ -641,47 +513,7 @@ __global__ __launch_bounds__(256) void vt_transpose_kernel(const bf16* __restric
 
 }  // namespace
 
-namespace {
-// the balanced form's geometry: G persistent workgroups (two per CU), eight XCD groups of GL; LX leftover units per group, each cut into at most pmax pieces
-struct SkPlan {
-    int G = 0, LX = 0, pmax = 0;
-    long bytes = 0;
-    bool ok = false;
-};
-SkPlan sk_plan(int Nq, int Nkv, int H, int head_dim) {
-    SkPlan s;
-    static int cus[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) return s;
-    if (!cus[dev]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return s;
-        cus[dev] = n;
-    }
-    s.G = 2 * cus[dev];
-    if (head_dim != 128 || H % 8 != 0 || s.G % 8 != 0) return s;
-    const int QT = (Nq + QB - 1) / QB, nt = (Nkv + KVB - 1) / KVB, GL = s.G / 8, UX = (H / 8) * QT;
-    const int W = UX / GL;
-    s.LX = UX - W * GL;
-    const long SX = (long)s.LX * nt;
-    const int w = (int)(SX / GL);                  // KV tiles of the leftover per workgroup (floor)
-    // worth it where the plain grid's last round is badly filled (< 90 %) and a piece is long enough to pay for its prologue and its 70 KB of partials
-    if (W < 1 || s.LX == 0 || s.LX * 10 >= GL * 9 || nt < 8 || w < 4) return s;
-    s.pmax = (nt + w - 1) / w + 1;
-    s.bytes = SK_CNT_BYTES + 8L * s.LX * s.pmax * SK_PART_BYTES;
-    s.ok = s.bytes < (1L << 31) && 8L * s.LX * 4 <= SK_CNT_BYTES;
-    return s;
-}
-}  // namespace
-
-long attn_sk_workspace_bytes(int Nq, int Nkv, int H, int head_dim) {
-    const SkPlan s = sk_plan(Nq, Nkv, H, head_dim == 0 ? 128 : head_dim);
-    return s.ok ? s.bytes : 0;
-}
-
-int attn_launch(const AttnParams& p_in, hipStream_t stream) {
-    AttnParams p = p_in;
+int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG(p.Nq > 0 && p.Nkv > 0 && p.H > 0, "attention: empty problem");
     LTX2_CHECK_ARG(p.head_dim == 0 || p.head_dim == 128 || p.head_dim == 64, "attention: head_dim=%d, only 128 and 64 are implemented", p.head_dim);
     LTX2_CHECK_ARG(p.Npad % 64 == 0 && p.Npad >= p.Nkv, "attention: Npad=%d must be a multiple of 64 >= Nkv", p.Npad);
@@ -691,37 +523,21 @@ int attn_launch(const AttnParams& p_in, hipStream_t stream) {
     if (p.q_ss)
         LTX2_CHECK_ARG(p.head_dim != 64 && p.q_ss_ld > 0 && p.q_ss_ld % 16 == 0 && p.q_norm_dim > 0, "attention: the per-row scale form needs head_dim 128 and q_ss_ld %% 16 == 0");
     dim3 grid((p.Nq + QB - 1) / QB, p.H);
-    bool sk = false;
-    if (p.sk_ws && p.head_dim != 64) {
-        const SkPlan s = sk_plan(p.Nq, p.Nkv, p.H, 128);
-        if (s.ok) {
-            LTX2_CHECK_ARG(p.sk_ws_bytes >= s.bytes && ((uintptr_t)p.sk_ws & 255) == 0, "attention: the balanced form needs a 256-byte aligned workspace of %ld bytes (given %ld)", s.bytes, p.sk_ws_bytes);
-            sk = true;
-            p.sk_pmax = s.pmax;
-            grid = dim3(s.G);
-        }
-    }
-#define AT_LAUNCH(HDV, QSV, KMV, SKV)                                                                                                                \
-    do {                                                                                                                                             \
-        static PerDeviceOnce once_;                                                                                                                  \
-        if (once_.first())                                                                                                                           \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDV, QSV, KMV, SKV>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<HDV>::LDS_BYTES); \
-        hipLaunchKernelGGL((attn_fwd_kernel<HDV, QSV, KMV, SKV>), grid, dim3(256), Geo<HDV>::LDS_BYTES, stream, p);                                   \
+#define AT_LAUNCH(HDV, QSV, KMV)                                                                                                                \
+    do {                                                                                                                                        \
+        static PerDeviceOnce once_;                                                                                                             \
+        if (once_.first())                                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDV, QSV, KMV>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<HDV>::LDS_BYTES); \
+        hipLaunchKernelGGL((attn_fwd_kernel<HDV, QSV, KMV>), grid, dim3(256), Geo<HDV>::LDS_BYTES, stream, p);                                   \
     } while (0)
     if (p.head_dim == 64) {
-        if (p.kmask) AT_LAUNCH(64, false, true, false);
-        else AT_LAUNCH(64, false, false, false);
-    } else if (sk) {
-        if (p.kmask) {
-            if (p.q_ss) AT_LAUNCH(128, true, true, true);
-            else AT_LAUNCH(128, false, true, true);
-        } else if (p.q_ss) AT_LAUNCH(128, true, false, true);
-        else AT_LAUNCH(128, false, false, true);
+        if (p.kmask) AT_LAUNCH(64, false, true);
+        else AT_LAUNCH(64, false, false);
     } else if (p.kmask) {
-        if (p.q_ss) AT_LAUNCH(128, true, true, false);
-        else AT_LAUNCH(128, false, true, false);
-    } else if (p.q_ss) AT_LAUNCH(128, true, false, false);
-    else AT_LAUNCH(128, false, false, false);
+        if (p.q_ss) AT_LAUNCH(128, true, true);
+        else AT_LAUNCH(128, false, true);
+    } else if (p.q_ss) AT_LAUNCH(128, true, false);
+    else AT_LAUNCH(128, false, false);
 #undef AT_LAUNCH
     LTX2_CHECK_LAUNCH("attn_fwd_kernel");
     return LTX2_OK;

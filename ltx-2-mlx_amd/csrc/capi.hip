@@ -104,37 +104,6 @@ int ltx2_gemm_bf16_fold(const void* A, int64_t lda, const void* W, const float* 
     return gemm_launch(p, epilogue, false, (hipStream_t)stream);
 }
 
-int64_t ltx2_flash_attn_balanced_workspace_bytes(int Nq, int Nkv, int H, int head_dim) { return attn_sk_workspace_bytes(Nq, Nkv, H, head_dim); }
-
-int ltx2_flash_attn_balanced(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
-                             int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, const void* kmask_words,
-                             void* workspace, int64_t workspace_bytes, void* stream) {
-    LTX2_CHECK_ARG(Q && K && VT && out && workspace, "flash_attn_balanced: null operand");
-    AttnParams a{};
-    a.Q = (const bf16*)Q;
-    a.ldq = ldq;
-    a.K = (const bf16*)K;
-    a.ldk = ldk;
-    a.VT = (const bf16*)VT;
-    a.vt_head_stride = (long)head_dim * Npad;
-    a.head_dim = head_dim;
-    a.O = (bf16*)out;
-    a.ldo = ldo;
-    a.Nq = Nq;
-    a.Nkv = Nkv;
-    a.Npad = Npad;
-    a.H = H;
-    a.scale_log2e = scale * 1.4426950408889634f;
-    a.q_ss = q_ss;
-    a.q_ss_ld = q_ss_ld;
-    a.q_norm_dim = q_norm_dim;
-    a.q_eps = q_eps;
-    a.kmask = (const unsigned long long*)kmask_words;
-    a.sk_ws = workspace;
-    a.sk_ws_bytes = workspace_bytes;
-    return attn_launch(a, (hipStream_t)stream);
-}
-
 int ltx2_flash_attn_rowscale(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
                              int H, int head_dim, float scale, const float* q_ss, int q_ss_ld, int q_norm_dim, float q_eps, void* stream) {
     LTX2_CHECK_ARG(Q && K && VT && out && q_ss, "flash_attn_rowscale: null operand");

@@ -89,8 +89,6 @@ struct Mod {        // per-modality geometry + workspace
     float* rss = nullptr;           //   partial sums of squares of the new residual rows, one per 256-column tile [D/256][rss_ld], left by attn1.to_out's epilogue
     long rss_ld = 0;                //   (the query projection turns them into its rows' RMS factors itself)
     int fold_max = 0;               //   what this geometry / model supports (prepare): 0 none, 1 the fold
-    char* skws = nullptr;           // round 6: workspace of the attention kernel's balanced launch form (self-attention and text cross-attention of this modality share it:
-    long skws_bytes = 0;            //   they run one after the other on the modality's stream); its counter words are zeroed at bind
     unsigned char* a8 = nullptr;    // fp8 compute: per-token e4m3fn codes of the current GEMM's activation operand [N][<= 4D]
     float* a8s = nullptr;           //              and their row scales [N]
 };
@@ -117,7 +115,6 @@ struct ltx2_dit {
     bool adaln_combine = true;         // ltx2_dit_set_option("adaln_combine"): round 4, see forward()
     bool text_kv_ahead = true;         // ltx2_dit_set_option("text_kv_ahead"): round 5, AudioVideo V2.3 -- the video stream's sigma-modulated text K / V of layer l are projected on the SIDE stream at the top of the layer
     hipEvent_t text_kv_ev = nullptr;   //   (they depend on the prompt and sigma only); the main stream waits on this event in front of its text cross-attention
-    bool attn_balanced = true;         // ltx2_dit_set_option("attn_balanced"): round 6, the attention kernel's balanced launch form for self- / text cross-attention grids with a badly filled last round
     int fold_norms = 1;                // ltx2_dit_set_option("fold_norms"): round 6, see block_attention(): 0 = every norm a pass of its own (round 5), 1 = the text cross-attention's
                                        //   plain RMS pre-norm rides on attn1.to_out's epilogue
     bool fp8_compute = false;          // ltx2_dit_set_option("fp8_compute"): fp8-resident weights x per-token fp8 activations on the fp8 MFMA
@@ -169,11 +166,6 @@ long carve(ltx2_dit* c, char* base, int N, int S, int Na, int Sa, int per_token)
         const bool fold_bufs = k == 0 && !c->av;
         m.rss_ld = align_up(n, 256) + 256;
         m.rss = (float*)take(fold_bufs ? 4L * (D / 256 + 1) * m.rss_ld : 0);
-        {
-            const long b1 = attn_sk_workspace_bytes((int)n, (int)n, m.H, m.hd), b2 = attn_sk_workspace_bytes((int)n, (int)s, m.H, m.hd);
-            m.skws_bytes = b1 > b2 ? b1 : b2;
-            m.skws = take(m.skws_bytes);
-        }
         m.a8 = (unsigned char*)take((c->fp8_compute && k == 0) ? n * 4 * D : 0);
         m.a8s = (float*)take((c->fp8_compute && k == 0) ? 4L * n : 0);
         m.sin_f = (float*)take(4L * 256);
@@ -582,10 +574,8 @@ struct GateRef {
 };
 int attend(const bf16* q, long ldq, const bf16* k, long ldk, const bf16* vt, int npad, bf16* out, long ldo, int nq,
            int nkv, int H, int hd, hipStream_t st, const float* q_ss = nullptr, float q_eps = 0.f,
-           const unsigned long long* kmask = nullptr, GateRef gate = GateRef{}, void* skws = nullptr, long skws_bytes = 0) {
+           const unsigned long long* kmask = nullptr, GateRef gate = GateRef{}) {
     AttnParams a{};
-    a.sk_ws = skws;             // the balanced launch form where the plain grid's last round would be badly filled (attention.hip "SK")
-    a.sk_ws_bytes = skws_bytes;
     a.kmask = kmask;
     a.gate = gate.p;        // per-head gate logits [nq][H] (V2.3): out *= 2 sigmoid(.) in the kernel's epilogue
     a.gate_ld = H;
@@ -741,7 +731,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, int fold
         TRY(qknorm_rope_launch(m.qkv, 3 * D, N, D, hd, 2, offs, wts, eps, m.cosb, m.sinb, st));
     }
     if (!vt_done) TRY(vt_transpose_launch(m.qkv + 2 * D, 3 * D, m.vt, N, m.Npad, H, st, hd));
-    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, nullptr, 0.f, nullptr, glog(c, m), c->attn_balanced ? m.skws : nullptr, m.skws_bytes));
+    TRY(attend(m.qkv, 3 * D, m.qkv + D, 3 * D, m.vt, m.Npad, m.att, D, N, N, H, hd, st, nullptr, 0.f, nullptr, glog(c, m)));
     Fold fo{};
     if (fl >= 1) fold_produce(fo, m, nullptr);          // the new residual rows also leave as the cross-attention query projection's operand (plain RMS norm: no scale, no shift)
     TRY(dense(c, m.att, D, w.self.o_w, w.self.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(2), es, tab + 2 * D, nullptr, nullptr, false, nullptr, fl >= 1 ? &fo : nullptr));
@@ -782,7 +772,7 @@ int block_attention(ltx2_dit* c, int k, int l, long es, hipStream_t st, int fold
         TRY(qknorm_rope_launch(m.qkv, D, N, D, hd, 1, offs, wts, eps, nullptr, nullptr, st));
     }
     TRY(attend(m.qkv, D, kk, 2 * D, vt, m.Spad, m.att, D, N, m.S, H, hd, st, m.qfold ? m.qss : nullptr, eps,
-               m.has_kmask ? m.kmask : nullptr, glog(c, m), c->attn_balanced ? m.skws : nullptr, m.skws_bytes));
+               m.has_kmask ? m.kmask : nullptr, glog(c, m)));
     if (c->v2)
         TRY(dense(c, m.att, D, w.text.o_w, w.text.o_b, m.x, D, N, D, D, EPI_RESID_GATE_F32, st, E(8), es, tab + 8 * D));
     else
@@ -1107,11 +1097,6 @@ int bind(ltx2_dit* c, void* ptr, int64_t bytes, int N, int S, int Na, int Sa, in
     }
     c->ws = (char*)ptr;
     c->ws_bytes = bytes;
-    for (int k = 0; k < 2; ++k)         // the balanced attention form's unit counters: zero at rest (the kernel puts them back)
-        if (c->m[k].skws && c->m[k].skws_bytes >= 65536 && hipMemset(c->m[k].skws, 0, 65536) != hipSuccess) {
-            ltx2_set_error("dit_bind_workspace: clearing the attention workspace failed");
-            return LTX2_E_HIP;
-        }
     const int n[2] = {N, Na}, s[2] = {S, Sa};
     for (int k = 0; k < 2; ++k) {
         c->m[k].N = n[k];
@@ -1439,10 +1424,6 @@ int ltx2_dit_set_option(ltx2_dit* c, const char* name, int value) {
     }
     if (!strcmp(name, "text_kv_ahead")) {       // 0: the video stream projects its sigma-modulated text K / V inline (round 4's schedule; same results bit for bit)
         c->text_kv_ahead = value != 0;
-        return LTX2_OK;
-    }
-    if (!strcmp(name, "attn_balanced")) {       // 0: the plain (q-tile, head) grid everywhere (round 5)
-        c->attn_balanced = value != 0;
         return LTX2_OK;
     }
     if (!strcmp(name, "fold_norms")) {          // 0 / 1: see block_attention(); 0 restores round 5's norm pass in front of the text cross-attention

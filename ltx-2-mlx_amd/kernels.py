@@ -406,31 +406,6 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n
     return out
 
 
-_SK_WS: dict = {}
-
-
-def flash_attn_balanced(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, scale: Optional[float] = None,
-                        q_ss: Optional[torch.Tensor] = None, eps: float = 1e-6, kmask_words: Optional[torch.Tensor] = None):
-    """flash_attn (optionally the per-row-scale / key-mask-words forms) through the BALANCED launch form (ltx2_flash_attn_balanced): returns (out, taken) --
-    taken is False when this geometry keeps the plain grid (the call then ran it).  The workspace is cached per (device, dtype) and grown on demand."""
-    assert q.dtype in ACT16 and k.dtype == q.dtype and vt.dtype == q.dtype and q.stride(1) == 1 and k.stride(1) == 1
-    nq, hd = q.shape[0], vt.shape[1]
-    out = torch.empty(nq, heads * hd, device=q.device, dtype=q.dtype)
-    if scale is None:
-        scale = 1.0 / math.sqrt(float(hd))
-    L = _L(q)
-    need = int(L.ltx2_flash_attn_balanced_workspace_bytes(nq, nkv, heads, hd))
-    key = (q.device, q.dtype)
-    ws = _SK_WS.get(key)
-    if ws is None or ws.numel() < max(need, 65536):
-        ws = torch.zeros(max(need, 65536), device=q.device, dtype=torch.uint8)
-        _SK_WS[key] = ws
-    nv.check(L.ltx2_flash_attn_balanced(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out), out.stride(0), nq, nkv, heads, hd,
-                                        scale, nv.ptr(q_ss), q_ss.shape[1] if q_ss is not None else 0, heads * hd, eps, nv.ptr(kmask_words), nv.ptr(ws), ws.numel(),
-                                        nv.stream()))
-    return out, need > 0
-
-
 def attn_head_gate_(att: torch.Tensor, x: torch.Tensor, gate_w: torch.Tensor, gate_b: torch.Tensor, heads: int) -> torch.Tensor:
     """In place: att [rows, H*hd] bf16 *= 2*sigmoid(x @ gate_w^T + gate_b) per head; returns the fp32 logits."""
     assert att.dtype in ACT16 and x.dtype == att.dtype and gate_w.dtype == att.dtype and att.is_contiguous() and x.stride(1) == 1

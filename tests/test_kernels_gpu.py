@@ -879,44 +879,3 @@ def test_norm_folded_around_the_gemms(dev, M, D, NO, must):
         og = KK.gemm_fold(y, wp, bp, nv.EPI_GELU_BF16, rf_parts=ss, rf_dim=D, eps=eps)
         eg = torch.nn.functional.gelu(exact.float(), approximate="tanh")
         assert rel_l2(og.float().cpu(), eg.cpu()) < 8e-3
-
-
-
-@pytest.mark.parametrize("Nq,Nkv,H", [(3456, 3456, 32), (3456, 1024, 32), (3456, 1000, 32), (3300, 3300, 16), (512, 512, 32)])
-def test_flash_attention_balanced_form(dev, Nq, Nkv, H):
-    """Round 6: the balanced launch form (one persistent workgroup per slot; leftover units cut into KV pieces, folded in piece order by the workgroup that finishes
-    a unit last) against the plain grid and fp64: plain, per-row-scale and key-mask variants, a ragged last KV tile, a geometry that keeps the plain grid; repeated
-    launches are bit-identical (the fold order is fixed) and leave the counters at zero (the next launch on the same workspace is right)."""
-    import ltx_2_mlx_amd.kernels as KK
-    g = torch.Generator().manual_seed(Nq + Nkv)
-    hd, D = 128, H * 128
-    q = torch.randn(Nq, D, generator=g).to(torch.bfloat16).to(dev)
-    k = torch.randn(Nkv, D, generator=g).to(torch.bfloat16).to(dev)
-    v = torch.randn(Nkv, D, generator=g).to(torch.bfloat16).to(dev)
-    vt = KK.vt_transpose(v, H)
-    ref = KK.flash_attn(q, k, vt, H, Nkv)
-    out, taken = KK.flash_attn_balanced(q, k, vt, H, Nkv)
-    assert taken == (Nq >= 3300 and Nkv >= 512)
-    if not taken:
-        assert torch.equal(out, ref)
-        return
-    rows = torch.arange(0, Nq, max(Nq // 96, 1), device=dev)[:96]
-    for h in (0, H // 2, H - 1):
-        sl = slice(h * hd, (h + 1) * hd)
-        sc = (q[rows][:, sl].double() @ k[:, sl].double().T) / math.sqrt(hd)
-        exact = torch.softmax(sc, -1) @ v[:, sl].double()
-        e_b, e_p = rel_l2(out[rows][:, sl].double().cpu(), exact.cpu()), rel_l2(ref[rows][:, sl].double().cpu(), exact.cpu())
-        assert e_b < 6e-3 and e_b < 1.3 * e_p + 1e-4
-    assert rel_l2(out.float().cpu(), ref.float().cpu()) < 4e-3
-    out2, _ = KK.flash_attn_balanced(q, k, vt, H, Nkv)
-    assert torch.equal(out, out2)
-    # the per-row-scale form (text cross-attention with q_norm folded in) and the key-mask form through the same launch form
-    if Nkv <= 1024:
-        qss = (torch.rand(Nq, D // 64, generator=g) * 64 + 32).to(dev)
-        a = KK.flash_attn_rowscale(q, k, vt, H, Nkv, qss)
-        b, _ = KK.flash_attn_balanced(q, k, vt, H, Nkv, q_ss=qss)
-        assert rel_l2(b.float().cpu(), a.float().cpu()) < 4e-3
-        c, _ = KK.flash_attn_balanced(q, k, vt, H, Nkv, q_ss=qss)
-        assert torch.equal(b, c)
-    out3, _ = KK.flash_attn_balanced(q, k, vt, H, Nkv)           # after another geometry on the same workspace
-    assert torch.equal(out, out3)

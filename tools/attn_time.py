@@ -20,13 +20,4 @@ for (Nq, Nkv, H, hd) in SHAPES[:int(sys.argv[1]) if len(sys.argv) > 1 else None]
     vt = K.vt_transpose(v, H, head_dim=hd)
     best = min(timeit(lambda: K.flash_attn(q, k, vt, H, Nkv)) for _ in range(3))
     fl = 4.0 * Nq * Nkv * D
-    bal = ""
-    if hasattr(K, "flash_attn_balanced") and hd == 128:
-        try:
-            _, taken = K.flash_attn_balanced(q, k, vt, H, Nkv)
-            if taken:
-                bb = min(timeit(lambda: K.flash_attn_balanced(q, k, vt, H, Nkv)) for _ in range(3))
-                bal = f" | balanced form {bb*1e6:8.1f} us {fl/bb/1e12:7.1f} TF/s ({(bb - best) * 1e6:+.1f})"
-        except AttributeError:      # an A/B library of an earlier round
-            pass
-    print(f"Nq={Nq} Nkv={Nkv} H={H} hd={hd}: {best*1e6:8.1f} us {fl/best/1e12:7.1f} TF/s{bal}", flush=True)
+    print(f"Nq={Nq} Nkv={Nkv} H={H} hd={hd}: {best*1e6:8.1f} us {fl/best/1e12:7.1f} TF/s", flush=True)
