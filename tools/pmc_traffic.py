@@ -12,7 +12,7 @@ def kernel_source_sha():
     for f in ("gemm_v4.hip", "gemm_v4_loop.inc", "gemm_epilogue.h", "gemm.h", "common.h"):
         h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()[:16]
-KEY = "gemm_v4_kernel<4, 3, 224, false, 0>"
+KEY = "gemm_v4_kernel<4, 3, 224, false, "       # both instantiations: plain (attn2.to_out, ff.net.2) and VAR 30 (attn1.to_out with the folded pre-norm's shadow, round 6)
 def mean(path, counter):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if KEY in r["Kernel_Name"] and r["Counter_Name"] == counter]
     return sum(v) / len(v), len(v)
@@ -20,7 +20,7 @@ f, nf = mean(fb, "FETCH_SIZE")
 w, nw = mean(fc, "WRITE_SIZE")
 fetch, write = f * 2 * 1024, w * 1024        # KB -> bytes; gfx950 reports half of wide coalesced reads (MI355X_MICROARCH.md)
 M, D = 3456, 4096
-alg = ((M * D + D * D) * 2 * 2 + (M * 4 * D + D * 4 * D) * 2) / 3 + 2 * M * D * 4      # operands (2 x K=4096, 1 x K=16384) + fp32 x read and write
+alg = ((M * D + D * D) * 2 * 2 + (M * 4 * D + D * 4 * D) * 2) / 3 + 2 * M * D * 4 + M * D * 2 / 3      # operands (2 x K=4096, 1 x K=16384) + fp32 x read and write + the bf16 shadow one launch in three writes
 json.dump({"kernel": "gemm_v4_kernel<EPI_RESID_GATE_F32, 3, 224>", "commit": commit, "kernel_source_sha16": kernel_source_sha(),
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; tools/pmc_bench.sh) over bench.py --steps 2 --warmup 1 "
                      "--no-extra --no-cpu-baseline --no-graph; mean over every launch of the kernel IN the model (2 x K=4096 to_out + 1 x K=16384 ff.net.2 per layer); "
