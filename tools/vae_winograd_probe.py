@@ -12,7 +12,7 @@ import os, sys, torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import vae
-dev = torch.device("cuda:0")
+dev = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
 LP = torch.float16 if "--f16" in sys.argv else torch.bfloat16
 torch.backends.cuda.matmul.allow_tf32 = False
 torch.backends.cudnn.allow_tf32 = False
@@ -37,15 +37,15 @@ def winograd(xp, w, bias):
     Bn, C, Tp, Hp, Wp = xp.shape
     O = w.shape[0]
     T, H, W = Tp - 2, Hp - 2, Wp - 2
-    U = q(torch.einsum("ai,ocdij,bj->ocdab", G, w.float(), G))                       # [O, C, 3, 4, 4], rounded: an MFMA operand
+    U = q(torch.einsum("pi,ocdij,qj->ocdpq", G, w.float(), G))                       # [O, C, 3, 4, 4], rounded: an MFMA operand
     out = torch.zeros(Bn, O, T, H // 2, W // 2, 4, 4, device=xp.device)
     for t0 in range(0, T, 4):                                                        # frames in slabs: V is 4x the activation
         t1 = min(T, t0 + 4)
         d = xp[:, :, t0:t1 + 2].unfold(3, 4, 2).unfold(4, 4, 2)                       # [1, C, t+2, H/2, W/2, 4, 4]
-        V = q(torch.einsum("ai,bctxyij,ej->bctxyae", BT, d, BT))                     # rounded: the other MFMA operand
+        V = q(torch.einsum("pi,nctxyij,qj->nctxypq", BT, d, BT))                     # rounded: the other MFMA operand
         for kt in range(3):
-            out[:, :, t0:t1] += torch.einsum("ocab,bctxyab->botxyab", U[:, :, kt], V[:, :, kt:kt + (t1 - t0)])
-    Y = torch.einsum("ia,botxyab,jb->botxyij", AT, out, AT)                          # [1, O, T, H/2, W/2, 2, 2]
+            out[:, :, t0:t1] += torch.einsum("ocpq,nctxypq->notxypq", U[:, :, kt], V[:, :, kt:kt + (t1 - t0)])
+    Y = torch.einsum("ip,notxypq,jq->notxyij", AT, out, AT)                          # [1, O, T, H/2, W/2, 2, 2]
     Y = Y.permute(0, 1, 2, 3, 5, 4, 6).reshape(Bn, O, T, H, W)
     return Y + bias.float()[None, :, None, None, None]
 
@@ -67,7 +67,8 @@ ORIG = vae.conv3d_simple
 vae.conv3d_simple = conv_emul
 torch.manual_seed(0)
 # ---- single convs against fp64
-for C, (T, H, W) in ((128, (5, 64, 96)), (256, (5, 32, 48))):
+SMALL = dev.type == "cpu"          # (a container without a GPU: tiny shapes, to check the algebra only)
+for C, (T, H, W) in (((128, (2, 8, 8)),) if SMALL else ((128, (5, 64, 96)), (256, (5, 32, 48)))):
     x = F.silu(torch.randn(1, C, T, H, W, device=dev))
     w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.02
     b = torch.zeros(C, device=dev)
@@ -76,6 +77,8 @@ for C, (T, H, W) in ((128, (5, 64, 96)), (256, (5, 32, 48))):
     e = lambda y: float((y.double() - ref).norm() / ref.norm())
     print(f"single conv {C}->{C}: direct {LP} rel-L2 {e(F.conv3d(xp, q(w))):.3e} | winograd F(2x2,3x3) {e(winograd(xp, w, b)):.3e}", flush=True)
 # ---- the whole decoder
+if SMALL:
+    sys.exit(0)
 cfg = vae.VAEConfig()
 wts = {k: v.to(dev) for k, v in vae.make_vae_weights(cfg, seed=5).items()}
 lat = torch.randn(1, 128, 3, 6, 8, device=dev)
