@@ -241,6 +241,13 @@ int ltx2_attn_head_gate(void* att, int64_t ld, const void* x, int64_t ldx, const
 int ltx2_flash_attn_gated(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
                           int H, int head_dim, float scale, const float* gate_logits, int gate_ld, void* stream);
 
+/* The engine's form of the gated attention for many rows (round 5): the gate logits x[Nq][Dq] @ gate_w[H][Dq]^T leave as 8 partial sums over K slices
+ * (parts: fp32 scratch [8][Nq][H]; H <= 32, Dq % 256 == 0, ldx % 8 == 0), and the attention kernel's epilogue adds the 8 values and gate_b in slice order before
+ * 2 * sigmoid(.) multiplies the fp32 result -- ltx2_attn_head_gate's logits up to the summation order.                                              */
+int ltx2_flash_attn_gated_parts(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
+                                int H, int head_dim, float scale, const void* x, int64_t ldx, const void* gate_w, const float* gate_b, int Dq, float* parts,
+                                void* stream);
+
 /* SPLIT-RoPE tables (precompute_freqs_cis with use_middle_indices_grid, rope.py:214-328,365-418): positions fp32
  * [n_dims][N][2] = [start, end) per axis, freq_grid [n_freq] = theta^linspace(0,1,n_freq)*pi/2 (host-computed, exact),
  * max_pos [n_dims]; writes cos/sin fp32 [N][half_dim], slot = pad + f*n_dims + d, pad = half_dim - n_dims*n_freq

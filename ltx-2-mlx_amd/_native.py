@@ -58,6 +58,7 @@ SIGNATURES = {
     "ltx2_flash_attn_keymask": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, vp, vp]),
     "ltx2_adaln_rmsnorm2": (i32, [vp, i64, vp, vp, i64, i32, i32, f32, vp, vp, vp, vp, vp]),
     "ltx2_flash_attn_gated": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, vp]),
+    "ltx2_flash_attn_gated_parts": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i64, vp, vp, i32, vp, vp]),
     "ltx2_flash_attn_rowscale": (i32, [vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, i32, i32, f32, vp, i32, i32, f32, vp]),
     "ltx2_gemm_route": (i32, [i32, i32, i32, i32, i32, i32]),
     "ltx2_quantize_rows_fp8": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),

@@ -357,6 +357,34 @@ int ltx2_flash_attn_gated(const void* Q, int64_t ldq, const void* K, int64_t ldk
     return attn_launch(a, (hipStream_t)stream);
 }
 
+int ltx2_flash_attn_gated_parts(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out, int64_t ldo, int Nq, int Nkv,
+                                int H, int head_dim, float scale, const void* x, int64_t ldx, const void* gate_w, const float* gate_b, int Dq, float* parts,
+                                void* stream) {
+    LTX2_CHECK_ARG(Q && K && VT && out && x && gate_w && gate_b && parts, "flash_attn_gated_parts: null operand");
+    LTX2_CHECK_ARG(head_dim == 128 || head_dim == 64, "flash_attn_gated_parts: head_dim=%d, only 128 and 64 are implemented", head_dim);
+    if (const int rc = gate_logits_parts_launch((const bf16*)x, ldx, (const bf16*)gate_w, parts, Nq, Dq, H, (hipStream_t)stream)) return rc;
+    AttnParams a{};
+    a.Q = (const bf16*)Q;
+    a.ldq = ldq;
+    a.K = (const bf16*)K;
+    a.ldk = ldk;
+    a.VT = (const bf16*)VT;
+    a.vt_head_stride = (long)head_dim * Npad;
+    a.head_dim = head_dim;
+    a.O = (bf16*)out;
+    a.ldo = ldo;
+    a.Nq = Nq;
+    a.Nkv = Nkv;
+    a.Npad = Npad;
+    a.H = H;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.gate = parts;
+    a.gate_ld = H;
+    a.gate_parts = GATE_LOGIT_PARTS;
+    a.gate_bias = gate_b;
+    return attn_launch(a, (hipStream_t)stream);
+}
+
 int ltx2_flash_attn(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* VT, int Npad, void* out,
                     int64_t ldo, int Nq, int Nkv, int H, int head_dim, float scale, void* stream) {
     LTX2_CHECK_ARG(Q && K && VT && out, "flash_attn: null operand");

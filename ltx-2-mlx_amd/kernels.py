@@ -149,6 +149,21 @@ def flash_attn_gated(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: 
     return out
 
 
+def flash_attn_gated_parts(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, x: torch.Tensor, gate_w: torch.Tensor,
+                           gate_b: torch.Tensor, scale: Optional[float] = None) -> torch.Tensor:
+    """The engine's many-row form of flash_attn_gated: gate logits x @ gate_w^T as 8 K-slice partial sums, added (with gate_b) in the attention epilogue."""
+    assert q.dtype in ACT16 and x.dtype == q.dtype and gate_w.dtype == q.dtype and x.stride(1) == 1
+    nq, hd = q.shape[0], vt.shape[1]
+    out = torch.empty(nq, heads * hd, device=q.device, dtype=q.dtype)
+    parts = torch.empty(8, nq, heads, device=q.device, dtype=torch.float32)
+    if scale is None:
+        scale = 1.0 / math.sqrt(float(hd))
+    nv.check(_L(q).ltx2_flash_attn_gated_parts(nv.ptr(q), q.stride(0), nv.ptr(k), k.stride(0), nv.ptr(vt), vt.shape[2], nv.ptr(out), out.stride(0), nq, nkv,
+                                               heads, hd, scale, nv.ptr(x), x.stride(0), nv.ptr(_c(gate_w)), nv.ptr(_c(gate_b.float())), x.shape[1], nv.ptr(parts),
+                                               nv.stream()))
+    return out
+
+
 def flash_attn_keymask(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nkv: int, mask: torch.Tensor,
                        scale: Optional[float] = None) -> torch.Tensor:
     """flash_attn with a key mask: mask [Nkv] bool / 0-1 (True = attend) -- the boolean context mask of the reference's text

@@ -836,6 +836,32 @@ def test_flash_attn_gated_epilogue(K, dev, heads, hd, Nq, Nkv):
 
 
 
+@pytest.mark.parametrize("heads,hd,Nq,Nkv,Dq", [(32, 128, 3456, 1024, 4096), (8, 128, 1111, 300, 1024), (16, 64, 1500, 68, 2048), (32, 64, 100, 200, 2048)])
+def test_flash_attn_gated_from_k_slice_partial_logits(K, dev, heads, hd, Nq, Nkv, Dq):
+    """the engine's many-row gate path (gate_logits_parts_kernel: 8 K-slice partial sums of x @ Wg^T, summed with the bias in the attention epilogue) had
+    no kernel-level test.  Against ltx2_attn_head_gate's one-launch logits + the gated attention, and fp64: ragged M, H < 16, H = 32, few rows."""
+    g = torch.Generator().manual_seed(heads * 1000 + Nq)
+    D = heads * hd
+    qq = torch.randn(Nq, D, generator=g).to(BF).to(dev)
+    kk = torch.randn(Nkv, D, generator=g).to(BF).to(dev)
+    vv = torch.randn(Nkv, D, generator=g).to(BF).to(dev)
+    x = torch.randn(Nq, Dq, generator=g).to(BF).to(dev)
+    wg = (torch.randn(heads, Dq, generator=g) / math.sqrt(Dq)).to(BF).to(dev)
+    bg = (0.5 * torch.randn(heads, generator=g)).to(dev)
+    vt = K.vt_transpose(vv, heads, head_dim=hd)
+    out = K.flash_attn_gated_parts(qq, kk, vt, heads, Nkv, x, wg, bg)
+    scratch = torch.ones(Nq, D, device=dev, dtype=BF)
+    logits = K.attn_head_gate_(scratch, x, wg, bg, heads)                                   # the one-launch kernel's logits
+    ref = K.flash_attn_gated(qq, kk, vt, heads, Nkv, logits)
+    assert rel_l2(out.float().cpu(), ref.float().cpu()) < 2e-3                               # same gates up to the summation order of the logits
+    lg = x.double() @ wg.double().T + bg.double()
+    gate = (2 * torch.sigmoid(lg))[..., None]
+    qh, kh, vh = [t.double().reshape(-1, heads, hd).transpose(0, 1) for t in (qq, kk, vv)]
+    exact = ((torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(hd), dim=-1) @ vh).transpose(0, 1) * gate).reshape(Nq, D)
+    assert rel_l2(out.double().cpu(), exact.cpu()) < 6e-3
+    assert torch.equal(out, K.flash_attn_gated_parts(qq, kk, vt, heads, Nkv, x, wg, bg))
+
+
 @pytest.mark.parametrize("M,D,NO,must", [(3456, 4096, 4096, True), (13824, 4096, 4096, True), (1300, 1024, 4096, False), (600, 512, 512, False)])
 def test_norm_folded_around_the_gemms(dev, M, D, NO, must):
     """Round 6 (GemmParams::shadow / rf_parts): rms_norm(x) (1 + s) in front of a projection (W, b) as r (x (1 + s)) W^T + b.  Producer = a gated-residual
