@@ -853,7 +853,7 @@ def test_flash_attn_gated_from_k_slice_partial_logits(K, dev, heads, hd, Nq, Nkv
     scratch = torch.ones(Nq, D, device=dev, dtype=BF)
     logits = K.attn_head_gate_(scratch, x, wg, bg, heads)                                   # the one-launch kernel's logits
     ref = K.flash_attn_gated(qq, kk, vt, heads, Nkv, logits)
-    assert rel_l2(out.float().cpu(), ref.float().cpu()) < 2e-3                               # same gates up to the summation order of the logits
+    assert rel_l2(out.float().cpu(), ref.float().cpu()) < 7e-5                               # same gates up to the summation order of the logits (measured 1.0e-5 ... 1.4e-5)
     lg = x.double() @ wg.double().T + bg.double()
     gate = (2 * torch.sigmoid(lg))[..., None]
     qh, kh, vh = [t.double().reshape(-1, heads, hd).transpose(0, 1) for t in (qq, kk, vv)]
