@@ -25,7 +25,7 @@
 
 namespace {
 
-constexpr int QB = 128, KVB = 64;
+constexpr int KVB = 64;
 // HD = 128 (video streams) or 64 (audio streams and audio<->video cross-modal attention):
 // K tile [64][HD] has rows of 2*HD bytes, V^T tile [HD][64] rows of 128 bytes.
 template <int HD>
@@ -132,10 +132,13 @@ __device__ __forceinline__ void mfma16_result_guard(f32x4 (&s)[4][2], float& t0,
 __device__ unsigned long long ltx2_at_counts[2];
 #endif
 
-template <int HD, bool QS = false, bool KM = false>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+// NW = waves per workgroup: 4 (128 query rows, two workgroups per CU, each with its own K / V^T stage) or 8 (256 query rows, ONE workgroup per CU: the
+// head's tiles are fetched and filled into LDS once per 256 rows instead of once per 128 -- half the LDS-DMA issues per wave, half the fills per unit of work)
+template <int HD, bool QS = false, bool KM = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(const AttnParams p) {
     using G = Geo<HD>;
-    constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NJ = G::NJ;
+    constexpr int K_TILE = G::K_TILE, STAGE = G::STAGE, NJ = G::NJ * 4 / NW, QB = NW * 32;
+    static_assert(NW == 4 || (NW == 8 && HD == 128), "waves per workgroup");
     constexpr int NKS = HD / 32, NDB = HD / 16;
     constexpr int NK = 4 * NKS, NV = 2 * NDB;
     constexpr int DK = AT_DK < NK ? AT_DK : NK, DV = AT_DV < NV ? AT_DV : NV;
@@ -522,23 +525,35 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG((long)p.Npad * (p.head_dim == 64 ? 64 : 128) * 2 < (1L << 31), "attention: Npad * head_dim exceeds the 31-bit V^T byte offset");
     if (p.q_ss)
         LTX2_CHECK_ARG(p.head_dim != 64 && p.q_ss_ld > 0 && p.q_ss_ld % 16 == 0 && p.q_norm_dim > 0, "attention: the per-row scale form needs head_dim 128 and q_ss_ld %% 16 == 0");
-    dim3 grid((p.Nq + QB - 1) / QB, p.H);
-#define AT_LAUNCH(HDV, QSV, KMV)                                                                                                                \
+#ifndef AT_NW_CROSS
+#define AT_NW_CROSS 4       // waves per workgroup of the per-row-scale form (the text cross-attention) / of the plain head_dim-128 form: 4 or 8 (same-box A/B builds)
+#endif
+#ifndef AT_NW_SELF
+#define AT_NW_SELF 4
+#endif
+    const int nw = (p.head_dim == 64 || p.kmask) ? 4 : p.q_ss ? AT_NW_CROSS : AT_NW_SELF;
+    dim3 grid((p.Nq + nw * 32 - 1) / (nw * 32), p.H);
+#define AT_LAUNCH_NW(HDV, QSV, KMV, NWV)                                                                                                        \
     do {                                                                                                                                        \
         static PerDeviceOnce once_;                                                                                                             \
         if (once_.first())                                                                                                                      \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDV, QSV, KMV>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<HDV>::LDS_BYTES); \
-        hipLaunchKernelGGL((attn_fwd_kernel<HDV, QSV, KMV>), grid, dim3(256), Geo<HDV>::LDS_BYTES, stream, p);                                   \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDV, QSV, KMV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<HDV>::LDS_BYTES); \
+        hipLaunchKernelGGL((attn_fwd_kernel<HDV, QSV, KMV, NWV>), grid, dim3(NWV * 64), Geo<HDV>::LDS_BYTES, stream, p);                         \
     } while (0)
+#define AT_LAUNCH(HDV, QSV, KMV) AT_LAUNCH_NW(HDV, QSV, KMV, 4)
     if (p.head_dim == 64) {
         if (p.kmask) AT_LAUNCH(64, false, true);
         else AT_LAUNCH(64, false, false);
     } else if (p.kmask) {
         if (p.q_ss) AT_LAUNCH(128, true, true);
         else AT_LAUNCH(128, false, true);
-    } else if (p.q_ss) AT_LAUNCH(128, true, false);
+    } else if (p.q_ss) {
+        if (nw == 8) AT_LAUNCH_NW(128, true, false, 8);
+        else AT_LAUNCH(128, true, false);
+    } else if (nw == 8) AT_LAUNCH_NW(128, false, false, 8);
     else AT_LAUNCH(128, false, false);
 #undef AT_LAUNCH
+#undef AT_LAUNCH_NW
     LTX2_CHECK_LAUNCH("attn_fwd_kernel");
     return LTX2_OK;
 }
