@@ -525,13 +525,21 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     LTX2_CHECK_ARG((long)p.Npad * (p.head_dim == 64 ? 64 : 128) * 2 < (1L << 31), "attention: Npad * head_dim exceeds the 31-bit V^T byte offset");
     if (p.q_ss)
         LTX2_CHECK_ARG(p.head_dim != 64 && p.q_ss_ld > 0 && p.q_ss_ld % 16 == 0 && p.q_norm_dim > 0, "attention: the per-row scale form needs head_dim 128 and q_ss_ld %% 16 == 0");
-#ifndef AT_NW_CROSS
-#define AT_NW_CROSS 4       // waves per workgroup of the per-row-scale form (the text cross-attention) / of the plain head_dim-128 form: 4 or 8 (same-box A/B builds)
+#ifndef AT_NW
+#define AT_NW 0         // waves per workgroup of the head_dim-128 forms without a key mask: 0 = by grid size (below), 4 / 8 = forced (same-box A/B builds)
 #endif
-#ifndef AT_NW_SELF
-#define AT_NW_SELF 4
-#endif
-    const int nw = (p.head_dim == 64 || p.kmask) ? 4 : p.q_ss ? AT_NW_CROSS : AT_NW_SELF;
+    // 8 waves / 256 query rows per workgroup (one per CU, ONE K / V^T stage for all of them) where the 128-row grid is many rounds deep: same-box A/B (round 6,
+    // tools/attn_time.py, two alternations) N = 13 824 self-attention 2469-2477 -> 2393-2417 us (-2.7 %); N = 3456 (864 workgroups, 1.69 rounds; 448 of 256 rows:
+    // 1.75) 184-185 -> 188-189 us and 3456 x 1024 61 -> 63.5 us, so grids under four rounds keep 128 rows
+    int nw = 4;
+    if (p.head_dim != 64 && !p.kmask) {
+        static int cus[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 0;
+        const long slots = 2L * ((dev >= 0 && dev < 64 && cus[dev] > 0) ? cus[dev] : 256);
+        nw = AT_NW ? AT_NW : (((long)((p.Nq + 127) / 128) * p.H >= 4 * slots) ? 8 : 4);
+    }
     dim3 grid((p.Nq + nw * 32 - 1) / (nw * 32), p.H);
 #define AT_LAUNCH_NW(HDV, QSV, KMV, NWV)                                                                                                        \
     do {                                                                                                                                        \
