@@ -526,20 +526,11 @@ int attn_launch(const AttnParams& p, hipStream_t stream) {
     if (p.q_ss)
         LTX2_CHECK_ARG(p.head_dim != 64 && p.q_ss_ld > 0 && p.q_ss_ld % 16 == 0 && p.q_norm_dim > 0, "attention: the per-row scale form needs head_dim 128 and q_ss_ld %% 16 == 0");
 #ifndef AT_NW
-#define AT_NW 0         // waves per workgroup of the head_dim-128 forms without a key mask: 0 = by grid size (below), 4 / 8 = forced (same-box A/B builds)
-#endif
-    // 8 waves / 256 query rows per workgroup (one per CU, ONE K / V^T stage for all of them) where the 128-row grid is many rounds deep: same-box A/B (round 6,
-    // tools/attn_time.py, two alternations) N = 13 824 self-attention 2469-2477 -> 2393-2417 us (-2.7 %); N = 3456 (864 workgroups, 1.69 rounds; 448 of 256 rows:
-    // 1.75) 184-185 -> 188-189 us and 3456 x 1024 61 -> 63.5 us, so grids under four rounds keep 128 rows
-    int nw = 4;
-    if (p.head_dim != 64 && !p.kmask) {
-        static int cus[64] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 0;
-        const long slots = 2L * ((dev >= 0 && dev < 64 && cus[dev] > 0) ? cus[dev] : 256);
-        nw = AT_NW ? AT_NW : (((long)((p.Nq + 127) / 128) * p.H >= 4 * slots) ? 8 : 4);
-    }
+#define AT_NW 4         // waves per workgroup of the head_dim-128 forms without a key mask: 4 (128 query rows, two workgroups per CU) or 8 (256 rows, one per CU, ONE K / V^T
+#endif                  // stage for all of them).  Round 6, same box: the 8-wave form is 2.7 % FASTER alone at N = 13 824 (2469-2477 -> 2393-2417 us) and 2-4 % slower at
+                        // N = 3456 (1.75 rounds of 256 rows against 1.69 of 128) -- and inside the two-stage pipeline (tools/bench_two_stage.py, two alternations) picking it
+                        // for the N = 13 824 steps made the 8 + 3 steps SLOWER: 1.796 / 1.818 s against 1.777 / 1.778.  Kept as an A/B build only (-DAT_NW=8).
+    const int nw = (p.head_dim != 64 && !p.kmask) ? AT_NW : 4;
     dim3 grid((p.Nq + nw * 32 - 1) / (nw * 32), p.H);
 #define AT_LAUNCH_NW(HDV, QSV, KMV, NWV)                                                                                                        \
     do {                                                                                                                                        \
