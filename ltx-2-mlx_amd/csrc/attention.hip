@@ -235,7 +235,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) o[d][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float M[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};     // M: reference exponent of the row (exp2 units); set by the first tile
-
     // one KV tile.  FAST: stale-maximum path with the exponentials inside the QK^T cluster; otherwise the classic path (FIRST: runtime flag)
     auto tile = [&](const int t, auto fast, auto masked, auto par, const bool first) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast)::value, MASKED = decltype(masked)::value;
