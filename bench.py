@@ -621,7 +621,8 @@ def main():
         kern_tflops = (k_fl / max(k_n, 1)) / (kern_avg_ms * 1e-3) / 1e12 if k_n else None
         out["roofline"] = {
             "kernel": "gemm_v4_kernel<EPI_RESID_GATE_F32, layout 3, 224> (224x256x64 tile, 4 waves, generated asm K loop, "
-                      "v_mfma_f32_16x16x32_bf16: attn1/attn2 to_out and ff.net.2 + bias + gate * (.) added into the fp32 residual)",
+                      "v_mfma_f32_16x16x32_bf16: attn1/attn2 to_out and ff.net.2 + bias + gate * (.) added into the fp32 residual; two instantiations since round 6: "
+                      "<4, 3, 224, false, 0> and, for attn1.to_out with the folded pre-norm's bf16 shadow + sums of squares, <4, 3, 224, false, 30>)",
             "bound": "mfma", "achieved": None if kern_tflops is None else round(kern_tflops, 1), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": None if kern_tflops is None else round(kern_tflops / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_source_commit": traffic_src, "traffic_stale": traffic_stale,
