@@ -393,6 +393,20 @@ __global__ __launch_bounds__(256) void gate_logits_parts_kernel(const bf16* __re
     const int Kc = K / KS, ks = blockIdx.y, ROWB = (Kc + 8) * 2;       // padded LDS row: 16 rows x 16 B land on 16 different bank groups
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * 64 + wv * 16;
+    const bf16* xp = X + (long)min(row0 + r16, M - 1) * ldx + (long)ks * Kc + kq * 8;
+    const char* w0 = gl_smem + r16 * ROWB + kq * 16;
+    const char* w1 = gl_smem + (16 + r16) * ROWB + kq * 16;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int DEPTH = 16;
+#ifndef LTX2_GATE_X_FIRST
+#define LTX2_GATE_X_FIRST 1     // (A/B) the first DEPTH activation fragments are requested BEFORE the weight slice is staged: the two memory round trips overlap
+#endif
+    bf16x8 a[DEPTH];
+    if (LTX2_GATE_X_FIRST) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) a[j] = (32 * j < Kc) ? *(const bf16x8*)(xp + 32 * j) : bf16x8{};
+    }
     // stage the weight slice: 32 rows x Kc columns as 16-byte pieces (rows >= H repeat row H - 1: their products are never stored)
     const int pieces_per_row = Kc / 8;
     for (int i = tid; i < 32 * pieces_per_row; i += 256) {
@@ -401,16 +415,11 @@ __global__ __launch_bounds__(256) void gate_logits_parts_kernel(const bf16* __re
         *(bf16x8*)(gl_smem + h * ROWB + c * 16) = v;
     }
     __syncthreads();
-    const int row0 = blockIdx.x * 64 + wv * 16;
-    const bf16* xp = X + (long)min(row0 + r16, M - 1) * ldx + (long)ks * Kc + kq * 8;
-    const char* w0 = gl_smem + r16 * ROWB + kq * 16;
-    const char* w1 = gl_smem + (16 + r16) * ROWB + kq * 16;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int DEPTH = 16;
     for (int k = 0; k < Kc; k += 32 * DEPTH) {
-        bf16x8 a[DEPTH];
+        if (!LTX2_GATE_X_FIRST || k > 0) {
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) a[j] = (k + 32 * j < Kc) ? *(const bf16x8*)(xp + k + 32 * j) : bf16x8{};
+            for (int j = 0; j < DEPTH; ++j) a[j] = (k + 32 * j < Kc) ? *(const bf16x8*)(xp + k + 32 * j) : bf16x8{};
+        }
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
             if (k + 32 * j < Kc) {
